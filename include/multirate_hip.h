@@ -1,0 +1,201 @@
+/*
+ * multirate_hip.h -- C ABI of libmultirate_hip.so, the MI355X (gfx950) engine behind
+ * Multirate.jl's FIRFilter / filt / filt! hot path.
+ *
+ * The reference (JayKickliter/Multirate.jl) has no FFI boundary: its seam is Julia
+ * multiple dispatch on
+ *     filt!(buffer::Vector{Tb}, self::FIRFilter{K{Th}}, x::Vector{Tx})
+ * (src/Filters.jl:450,489,536,598,693) reached through filt(self, x)
+ * (src/Filters.jl:475,519,577,633,744) and filt(h, x, ratio|rate)
+ * (src/Filters.jl:858,864).  Each entry point below names the reference
+ * interface it replaces.  The Julia-side binding is in
+ * multirate.jl_amd/julia/MultirateHIP.jl and described in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross the boundary
+ *   - every function returns an mrhip_status (0 = ok) unless noted;
+ *     mrhip_last_error() returns the message of the calling thread's last failure
+ *     (the reference raises Julia error("...") in the same places)
+ *   - complex samples are interleaved (re, im) pairs (Julia Complex{T} layout)
+ *   - a filter object carries `nchannels` independent streams that share taps and
+ *     the data-independent state (phase index, input deficit, phase accumulator)
+ *     and own one history vector each: the batched form of the reference's
+ *     one-Vector-per-FIRFilter model (SURVEY.md 8b "Batch")
+ *   - channel c of a signal buffer starts at base + c * stride (stride in SAMPLES,
+ *     not bytes): planar layout, the layout of a Julia Matrix with one channel per column
+ *   - lengths are per channel, in samples
+ *   - a handle is a mutable stream object exactly like the reference's FIRFilter:
+ *     not to be used from two threads at once
+ */
+#ifndef MULTIRATE_HIP_H
+#define MULTIRATE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRHIP_ABI_VERSION 1
+
+typedef enum {
+    MRHIP_OK = 0,
+    MRHIP_ERR_INVALID_ARG = 1,      /* reference: error("rate must be greater than 0") etc. */
+    MRHIP_ERR_BUFFER_TOO_SMALL = 2, /* reference: error("buffer is too small"), Filters.jl:460,503,550 */
+    MRHIP_ERR_HIP = 3,              /* a HIP runtime call failed; message holds hipGetErrorString */
+    MRHIP_ERR_NO_DEVICE = 4,        /* no gfx950 device visible: the engine has no CPU fallback */
+    MRHIP_ERR_UNSUPPORTED = 5       /* e.g. complex taps (the reference tests never use them) */
+} mrhip_status;
+
+/* element types: Th in {F32,F64}; Tx in {F32,F64,C64,C128}; Tb = promote_type(Th,Tx) */
+typedef enum { MRHIP_F32 = 0, MRHIP_F64 = 1, MRHIP_C64 = 2, MRHIP_C128 = 3 } mrhip_dtype;
+
+/* kernel kinds == the reference's FIRKernel subtypes, src/Filters.jl:15-117 */
+typedef enum {
+    MRHIP_FIR_STANDARD = 0,     /* FIRStandard     src/Filters.jl:15-24   */
+    MRHIP_FIR_DECIMATOR = 1,    /* FIRDecimator    src/Filters.jl:45-58   */
+    MRHIP_FIR_INTERPOLATOR = 2, /* FIRInterpolator src/Filters.jl:28-41   */
+    MRHIP_FIR_RATIONAL = 3,     /* FIRRational     src/Filters.jl:62-80   */
+    MRHIP_FIR_ARBITRARY = 4     /* FIRArbitrary    src/Filters.jl:91-117  */
+} mrhip_kind;
+
+/* Arithmetic contract for the tap dot product (src/support.jl:5-55).
+ *   STRICT: the order and roundings the reference source states -- oldest sample first,
+ *           first product initialises the accumulator, separately rounded multiply and add
+ *           in promote_type(Th,Tx) (no FMA; Julia 0.3 never fused).  Default.
+ *   FUSED : same order, each step one fused multiply-add.  Faster where the kernel is
+ *           VALU-bound; differs from STRICT by <= 1 rounding per tap. */
+typedef enum { MRHIP_NUMERICS_STRICT = 0, MRHIP_NUMERICS_FUSED = 1 } mrhip_numerics;
+
+typedef struct mrhip_filter mrhip_filter; /* opaque; replaces FIRFilter{Tk}, src/Filters.jl:151-155 */
+
+/* Snapshot of the kernel fields of the reference structs (src/Filters.jl:15-117,151-155).
+ * Indices are 1-based like the reference's. */
+typedef struct {
+    int32_t kind;            /* mrhip_kind */
+    int32_t tap_dtype;       /* Th */
+    int32_t sample_dtype;    /* Tx */
+    int32_t output_dtype;    /* Tb = promote_type(Th,Tx) */
+    int64_t nchannels;
+    int64_t hLen;            /* length(h) as passed */
+    int64_t interpolation;   /* L (reduced) ; Nphi for ARBITRARY */
+    int64_t decimation;      /* M (reduced) */
+    int64_t Nphi;            /* N𝜙 */
+    int64_t tapsPerPhi;      /* tapsPer𝜙 (== hLen for STANDARD/DECIMATOR) */
+    int64_t historyLen;
+    int64_t phiIdx;          /* 𝜙Idx          FIRRational :68, FIRArbitrary :98 */
+    int64_t inputDeficit;    /* inputDeficit  :49, :69, :101 */
+    int64_t xIdx;            /* FIRArbitrary.xIdx :102 */
+    double rate;             /* FIRArbitrary.rate :92 */
+    double phiAccumulator;   /* 𝜙Accumulator :97 */
+    double alpha;            /* α :99 */
+    double delta;            /* Δ :100 */
+} mrhip_state;
+
+/* ---- library ------------------------------------------------------------------------- */
+int mrhip_abi_version(void);
+const char *mrhip_last_error(void);
+/* number of visible HIP devices whose arch is gfx950 (0 => every create fails with NO_DEVICE) */
+int mrhip_device_count(void);
+
+/* ---- host-only helpers (no GPU needed) ------------------------------------------------ */
+/* replaces taps2pfb(h, Nphi), src/Filters.jl:284-298.  `pfb` receives tapsPerPhi*Nphi elements,
+ * column-major (column = phase, contiguous); pass pfb = NULL to query.  Returns tapsPerPhi. */
+int64_t mrhip_taps2pfb(const void *h, int64_t hLen, int tap_dtype, int64_t Nphi, void *pfb);
+/* replaces nextphase(currentphase, ratio), src/Filters.jl:433-439 */
+int64_t mrhip_nextphase(int64_t currentphase, int64_t interpolation, int64_t decimation);
+/* replaces outputlength(inputlength, ratio, initial𝜙), src/Filters.jl:352-357 */
+int64_t mrhip_outputlength_ratio(int64_t inputlength, int64_t interpolation, int64_t decimation,
+                                 int64_t initialPhi);
+/* replaces inputlength(outputlength, ratio, initial𝜙), src/Filters.jl:396-401 */
+int64_t mrhip_inputlength_ratio(int64_t outputlength, int64_t interpolation, int64_t decimation,
+                                int64_t initialPhi);
+/* promote_type(Th, Tx) as used by every filt wrapper, e.g. src/Filters.jl:581 */
+int mrhip_output_dtype(int tap_dtype, int sample_dtype);
+
+/* ---- construction --------------------------------------------------------------------- */
+/* replaces FIRFilter(h::Vector, resampleRatio::Rational = 1//1), src/Filters.jl:158-180.
+ * num//den is reduced like a Julia Rational; the kernel kind is chosen exactly as :163-175
+ * (ratio == 1 -> STANDARD, L == 1 -> DECIMATOR, M == 1 -> INTERPOLATOR, else RATIONAL).
+ * `h` is a host pointer to hLen taps of tap_dtype (F32 | F64).  `device` is a HIP ordinal. */
+int mrhip_create_rational(const void *h, int64_t hLen, int tap_dtype, int64_t num, int64_t den,
+                          int sample_dtype, int64_t nchannels, int device, mrhip_filter **out);
+/* replaces FIRFilter(h::Vector, rate::FloatingPoint, Nphi::Integer = 32), src/Filters.jl:183-189
+ * (+ FIRArbitrary(h, rate, Nphi), :105-117: dh = [diff(h), 0], two PFBs).  rate <= 0 is
+ * MRHIP_ERR_INVALID_ARG ("rate must be greater than 0", :184). */
+int mrhip_create_arbitrary(const void *h, int64_t hLen, int tap_dtype, double rate, int64_t Nphi,
+                           int sample_dtype, int64_t nchannels, int device, mrhip_filter **out);
+void mrhip_destroy(mrhip_filter *f);
+
+/* ---- bookkeeping ---------------------------------------------------------------------- */
+/* replaces outputlength(self::FIRFilter, inputlength), src/Filters.jl:359-385 (per channel).
+ * For ARBITRARY this is the reference's ceil((n - deficit + 1) * rate) estimate (:375-377). */
+int64_t mrhip_outputlength(const mrhip_filter *f, int64_t inputlength);
+/* exact number of samples the next filt call with `inputlength` samples will write per channel
+ * (== outputlength for the rational family when inputlength >= inputDeficit, else 0; for ARBITRARY it
+ * runs the phase recurrence of update(), src/Filters.jl:663-673, without touching the state). */
+int64_t mrhip_next_output_count(const mrhip_filter *f, int64_t inputlength);
+/* replaces inputlength(self::FIRFilter, outputlength), src/Filters.jl:403-422 */
+int64_t mrhip_inputlength(const mrhip_filter *f, int64_t outputlength);
+int mrhip_get_state(const mrhip_filter *f, mrhip_state *st);
+/* restore a stream position (phiIdx, inputDeficit; phiAccumulator for ARBITRARY, from which
+ * phiIdx and alpha are re-derived as update() does).  The reference has no such call; it is the
+ * working counterpart of setphase/reset (src/Filters.jl:210-260, several of which are broken). */
+int mrhip_set_state(mrhip_filter *f, int64_t phiIdx, int64_t inputDeficit, double phiAccumulator);
+/* copy the history vectors (FIRFilter.history, src/Filters.jl:153) of all channels to / from a
+ * host buffer laid out [nchannels][historyLen] in sample_dtype.  Synchronous. */
+int mrhip_get_history(mrhip_filter *f, void *host_out);
+int mrhip_set_history(mrhip_filter *f, const void *host_in);
+/* replaces reset(self::FIRFilter), src/Filters.jl:256-260: zero history; state back to the
+ * constructor's (the reference resets 𝜙Idx only and is broken for FIRArbitrary, :247-253). */
+int mrhip_reset(mrhip_filter *f);
+int mrhip_set_numerics(mrhip_filter *f, int numerics);
+/* the polyphase taps as stored on the device, converted back to tap_dtype (which = 0: h flipped or
+ * pfb; which = 1: dpfb).  Column-major tapsPerPhi x Nphi.  For tests / tapsforphase. */
+int mrhip_get_taps(mrhip_filter *f, int which, void *host_out);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+/* replaces filt!(buffer, self, x) for all five kernels, src/Filters.jl:450,489,536,598,693,
+ * on DEVICE memory: x and y are device pointers on f's device; channel c is read from
+ * x + c*x_stride and written to y + c*y_stride (strides in samples).  y holds elements of
+ * output_dtype.  y_capacity is the per-channel room in y; if it is smaller than the number of
+ * samples the call will produce the call fails with MRHIP_ERR_BUFFER_TOO_SMALL and the filter
+ * state is unchanged (reference: error() before the loop, :460,:503,:550).
+ * *n_written receives the per-channel output count (the Int that the Rational/Decimator/
+ * Arbitrary filt! return, :574,:630,:741; xLen resp. L*xLen for Standard/Interpolator).  It is a
+ * pure function of (state, x_len) and is valid on return even though the kernels are only
+ * enqueued: the call is asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ * A short input (x_len < inputDeficit) is not an error: history is shifted, inputDeficit
+ * reduced, *n_written = 0 (:543-547, :638-643, :705-709). */
+int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
+                      int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream);
+/* same contract with HOST pointers: copies x in, runs mrhip_filt_device, copies y out,
+ * synchronises.  Replaces filt!(buffer, self, x) for a caller whose data lives in host memory. */
+int mrhip_filt_host(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
+                    int64_t y_capacity, int64_t y_stride, int64_t *n_written);
+/* block until everything enqueued on the filter's behalf on `stream` has finished */
+int mrhip_synchronize(mrhip_filter *f, void *stream);
+
+/* replaces the stateless filt(h, x, ratio), src/Filters.jl:858-861, and
+ * filt(h, x, rate, Nphi), :864-867, for host data, one channel: construct, filter once,
+ * destroy.  rate <= 0 selects the rational form with num//den; rate > 0 the arbitrary form. */
+int mrhip_filt_once(const void *h, int64_t hLen, int tap_dtype, int64_t num, int64_t den, double rate,
+                    int64_t Nphi, const void *x, int64_t x_len, int sample_dtype, void *y,
+                    int64_t y_capacity, int64_t *n_written, int device);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+/* With timing enabled every compute-kernel launch made by mrhip_filt_device on this filter is
+ * bracketed by a pair of HIP events recorded on the launch stream (the history-shift kernel and
+ * the copies are outside the bracket).  Nothing synchronises until mrhip_timing_read, which waits
+ * for the recorded events, returns how many launches were bracketed since the last read and the sum
+ * of their durations in milliseconds, and clears the log.  bench.py uses it for roofline.achieved. */
+int mrhip_set_timing(mrhip_filter *f, int enabled);
+int mrhip_timing_read(mrhip_filter *f, int64_t *n_launches, double *total_ms);
+/* name of the device kernel the last filt call dispatched (for profiles / logs) */
+const char *mrhip_last_kernel_name(const mrhip_filter *f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MULTIRATE_HIP_H */

@@ -1,0 +1,40 @@
+"""multirate.jl_amd -- MI355X-native engine for Multirate.jl's FIRFilter / filt / filt! hot path.
+
+This package is the host-side mirror of the reference's operator interface
+(``FIRFilter``, ``filt``, ``filt!`` -> ``filt_``, ``taps2pfb``, ``outputlength``, ``inputlength``,
+``reset``: export list of /root/reference/src/Multirate.jl:26-41) on top of the C ABI in
+``include/multirate_hip.h`` (``libmultirate_hip.so``, hand-written gfx950 HIP kernels in ``csrc/``).
+
+The Julia binding a Multirate.jl maintainer would use is ``julia/MultirateHIP.jl``; this Python
+mirror exists because the build image has no Julia, and is what the parity tests and ``bench.py``
+drive.  All arithmetic happens in the HIP library: there is no CPU fallback here, and importing
+this package never touches ``oracle/``.
+
+The directory name contains a dot, so import it through ``__graft_entry__.load_package()``
+(registers it as ``multirate_jl_amd``).
+"""
+from __future__ import annotations
+
+from .host import (  # noqa: F401
+    FIRFilter,
+    MultirateHIPError,
+    NUMERICS_FUSED,
+    NUMERICS_STRICT,
+    filt,
+    filt_,
+    inputlength,
+    library_path,
+    load_library,
+    nextphase,
+    outputlength,
+    reset,
+    taps2pfb,
+)
+from .design import firdes, kaiserlength  # noqa: F401
+from .sharding import ChannelShardedFilter, shard_channels  # noqa: F401
+
+__all__ = [
+    "FIRFilter", "filt", "filt_", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
+    "firdes", "kaiserlength", "ChannelShardedFilter", "shard_channels", "load_library",
+    "library_path", "MultirateHIPError", "NUMERICS_STRICT", "NUMERICS_FUSED",
+]

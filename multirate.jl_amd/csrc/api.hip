@@ -1,0 +1,582 @@
+// api.hip -- the extern "C" surface of libmultirate_hip.so (include/multirate_hip.h).
+//
+// There is deliberately NO CPU execution path in this library: if no gfx950 device is visible
+// every constructor fails with MRHIP_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "mrhip_internal.h"
+
+namespace mrhip {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+namespace {
+
+// RAII: make the filter's device current for the duration of an API call, then restore.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+bool device_is_gfx950(int dev)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+TypeKey type_key(const mrhip_filter *f)
+{
+    return TypeKey{dtype_is_f64(f->tx), f->r_f64, f->nc == 2};
+}
+
+size_t r_size(const mrhip_filter *f) { return f->r_f64 ? 8 : 4; }
+size_t x_elt(const mrhip_filter *f) { return dtype_size(f->tx); }
+size_t y_elt(const mrhip_filter *f) { return dtype_size(f->ty); }
+
+// upload taps (tap dtype on the host) as R-typed device array; f32 -> f64 widening is exact and is
+// what Julia's promotion does on every multiply (Real*Real / Real*Complex methods).
+int upload_taps(mrhip_filter *f, const std::vector<unsigned char> &src, void **dptr)
+{
+    const size_t n = src.size() / dtype_scalar_size(f->th);
+    const size_t bytes = std::max<size_t>(n * r_size(f), 16);
+    MRHIP_CHECK_HIP(hipMalloc(dptr, bytes));
+    if (f->r_f64 && f->th == MRHIP_F32) {
+        std::vector<double> w(n);
+        const float *s = reinterpret_cast<const float *>(src.data());
+        for (size_t i = 0; i < n; ++i) w[i] = static_cast<double>(s[i]);
+        MRHIP_CHECK_HIP(hipMemcpy(*dptr, w.data(), n * 8, hipMemcpyHostToDevice));
+    } else {
+        MRHIP_CHECK_HIP(hipMemcpy(*dptr, src.data(), src.size(), hipMemcpyHostToDevice));
+    }
+    return MRHIP_OK;
+}
+
+int alloc_common(mrhip_filter *f)
+{
+    const size_t hbytes = std::max<size_t>(static_cast<size_t>(f->nch) * f->H * x_elt(f), 16);
+    for (int i = 0; i < 2; ++i) {
+        MRHIP_CHECK_HIP(hipMalloc(&f->d_hist[i], hbytes));
+        MRHIP_CHECK_HIP(hipMemset(f->d_hist[i], 0, hbytes));   // history = zeros(historyLen), Filters.jl:177
+    }
+    MRHIP_CHECK_HIP(hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking));
+    MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->sched_copied, hipEventDisableTiming));
+    return MRHIP_OK;
+}
+
+int check_create_args(const void *h, int64_t hLen, int th, int tx, int64_t nch, int device, mrhip_filter **out)
+{
+    if (!out) return fail(MRHIP_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!h || hLen < 1) return fail(MRHIP_ERR_INVALID_ARG, "h must hold at least one tap");
+    if (th != MRHIP_F32 && th != MRHIP_F64)
+        return fail(MRHIP_ERR_UNSUPPORTED, "taps must be Float32 or Float64 (complex taps are not supported)");
+    if (tx < MRHIP_F32 || tx > MRHIP_C128) return fail(MRHIP_ERR_INVALID_ARG, "bad sample dtype");
+    if (nch < 1) return fail(MRHIP_ERR_INVALID_ARG, "nchannels must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MRHIP_ERR_NO_DEVICE, "no HIP device visible; libmultirate_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MRHIP_ERR_INVALID_ARG, "device ordinal out of range");
+    if (!device_is_gfx950(device))
+        return fail(MRHIP_ERR_NO_DEVICE, "device is not gfx950 (MI355X); kernels are built for gfx950 only");
+    return MRHIP_OK;
+}
+
+// Kernel selection for the rational family.  Tuned kernels are tried first; the universal
+// one-thread-per-output kernel accepts everything.
+hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s,
+                       const char **kname)
+{
+    (void)f;
+    return launch_poly_generic(tk, fused, a, s, kname);
+}
+
+}  // namespace
+}  // namespace mrhip
+
+using namespace mrhip;
+
+extern "C" {
+
+int mrhip_abi_version(void) { return MRHIP_ABI_VERSION; }
+const char *mrhip_last_error(void) { return g_last_error.c_str(); }
+
+int mrhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) ok += device_is_gfx950(d) ? 1 : 0;
+    return ok;
+}
+
+int64_t mrhip_taps2pfb(const void *h, int64_t hLen, int tap_dtype, int64_t Nphi, void *pfb)
+{
+    if (!h || hLen < 1 || Nphi < 1) return -1;
+    return taps2pfb(h, hLen, tap_dtype, Nphi, pfb);
+}
+int64_t mrhip_nextphase(int64_t p, int64_t L, int64_t M) { return nextphase(p, L, M); }
+int64_t mrhip_outputlength_ratio(int64_t n, int64_t L, int64_t M, int64_t phi) { return outputlength_ratio(n, L, M, phi); }
+int64_t mrhip_inputlength_ratio(int64_t n, int64_t L, int64_t M, int64_t phi) { return inputlength_ratio(n, L, M, phi); }
+
+int mrhip_output_dtype(int th, int tx)
+{
+    const bool f64 = dtype_is_f64(th) || dtype_is_f64(tx);
+    if (dtype_is_complex(tx)) return f64 ? MRHIP_C128 : MRHIP_C64;
+    return f64 ? MRHIP_F64 : MRHIP_F32;
+}
+
+int mrhip_create_rational(const void *h, int64_t hLen, int th, int64_t num, int64_t den, int tx, int64_t nch,
+                          int device, mrhip_filter **out)
+{
+    if (int rc = check_create_args(h, hLen, th, tx, nch, device, out)) return rc;
+    if (num < 1 || den < 1) return fail(MRHIP_ERR_INVALID_ARG, "ratio must be positive");
+    const int64_t g = std::gcd(num, den);
+    const int64_t L = num / g, M = den / g;
+    if (L > 0x7fffffff || M > 0x7fffffff || hLen > 0x7fffffff)
+        return fail(MRHIP_ERR_INVALID_ARG, "L, M and hLen must fit in 31 bits");
+
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
+    auto *f = new mrhip_filter();
+    f->th = th; f->tx = tx; f->ty = mrhip_output_dtype(th, tx);
+    f->nc = dtype_is_complex(tx) ? 2 : 1;
+    f->r_f64 = dtype_is_f64(f->ty);
+    f->nch = nch; f->hLen = hLen; f->L = L; f->M = M; f->device = device;
+    const size_t es = dtype_scalar_size(th);
+
+    if (L == 1) {            // STANDARD (Filters.jl:163-165) / DECIMATOR (:166-168): h = flipud(h)
+        f->kind = M == 1 ? MRHIP_FIR_STANDARD : MRHIP_FIR_DECIMATOR;
+        f->Nphi = 1; f->T = hLen; f->H = hLen - 1;
+        f->h_taps.resize(static_cast<size_t>(hLen) * es);
+        taps2pfb(h, hLen, th, 1, f->h_taps.data());   // one column, reversed == flipud
+    } else {                 // INTERPOLATOR (:169-171) / RATIONAL (:172-174)
+        f->kind = M == 1 ? MRHIP_FIR_INTERPOLATOR : MRHIP_FIR_RATIONAL;
+        f->Nphi = L;
+        f->T = taps2pfb(h, hLen, th, L, nullptr);
+        f->H = f->T - 1;
+        f->h_taps.resize(static_cast<size_t>(f->T) * L * es);
+        taps2pfb(h, hLen, th, L, f->h_taps.data());
+    }
+    int rc = upload_taps(f, f->h_taps, &f->d_taps);
+    if (!rc) rc = alloc_common(f);
+    if (rc) { mrhip_destroy(f); return rc; }
+    *out = f;
+    return MRHIP_OK;
+}
+
+int mrhip_create_arbitrary(const void *h, int64_t hLen, int th, double rate, int64_t Nphi, int tx, int64_t nch,
+                           int device, mrhip_filter **out)
+{
+    if (int rc = check_create_args(h, hLen, th, tx, nch, device, out)) return rc;
+    if (!(rate > 0.0)) return fail(MRHIP_ERR_INVALID_ARG, "rate must be greater than 0");
+    if (Nphi < 1 || Nphi > 0x7fffffff || hLen > 0x7fffffff) return fail(MRHIP_ERR_INVALID_ARG, "bad Nphi");
+
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
+    auto *f = new mrhip_filter();
+    f->kind = MRHIP_FIR_ARBITRARY;
+    f->th = th; f->tx = tx; f->ty = mrhip_output_dtype(th, tx);
+    f->nc = dtype_is_complex(tx) ? 2 : 1;
+    f->r_f64 = dtype_is_f64(f->ty);
+    f->nch = nch; f->hLen = hLen; f->L = Nphi; f->M = 1; f->Nphi = Nphi; f->device = device;
+    f->rate = rate;
+    f->delta = static_cast<double>(Nphi) / rate;   // Δ = N𝜙/rate, Filters.jl:113
+    const size_t es = dtype_scalar_size(th);
+
+    // dh = [diff(h), 0] in the tap type (Filters.jl:106)
+    std::vector<unsigned char> dh(static_cast<size_t>(hLen) * es, 0);
+    if (th == MRHIP_F32) {
+        const float *s = static_cast<const float *>(h);
+        float *d = reinterpret_cast<float *>(dh.data());
+        for (int64_t i = 0; i + 1 < hLen; ++i) d[i] = s[i + 1] - s[i];
+    } else {
+        const double *s = static_cast<const double *>(h);
+        double *d = reinterpret_cast<double *>(dh.data());
+        for (int64_t i = 0; i + 1 < hLen; ++i) d[i] = s[i + 1] - s[i];
+    }
+    f->T = taps2pfb(h, hLen, th, Nphi, nullptr);
+    f->H = f->T - 1;
+    f->h_taps.resize(static_cast<size_t>(f->T) * Nphi * es);
+    f->h_dtaps.resize(static_cast<size_t>(f->T) * Nphi * es);
+    taps2pfb(h, hLen, th, Nphi, f->h_taps.data());
+    taps2pfb(dh.data(), hLen, th, Nphi, f->h_dtaps.data());
+
+    int rc = upload_taps(f, f->h_taps, &f->d_taps);
+    if (!rc) rc = upload_taps(f, f->h_dtaps, &f->d_dtaps);
+    if (!rc) rc = alloc_common(f);
+    if (rc) { mrhip_destroy(f); return rc; }
+    *out = f;
+    return MRHIP_OK;
+}
+
+void mrhip_destroy(mrhip_filter *f)
+{
+    if (!f) return;
+    DeviceGuard guard(f->device);
+    (void)hipDeviceSynchronize();
+    for (void *p : {f->d_taps, f->d_dtaps, f->d_hist[0], f->d_hist[1], f->d_sched_n, f->d_sched_acc, f->d_xbuf, f->d_ybuf})
+        if (p) (void)hipFree(p);
+    if (f->pin_n) (void)hipHostFree(f->pin_n);
+    if (f->pin_acc) (void)hipHostFree(f->pin_acc);
+    if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
+    if (f->sched_copied) (void)hipEventDestroy(f->sched_copied);
+    for (hipEvent_t e : f->ev_pool) (void)hipEventDestroy(e);
+    delete f;
+}
+
+int64_t mrhip_outputlength(const mrhip_filter *f, int64_t n)
+{
+    if (!f) return -1;
+    switch (f->kind) {
+    case MRHIP_FIR_STANDARD: return n;                                                   // Filters.jl:359
+    case MRHIP_FIR_INTERPOLATOR: return f->L * n;                                        // :363
+    case MRHIP_FIR_DECIMATOR: return outputlength_ratio(n - f->inputDeficit + 1, 1, f->M, 1);   // :367
+    case MRHIP_FIR_RATIONAL: return outputlength_ratio(n - f->inputDeficit + 1, f->L, f->M, f->phiIdx); // :371
+    case MRHIP_FIR_ARBITRARY: return static_cast<int64_t>(std::ceil(static_cast<double>(n - f->inputDeficit + 1) * f->rate)); // :375
+    }
+    return -1;
+}
+
+int64_t mrhip_next_output_count(const mrhip_filter *f, int64_t n)
+{
+    if (!f || n < 0) return -1;
+    if (f->kind == MRHIP_FIR_ARBITRARY) {
+        ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
+        return run_arbitrary_schedule(st, f->delta, f->Nphi, n, nullptr, nullptr);
+    }
+    return plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, n).n_out;
+}
+
+int64_t mrhip_inputlength(const mrhip_filter *f, int64_t n)
+{
+    if (!f) return -1;
+    switch (f->kind) {
+    case MRHIP_FIR_STANDARD: return n;                                                    // Filters.jl:403
+    case MRHIP_FIR_INTERPOLATOR: return inputlength_ratio(n, f->L, 1, 1);                 // :407
+    // :412-416 reads a non-existent field; restated with the Rational method's intent (:418-422)
+    case MRHIP_FIR_DECIMATOR: return inputlength_ratio(n, 1, f->M, 1) + f->inputDeficit - 1;
+    case MRHIP_FIR_RATIONAL: return inputlength_ratio(n, f->L, f->M, f->phiIdx) + f->inputDeficit - 1;
+    default: return -1;
+    }
+}
+
+int mrhip_get_state(const mrhip_filter *f, mrhip_state *st)
+{
+    if (!f || !st) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    st->kind = f->kind; st->tap_dtype = f->th; st->sample_dtype = f->tx; st->output_dtype = f->ty;
+    st->nchannels = f->nch; st->hLen = f->hLen; st->interpolation = f->L; st->decimation = f->M;
+    st->Nphi = f->Nphi; st->tapsPerPhi = f->T; st->historyLen = f->H;
+    st->phiIdx = f->phiIdx; st->inputDeficit = f->inputDeficit; st->xIdx = f->xIdx;
+    st->rate = f->rate; st->phiAccumulator = f->phiAcc; st->alpha = f->alpha; st->delta = f->delta;
+    return MRHIP_OK;
+}
+
+int mrhip_set_state(mrhip_filter *f, int64_t phiIdx, int64_t inputDeficit, double phiAccumulator)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    if (inputDeficit < 1) return fail(MRHIP_ERR_INVALID_ARG, "inputDeficit must be >= 1");
+    if (f->kind == MRHIP_FIR_ARBITRARY) {
+        if (!(phiAccumulator >= 1.0) || !(phiAccumulator < static_cast<double>(f->Nphi) + 1.0))
+            return fail(MRHIP_ERR_INVALID_ARG, "phiAccumulator must be in [1, Nphi+1)");
+        f->phiAcc = phiAccumulator;
+        f->phiIdx = static_cast<int64_t>(std::floor(phiAccumulator));
+        f->alpha = phiAccumulator - static_cast<double>(f->phiIdx);
+    } else {
+        if (phiIdx < 1 || phiIdx > f->Nphi) return fail(MRHIP_ERR_INVALID_ARG, "phiIdx must be in 1..Nphi");
+        f->phiIdx = phiIdx;
+    }
+    f->inputDeficit = inputDeficit;
+    return MRHIP_OK;
+}
+
+int mrhip_get_history(mrhip_filter *f, void *host_out)
+{
+    if (!f || !host_out) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    DeviceGuard guard(f->device);
+    MRHIP_CHECK_HIP(hipDeviceSynchronize());
+    const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
+    if (bytes) MRHIP_CHECK_HIP(hipMemcpy(host_out, f->d_hist[f->hist_cur], bytes, hipMemcpyDeviceToHost));
+    return MRHIP_OK;
+}
+
+int mrhip_set_history(mrhip_filter *f, const void *host_in)
+{
+    if (!f || !host_in) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    DeviceGuard guard(f->device);
+    MRHIP_CHECK_HIP(hipDeviceSynchronize());
+    const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
+    if (bytes) MRHIP_CHECK_HIP(hipMemcpy(f->d_hist[f->hist_cur], host_in, bytes, hipMemcpyHostToDevice));
+    return MRHIP_OK;
+}
+
+int mrhip_reset(mrhip_filter *f)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    DeviceGuard guard(f->device);
+    MRHIP_CHECK_HIP(hipDeviceSynchronize());
+    const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
+    if (bytes) MRHIP_CHECK_HIP(hipMemset(f->d_hist[f->hist_cur], 0, bytes));
+    f->phiIdx = 1; f->inputDeficit = 1; f->xIdx = 1; f->phiAcc = 1.0; f->alpha = 0.0;
+    return MRHIP_OK;
+}
+
+int mrhip_set_numerics(mrhip_filter *f, int numerics)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    if (numerics != MRHIP_NUMERICS_STRICT && numerics != MRHIP_NUMERICS_FUSED)
+        return fail(MRHIP_ERR_INVALID_ARG, "unknown numerics mode");
+    f->numerics = numerics;
+    return MRHIP_OK;
+}
+
+int mrhip_get_taps(mrhip_filter *f, int which, void *host_out)
+{
+    if (!f || !host_out) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    const auto &src = which ? f->h_dtaps : f->h_taps;
+    if (src.empty()) return fail(MRHIP_ERR_INVALID_ARG, "filter has no such tap bank");
+    std::memcpy(host_out, src.data(), src.size());
+    return MRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// the hot path
+// ---------------------------------------------------------------------------------------
+// record the next event of the timing log on `stream` (no-op unless timing is enabled)
+static int timing_mark(mrhip_filter *f, hipStream_t stream)
+{
+    if (!f->timing) return MRHIP_OK;
+    if (f->ev_used == f->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        MRHIP_CHECK_HIP(hipEventCreate(&e));
+        f->ev_pool.push_back(e);
+    }
+    MRHIP_CHECK_HIP(hipEventRecord(f->ev_pool[f->ev_used++], stream));
+    return MRHIP_OK;
+}
+
+static int ensure_sched_capacity(mrhip_filter *f, size_t n)
+{
+    if (n > f->pin_cap) {
+        const size_t cap = std::max<size_t>(n + n / 4, 4096);
+        if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
+        if (f->pin_n) (void)hipHostFree(f->pin_n);
+        if (f->pin_acc) (void)hipHostFree(f->pin_acc);
+        f->pin_n = f->pin_acc = nullptr;
+        MRHIP_CHECK_HIP(hipHostMalloc(&f->pin_n, cap * sizeof(int32_t), hipHostMallocDefault));
+        MRHIP_CHECK_HIP(hipHostMalloc(&f->pin_acc, cap * sizeof(double), hipHostMallocDefault));
+        f->pin_cap = cap;
+    }
+    if (n > f->d_sched_cap) {
+        const size_t cap = std::max<size_t>(n + n / 4, 4096);
+        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        if (f->d_sched_n) (void)hipFree(f->d_sched_n);
+        if (f->d_sched_acc) (void)hipFree(f->d_sched_acc);
+        f->d_sched_n = f->d_sched_acc = nullptr;
+        MRHIP_CHECK_HIP(hipMalloc(&f->d_sched_n, cap * sizeof(int32_t)));
+        MRHIP_CHECK_HIP(hipMalloc(&f->d_sched_acc, cap * sizeof(double)));
+        f->d_sched_cap = cap;
+    }
+    return MRHIP_OK;
+}
+
+int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
+                      int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream_)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    if (n_written) *n_written = 0;
+    if (x_len < 0 || y_capacity < 0) return fail(MRHIP_ERR_INVALID_ARG, "negative length");
+    if (x_len > 0 && !x) return fail(MRHIP_ERR_INVALID_ARG, "x is NULL");
+    if (x_len >= 0x7fffffffLL) return fail(MRHIP_ERR_INVALID_ARG, "x_len per call must be < 2^31-1");
+    if (f->nch > 1 && (x_stride < x_len)) return fail(MRHIP_ERR_INVALID_ARG, "x_stride < x_len");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceGuard guard(f->device);
+    if (!guard.ok) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
+    const TypeKey tk = type_key(f);
+    const bool fused = f->numerics == MRHIP_NUMERICS_FUSED;
+    if (x_len == 0) return MRHIP_OK;   // nothing to do: zero outputs, history and state unchanged
+
+    int64_t n_out = 0;
+    if (f->kind == MRHIP_FIR_ARBITRARY) {
+        ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
+        if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
+        n_out = run_arbitrary_schedule(st, f->delta, f->Nphi, x_len, &f->sched_n, &f->sched_acc);
+        if (n_out > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
+        if (n_out > 0) {
+            if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
+            if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
+            if (int rc = ensure_sched_capacity(f, static_cast<size_t>(n_out))) return rc;
+            std::memcpy(f->pin_n, f->sched_n.data(), static_cast<size_t>(n_out) * sizeof(int32_t));
+            std::memcpy(f->pin_acc, f->sched_acc.data(), static_cast<size_t>(n_out) * sizeof(double));
+            MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_sched_n, f->pin_n, static_cast<size_t>(n_out) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+            MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_sched_acc, f->pin_acc, static_cast<size_t>(n_out) * sizeof(double), hipMemcpyHostToDevice, stream));
+            MRHIP_CHECK_HIP(hipEventRecord(f->sched_copied, stream));
+            f->sched_in_flight = true;
+            ArbArgs a{};
+            a.x = x; a.y = y; a.hist = f->d_hist[f->hist_cur]; a.taps = f->d_taps; a.dtaps = f->d_dtaps;
+            a.n_idx = static_cast<const int *>(f->d_sched_n); a.acc = static_cast<const double *>(f->d_sched_acc);
+            a.x_stride = x_stride; a.y_stride = y_stride; a.x_len = x_len; a.n_out = n_out;
+            a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H); a.Nphi = static_cast<int>(f->Nphi);
+            a.nch = static_cast<int>(f->nch);
+            if (int rc = timing_mark(f, stream)) return rc;
+            MRHIP_CHECK_HIP(launch_arb_generic(tk, fused, a, stream, &f->last_kernel));
+            if (int rc = timing_mark(f, stream)) return rc;
+        }
+        // commit the post-call state (Filters.jl:731-735)
+        f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;
+        f->inputDeficit = st.inputDeficit;
+    } else {
+        const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len);
+        n_out = p.n_out;
+        // reference: error() before any work, Filters.jl:460 (Standard), :503 (Interpolator), :550 (Rational)
+        if (n_out > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
+        if (n_out > 0) {
+            if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
+            if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
+            PolyArgs a{};
+            a.x = x; a.y = y; a.hist = f->d_hist[f->hist_cur]; a.taps = f->d_taps;
+            a.x_stride = x_stride; a.y_stride = y_stride; a.x_len = x_len; a.n_out = n_out;
+            a.u0 = p.phi0 - 1; a.d0 = p.d0;
+            a.zero_start_below = f->kind == MRHIP_FIR_STANDARD ? f->hLen + 1
+                               : f->kind == MRHIP_FIR_DECIMATOR ? f->hLen : 0;
+            a.L = static_cast<int>(f->L); a.M = static_cast<int>(f->M);
+            a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H);
+            a.nch = static_cast<int>(f->nch);
+            if (int rc = timing_mark(f, stream)) return rc;
+            MRHIP_CHECK_HIP(launch_poly(f, tk, fused, a, stream, &f->last_kernel));
+            if (int rc = timing_mark(f, stream)) return rc;
+        }
+        f->phiIdx = p.phi_end;
+        f->inputDeficit = p.d_end;
+    }
+
+    // history <- last H samples of [history ; x]   (shiftin!, support.jl:61-80), ping-pong buffers
+    if (f->H > 0) {
+        HistArgs ha{};
+        ha.x = x; ha.hist_old = f->d_hist[f->hist_cur]; ha.hist_new = f->d_hist[f->hist_cur ^ 1];
+        ha.x_stride = x_stride; ha.x_len = x_len; ha.H = static_cast<int>(f->H); ha.nch = static_cast<int>(f->nch);
+        MRHIP_CHECK_HIP(launch_shiftin(tk, ha, stream));
+        f->hist_cur ^= 1;
+    }
+    if (n_written) *n_written = n_out;
+    return MRHIP_OK;
+}
+
+static int ensure_staging(mrhip_filter *f, size_t xbytes, size_t ybytes)
+{
+    if (xbytes > f->d_xcap) {
+        if (f->d_xbuf) (void)hipFree(f->d_xbuf);
+        f->d_xbuf = nullptr; f->d_xcap = 0;
+        MRHIP_CHECK_HIP(hipMalloc(&f->d_xbuf, xbytes));
+        f->d_xcap = xbytes;
+    }
+    if (ybytes > f->d_ycap) {
+        if (f->d_ybuf) (void)hipFree(f->d_ybuf);
+        f->d_ybuf = nullptr; f->d_ycap = 0;
+        MRHIP_CHECK_HIP(hipMalloc(&f->d_ybuf, ybytes));
+        f->d_ycap = ybytes;
+    }
+    return MRHIP_OK;
+}
+
+int mrhip_filt_host(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y, int64_t y_capacity,
+                    int64_t y_stride, int64_t *n_written)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    if (n_written) *n_written = 0;
+    if (x_len < 0 || y_capacity < 0) return fail(MRHIP_ERR_INVALID_ARG, "negative length");
+    if (x_len == 0) return MRHIP_OK;
+    if (!x) return fail(MRHIP_ERR_INVALID_ARG, "x is NULL");
+    if (f->nch > 1 && x_stride < x_len) return fail(MRHIP_ERR_INVALID_ARG, "x_stride < x_len");
+    const int64_t count = mrhip_next_output_count(f, x_len);
+    if (count > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
+    if (count > 0 && !y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
+    if (f->nch > 1 && y_stride < count) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
+
+    DeviceGuard guard(f->device);
+    if (!guard.ok) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
+    const size_t xe = x_elt(f), ye = y_elt(f);
+    const size_t xrow = static_cast<size_t>(x_len) * xe, yrow = static_cast<size_t>(count) * ye;
+    if (int rc = ensure_staging(f, std::max<size_t>(xrow * f->nch, 16), std::max<size_t>(yrow * f->nch, 16))) return rc;
+    hipStream_t s = f->own_stream;
+    MRHIP_CHECK_HIP(hipMemcpy2DAsync(f->d_xbuf, xrow, x, static_cast<size_t>(f->nch > 1 ? x_stride : x_len) * xe, xrow,
+                                     static_cast<size_t>(f->nch), hipMemcpyHostToDevice, s));
+    int64_t nw = 0;
+    if (int rc = mrhip_filt_device(f, f->d_xbuf, x_len, x_len, f->d_ybuf, count, count, &nw, s)) return rc;
+    if (nw > 0)
+        MRHIP_CHECK_HIP(hipMemcpy2DAsync(y, static_cast<size_t>(f->nch > 1 ? y_stride : nw) * ye, f->d_ybuf, yrow, yrow,
+                                         static_cast<size_t>(f->nch), hipMemcpyDeviceToHost, s));
+    MRHIP_CHECK_HIP(hipStreamSynchronize(s));
+    if (n_written) *n_written = nw;
+    return MRHIP_OK;
+}
+
+int mrhip_synchronize(mrhip_filter *f, void *stream)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    DeviceGuard guard(f->device);
+    MRHIP_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return MRHIP_OK;
+}
+
+int mrhip_filt_once(const void *h, int64_t hLen, int th, int64_t num, int64_t den, double rate, int64_t Nphi,
+                    const void *x, int64_t x_len, int tx, void *y, int64_t y_capacity, int64_t *n_written, int device)
+{
+    mrhip_filter *f = nullptr;
+    int rc = rate > 0.0 ? mrhip_create_arbitrary(h, hLen, th, rate, Nphi, tx, 1, device, &f)
+                        : mrhip_create_rational(h, hLen, th, num, den, tx, 1, device, &f);
+    if (rc) return rc;
+    rc = mrhip_filt_host(f, x, x_len, x_len, y, y_capacity, y_capacity, n_written);
+    mrhip_destroy(f);
+    return rc;
+}
+
+int mrhip_set_timing(mrhip_filter *f, int enabled)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    f->timing = enabled != 0;
+    f->ev_used = 0;
+    return MRHIP_OK;
+}
+
+int mrhip_timing_read(mrhip_filter *f, int64_t *n_launches, double *total_ms)
+{
+    if (!f || !n_launches || !total_ms) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    DeviceGuard guard(f->device);
+    *n_launches = 0;
+    *total_ms = 0.0;
+    const size_t pairs = f->ev_used / 2;
+    for (size_t i = 0; i < pairs; ++i) {
+        float ms = 0.f;
+        MRHIP_CHECK_HIP(hipEventSynchronize(f->ev_pool[2 * i + 1]));
+        MRHIP_CHECK_HIP(hipEventElapsedTime(&ms, f->ev_pool[2 * i], f->ev_pool[2 * i + 1]));
+        *total_ms += ms;
+    }
+    *n_launches = static_cast<int64_t>(pairs);
+    f->ev_used = 0;
+    return MRHIP_OK;
+}
+
+const char *mrhip_last_kernel_name(const mrhip_filter *f) { return f ? f->last_kernel : ""; }
+
+}  // extern "C"

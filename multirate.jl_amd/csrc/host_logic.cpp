@@ -1,0 +1,126 @@
+// host_logic.cpp -- data-independent bookkeeping of the filt! hot path.
+//
+// Everything here depends only on lengths and on the (phase, deficit) state, never on sample
+// values, so the host can size buffers, pick grids and advance the stream state without ever
+// reading back from the device.
+#include <cmath>
+#include <cstring>
+
+#include "mrhip_internal.h"
+
+namespace mrhip {
+
+// Polyphase decomposition of the prototype filter.
+// Behaviour to match: src/Filters.jl:284-298 -- tapsPerPhi = ceil(hLen/Nphi); the matrix is
+// tapsPerPhi x Nphi, column-major; column p holds h[p], h[p+Nphi], ... REVERSED (so that a dot
+// with a forward-running sample window is a convolution), zero padded past hLen.
+// Formulation here: element (row r, col c), 0-based, is h[(T-1-r)*Nphi + c].
+int64_t taps2pfb(const void *h, int64_t hLen, int th, int64_t Nphi, void *out)
+{
+    const int64_t T = (hLen + Nphi - 1) / Nphi;
+    if (!out) return T;
+    const size_t es = dtype_scalar_size(th);
+    auto *dst = static_cast<unsigned char *>(out);
+    const auto *src = static_cast<const unsigned char *>(h);
+    for (int64_t c = 0; c < Nphi; ++c) {
+        for (int64_t r = 0; r < T; ++r) {
+            const int64_t hi = (T - 1 - r) * Nphi + c;
+            unsigned char *d = dst + static_cast<size_t>(c * T + r) * es;
+            if (hi < hLen) std::memcpy(d, src + static_cast<size_t>(hi) * es, es);
+            else std::memset(d, 0, es);
+        }
+    }
+    return T;
+}
+
+// src/Filters.jl:433-439
+int64_t nextphase(int64_t phase, int64_t L, int64_t M)
+{
+    const int64_t next = phase + M % L;
+    return next > L ? next - L : next;
+}
+
+// src/Filters.jl:352-357.  The reference divides in Float64 and takes iceil; for every length
+// that fits a double exactly (< 2^53) that equals the integer ceiling computed here.
+int64_t outputlength_ratio(int64_t inputlength, int64_t L, int64_t M, int64_t initialPhi)
+{
+    const int64_t a = inputlength * L - initialPhi + 1;
+    return a >= 0 ? (a + M - 1) / M : -((-a) / M);
+}
+
+// src/Filters.jl:396-401
+int64_t inputlength_ratio(int64_t outputlength, int64_t L, int64_t M, int64_t initialPhi)
+{
+    const int64_t a = outputlength * M + initialPhi - 1;
+    return a >= 0 ? (a + L - 1) / L : -((-a) / L);
+}
+
+// Closed form of the rational loop (src/Filters.jl:558-571): with u_k = (phi0-1) + k*M,
+// output k uses phase u_k mod L and input index d0 + u_k div L, and exists while that index
+// is <= xLen.  STANDARD and DECIMATOR are L == 1; INTERPOLATOR restarts at (phi, idx) = (1, 1)
+// on every call (src/Filters.jl:500-501) and never carries a deficit.
+CallPlan plan_rational(int kind, int64_t L, int64_t M, int64_t phiIdx, int64_t inputDeficit, int64_t xLen)
+{
+    CallPlan p;
+    switch (kind) {
+    case MRHIP_FIR_STANDARD:
+        p.phi0 = 1; p.d0 = 1; p.n_out = xLen; p.phi_end = 1; p.d_end = 1;
+        return p;
+    case MRHIP_FIR_INTERPOLATOR:
+        p.phi0 = 1; p.d0 = 1; p.n_out = L * xLen; p.phi_end = 1; p.d_end = 1;
+        return p;
+    default:
+        break;
+    }
+    p.phi0 = (kind == MRHIP_FIR_DECIMATOR) ? 1 : phiIdx;
+    p.d0 = inputDeficit;
+    if (xLen < inputDeficit) {  // not enough input for a single output
+        p.short_input = true;
+        p.n_out = 0;
+        p.phi_end = phiIdx;
+        p.d_end = inputDeficit - xLen;
+        return p;
+    }
+    p.n_out = outputlength_ratio(xLen - inputDeficit + 1, L, M, p.phi0);
+    const int64_t u_end = (p.phi0 - 1) + p.n_out * M;
+    p.phi_end = u_end % L + 1;
+    p.d_end = p.d0 + u_end / L - xLen;
+    return p;
+}
+
+// FIRArbitrary: the phase accumulator is a serial Float64 recurrence whose roundings the
+// reference's outputs depend on (src/Filters.jl:663-673), so it is evaluated here, in order,
+// with the same IEEE operations, once per call; every channel shares the result.
+int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t xLen,
+                               std::vector<int32_t> *n_idx, std::vector<double> *acc_out)
+{
+    if (xLen < st.inputDeficit) {          // src/Filters.jl:705-709
+        st.inputDeficit -= xLen;
+        return 0;
+    }
+    const double N = static_cast<double>(Nphi);
+    double acc = st.acc;
+    int64_t xIdx = st.inputDeficit;        // :715
+    int64_t count = 0;
+    if (n_idx) n_idx->clear();
+    if (acc_out) acc_out->clear();
+    while (xIdx <= xLen) {                 // :717
+        if (n_idx) n_idx->push_back(static_cast<int32_t>(xIdx));
+        if (acc_out) acc_out->push_back(acc);
+        ++count;
+        acc += delta;                      // update(), :664
+        if (acc > N) {                     // :666-669
+            const double am1 = acc - 1.0;
+            xIdx += static_cast<int64_t>(std::floor(am1 / N));
+            acc = std::fmod(am1, N) + 1.0;
+        }
+    }
+    st.acc = acc;
+    st.phiIdx = static_cast<int64_t>(std::floor(acc));   // :671
+    st.alpha = acc - static_cast<double>(st.phiIdx);     // :672
+    st.xIdx = xIdx;
+    st.inputDeficit = xIdx - xLen;         // :734
+    return count;
+}
+
+}  // namespace mrhip

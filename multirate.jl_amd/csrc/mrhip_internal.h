@@ -1,0 +1,175 @@
+// mrhip_internal.h -- shared declarations of libmultirate_hip.so (not installed).
+//
+// Layering inside csrc/:
+//   host_logic.cpp      data-independent bookkeeping (taps2pfb, outputlength, closed-form state
+//                       advance, FIRArbitrary phase schedule).  No HIP calls.
+//   kernels_*.hip       gfx950 device kernels + their launchers.
+//   api.hip             the extern "C" surface declared in include/multirate_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "multirate_hip.h"
+
+namespace mrhip {
+
+// ---------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define MRHIP_CHECK_HIP(expr)                                                                  \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::mrhip::fail(MRHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+inline bool dtype_is_complex(int dt) { return dt == MRHIP_C64 || dt == MRHIP_C128; }
+inline bool dtype_is_f64(int dt) { return dt == MRHIP_F64 || dt == MRHIP_C128; }
+inline size_t dtype_scalar_size(int dt) { return dtype_is_f64(dt) ? 8 : 4; }
+inline size_t dtype_size(int dt) { return dtype_scalar_size(dt) * (dtype_is_complex(dt) ? 2 : 1); }
+
+// ---------------------------------------------------------------------------------------
+// host logic (host_logic.cpp)
+// ---------------------------------------------------------------------------------------
+int64_t taps2pfb(const void *h, int64_t hLen, int th, int64_t Nphi, void *out);
+int64_t nextphase(int64_t phase, int64_t L, int64_t M);
+int64_t outputlength_ratio(int64_t inputlength, int64_t L, int64_t M, int64_t initialPhi);
+int64_t inputlength_ratio(int64_t outputlength, int64_t L, int64_t M, int64_t initialPhi);
+
+// What one filt call on the rational family will do, from the call-start state alone
+// (SURVEY.md Appendix A "Per-call view"; reference loop: src/Filters.jl:558-571).
+struct CallPlan {
+    int64_t n_out = 0;         // outputs this call (per channel)
+    int64_t phi0 = 1, d0 = 1;  // call-start (phiIdx, inputDeficit), 1-based
+    int64_t phi_end = 1;       // state after the call
+    int64_t d_end = 1;
+    bool short_input = false;  // xLen < inputDeficit  (Filters.jl:543-547)
+};
+CallPlan plan_rational(int kind, int64_t L, int64_t M, int64_t phiIdx, int64_t inputDeficit, int64_t xLen);
+
+// FIRArbitrary phase recurrence (src/Filters.jl:663-673, 715-734) run on the host.
+struct ArbState {
+    double acc = 1.0;   // 𝜙Accumulator
+    int64_t phiIdx = 1;
+    double alpha = 0.0;
+    int64_t xIdx = 1;
+    int64_t inputDeficit = 1;
+};
+// Runs the schedule for one call.  If n_idx/acc_out are non-null they receive, per output, the
+// 1-based input index and the phase accumulator value used (phiIdx = floor(acc), alpha = acc - phiIdx).
+// Returns the number of outputs; `st` is advanced to the post-call state.
+int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t xLen,
+                               std::vector<int32_t> *n_idx, std::vector<double> *acc_out);
+
+// ---------------------------------------------------------------------------------------
+// device-side parameter blocks
+// ---------------------------------------------------------------------------------------
+struct PolyArgs {            // rational family: STANDARD / DECIMATOR / INTERPOLATOR / RATIONAL
+    const void *x;           // device, planar [ch][x_stride]
+    void *y;                 // device, planar [ch][y_stride]
+    const void *hist;        // device, [ch][H] samples of Tx (call-start history)
+    const void *taps;        // device, R-typed, [Nphi][T] (column = phase, oldest-sample tap first)
+    long long x_stride, y_stride;
+    long long x_len;         // samples per channel in this call
+    long long n_out;         // outputs per channel in this call
+    long long u0;            // phi0 - 1
+    long long d0;            // inputDeficit at call start (1-based)
+    long long zero_start_below;  // outputs whose 1-based input index n < this start from +0
+                                 // (support.jl:46; STANDARD: hLen+1, DECIMATOR: hLen, else 0)
+    int L, M, T, H;
+    int nch;
+};
+
+struct ArbArgs {             // FIRArbitrary
+    const void *x;
+    void *y;
+    const void *hist;
+    const void *taps;        // pfb  [Nphi][T]
+    const void *dtaps;       // dpfb [Nphi][T]
+    const int *n_idx;        // device, per output: 1-based input index
+    const double *acc;       // device, per output: phase accumulator
+    long long x_stride, y_stride;
+    long long x_len;
+    long long n_out;
+    int T, H, Nphi;
+    int nch;
+};
+
+struct HistArgs {            // shiftin! (src/support.jl:61-80) for every channel
+    const void *x;
+    const void *hist_old;
+    void *hist_new;
+    long long x_stride;
+    long long x_len;
+    int H;
+    int nch;
+};
+
+// dtype combination a kernel is instantiated for
+struct TypeKey {
+    bool x_f64;      // Tx scalar is double
+    bool r_f64;      // compute/output scalar is double
+    bool complex_x;  // NC == 2
+};
+
+// ---------------------------------------------------------------------------------------
+// launchers (kernels_*.hip).  Each returns hipSuccess or the launch error and writes the kernel
+// name it dispatched into *kname.
+// ---------------------------------------------------------------------------------------
+hipError_t launch_poly_generic(const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s, const char **kname);
+hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, hipStream_t s, const char **kname);
+hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
+
+}  // namespace mrhip
+
+// ---------------------------------------------------------------------------------------
+// the filter object
+// ---------------------------------------------------------------------------------------
+struct mrhip_filter {
+    int kind = 0, th = 0, tx = 0, ty = 0;
+    int nc = 1;
+    bool r_f64 = false;
+    int64_t nch = 1;
+    int64_t hLen = 0, L = 1, M = 1, Nphi = 1, T = 1, H = 0;
+    int device = 0;
+    int numerics = MRHIP_NUMERICS_STRICT;
+
+    // device memory
+    void *d_taps = nullptr, *d_dtaps = nullptr;
+    void *d_hist[2] = {nullptr, nullptr};
+    int hist_cur = 0;
+    // host copies of the taps in tap dtype (for get_taps)
+    std::vector<unsigned char> h_taps, h_dtaps;
+
+    // streaming state (1-based, reference field names in multirate_hip.h)
+    int64_t phiIdx = 1, inputDeficit = 1, xIdx = 1;
+    double rate = 0.0, phiAcc = 1.0, alpha = 0.0, delta = 0.0;
+
+    // FIRArbitrary schedule staging
+    std::vector<int32_t> sched_n;
+    std::vector<double> sched_acc;
+    void *pin_n = nullptr, *pin_acc = nullptr;   // pinned host
+    size_t pin_cap = 0;
+    void *d_sched_n = nullptr, *d_sched_acc = nullptr;
+    size_t d_sched_cap = 0;
+    hipEvent_t sched_copied = nullptr;
+    bool sched_in_flight = false;
+
+    // host-pointer path staging
+    void *d_xbuf = nullptr, *d_ybuf = nullptr;
+    size_t d_xcap = 0, d_ycap = 0;
+    hipStream_t own_stream = nullptr;
+
+    // measurement
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;   // pairs: [2i] start, [2i+1] stop
+    size_t ev_used = 0;                // events handed out since the last mrhip_timing_read
+    const char *last_kernel = "";
+};

@@ -1,0 +1,465 @@
+"""Host-side mirror of the reference operator interface over the C ABI (ctypes).
+
+Reference interface mirrored (paths relative to /root/reference):
+  FIRFilter(h, ratio) / FIRFilter(h, rate, Nphi)        src/Filters.jl:158-189
+  filt(self, x) / filt(h, x, ratio) / filt(h, x, rate, Nphi)   src/Filters.jl:475-873
+  filt!(buffer, self, x)  (here ``filt_``)               src/Filters.jl:450,489,536,598,693
+  taps2pfb, outputlength, inputlength, nextphase, reset  src/Filters.jl:284,352,396,433,244
+
+Signals are numpy arrays (host path, ``mrhip_filt_host``) or torch tensors on a ROCm device
+(device path, ``mrhip_filt_device`` on torch's current stream).  Shape ``(n,)`` is one channel;
+shape ``(nchannels, n)`` (C-contiguous: one channel per row == one channel per column of a Julia
+Matrix) is a batch of independent streams sharing taps and phase state.
+
+No arithmetic is done in Python and nothing here imports ``oracle/``: if ``libmultirate_hip.so``
+is missing, or no gfx950 device is visible, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from fractions import Fraction
+
+import numpy as np
+
+try:  # torch first: its bundled libamdhip64 must be the one HIP runtime of the process
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for pure-numpy use
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+F32, F64, C64, C128 = 0, 1, 2, 3
+STANDARD, DECIMATOR, INTERPOLATOR, RATIONAL, ARBITRARY = 0, 1, 2, 3, 4
+KIND_NAMES = {STANDARD: "FIRStandard", DECIMATOR: "FIRDecimator", INTERPOLATOR: "FIRInterpolator",
+              RATIONAL: "FIRRational", ARBITRARY: "FIRArbitrary"}
+NUMERICS_STRICT, NUMERICS_FUSED = 0, 1
+
+_NP2DT = {np.dtype(np.float32): F32, np.dtype(np.float64): F64,
+          np.dtype(np.complex64): C64, np.dtype(np.complex128): C128}
+_DT2NP = {v: k for k, v in _NP2DT.items()}
+
+
+class MultirateHIPError(RuntimeError):
+    """Raised where the reference raises Julia ``error(...)`` (and for HIP/runtime failures)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[mrhip status {code}] {msg}")
+        self.code = code
+
+
+class _State(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("tap_dtype", C.c_int32), ("sample_dtype", C.c_int32),
+                ("output_dtype", C.c_int32), ("nchannels", C.c_int64), ("hLen", C.c_int64),
+                ("interpolation", C.c_int64), ("decimation", C.c_int64), ("Nphi", C.c_int64),
+                ("tapsPerPhi", C.c_int64), ("historyLen", C.c_int64), ("phiIdx", C.c_int64),
+                ("inputDeficit", C.c_int64), ("xIdx", C.c_int64), ("rate", C.c_double),
+                ("phiAccumulator", C.c_double), ("alpha", C.c_double), ("delta", C.c_double)]
+
+
+# every symbol include/multirate_hip.h declares: (name, restype, argtypes)
+_vp, _i64, _i, _d = C.c_void_p, C.c_int64, C.c_int, C.c_double
+_pi64 = C.POINTER(C.c_int64)
+ABI = [
+    ("mrhip_abi_version", _i, []),
+    ("mrhip_last_error", C.c_char_p, []),
+    ("mrhip_device_count", _i, []),
+    ("mrhip_taps2pfb", _i64, [_vp, _i64, _i, _i64, _vp]),
+    ("mrhip_nextphase", _i64, [_i64, _i64, _i64]),
+    ("mrhip_outputlength_ratio", _i64, [_i64, _i64, _i64, _i64]),
+    ("mrhip_inputlength_ratio", _i64, [_i64, _i64, _i64, _i64]),
+    ("mrhip_output_dtype", _i, [_i, _i]),
+    ("mrhip_create_rational", _i, [_vp, _i64, _i, _i64, _i64, _i, _i64, _i, C.POINTER(_vp)]),
+    ("mrhip_create_arbitrary", _i, [_vp, _i64, _i, _d, _i64, _i, _i64, _i, C.POINTER(_vp)]),
+    ("mrhip_destroy", None, [_vp]),
+    ("mrhip_outputlength", _i64, [_vp, _i64]),
+    ("mrhip_next_output_count", _i64, [_vp, _i64]),
+    ("mrhip_inputlength", _i64, [_vp, _i64]),
+    ("mrhip_get_state", _i, [_vp, C.POINTER(_State)]),
+    ("mrhip_set_state", _i, [_vp, _i64, _i64, _d]),
+    ("mrhip_get_history", _i, [_vp, _vp]),
+    ("mrhip_set_history", _i, [_vp, _vp]),
+    ("mrhip_reset", _i, [_vp]),
+    ("mrhip_set_numerics", _i, [_vp, _i]),
+    ("mrhip_get_taps", _i, [_vp, _i, _vp]),
+    ("mrhip_filt_device", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
+    ("mrhip_filt_host", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64]),
+    ("mrhip_synchronize", _i, [_vp, _vp]),
+    ("mrhip_filt_once", _i, [_vp, _i64, _i, _i64, _i64, _d, _i64, _vp, _i64, _i, _vp, _i64, _pi64, _i]),
+    ("mrhip_set_timing", _i, [_vp, _i]),
+    ("mrhip_timing_read", _i, [_vp, _pi64, C.POINTER(C.c_double)]),
+    ("mrhip_last_kernel_name", C.c_char_p, [_vp]),
+]
+
+_lib = None
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libmultirate_hip.so")
+
+
+def load_library():
+    """dlopen libmultirate_hip.so and bind every ABI symbol.  Raises if the library is missing --
+    there is no fallback implementation."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise MultirateHIPError(-1, f"{path} not found: build it with `make -C multirate.jl_amd/csrc` "
+                                        "(or __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(path)
+        for name, res, args in ABI:
+            fn = getattr(lib, name)  # AttributeError if the header and the .so ever disagree
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mrhip_abi_version() != 1:
+            raise MultirateHIPError(-1, "ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise MultirateHIPError(rc, load_library().mrhip_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _as_taps(h) -> np.ndarray:
+    h = np.ascontiguousarray(h)
+    if h.dtype == np.float32 or h.dtype == np.float64:
+        return h
+    if np.issubdtype(h.dtype, np.integer) or h.dtype == np.float16:
+        return h.astype(np.float64)
+    raise MultirateHIPError(5, f"unsupported tap dtype {h.dtype} (taps must be Float32/Float64)")
+
+
+def _is_torch(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _torch_np_dtype(t):
+    return {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64),
+            torch.complex64: np.dtype(np.complex64), torch.complex128: np.dtype(np.complex128)}[t]
+
+
+def _np_torch_dtype(d):
+    return {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+            np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}[np.dtype(d)]
+
+
+# ---- host-only helpers ------------------------------------------------------------------------
+def taps2pfb(h, Nphi: int) -> np.ndarray:
+    """taps2pfb(h, N𝜙), src/Filters.jl:284-298.  Returns the tapsPer𝜙 x N𝜙 matrix."""
+    h = _as_taps(h)
+    lib = load_library()
+    T = lib.mrhip_taps2pfb(_ptr(h), len(h), _NP2DT[h.dtype], Nphi, None)
+    if T < 0:
+        raise MultirateHIPError(1, "bad taps2pfb arguments")
+    out = np.empty(T * Nphi, dtype=h.dtype)
+    lib.mrhip_taps2pfb(_ptr(h), len(h), _NP2DT[h.dtype], Nphi, _ptr(out))
+    return out.reshape(Nphi, T).T.copy()
+
+
+def nextphase(currentphase: int, ratio) -> int:
+    """nextphase(currentphase, ratio), src/Filters.jl:433-439."""
+    r = Fraction(ratio)
+    return load_library().mrhip_nextphase(currentphase, r.numerator, r.denominator)
+
+
+# ---- the filter object ------------------------------------------------------------------------
+class FIRFilter:
+    """FIRFilter(h, ratio::Rational = 1//1)  or  FIRFilter(h, rate::Float, N𝜙 = 32).
+
+    Mirrors src/Filters.jl:158-189: a ``Fraction``/int/(num, den) ratio selects FIRStandard,
+    FIRDecimator, FIRInterpolator or FIRRational exactly as the reference does; a ``float`` selects
+    FIRArbitrary.  Like the reference, whose ``history`` vector takes the sample type of the first
+    ``filt`` call (src/Filters.jl:452), the device-side object is created on the first call, when
+    the sample dtype and the number of channels are known.
+    """
+
+    def __init__(self, h, ratio=Fraction(1, 1), Nphi: int = 32, *, device: int = 0,
+                 numerics: int = NUMERICS_STRICT):
+        self._lib = load_library()
+        self.h = _as_taps(h).copy()
+        if len(self.h) < 1:
+            raise MultirateHIPError(1, "h must hold at least one tap")
+        self.device = int(device)
+        self.numerics = int(numerics)
+        self._handle = None
+        self._tx = None
+        self._nch = None
+        if isinstance(ratio, (float, np.floating)):
+            if not ratio > 0.0:
+                raise MultirateHIPError(1, "rate must be greater than 0")  # Filters.jl:184
+            self.rate = float(ratio)
+            self.ratio = None
+            self.Nphi = int(Nphi)
+            self.kind = ARBITRARY
+            self.interpolation, self.decimation = self.Nphi, 1
+            self.tapsPerPhi = -(-len(self.h) // self.Nphi)
+            self.historyLen = self.tapsPerPhi - 1
+        else:
+            if isinstance(ratio, tuple):
+                ratio = Fraction(*ratio)
+            self.ratio = Fraction(ratio)
+            if self.ratio <= 0:
+                raise MultirateHIPError(1, "ratio must be positive")
+            self.rate = None
+            L, M = self.ratio.numerator, self.ratio.denominator
+            self.interpolation, self.decimation = L, M
+            if L == 1 and M == 1:
+                self.kind = STANDARD
+            elif L == 1:
+                self.kind = DECIMATOR
+            elif M == 1:
+                self.kind = INTERPOLATOR
+            else:
+                self.kind = RATIONAL
+            self.Nphi = L
+            self.tapsPerPhi = len(self.h) if L == 1 else -(-len(self.h) // L)
+            self.historyLen = self.tapsPerPhi - 1
+
+    # -- lifetime
+    def _ensure(self, tx: np.dtype, nch: int):
+        tx = np.dtype(tx)
+        if self._handle is not None:
+            if tx != self._tx or nch != self._nch:
+                raise MultirateHIPError(1, f"filter was bound to {self._nch} channel(s) of {self._tx}; "
+                                           f"got {nch} of {tx}")
+            return
+        if tx not in _NP2DT:
+            raise MultirateHIPError(1, f"unsupported sample dtype {tx}")
+        out = C.c_void_p()
+        if self.kind == ARBITRARY:
+            rc = self._lib.mrhip_create_arbitrary(_ptr(self.h), len(self.h), _NP2DT[self.h.dtype], self.rate,
+                                                  self.Nphi, _NP2DT[tx], nch, self.device, C.byref(out))
+        else:
+            rc = self._lib.mrhip_create_rational(_ptr(self.h), len(self.h), _NP2DT[self.h.dtype],
+                                                 self.ratio.numerator, self.ratio.denominator, _NP2DT[tx], nch,
+                                                 self.device, C.byref(out))
+        _check(rc)
+        self._handle, self._tx, self._nch = out, tx, nch
+        if self.numerics != NUMERICS_STRICT:
+            _check(self._lib.mrhip_set_numerics(self._handle, self.numerics))
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.mrhip_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- introspection
+    @property
+    def kernel_name(self) -> str:
+        return KIND_NAMES[self.kind]
+
+    @property
+    def output_dtype(self):
+        if self._tx is None:
+            return None
+        return _DT2NP[self._lib.mrhip_output_dtype(_NP2DT[self.h.dtype], _NP2DT[self._tx])]
+
+    @property
+    def state(self) -> _State:
+        st = _State()
+        if self._handle is None:  # constructor state, src/Filters.jl:77-78,110-115
+            st.kind = self.kind
+            st.phiIdx, st.inputDeficit, st.xIdx = 1, 1, 1
+            st.phiAccumulator, st.alpha = 1.0, 0.0
+            st.Nphi, st.tapsPerPhi, st.historyLen = self.Nphi, self.tapsPerPhi, self.historyLen
+            st.interpolation, st.decimation, st.hLen = self.interpolation, self.decimation, len(self.h)
+            st.rate = self.rate or 0.0
+            st.delta = self.Nphi / self.rate if self.rate else 0.0
+            return st
+        _check(self._lib.mrhip_get_state(self._handle, C.byref(st)))
+        return st
+
+    def set_state(self, phiIdx: int = 1, inputDeficit: int = 1, phiAccumulator: float = 1.0):
+        if self._handle is None:
+            raise MultirateHIPError(1, "set_state needs a bound filter (call filt once, or bind())")
+        _check(self._lib.mrhip_set_state(self._handle, phiIdx, inputDeficit, phiAccumulator))
+
+    def bind(self, dtype, nchannels: int = 1):
+        """Create the device object now (normally done by the first filt call)."""
+        self._ensure(np.dtype(dtype), int(nchannels))
+        return self
+
+    @property
+    def history(self) -> np.ndarray:
+        """FIRFilter.history (src/Filters.jl:153); shape (historyLen,) or (nchannels, historyLen)."""
+        if self._handle is None:
+            return np.zeros(self.historyLen)
+        out = np.zeros((self._nch, self.historyLen), dtype=self._tx)
+        _check(self._lib.mrhip_get_history(self._handle, _ptr(out)))
+        return out[0] if self._nch == 1 else out
+
+    def set_history(self, hist):
+        hist = np.ascontiguousarray(hist, dtype=self._tx).reshape(self._nch, self.historyLen)
+        _check(self._lib.mrhip_set_history(self._handle, _ptr(hist)))
+
+    def taps(self, which: int = 0) -> np.ndarray:
+        """kernel.h (flipped) / kernel.pfb (which=0) or kernel.dpfb (which=1) as stored."""
+        if self._handle is None:
+            raise MultirateHIPError(1, "taps() needs a bound filter")
+        out = np.zeros(self.tapsPerPhi * self.Nphi, dtype=self.h.dtype)
+        _check(self._lib.mrhip_get_taps(self._handle, which, _ptr(out)))
+        return out.reshape(self.Nphi, self.tapsPerPhi).T.copy()
+
+    def set_timing(self, enabled: bool = True):
+        _check(self._lib.mrhip_set_timing(self._handle, 1 if enabled else 0))
+
+    def timing_read(self):
+        """(number of compute-kernel launches since the last read, sum of their durations in ms)."""
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        _check(self._lib.mrhip_timing_read(self._handle, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    def last_kernel_name(self) -> str:
+        return self._lib.mrhip_last_kernel_name(self._handle).decode()
+
+    # -- bookkeeping (src/Filters.jl:352-422)
+    def outputlength(self, inputlength: int) -> int:
+        if self._handle is None:
+            self_state = self.state
+            if self.kind == STANDARD:
+                return inputlength
+            if self.kind == INTERPOLATOR:
+                return self.interpolation * inputlength
+            if self.kind == ARBITRARY:
+                import math
+                return int(math.ceil((inputlength - self_state.inputDeficit + 1) * self.rate))
+            return self._lib.mrhip_outputlength_ratio(inputlength, self.interpolation, self.decimation, 1)
+        return self._lib.mrhip_outputlength(self._handle, inputlength)
+
+    def inputlength(self, outputlength: int) -> int:
+        if self._handle is None:
+            if self.kind == ARBITRARY:
+                raise MultirateHIPError(5, "inputlength is not defined for FIRArbitrary in the reference")
+            return self._lib.mrhip_inputlength_ratio(outputlength, self.interpolation, self.decimation, 1)
+        n = self._lib.mrhip_inputlength(self._handle, outputlength)
+        if n < 0:
+            raise MultirateHIPError(5, "inputlength is not defined for FIRArbitrary in the reference")
+        return n
+
+    def next_output_count(self, inputlength: int) -> int:
+        if self._handle is None:
+            raise MultirateHIPError(1, "next_output_count needs a bound filter")
+        return self._lib.mrhip_next_output_count(self._handle, inputlength)
+
+    def reset(self):
+        """reset(self::FIRFilter), src/Filters.jl:256-260."""
+        if self._handle is not None:
+            _check(self._lib.mrhip_reset(self._handle))
+        return self
+
+    # -- the hot path
+    def _shape(self, x):
+        if x.ndim == 1:
+            return 1, x.shape[0], True
+        if x.ndim == 2:
+            return x.shape[0], x.shape[1], False
+        raise MultirateHIPError(1, "x must be (n,) or (nchannels, n)")
+
+    def filt_into(self, buffer, x) -> int:
+        """filt!(buffer, self, x): writes per-channel outputs into ``buffer`` (same container kind as
+        ``x``), returns the per-channel output count."""
+        nw = C.c_int64(0)
+        if _is_torch(x):
+            if not x.is_cuda:
+                raise MultirateHIPError(1, "torch input must live on the GPU (use numpy for host data)")
+            if x.stride(-1) != 1 or buffer.stride(-1) != 1:
+                raise MultirateHIPError(1, "x and buffer must be contiguous along time (planar channels)")
+            nch, n, _ = self._shape(x)
+            self._ensure(_torch_np_dtype(x.dtype), nch)
+            if _torch_np_dtype(buffer.dtype) != self.output_dtype:
+                raise MultirateHIPError(1, f"buffer dtype must be {self.output_dtype}")
+            if x.device.index != self.device or buffer.device != x.device:
+                raise MultirateHIPError(1, "x / buffer are not on the filter's device")
+            cap = buffer.shape[-1]
+            # channel strides in samples: views such as big[:, a:b] are filtered in place, no copy
+            xs = x.stride(0) if x.ndim == 2 and nch > 1 else n
+            ys = buffer.stride(0) if buffer.ndim == 2 and nch > 1 else cap
+            if buffer.ndim != x.ndim or (x.ndim == 2 and buffer.shape[0] != nch):
+                raise MultirateHIPError(1, "buffer must have one row per channel")
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _check(self._lib.mrhip_filt_device(self._handle, C.c_void_p(x.data_ptr()), n, xs,
+                                               C.c_void_p(buffer.data_ptr()), cap, ys, C.byref(nw),
+                                               C.c_void_p(stream)))
+            return nw.value
+        x = np.asarray(x)
+        if not x.flags.c_contiguous:
+            x = np.ascontiguousarray(x)
+        nch, n, _ = self._shape(x)
+        self._ensure(x.dtype, nch)
+        if not isinstance(buffer, np.ndarray) or buffer.dtype != self.output_dtype or not buffer.flags.c_contiguous:
+            raise MultirateHIPError(1, f"buffer must be a C-contiguous numpy array of {self.output_dtype}")
+        cap = buffer.shape[-1]
+        _check(self._lib.mrhip_filt_host(self._handle, _ptr(x), n, n, _ptr(buffer), cap, cap, C.byref(nw)))
+        return nw.value
+
+    def filt(self, x):
+        """filt(self, x): allocate the output, run filt!, trim to the samples written
+        (src/Filters.jl:475,519,577,633,744)."""
+        if _is_torch(x):
+            nch, n, one = self._shape(x)
+            self._ensure(_torch_np_dtype(x.dtype), nch)
+            cnt = max(self.next_output_count(n), 0)
+            y = torch.empty((nch, cnt), dtype=_np_torch_dtype(self.output_dtype), device=x.device)
+            if n > 0:
+                got = self.filt_into(y[0] if one else y, x if x.stride(-1) == 1 else x.contiguous())
+                assert got == cnt
+            return y[0] if one else y
+        x = np.ascontiguousarray(x)
+        nch, n, one = self._shape(x)
+        self._ensure(x.dtype, nch)
+        cnt = max(self.next_output_count(n), 0)
+        y = np.empty((nch, cnt), dtype=self.output_dtype)
+        if n > 0:
+            got = self.filt_into(y, x)
+            assert got == cnt
+        return y[0] if one else y
+
+
+# ---- free functions with the reference's names -------------------------------------------------
+def filt(a, x, ratio=Fraction(1, 1), Nphi: int = 32, **kw):
+    """filt(self::FIRFilter, x)                      src/Filters.jl:475,519,577,633,744
+       filt(h::Vector, x::Vector, ratio::Rational)   src/Filters.jl:858-861
+       filt(h::Vector, x::Vector, rate::Float, N𝜙)   src/Filters.jl:864-867"""
+    if isinstance(a, FIRFilter):
+        return a.filt(x)
+    f = FIRFilter(a, ratio, Nphi, **kw)
+    try:
+        return f.filt(x)
+    finally:
+        f.close()
+
+
+def filt_(buffer, self: FIRFilter, x):
+    """filt!(buffer, self, x).  Returns what the reference returns: ``buffer`` for FIRStandard /
+    FIRInterpolator (src/Filters.jl:472,516), the number of samples written for FIRRational /
+    FIRDecimator / FIRArbitrary (:574,:630,:741)."""
+    n = self.filt_into(buffer, x)
+    return buffer if self.kind in (STANDARD, INTERPOLATOR) else n
+
+
+def outputlength(self: FIRFilter, inputlength: int) -> int:
+    """outputlength(self::FIRFilter, inputlength), src/Filters.jl:383-385."""
+    return self.outputlength(inputlength)
+
+
+def inputlength(self: FIRFilter, outputlength: int) -> int:
+    """inputlength(self::FIRFilter, outputlength), src/Filters.jl:403-422."""
+    return self.inputlength(outputlength)
+
+
+def reset(self: FIRFilter) -> FIRFilter:
+    """reset(self::FIRFilter), src/Filters.jl:256-260."""
+    return self.reset()

