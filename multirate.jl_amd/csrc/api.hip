@@ -79,6 +79,13 @@ int alloc_common(mrhip_filter *f)
         MRHIP_CHECK_HIP(hipMalloc(&f->d_hist[i], hbytes));
         MRHIP_CHECK_HIP(hipMemset(f->d_hist[i], 0, hbytes));   // history = zeros(historyLen), Filters.jl:177
     }
+    {
+        hipDeviceProp_t prop;
+        MRHIP_CHECK_HIP(hipGetDeviceProperties(&prop, f->device));
+        f->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const char *fg = std::getenv("MRHIP_FORCE_GENERIC");
+        f->force_generic = fg && fg[0] == '1';
+    }
     MRHIP_CHECK_HIP(hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking));
     MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->sched_copied, hipEventDisableTiming));
     return MRHIP_OK;
@@ -107,7 +114,13 @@ int check_create_args(const void *h, int64_t hLen, int th, int tx, int64_t nch, 
 hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s,
                        const char **kname)
 {
-    (void)f;
+    if (!f->force_generic) {
+        TileArgs ta;
+        dim3 grid, block;
+        size_t lds = 0;
+        if (plan_phase_stationary(tk, a, f->num_cus, &ta, &grid, &block, &lds))
+            return launch_poly_phase_stationary(tk, fused, a, ta, grid, block, lds, s, kname);
+    }
     return launch_poly_generic(tk, fused, a, s, kname);
 }
 

@@ -112,6 +112,17 @@ struct HistArgs {            // shiftin! (src/support.jl:61-80) for every channe
     int nch;
 };
 
+struct TileArgs {            // tiling of the phase-stationary kernel (kernels_phase_stationary.hip)
+    int c;                   // P = c*L active lanes per workgroup
+    int P;
+    int J;                   // outputs per lane per tile
+    int tile_len;            // samples staged in LDS per tile (per copy)
+    int copyB_offset_bytes;  // LDS byte offset of the shifted copy (4-byte samples only)
+    int x_aligned16;         // channel bases allow 16-byte vector loads
+    long long tiles_per_channel;
+    long long total_tiles;
+};
+
 // dtype combination a kernel is instantiated for
 struct TypeKey {
     bool x_f64;      // Tx scalar is double
@@ -126,6 +137,10 @@ struct TypeKey {
 hipError_t launch_poly_generic(const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
+bool plan_phase_stationary(const TypeKey &tk, const PolyArgs &a, int num_cus, TileArgs *out, dim3 *grid, dim3 *block,
+                           size_t *lds);
+hipError_t launch_poly_phase_stationary(const TypeKey &tk, bool fused, const PolyArgs &a, const TileArgs &ta, dim3 grid,
+                                        dim3 block, size_t lds, hipStream_t s, const char **kname);
 
 }  // namespace mrhip
 
@@ -139,7 +154,9 @@ struct mrhip_filter {
     int64_t nch = 1;
     int64_t hLen = 0, L = 1, M = 1, Nphi = 1, T = 1, H = 0;
     int device = 0;
+    int num_cus = 256;
     int numerics = MRHIP_NUMERICS_STRICT;
+    int force_generic = 0;   // MRHIP_FORCE_GENERIC=1 in the environment: always use the universal kernels
 
     // device memory
     void *d_taps = nullptr, *d_dtaps = nullptr;

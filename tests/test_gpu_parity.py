@@ -282,3 +282,30 @@ def test_headline_64ch_properties(pkg, O, torch_cuda):
         yo = fo.filt(seg[23:])
         k0 = a * 147 // 160
         assert_bit_equal(y_whole[c, k0:k0 + len(yo)].cpu().numpy(), yo, f"spot ch {c} offset {a}")
+
+
+def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
+    """The phase-stationary kernel and the universal kernel are two schedules of the same arithmetic:
+    outputs must be bit-identical (also checks the dispatcher really picks the tuned kernel)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    cases = [(147, 160, 3528, np.float32, np.float32), (147, 160, 3500, np.float32, np.complex64),
+             (4, 1, 128, np.float32, np.complex64), (3, 17, 50, np.float64, np.float64),
+             (7, 5, 100, np.float64, np.float32), (160, 147, 1000, np.float64, np.complex128),
+             (1, 3, 31, np.float32, np.float32), (1, 1, 17, np.float32, np.float64), (5, 2, 160, np.float32, np.float32)]
+    for (L, M, hl, th, tx) in cases:
+        h = rng.standard_normal(hl).astype(th)
+        x = _rand(rng, (3, 50_000), tx) - 0.5
+        xd = torch.from_numpy(x).cuda()
+        sizes = [20_000, 1, 29_999]
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        f = pkg.FIRFilter(h, Fraction(L, M))
+        y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+        assert f.last_kernel_name() == "poly_phase_stationary_kernel", (L, M, hl)
+        monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+        g = pkg.FIRFilter(h, Fraction(L, M))
+        y_g = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
+        assert g.last_kernel_name() == "poly_generic_kernel"
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        assert_bit_equal(y_t, y_g, f"tuned vs generic L={L} M={M} hLen={hl} {th} {tx}")
+        assert_bit_equal(f.history, g.history, "history")
