@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (kernel stats and PMC counter_collection) for the mrhip kernels.
+usage: summarize_rocprof.py <dir> [<dir> ...]   -> prints compact JSON (kernel names shortened)"""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+def short(name):
+    m = re.search(r"(mrhip::\(anonymous namespace\)::)?(\w+_kernel<[^>]*>|\w+_kernel)", name)
+    return m.group(2) if m and "mrhip" in name else ("torch:" + name[:40] if "at::" in name else name[:60])
+
+out = {}
+for d in sys.argv[1:]:
+    for f in glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        out.setdefault(d, {})["kernel_stats"] = [
+            {"kernel": short(r["Name"]), "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
+             "min_us": round(float(r["MinNs"]) / 1e3, 2), "max_us": round(float(r["MaxNs"]) / 1e3, 2),
+             "pct": float(r["Percentage"])} for r in rows]
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        agg = defaultdict(lambda: defaultdict(list))
+        meta = {}
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if not k.startswith("poly") and not k.startswith("arb") and not k.startswith("shiftin") and not k.startswith("deci"):
+                continue
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"]),
+                       "wg": int(r["Workgroup_Size"]), "grid": int(r["Grid_Size"])}
+        out.setdefault(d, {})["counters_avg_per_dispatch"] = {
+            k: dict(meta[k], dispatches=len(next(iter(v.values()))), **{c: round(sum(x) / len(x), 1) for c, x in v.items()})
+            for k, v in agg.items()}
+print(json.dumps(out, indent=1))
