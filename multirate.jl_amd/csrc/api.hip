@@ -115,11 +115,18 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
                        const char **kname)
 {
     if (!f->force_generic) {
+        {
+            PairArgs pa;
+            dim3 block;
+            size_t lds = 0;
+            if (plan_rational_pair(tk, a, &pa, &block, &lds))
+                return launch_rational_pair(fused, a, pa, block, lds, s, kname, f->num_cus);
+        }
         TileArgs ta;
         dim3 grid, block;
         size_t lds = 0;
         if (plan_phase_stationary(tk, a, f->num_cus, &ta, &grid, &block, &lds))
-            return launch_poly_phase_stationary(tk, fused, a, ta, grid, block, lds, s, kname);
+            return launch_poly_phase_stationary(tk, fused, a, ta, grid, block, lds, s, kname, f->num_cus);
     }
     return launch_poly_generic(tk, fused, a, s, kname);
 }

@@ -2,24 +2,34 @@
 // FIRRational, FIRInterpolator (and short FIRStandard / FIRDecimator), tapsPerPhi <= 32.
 //
 // Idea ("phase-stationary"): the phase of output k is (u0 + k*M) mod L, so outputs k and k + c*L
-// use the same tap column.  A workgroup has P = c*L active lanes; lane t owns the outputs
+// use the same tap column.  A workgroup covers P = c*L outputs per step; a lane owns the outputs
 // k = tile*P*J + j*P + t, j = 0..J-1, of every tile it is handed, and therefore ONE tap column for
-// its whole life: the T taps sit in VGPRs, loaded once per workgroup (persistent grid).  The
-// consecutive-lane -> consecutive-output map keeps the y stores fully coalesced and makes the LDS
-// window reads of a wave walk forward by M/L samples per lane.
+// its whole life: the T taps sit in VGPRs, loaded once per workgroup (persistent grid).
 //
-// Per tile the workgroup stages J*c*M + T (+ alignment slack) input samples of one channel into
-// LDS with 16-byte global loads (the seam with the previous call's history is resolved here, once,
-// instead of per output).  4-byte samples are stored twice, the second copy shifted by one sample
-// and placed 32 banks away, so that every lane can fetch its T-sample window with 8-byte-aligned
-// ds_read_b64 (256 B/clk/CU instead of 128 for ds_read_b32) whatever the parity of its window start.
-// LDS traffic is T*sizeof(sample) per output (taps cost nothing), HBM traffic is the algorithmic
+// Staging.  Per tile the workgroup needs J*c*M + T input samples of one channel.  Interior tiles are
+// brought in by LDS-DMA (global_load_lds_dwordx4: HBM -> LDS without touching VGPRs), double
+// buffered: the DMA for tile i+1 is issued right after the barrier that opens tile i and lands while
+// tile i is being computed, so there is ONE barrier per tile and no staging registers.  The first and
+// last tile of a channel (history seam, end of input) take a checked register path into the same
+// buffer.  4-byte samples are stored twice, the second copy shifted by one sample (DMA from
+// source + 4 bytes) and placed 32 banks away, so every lane fetches its T-sample window with
+// 8-byte-aligned ds_read_b64 (256 B/clk/CU; ds_read_b32 gives 128) whatever the parity of its start.
+//
+// Lane map.  For M <= L a lane is an output (consecutive lanes start 0 or 1 sample apart).  For M > L
+// consecutive outputs skip input positions, 32 outputs would span more than 32 window starts and two
+// lanes of a half-wave would hit one LDS bank pair; there a lane is an input POSITION (lanes whose
+// position produces no output idle), which keeps every half-wave on 32 consecutive starts:
+// conflict-free reads for the price of (M/L - 1) idle lanes.
+//
+// LDS traffic is T*sizeof(sample) per output (taps cost nothing); HBM traffic is the algorithmic
 // sizeof(Tx) + (L/M)*sizeof(Tb) per input sample plus the (T-1)-sample halo per tile.
 //
 // Arithmetic: identical to the generic kernel (STRICT: separately rounded multiply and add, oldest
 // sample first, first product initialises; FUSED: explicit fma), so results are bit-identical
 // between the two kernels and the oracle.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "mrhip_internal.h"
@@ -30,6 +40,21 @@ namespace mrhip {
 namespace {
 
 constexpr int kMaxThreads = 512;
+constexpr int kMaxDmaRounds = 4;   // LDS-DMA instructions per wave, per copy, per tile
+
+inline bool debug_once()
+{
+    static int state = -1;   // -1 unknown, 0 off, 1 armed
+    if (state < 0) { const char *v = std::getenv("MRHIP_DEBUG"); state = (v && v[0] == '1') ? 1 : 0; }
+    if (state == 1) { state = 0; return true; }
+    return false;
+}
+
+inline int env_int(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
 
 template <typename R, bool FUSED>
 __device__ __forceinline__ R mac(R t, R x, R acc)
@@ -83,7 +108,17 @@ __device__ __forceinline__ void lgkm_wait(V &reg)
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(N < 15 ? N : 15));
 }
 
-// One 16-byte chunk = VPS samples of SW 32-bit words each.
+// HBM -> LDS, 16 bytes per lane, no VGPR data: LDS destination = lds_wave_base + lane*16 (the base
+// must be wave-uniform), global source is per lane and only needs 4-byte alignment (verified on
+// gfx950 by scripts/ubench/dma_test.hip).
+__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// One 16-byte chunk = VPS samples of SW 32-bit words each; checked element by element against the
+// history seam (negative indices) and the end of the input.
 template <int SW>
 __device__ __forceinline__ uint4 load_chunk_checked(const unsigned *__restrict__ xc, const unsigned *__restrict__ hc,
                                                    int H, long long g, long long x_len)
@@ -110,19 +145,32 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
     constexpr bool TWO_COPIES = SW == 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned *const ldsA = reinterpret_cast<unsigned *>(smem);
-    unsigned *const ldsB = reinterpret_cast<unsigned *>(smem + ta.copyB_offset_bytes);
     // LDS byte offset of smem[0] (low 32 bits of the flat address of an LDS object are its LDS offset)
     const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
 
-    const int t = threadIdx.x;
-    const bool active = t < ta.P;
-
-    // per-lane phase and input offset: u = u0 + t*M ; phi = u mod L ; q = u div L
-    const long long u = a.u0 + static_cast<long long>(t) * a.M;
-    const long long qll = u / a.L;
-    const int phi = static_cast<int>(u - qll * a.L);
-    const int q = static_cast<int>(qll);
+    // ---- lane -> output map:  u = u0 + t*M ; phi = u mod L ; q = u div L (window offset, samples)
+    int t, q, phi;
+    bool active;
+    if (ta.by_position) {
+        q = threadIdx.x;
+        const long long num = static_cast<long long>(q) * a.L - a.u0;
+        const long long tt = num <= 0 ? 0 : (num + a.M - 1) / a.M;
+        const long long u = a.u0 + tt * a.M;
+        const long long qq = u / a.L;
+        t = static_cast<int>(tt);
+        phi = static_cast<int>(u - qq * a.L);
+        active = tt < ta.P && qq == q;
+    } else {
+        t = threadIdx.x;
+        const long long u = a.u0 + static_cast<long long>(t) * a.M;
+        const long long qll = u / a.L;
+        phi = static_cast<int>(u - qll * a.L);
+        q = static_cast<int>(qll);
+        active = t < ta.P;
+    }
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nwaves = blockDim.x >> 6;
 
     R taps[T];
     {
@@ -136,37 +184,67 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
     const long long tile_out = static_cast<long long>(ta.J) * ta.P;
     const int nchunks = ta.tile_len / VPS;
 
-    for (long long tile = blockIdx.x; tile < ta.total_tiles; tile += gridDim.x) {
+    // ---- staging of one tile into LDS stage `s` (asynchronous for interior tiles)
+    auto stage_tile = [&](long long tile, int s) {
         const int ch = static_cast<int>(tile / ta.tiles_per_channel);
         const long long tau = tile - static_cast<long long>(ch) * ta.tiles_per_channel;
         const unsigned *__restrict__ xc = static_cast<const unsigned *>(a.x) + static_cast<long long>(ch) * a.x_stride * SW;
-        const unsigned *__restrict__ hc = static_cast<const unsigned *>(a.hist) + static_cast<long long>(ch) * a.H * SW;
-        R *__restrict__ yc = static_cast<R *>(a.y) + static_cast<long long>(ch) * a.y_stride * NC;
-
-        // 0-based x index of the oldest sample any lane of this tile needs, aligned down to a chunk
+        // 0-based x index of the oldest sample any lane of this tile needs; chunks start at its
+        // 16-byte-aligned floor
         const long long o = a.d0 - T + tau * tile_in;
         const long long g0 = o & ~static_cast<long long>(VPS - 1);
-        const int sh = static_cast<int>(o - g0);
-
-        __syncthreads();   // previous tile's window reads are done
-        for (int ci = t; ci < nchunks; ci += blockDim.x) {
-            const long long g = g0 + static_cast<long long>(ci) * VPS;
-            uint4 v;
-            if (ta.x_aligned16 && g >= 0 && g + VPS <= a.x_len)
-                v = *reinterpret_cast<const uint4 *>(xc + g * SW);
-            else
-                v = load_chunk_checked<SW>(xc, hc, a.H, g, a.x_len);
-            *reinterpret_cast<uint4 *>(ldsA + ci * 4) = v;
-            if constexpr (TWO_COPIES) {
-                // B[i] = A[i+1]  =>  B[4ci-1 .. 4ci+2] = v.x .. v.w
-                if (ci > 0) ldsB[ci * 4 - 1] = v.x;
-                *reinterpret_cast<uint2 *>(ldsB + ci * 4) = make_uint2(v.y, v.z);
-                ldsB[ci * 4 + 2] = v.w;
+        unsigned char *stA = smem + static_cast<size_t>(s) * ta.stage_bytes;
+        unsigned char *stB = stA + ta.copyB_offset_bytes;
+        // wave-uniform: every byte the DMA touches (copy B reads one sample further) is inside x
+        const bool interior = ta.x_aligned16 && g0 >= 0 && g0 + ta.tile_len + (TWO_COPIES ? 1 : 0) <= a.x_len;
+        if (interior) {
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + g0 * SW);
+#pragma unroll
+            for (int d = 0; d < kMaxDmaRounds; ++d) {
+                if (d < ta.dma_rounds) {
+                    const int slot = d * nwaves + wave;            // 1 KiB slot of the stage copy
+                    const int ci = slot * 64 + lane;
+                    const int cis = ci < nchunks ? ci : 0;         // padding lanes re-read chunk 0 (lands in LDS padding)
+                    dma16(src + static_cast<size_t>(cis) * 16, stA + static_cast<size_t>(slot) * 1024);
+                    if constexpr (TWO_COPIES)
+                        dma16(src + static_cast<size_t>(cis) * 16 + 4, stB + static_cast<size_t>(slot) * 1024);
+                }
+            }
+        } else {
+            const unsigned *__restrict__ hc = static_cast<const unsigned *>(a.hist) + static_cast<long long>(ch) * a.H * SW;
+            unsigned *lA = reinterpret_cast<unsigned *>(stA), *lB = reinterpret_cast<unsigned *>(stB);
+            for (int ci = tid; ci < nchunks; ci += blockDim.x) {
+                const uint4 v = load_chunk_checked<SW>(xc, hc, a.H, g0 + static_cast<long long>(ci) * VPS, a.x_len);
+                *reinterpret_cast<uint4 *>(lA + ci * 4) = v;
+                if constexpr (TWO_COPIES) {
+                    // B[i] = A[i+1]  =>  B[4ci-1 .. 4ci+2] = v.x .. v.w ; the last word of the copy
+                    // (index 4*nchunks-1) belongs to the next chunk and is never read
+                    if (ci > 0) lB[ci * 4 - 1] = v.x;
+                    *reinterpret_cast<uint2 *>(lB + ci * 4) = make_uint2(v.y, v.z);
+                    lB[ci * 4 + 2] = v.w;
+                }
             }
         }
+    };
+
+    long long tile = blockIdx.x;
+    int s = 0;
+    if (tile < ta.total_tiles) stage_tile(tile, 0);
+    for (; tile < ta.total_tiles; tile += gridDim.x, s ^= 1) {
+        const int ch = static_cast<int>(tile / ta.tiles_per_channel);
+        const long long tau = tile - static_cast<long long>(ch) * ta.tiles_per_channel;
+        R *__restrict__ yc = static_cast<R *>(a.y) + static_cast<long long>(ch) * a.y_stride * NC;
+        const long long o = a.d0 - T + tau * tile_in;
+        const int sh = static_cast<int>(o - (o & ~static_cast<long long>(VPS - 1)));   // origin offset inside chunk 0
+
+        // One barrier per tile: it (a) publishes this tile's staged data -- every wave waits for its
+        // own DMA / LDS writes first (__syncthreads drains vmcnt and lgkmcnt) -- and (b) proves that
+        // every wave has finished reading the other stage, which the next DMA is about to overwrite.
         __syncthreads();
+        if (tile + gridDim.x < ta.total_tiles && !(ta.ablate & 1)) stage_tile(tile + gridDim.x, s ^ 1);
 
         if (active) {
+            const unsigned stage_base = lds_base + static_cast<unsigned>(s) * ta.stage_bytes;
             const long long kbase = tau * tile_out + t;
             const long long nbase = a.d0 + q + tau * tile_in;     // 1-based newest-sample index, j = 0
 #pragma unroll 1
@@ -194,7 +272,7 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
                     // 4-byte samples: T/2 aligned 8-byte reads from whichever copy makes the window start even
                     constexpr int NP = T / 2;
                     constexpr int NR = NP + (T & 1);
-                    const unsigned waddr = lds_base + ((start & 1) ? ta.copyB_offset_bytes + (start - 1) * 4 : start * 4);
+                    const unsigned waddr = stage_base + ((start & 1) ? ta.copyB_offset_bytes + (start - 1) * 4 : start * 4);
                     v2u_t pr[NP > 0 ? NP : 1];
                     unsigned last = 0;
                     static_for<0, NP>([&](auto I) { pr[decltype(I)::value] = lds_read_b64<decltype(I)::value * 8>(waddr); });
@@ -214,7 +292,7 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
                     }
                 } else if constexpr (SW == 2) {
                     // 8-byte samples (ComplexF32 or Float64): one naturally aligned ds_read_b64 per tap
-                    const unsigned waddr = lds_base + start * 8;
+                    const unsigned waddr = stage_base + start * 8;
                     v2u_t pr[T];
                     static_for<0, T>([&](auto I) { pr[decltype(I)::value] = lds_read_b64<decltype(I)::value * 8>(waddr); });
                     static_for<0, T>([&](auto I) {
@@ -229,7 +307,7 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
                     });
                 } else {
                     // 16-byte samples (ComplexF64): ds_read_b128, left to the compiler
-                    const uint4 *wp = reinterpret_cast<const uint4 *>(ldsA + start * 4);
+                    const uint4 *wp = reinterpret_cast<const uint4 *>(smem + static_cast<size_t>(s) * ta.stage_bytes) + start;
                     static_for<0, T>([&](auto I) {
                         const uint4 v = wp[decltype(I)::value];
                         TX tmp[NC];
@@ -240,7 +318,9 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
                         step(I, xv);
                     });
                 }
-                if constexpr (NC == 1) {
+                if (ta.ablate & 2) {          // timing experiments only: keep the math live, drop the store
+                    if (acc[0] == static_cast<R>(1.2345e30)) yc[k * NC] = acc[0];
+                } else if constexpr (NC == 1) {
                     yc[k] = acc[0];
                 } else {
                     using RV = typename std::conditional<sizeof(R) == 4, float2, double2>::type;
@@ -255,7 +335,8 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
 }
 
 template <typename TX, typename R, int NC, bool FUSED>
-hipError_t launch_T(int T, dim3 grid, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const TileArgs &ta)
+hipError_t launch_T(int T, dim3 grid, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const TileArgs &ta,
+                    int num_cus, int blocks_per_cu_override)
 {
 #define MRHIP_CASE(TT)                                                                              \
     case TT: {                                                                                      \
@@ -265,14 +346,34 @@ hipError_t launch_T(int T, dim3 grid, dim3 block, size_t lds, hipStream_t s, con
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
             if (e != hipSuccess) return e;                                                          \
         }                                                                                           \
+        /* persistent grid = what is actually co-resident (registers, LDS and waves all count) */   \
+        int per_cu = 0;                                                                             \
+        hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, static_cast<int>(block.x), lds); \
+        if (eo != hipSuccess) return eo;                                                            \
+        if (per_cu < 1) per_cu = 1;                                                                 \
+        if (blocks_per_cu_override > 0) per_cu = blocks_per_cu_override;                            \
+        long long g = static_cast<long long>(num_cus) * per_cu;                                     \
+        if (g > ta.total_tiles) g = ta.total_tiles;                                                 \
+        grid = dim3(static_cast<unsigned>(g < 1 ? 1 : g));                                          \
+        if (debug_once()) {                                                                         \
+            hipFuncAttributes fa;                                                                   \
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kfn));                   \
+            std::fprintf(stderr, "[mrhip] phase_stationary T=%d grid=%u block=%u lds=%zu occ/CU=%d regs=%d c=%d P=%d J=%d " \
+                         "bypos=%d tile_len=%d dma_rounds=%d tiles=%lld\n", TT, grid.x, block.x, lds, per_cu, fa.numRegs, \
+                         ta.c, ta.P, ta.J, ta.by_position, ta.tile_len, ta.dma_rounds, ta.total_tiles); \
+        }                                                                                           \
         hipLaunchKernelGGL(kfn, grid, block, lds, s, a, ta);                                        \
         return hipGetLastError();                                                                   \
     }
     switch (T) {
+#ifdef MRHIP_PS_FAST_BUILD   /* developer builds: one tap count only (seconds instead of minutes) */
+        MRHIP_CASE(24)
+#else
         MRHIP_CASE(1) MRHIP_CASE(2) MRHIP_CASE(3) MRHIP_CASE(4) MRHIP_CASE(5) MRHIP_CASE(6) MRHIP_CASE(7) MRHIP_CASE(8)
         MRHIP_CASE(9) MRHIP_CASE(10) MRHIP_CASE(11) MRHIP_CASE(12) MRHIP_CASE(13) MRHIP_CASE(14) MRHIP_CASE(15) MRHIP_CASE(16)
         MRHIP_CASE(17) MRHIP_CASE(18) MRHIP_CASE(19) MRHIP_CASE(20) MRHIP_CASE(21) MRHIP_CASE(22) MRHIP_CASE(23) MRHIP_CASE(24)
         MRHIP_CASE(25) MRHIP_CASE(26) MRHIP_CASE(27) MRHIP_CASE(28) MRHIP_CASE(29) MRHIP_CASE(30) MRHIP_CASE(31) MRHIP_CASE(32)
+#endif
     default: return hipErrorInvalidValue;
     }
 #undef MRHIP_CASE
@@ -280,70 +381,100 @@ hipError_t launch_T(int T, dim3 grid, dim3 block, size_t lds, hipStream_t s, con
 
 }  // namespace
 
-// Host-side planning: pick c (P = c*L lanes), J (outputs per lane per tile) and the grid.
+// Host-side planning: pick the lane map, c (lanes per step), J (steps per tile) and the LDS layout.
 // Returns false if the configuration is outside what this kernel covers (caller falls back).
 bool plan_phase_stationary(const TypeKey &tk, const PolyArgs &a, int num_cus, TileArgs *out, dim3 *grid, dim3 *block, size_t *lds)
 {
+#ifdef MRHIP_PS_FAST_BUILD
+    if (a.T != 24) return false;
+#endif
     if (a.T < 1 || a.T > 32) return false;
     if (a.L > kMaxThreads) return false;
     const int sw = (tk.x_f64 ? 2 : 1) * (tk.complex_x ? 2 : 1);
     const int vps = 4 / sw;
-    // choose c: P = c*L as close as possible to a multiple of 64 within [<=1024], prefer ~256-512 lanes
+    // tuning overrides for experiments (unset in production): MRHIP_PS_C / _J / _BYPOS / _BPC
+    static const int env_c = env_int("MRHIP_PS_C", 0), env_j = env_int("MRHIP_PS_J", 0),
+                     env_bypos = env_int("MRHIP_PS_BYPOS", -1);
+    // lane map: by output (M <= L) or by input position (M > L, worthwhile while >= 70 % of lanes work)
+    bool by_position = a.M > a.L && static_cast<double>(a.L) / a.M >= 0.70;
+    if (env_bypos >= 0) by_position = env_bypos != 0 && a.M > a.L;
+    // choose c: lanes per j-step (c*L outputs, or c*M positions) as close as possible to a multiple
+    // of 64, at most kMaxThreads
     int best_c = 0;
     double best_score = -1.0;
-    for (int c = 1; static_cast<long long>(c) * a.L <= kMaxThreads; ++c) {
+    for (int c = 1; static_cast<long long>(c) * (by_position ? a.M : a.L) <= kMaxThreads; ++c) {
         const int P = c * a.L;
-        const int padded = (P + 63) / 64 * 64;
+        const int lanes = by_position ? c * a.M : P;
+        const int padded = (lanes + 63) / 64 * 64;
         double score = static_cast<double>(P) / padded;                  // lane utilisation
-        if (P < 192) score *= 0.5 + 0.5 * P / 192.0;                      // too few waves per block
-        if (P > 512) score *= 0.97;                                       // mild preference for <= 512
+        if (padded < 192) score *= 0.5 + 0.5 * padded / 192.0;            // too few waves per block
         if (score > best_score + 1e-9) { best_score = score; best_c = c; }
     }
     if (!best_c) return false;
+    if (env_c > 0 && static_cast<long long>(env_c) * (by_position ? a.M : a.L) <= kMaxThreads) best_c = env_c;
     const int c = best_c, P = c * a.L;
+    const int lanes = by_position ? c * a.M : P;
+    const int padded = (lanes + 63) / 64 * 64;
+    const int nwaves = padded / 64;
     const long long cM = static_cast<long long>(c) * a.M;
-    // J: keep the LDS tile around 24 KiB per copy-set so ~4 workgroups fit a CU
-    const long long budget_samples = 24 * 1024 / (sw * 4);
-    long long J = (budget_samples - a.T - 8) / (cM > 0 ? cM : 1);
+
+    // J: as many steps as fit kDmaRoundsTarget KiB-slots per wave (each DMA round moves nwaves KiB per copy)
+    const int rounds_target = sw == 1 ? 2 : 4;
+    long long J = (static_cast<long long>(rounds_target) * nwaves * 64 * vps - a.T - 8) / (cM > 0 ? cM : 1);
     if (J > 16) J = 16;
+    if (env_j > 0) J = env_j;
     if (J < 1) J = 1;
+    // keep J*c*M a multiple of the chunk size so the offset of the tile origin inside its first
+    // chunk (and with it the parity of every lane's window start) is the same for every tile
+    while (J > 1 && (J * cM) % vps != 0) --J;
     long long tile_len = J * cM + a.T + 1 + (vps - 1);
-    tile_len = (tile_len + 3) / 4 * 4;                                    // whole chunks (and 16-byte multiple)
-    if (tile_len % vps) tile_len += vps - tile_len % vps;
-    const size_t bytesA = (static_cast<size_t>(tile_len) * sw * 4 + 255) / 256 * 256;
-    const size_t total = sw == 1 ? bytesA + 128 + bytesA : bytesA;        // copy B sits 32 banks (128 B) off copy A
-    if (total > 150 * 1024) return false;
+    tile_len = (tile_len + vps - 1) / vps * vps;                          // whole 16-byte chunks
+    const long long nchunks = tile_len / vps;
+    const long long rounds = (nchunks + static_cast<long long>(nwaves) * 64 - 1) / (static_cast<long long>(nwaves) * 64);
+    if (rounds > kMaxDmaRounds) return false;
+    const size_t copy_bytes = static_cast<size_t>(rounds) * nwaves * 1024;        // multiple of 1 KiB (and of 256 B)
+    // Copy B sits 32 banks (128 B) after copy A so that, of 32 consecutive window starts, the 16
+    // even ones (copy A) and the 16 odd ones (copy B) together cover all 64 banks exactly once.  That
+    // needs the first start of a half-wave to be even; when the tile origin makes it odd, two more
+    // words of offset restore the disjoint cover.
+    const long long o0 = a.d0 - a.T;
+    const int sh0 = static_cast<int>(((o0 % vps) + vps) % vps);
+    const bool sh_constant = (J * cM) % vps == 0;
+    const size_t copyB_off = copy_bytes + 128 + ((sh_constant && (sh0 & 1)) ? 8 : 0);
+    const size_t stage_bytes = sw == 1 ? (copyB_off + copy_bytes + 127) / 128 * 128 + 128 : copy_bytes;
+    const size_t total = 2 * stage_bytes;
+    if (total > 156 * 1024) return false;
+
     TileArgs ta{};
     ta.c = c; ta.P = P; ta.J = static_cast<int>(J);
+    ta.by_position = by_position ? 1 : 0;
+    static const int env_ablate = env_int("MRHIP_PS_ABLATE", 0);   // timing experiments: 1 = no staging, 2 = no stores
+    ta.ablate = env_ablate;
     ta.tile_len = static_cast<int>(tile_len);
-    ta.copyB_offset_bytes = static_cast<int>(bytesA + 128);
+    ta.dma_rounds = static_cast<int>(rounds);
+    ta.copyB_offset_bytes = static_cast<int>(copyB_off);
+    ta.stage_bytes = static_cast<int>(stage_bytes);
     const long long tile_out = J * P;
     ta.tiles_per_channel = (a.n_out + tile_out - 1) / tile_out;
     ta.total_tiles = ta.tiles_per_channel * a.nch;
     const uintptr_t xb = reinterpret_cast<uintptr_t>(a.x);
     ta.x_aligned16 = (xb % 16 == 0) && ((a.x_stride * sw * 4) % 16 == 0 || a.nch == 1);
-    const int padded = (P + 63) / 64 * 64;
-    // persistent grid: enough workgroups to fill every CU at the occupancy LDS/waves allow
-    int per_cu = static_cast<int>(std::min<size_t>(160 * 1024 / std::max<size_t>(total, 1), static_cast<size_t>(2048 / padded)));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    long long g = static_cast<long long>(num_cus) * per_cu;
-    if (g > ta.total_tiles) g = ta.total_tiles;
-    if (g < 1) g = 1;
+    (void)num_cus;
     *out = ta;
-    *grid = dim3(static_cast<unsigned>(g));
+    *grid = dim3(1);            // sized at launch from the occupancy of the chosen instantiation
     *block = dim3(static_cast<unsigned>(padded));
     *lds = total;
     return true;
 }
 
 hipError_t launch_poly_phase_stationary(const TypeKey &tk, bool fused, const PolyArgs &a, const TileArgs &ta, dim3 grid,
-                                        dim3 block, size_t lds, hipStream_t s, const char **kname)
+                                        dim3 block, size_t lds, hipStream_t s, const char **kname, int num_cus)
 {
     *kname = "poly_phase_stationary_kernel";
+    static const int bpc = env_int("MRHIP_PS_BPC", 0);
 #define MRHIP_GO(TX, R, NC)                                                                          \
-    return fused ? launch_T<TX, R, NC, true>(a.T, grid, block, lds, s, a, ta)                        \
-                 : launch_T<TX, R, NC, false>(a.T, grid, block, lds, s, a, ta)
+    return fused ? launch_T<TX, R, NC, true>(a.T, grid, block, lds, s, a, ta, num_cus, bpc)          \
+                 : launch_T<TX, R, NC, false>(a.T, grid, block, lds, s, a, ta, num_cus, bpc)
     if (!tk.x_f64 && !tk.r_f64) { if (tk.complex_x) { MRHIP_GO(float, float, 2); } else { MRHIP_GO(float, float, 1); } }
     if (!tk.x_f64 && tk.r_f64) { if (tk.complex_x) { MRHIP_GO(float, double, 2); } else { MRHIP_GO(float, double, 1); } }
     if (tk.x_f64 && tk.r_f64) { if (tk.complex_x) { MRHIP_GO(double, double, 2); } else { MRHIP_GO(double, double, 1); } }

@@ -117,8 +117,30 @@ struct TileArgs {            // tiling of the phase-stationary kernel (kernels_p
     int P;
     int J;                   // outputs per lane per tile
     int tile_len;            // samples staged in LDS per tile (per copy)
-    int copyB_offset_bytes;  // LDS byte offset of the shifted copy (4-byte samples only)
+    int copyB_offset_bytes;  // byte offset of the shifted copy inside a stage (4-byte samples only)
+    int stage_bytes;         // LDS bytes per pipeline stage (two stages)
+    int dma_rounds;          // LDS-DMA instructions per wave, per copy, per tile
+    int ablate;              // timing experiments only (MRHIP_PS_ABLATE): bit0 skip staging, bit1 skip stores
     int x_aligned16;         // channel bases allow 16-byte vector loads
+    int by_position;         // lane map: 0 = one lane per output, 1 = one lane per input position
+    long long tiles_per_channel;
+    long long total_tiles;
+};
+
+struct PairArgs {            // tiling of the pair-per-lane rational kernel (kernels_rational_pair.hip)
+    int c;                   // period = c*M input positions = c*L outputs per step
+    int P;                   // c*L
+    int cM;                  // c*M
+    int J;                   // steps per tile
+    int tile_len;            // samples staged per tile (multiple of 4)
+    int dma_rounds;          // LDS-DMA instructions per wave per tile
+    int stage_bytes;         // LDS bytes per pipeline stage (three stages)
+    int ablate;              // timing experiments only (MRHIP_PS_ABLATE)
+    int grid_div;            // gridDim.x / tiles_per_channel   } so the tile -> (channel, tile-in-channel)
+    long long grid_mod;      // gridDim.x % tiles_per_channel   } walk needs no division per tile
+    long long o0;            // d0 - T: x index of LDS sample 0 of tile 0 (negative => history)
+    long long tile_in;       // J*c*M
+    long long tile_out;      // J*c*L
     long long tiles_per_channel;
     long long total_tiles;
 };
@@ -137,10 +159,13 @@ struct TypeKey {
 hipError_t launch_poly_generic(const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
+bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, PairArgs *out, dim3 *block, size_t *lds);
+hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
+                                const char **kname, int num_cus);
 bool plan_phase_stationary(const TypeKey &tk, const PolyArgs &a, int num_cus, TileArgs *out, dim3 *grid, dim3 *block,
                            size_t *lds);
 hipError_t launch_poly_phase_stationary(const TypeKey &tk, bool fused, const PolyArgs &a, const TileArgs &ta, dim3 grid,
-                                        dim3 block, size_t lds, hipStream_t s, const char **kname);
+                                        dim3 block, size_t lds, hipStream_t s, const char **kname, int num_cus);
 
 }  // namespace mrhip
 

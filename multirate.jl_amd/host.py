@@ -95,7 +95,8 @@ _lib = None
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libmultirate_hip.so")
+    # MRHIP_LIB_PATH: developer override used to A/B-test alternative builds of the same ABI
+    return os.environ.get("MRHIP_LIB_PATH") or os.path.join(_HERE, "libmultirate_hip.so")
 
 
 def load_library():
