@@ -21,7 +21,7 @@ for d in sys.argv[1:]:
         meta = {}
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if not k.startswith("poly") and not k.startswith("arb") and not k.startswith("shiftin") and not k.startswith("deci"):
+            if not k.startswith(("poly", "arb", "shiftin", "deci", "rational", "fir")):
                 continue
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"]),
