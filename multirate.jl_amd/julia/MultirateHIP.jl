@@ -1,0 +1,176 @@
+# MultirateHIP.jl -- thin Julia binding of libmultirate_hip.so (include/multirate_hip.h).
+#
+# Drop-in for the hot path of Multirate.jl's src/Filters.jl: same type and function names
+# (FIRFilter, FIRStandard/FIRDecimator/FIRInterpolator/FIRRational/FIRArbitrary, filt, filt!,
+# taps2pfb, outputlength, inputlength, reset, nextphase), same argument meaning, same return values,
+# same errors -- every method body is a ccall.  Modern Julia (>= 1.6) syntax; the reference is
+# Julia-0.3 source and cannot be loaded by a current Julia, so this module stands beside it rather
+# than patching it.  See INTEGRATION.md for how a maintainer wires it into Multirate.jl.
+#
+# NOTE: the build image has no Julia, so this file has not been executed there; it is kept
+# deliberately free of logic (all logic lives behind the C ABI, which the Python mirror in
+# ../host.py exercises symbol by symbol in tests/).
+module MultirateHIP
+
+export FIRFilter, FIRKernel, FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary,
+       filt, filt!, taps2pfb, outputlength, inputlength, reset, nextphase
+
+const libmr = get(ENV, "MRHIP_LIB_PATH", joinpath(@__DIR__, "..", "libmultirate_hip.so"))
+
+# ---- enums of multirate_hip.h ------------------------------------------------------------------
+const MRHIP_F32, MRHIP_F64, MRHIP_C64, MRHIP_C128 = Cint(0), Cint(1), Cint(2), Cint(3)
+dtypecode(::Type{Float32}) = MRHIP_F32
+dtypecode(::Type{Float64}) = MRHIP_F64
+dtypecode(::Type{ComplexF32}) = MRHIP_C64
+dtypecode(::Type{ComplexF64}) = MRHIP_C128
+
+# kernel kinds == the reference's FIRKernel subtypes (src/Filters.jl:15-117); kept as marker types so
+# that FIRFilter{FIRRational} etc. dispatch and print like the reference's
+abstract type FIRKernel end
+struct FIRStandard <: FIRKernel end
+struct FIRDecimator <: FIRKernel end
+struct FIRInterpolator <: FIRKernel end
+struct FIRRational <: FIRKernel end
+struct FIRArbitrary <: FIRKernel end
+const KINDS = (FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary)
+
+struct MRHIPState                      # mirror of `mrhip_state`
+    kind::Int32; tap_dtype::Int32; sample_dtype::Int32; output_dtype::Int32
+    nchannels::Int64; hLen::Int64; interpolation::Int64; decimation::Int64; Nphi::Int64
+    tapsPerPhi::Int64; historyLen::Int64; phiIdx::Int64; inputDeficit::Int64; xIdx::Int64
+    rate::Float64; phiAccumulator::Float64; alpha::Float64; delta::Float64
+end
+
+lasterror() = unsafe_string(ccall((:mrhip_last_error, libmr), Cstring, ()))
+check(rc::Integer) = rc == 0 ? nothing : error(lasterror())   # reference: error("...") in the same places
+
+# ---- FIRFilter -----------------------------------------------------------------------------------
+# Like the reference's FIRFilter (src/Filters.jl:151-198), whose `history` takes the element type of
+# the first x it sees (:452), the device object is created on the first filt call.
+mutable struct FIRFilter{Tk<:FIRKernel}
+    h::Vector
+    ratio::Union{Rational{Int},Nothing}
+    rate::Float64
+    Nphi::Int
+    device::Int
+    handle::Ptr{Cvoid}
+    Tx::Union{DataType,Nothing}
+    nchannels::Int
+end
+
+function kindof(ratio::Rational)
+    L, M = numerator(ratio), denominator(ratio)
+    ratio == 1 ? FIRStandard : L == 1 ? FIRDecimator : M == 1 ? FIRInterpolator : FIRRational   # :163-175
+end
+
+# FIRFilter(h, resampleRatio::Rational = 1//1)            src/Filters.jl:158-180
+function FIRFilter(h::Vector{Th}, ratio::Rational = 1//1; device::Integer = 0) where {Th<:Union{Float32,Float64}}
+    r = Rational{Int}(ratio)
+    f = FIRFilter{kindof(r)}(copy(h), r, 0.0, 0, device, C_NULL, nothing, 0)
+    finalizer(destroy!, f)
+end
+# FIRFilter(h, rate::AbstractFloat, Nphi = 32)            src/Filters.jl:183-189
+function FIRFilter(h::Vector{Th}, rate::AbstractFloat, Nphi::Integer = 32; device::Integer = 0) where {Th<:Union{Float32,Float64}}
+    rate > 0.0 || error("rate must be greater than 0")
+    f = FIRFilter{FIRArbitrary}(copy(h), nothing, Float64(rate), Nphi, device, C_NULL, nothing, 0)
+    finalizer(destroy!, f)
+end
+
+function destroy!(f::FIRFilter)
+    f.handle == C_NULL || ccall((:mrhip_destroy, libmr), Cvoid, (Ptr{Cvoid},), f.handle)
+    f.handle = C_NULL
+    nothing
+end
+
+function bind!(f::FIRFilter, ::Type{Tx}, nch::Integer) where {Tx}
+    if f.handle != C_NULL
+        (f.Tx === Tx && f.nchannels == nch) || error("filter is bound to $(f.nchannels) channel(s) of $(f.Tx)")
+        return f
+    end
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    Th = eltype(f.h)
+    if f.ratio === nothing
+        check(ccall((:mrhip_create_arbitrary, libmr), Cint,
+                    (Ptr{Cvoid}, Int64, Cint, Cdouble, Int64, Cint, Int64, Cint, Ptr{Ptr{Cvoid}}),
+                    f.h, length(f.h), dtypecode(Th), f.rate, f.Nphi, dtypecode(Tx), nch, f.device, out))
+    else
+        check(ccall((:mrhip_create_rational, libmr), Cint,
+                    (Ptr{Cvoid}, Int64, Cint, Int64, Int64, Cint, Int64, Cint, Ptr{Ptr{Cvoid}}),
+                    f.h, length(f.h), dtypecode(Th), numerator(f.ratio), denominator(f.ratio), dtypecode(Tx), nch,
+                    f.device, out))
+    end
+    f.handle, f.Tx, f.nchannels = out[], Tx, nch
+    f
+end
+
+function state(f::FIRFilter)
+    st = Ref{MRHIPState}()
+    check(ccall((:mrhip_get_state, libmr), Cint, (Ptr{Cvoid}, Ptr{MRHIPState}), f.handle, st))
+    st[]
+end
+
+# ---- bookkeeping ---------------------------------------------------------------------------------
+# taps2pfb(h, Nphi)                                        src/Filters.jl:284-298
+function taps2pfb(h::Vector{T}, Nphi::Integer) where {T<:Union{Float32,Float64}}
+    t = ccall((:mrhip_taps2pfb, libmr), Int64, (Ptr{Cvoid}, Int64, Cint, Int64, Ptr{Cvoid}), h, length(h), dtypecode(T), Nphi, C_NULL)
+    pfb = Matrix{T}(undef, t, Nphi)                       # column-major tapsPerPhi x Nphi, as the reference's
+    ccall((:mrhip_taps2pfb, libmr), Int64, (Ptr{Cvoid}, Int64, Cint, Int64, Ptr{Cvoid}), h, length(h), dtypecode(T), Nphi, pfb)
+    pfb
+end
+# nextphase(currentphase, ratio)                           src/Filters.jl:433-439
+nextphase(p::Integer, ratio::Rational) =
+    Int(ccall((:mrhip_nextphase, libmr), Int64, (Int64, Int64, Int64), p, numerator(ratio), denominator(ratio)))
+# outputlength / inputlength                               src/Filters.jl:352-422
+outputlength(f::FIRFilter, n::Integer) = Int(ccall((:mrhip_outputlength, libmr), Int64, (Ptr{Cvoid}, Int64), f.handle, n))
+inputlength(f::FIRFilter, n::Integer) = Int(ccall((:mrhip_inputlength, libmr), Int64, (Ptr{Cvoid}, Int64), f.handle, n))
+nextoutputcount(f::FIRFilter, n::Integer) = Int(ccall((:mrhip_next_output_count, libmr), Int64, (Ptr{Cvoid}, Int64), f.handle, n))
+# reset(self::FIRFilter)                                   src/Filters.jl:256-260
+function reset(f::FIRFilter)
+    f.handle == C_NULL || check(ccall((:mrhip_reset, libmr), Cint, (Ptr{Cvoid},), f.handle))
+    f
+end
+
+# ---- the hot path --------------------------------------------------------------------------------
+promote_out(::Type{Th}, ::Type{Tx}) where {Th,Tx} = promote_type(Th, Tx)   # Filters.jl:476,522,581,636,746
+
+# filt!(buffer, self, x): one channel (Vector) or one channel per column (Matrix), host memory.
+# Returns `buffer` for FIRStandard / FIRInterpolator (:472,:516) and the number of samples written for
+# FIRRational / FIRDecimator / FIRArbitrary (:574,:630,:741), exactly like the reference.
+function filt!(buffer::VecOrMat{Tb}, f::FIRFilter{Tk}, x::VecOrMat{Tx}) where {Tb,Tk,Tx}
+    nch = size(x, 2)
+    bind!(f, Tx, nch)
+    Tb === promote_out(eltype(f.h), Tx) || error("buffer eltype must be $(promote_out(eltype(f.h), Tx))")
+    nw = Ref{Int64}(0)
+    check(ccall((:mrhip_filt_host, libmr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}),
+                f.handle, x, size(x, 1), size(x, 1), buffer, size(buffer, 1), size(buffer, 1), nw))
+    (Tk === FIRStandard || Tk === FIRInterpolator) ? buffer : Int(nw[])
+end
+
+# filt(self, x): allocate, filt!, trim to the samples written (src/Filters.jl:475,519,577,633,744)
+function filt(f::FIRFilter, x::VecOrMat{Tx}) where {Tx}
+    bind!(f, Tx, size(x, 2))
+    n = max(nextoutputcount(f, size(x, 1)), 0)
+    Tb = promote_out(eltype(f.h), Tx)
+    buffer = x isa Vector ? Vector{Tb}(undef, n) : Matrix{Tb}(undef, n, size(x, 2))
+    size(x, 1) == 0 || filt!(buffer, f, x)
+    buffer
+end
+
+# stateless forms, src/Filters.jl:858-867
+filt(h::Vector, x::VecOrMat, ratio::Rational = 1//1) = filt(FIRFilter(h, ratio), x)
+filt(h::Vector, x::VecOrMat, rate::AbstractFloat, Nphi::Integer = 32) = filt(FIRFilter(h, rate, Nphi), x)
+
+# Device-resident data (e.g. AMDGPU.jl ROCArray): pass raw device pointers and a HIP stream.
+# x and y are (n x nchannels) column-major on the filter's device; returns the per-channel output count.
+function filt_device!(f::FIRFilter, yptr::Ptr{Cvoid}, ycap::Integer, ystride::Integer, xptr::Ptr{Cvoid}, xlen::Integer,
+                      xstride::Integer, ::Type{Tx}, nch::Integer; stream::Ptr{Cvoid} = C_NULL) where {Tx}
+    bind!(f, Tx, nch)
+    nw = Ref{Int64}(0)
+    check(ccall((:mrhip_filt_device, libmr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Cvoid}),
+                f.handle, xptr, xlen, xstride, yptr, ycap, ystride, nw, stream))
+    Int(nw[])
+end
+
+end # module
