@@ -115,11 +115,17 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
                        const char **kname)
 {
     if (!f->force_generic) {
+        if (a.L == 1) {
+            DirectArgs da;
+            size_t lds = 0;
+            if (plan_fir_direct(tk, a, f->num_cus, &da, &lds))
+                return launch_fir_direct(tk, fused, a, da, lds, s, kname, f->num_cus);
+        }
         {
             PairArgs pa;
             dim3 block;
             size_t lds = 0;
-            if (plan_rational_pair(tk, a, &pa, &block, &lds))
+            if (plan_rational_pair(tk, a, f->num_cus, &pa, &block, &lds))
                 return launch_rational_pair(fused, a, pa, block, lds, s, kname, f->num_cus);
         }
         TileArgs ta;
@@ -459,7 +465,14 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H); a.Nphi = static_cast<int>(f->Nphi);
             a.nch = static_cast<int>(f->nch);
             if (int rc = timing_mark(f, stream)) return rc;
-            MRHIP_CHECK_HIP(launch_arb_generic(tk, fused, a, stream, &f->last_kernel));
+            {
+                ArbTileArgs ta;
+                size_t lds = 0;
+                if (!f->force_generic && plan_arb_tiled(tk, a, f->sched_n.data(), f->num_cus, &ta, &lds))
+                    MRHIP_CHECK_HIP(launch_arb_tiled(tk, fused, a, ta, lds, stream, &f->last_kernel, f->num_cus));
+                else
+                    MRHIP_CHECK_HIP(launch_arb_generic(tk, fused, a, stream, &f->last_kernel));
+            }
             if (int rc = timing_mark(f, stream)) return rc;
         }
         // commit the post-call state (Filters.jl:731-735)

@@ -1,0 +1,208 @@
+// kernels_arbitrary.hip -- tuned gfx950 kernel for FIRArbitrary (src/Filters.jl:693-742).
+//
+// Per output k the host-evaluated phase recurrence (src/Filters.jl:663-673) supplies the input index
+// n_k and the accumulator value acc_k; phi = floor(acc), alpha = acc - phi.  The output is
+//     y = dot(pfb[:,phi], window) + dot(dpfb[:,phi], window) * alpha        (:724-730)
+// with the combine done in Float64 and rounded once to the output type.
+//
+// A persistent workgroup keeps both polyphase banks in LDS (column pitch T+1 elements, so lanes with
+// different phases land on different banks) and, per tile of consecutive outputs of one channel,
+// stages the contiguous run of input samples those outputs touch.  One lane = one output; the sample
+// is read once per tap and feeds both dot products.
+//
+// Arithmetic: identical to arb_generic_kernel (STRICT / FUSED) => bit-identical results.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "mrhip_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace mrhip {
+namespace {
+
+constexpr int kArbThreads = 256;
+
+template <typename R, bool FUSED>
+__device__ __forceinline__ R mac(R t, R x, R acc)
+{
+    if constexpr (FUSED) {
+        if constexpr (sizeof(R) == 4) return __builtin_fmaf(t, x, acc);
+        else return __builtin_fma(t, x, acc);
+    } else {
+        R p = t * x;
+        return acc + p;
+    }
+}
+
+template <typename TX, typename R, int NC, bool FUSED>
+__global__ __launch_bounds__(kArbThreads) void arb_tiled_kernel(ArbArgs a, ArbTileArgs ta)
+{
+    struct alignas(sizeof(TX) * NC) Sample { TX c[NC]; };
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R *const lpfb = reinterpret_cast<R *>(smem);
+    R *const ldpfb = lpfb + ta.bank_elems;
+    Sample *const lx = reinterpret_cast<Sample *>(smem + ta.x_offset_bytes);
+
+    const int tid = threadIdx.x;
+    const int T = a.T, TP = ta.tap_pitch;
+    // both tap banks -> LDS once per workgroup: element (phi, i) at phi*TP + i
+    {
+        const R *__restrict__ g0 = static_cast<const R *>(a.taps);
+        const R *__restrict__ g1 = static_cast<const R *>(a.dtaps);
+        const int total = a.Nphi * T;
+        for (int e = tid; e < total; e += kArbThreads) {
+            const int phi = e / T, i = e - phi * T;
+            lpfb[phi * TP + i] = g0[e];
+            ldpfb[phi * TP + i] = g1[e];
+        }
+    }
+
+    for (long long tile = blockIdx.x; tile < ta.total_tiles; tile += gridDim.x) {
+        const int ch = static_cast<int>(tile / ta.tiles_per_channel);
+        const long long tau = tile - static_cast<long long>(ch) * ta.tiles_per_channel;
+        const long long k0 = tau * ta.tile_out;
+        const long long klast = (k0 + ta.tile_out < a.n_out ? k0 + ta.tile_out : a.n_out) - 1;
+        const Sample *__restrict__ xc = static_cast<const Sample *>(a.x) + static_cast<long long>(ch) * a.x_stride;
+        const Sample *__restrict__ hc = static_cast<const Sample *>(a.hist) + static_cast<long long>(ch) * a.H;
+        R *__restrict__ yc = static_cast<R *>(a.y) + static_cast<long long>(ch) * a.y_stride * NC;
+        // samples this tile touches: x[n_lo - T .. n_hi - 1] (0-based), n = 1-based newest-sample index
+        const long long n_lo = a.n_idx[k0], n_hi = a.n_idx[klast];
+        const long long o = n_lo - T;
+        const int span = static_cast<int>(n_hi - n_lo) + T;
+
+        __syncthreads();   // previous tile's reads are done (and, first time, the tap banks are written)
+        for (int s = tid; s < span; s += kArbThreads) {
+            const long long gi = o + s;
+            Sample v;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v.c[c] = static_cast<TX>(0);
+            if (gi >= 0) { if (gi < a.x_len) v = xc[gi]; }
+            else if (gi >= -static_cast<long long>(a.H)) v = hc[a.H + gi];
+            lx[s] = v;
+        }
+        __syncthreads();
+
+        for (long long k = k0 + tid; k <= klast; k += kArbThreads) {
+            const long long n = a.n_idx[k];
+            const double pacc = a.acc[k];
+            const double phif = __builtin_floor(pacc);
+            const double alpha = pacc - phif;               // src/Filters.jl:671-672
+            const int phi = static_cast<int>(phif) - 1;     // 0-based column
+            const R *tp = lpfb + phi * TP;
+            const R *dp = ldpfb + phi * TP;
+            const Sample *wp = lx + (n - n_lo);             // oldest sample of this output's window
+            R lo[NC], up[NC];
+            {
+                const Sample v = wp[0];
+                const R t = tp[0], d = dp[0];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { lo[c] = t * static_cast<R>(v.c[c]); up[c] = d * static_cast<R>(v.c[c]); }
+            }
+#pragma unroll 8
+            for (int i = 1; i < T; ++i) {
+                const Sample v = wp[i];
+                const R t = tp[i], d = dp[i];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    lo[c] = mac<R, FUSED>(t, static_cast<R>(v.c[c]), lo[c]);
+                    up[c] = mac<R, FUSED>(d, static_cast<R>(v.c[c]), up[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double prod = static_cast<double>(up[c]) * alpha;      // Filters.jl:730, Float64 combine
+                const double sum = static_cast<double>(lo[c]) + prod;
+                yc[k * NC + c] = static_cast<R>(sum);
+            }
+        }
+    }
+}
+
+template <typename TX, typename R, int NC>
+hipError_t launch_arb(bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s, int num_cus)
+{
+    auto go = [&](auto kfn) -> hipError_t {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+        }
+        int per_cu = 0;
+        hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kArbThreads, lds);
+        if (eo != hipSuccess) return eo;
+        if (per_cu < 1) per_cu = 1;
+        long long g = static_cast<long long>(num_cus) * per_cu;
+        if (g > ta.total_tiles) g = ta.total_tiles;
+        if (g < 1) g = 1;
+        static int dbg = -1;
+        if (dbg < 0) { const char *v = std::getenv("MRHIP_DEBUG"); dbg = (v && v[0] == '1') ? 1 : 0; }
+        if (dbg == 1) {
+            dbg = 0;
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kfn));
+            std::fprintf(stderr, "[mrhip] arb_tiled T=%d Nphi=%d grid=%lld lds=%zu occ/CU=%d regs=%d tile_out=%lld max_span=%d tiles=%lld\n",
+                         a.T, a.Nphi, g, lds, per_cu, fa.numRegs, ta.tile_out, ta.max_span, ta.total_tiles);
+        }
+        hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, ta);
+        return hipGetLastError();
+    };
+    return fused ? go(arb_tiled_kernel<TX, R, NC, true>) : go(arb_tiled_kernel<TX, R, NC, false>);
+}
+
+}  // namespace
+
+// `n_idx_host` is the host copy of the per-output input indices (non-decreasing).  Returns false when
+// the tap banks plus a useful sample tile do not fit LDS (caller uses the generic kernel).
+bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_host, int num_cus, ArbTileArgs *out, size_t *lds)
+{
+    static const int enabled = [] { const char *v = std::getenv("MRHIP_ARB_TILED"); return !(v && v[0] == '0'); }();
+    if (!enabled || a.n_out < 1) return false;
+    const size_t rs = tk.r_f64 ? 8 : 4;
+    const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
+    const int TP = a.T + 1;
+    const size_t bank_elems = static_cast<size_t>(a.Nphi) * TP;
+    const size_t banks_bytes = (2 * bank_elems * rs + 15) / 16 * 16;
+    if (banks_bytes > 96 * 1024) return false;
+    // tile: a multiple of 256 outputs whose sample span fits the remaining budget
+    long long tile_out = 1024;
+    const long long want_tiles = 4LL * num_cus;
+    while (tile_out > 256 && ((a.n_out + tile_out - 1) / tile_out) * a.nch < want_tiles) tile_out /= 2;
+    for (;;) {
+        long long max_span = 0;
+        for (long long k0 = 0; k0 < a.n_out; k0 += tile_out) {
+            const long long kl = std::min<long long>(k0 + tile_out, a.n_out) - 1;
+            max_span = std::max<long long>(max_span, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0] + a.T);
+        }
+        const size_t total = banks_bytes + static_cast<size_t>(max_span) * sb;
+        if (total <= 64 * 1024 || tile_out == 256) {
+            if (total > 150 * 1024) return false;
+            ArbTileArgs ta{};
+            ta.tap_pitch = TP;
+            ta.bank_elems = static_cast<int>(bank_elems);
+            ta.x_offset_bytes = static_cast<int>(banks_bytes);
+            ta.max_span = static_cast<int>(max_span);
+            ta.tile_out = tile_out;
+            ta.tiles_per_channel = (a.n_out + tile_out - 1) / tile_out;
+            ta.total_tiles = ta.tiles_per_channel * a.nch;
+            *out = ta;
+            *lds = total;
+            return true;
+        }
+        tile_out /= 2;
+    }
+}
+
+hipError_t launch_arb_tiled(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
+                            const char **kname, int num_cus)
+{
+    *kname = "arb_tiled_kernel";
+    if (!tk.x_f64 && !tk.r_f64) return tk.complex_x ? launch_arb<float, float, 2>(fused, a, ta, lds, s, num_cus) : launch_arb<float, float, 1>(fused, a, ta, lds, s, num_cus);
+    if (!tk.x_f64 && tk.r_f64) return tk.complex_x ? launch_arb<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_arb<float, double, 1>(fused, a, ta, lds, s, num_cus);
+    if (tk.x_f64 && tk.r_f64) return tk.complex_x ? launch_arb<double, double, 2>(fused, a, ta, lds, s, num_cus) : launch_arb<double, double, 1>(fused, a, ta, lds, s, num_cus);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mrhip

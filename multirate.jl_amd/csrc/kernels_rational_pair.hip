@@ -343,7 +343,7 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
 
 // Covers: Float32 samples and taps (R = Float32), M > L with L/M >= 0.7, tapsPerPhi <= 32, no zero-start
 // quirk (i.e. a pfb kernel: FIRRational).  Returns false otherwise (caller tries the next kernel).
-bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, PairArgs *out, dim3 *block, size_t *lds)
+bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {
     static const int enabled = pair_env_int("MRHIP_PAIR", 1);
     if (!enabled) return false;
@@ -384,6 +384,12 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, PairArgs *out, dim
         J = 1;
     }
     if (J > 64) J = 64;
+    // small problems (few channels, short calls): shrink the tile until there are enough tiles to give
+    // every CU a few workgroups -- a launch that occupies a third of the chip is latency-bound
+    if (env_r <= 0) {
+        const long long want_tiles = 4LL * num_cus;
+        while (J > 2 && ((a.n_out + J * c * a.L - 1) / (J * c * a.L)) * a.nch < want_tiles) J = (J + 1) / 2;
+    }
     long long tile_len = J * cM + a.T + 2;
     tile_len = (tile_len + 3) / 4 * 4;
     const long long nslots = (tile_len / 4 + 63) / 64;

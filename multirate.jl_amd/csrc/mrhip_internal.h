@@ -145,6 +145,24 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     long long total_tiles;
 };
 
+struct DirectArgs {          // tiling of the single-column kernel (kernels_fir_direct.hip)
+    int J;                   // steps of 256 outputs per tile
+    int tile_len;            // samples staged per tile
+    int row_pitch;           // samples per residue row of the transposed LDS tile
+    long long tiles_per_channel;
+    long long total_tiles;
+};
+
+struct ArbTileArgs {         // tiling of the FIRArbitrary kernel (kernels_arbitrary.hip)
+    int tap_pitch;           // elements between PFB columns in LDS (T + 1)
+    int bank_elems;          // elements per tap bank in LDS
+    int x_offset_bytes;      // byte offset of the sample tile in LDS
+    int max_span;            // samples the largest tile touches
+    long long tile_out;      // outputs per tile
+    long long tiles_per_channel;
+    long long total_tiles;
+};
+
 // dtype combination a kernel is instantiated for
 struct TypeKey {
     bool x_f64;      // Tx scalar is double
@@ -159,9 +177,15 @@ struct TypeKey {
 hipError_t launch_poly_generic(const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
-bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, PairArgs *out, dim3 *block, size_t *lds);
+bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                                 const char **kname, int num_cus);
+bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectArgs *out, size_t *lds);
+hipError_t launch_fir_direct(const TypeKey &tk, bool fused, const PolyArgs &a, const DirectArgs &da, size_t lds, hipStream_t s,
+                             const char **kname, int num_cus);
+bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_host, int num_cus, ArbTileArgs *out, size_t *lds);
+hipError_t launch_arb_tiled(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
+                            const char **kname, int num_cus);
 bool plan_phase_stationary(const TypeKey &tk, const PolyArgs &a, int num_cus, TileArgs *out, dim3 *grid, dim3 *block,
                            size_t *lds);
 hipError_t launch_poly_phase_stationary(const TypeKey &tk, bool fused, const PolyArgs &a, const TileArgs &ta, dim3 grid,

@@ -294,7 +294,8 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
              (7, 5, 100, np.float64, np.float32), (160, 147, 1000, np.float64, np.complex128),
              (1, 3, 31, np.float32, np.float32), (1, 1, 17, np.float32, np.float64), (5, 2, 160, np.float32, np.float32),
              (9, 10, 200, np.float32, np.float32), (31, 32, 31 * 7, np.float32, np.float32), (5, 7, 33, np.float32, np.float32),
-             (146, 147, 146 * 32, np.float32, np.float32)]
+             (146, 147, 146 * 32, np.float32, np.float32), (1, 4, 128, np.float32, np.complex64), (1, 1, 300, np.float64, np.float64),
+             (1, 7, 129, np.float64, np.complex128), (1, 32, 1, np.float32, np.float32), (1, 5, 64, np.float64, np.float32)]
     tuned_seen = set()
     for (L, M, hl, th, tx) in cases:
         h = rng.standard_normal(hl).astype(th)
@@ -304,7 +305,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, Fraction(L, M))
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_pair_kernel"), (L, M, hl)
+        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_pair_kernel", "fir_direct_kernel"), (L, M, hl)
         tuned_seen.add(f.last_kernel_name())
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, Fraction(L, M))
@@ -313,4 +314,26 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         assert_bit_equal(y_t, y_g, f"tuned vs generic L={L} M={M} hLen={hl} {th} {tx}")
         assert_bit_equal(f.history, g.history, "history")
-    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_pair_kernel"}, tuned_seen
+    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_pair_kernel", "fir_direct_kernel"}, tuned_seen
+
+
+def test_arbitrary_tuned_and_generic_agree(pkg, torch_cuda, monkeypatch):
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    for (Nphi, T, rate, th, tx) in [(32, 32, math.pi / 3, np.float64, np.float64), (32, 10, 0.37, np.float32, np.complex64),
+                                    (8, 5, 2.7, np.float32, np.float32), (48, 17, 0.9991, np.float64, np.complex128),
+                                    (32, 24, 1.0, np.float64, np.float32)]:
+        h = (pkg.firdes(T * Nphi, 0.45 / Nphi, beta=7.0) * Nphi).astype(th)
+        x = _rand(rng, (3, 40_000), tx) - 0.5
+        xd = torch.from_numpy(x).cuda()
+        sizes = [15_000, 2, 24_998]
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        f = pkg.FIRFilter(h, float(rate), Nphi)
+        y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+        assert f.last_kernel_name() == "arb_tiled_kernel"
+        monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+        g = pkg.FIRFilter(h, float(rate), Nphi)
+        y_g = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
+        assert g.last_kernel_name() == "arb_generic_kernel"
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        assert_bit_equal(y_t, y_g, f"arb tuned vs generic Nphi={Nphi} T={T} rate={rate} {th} {tx}")
