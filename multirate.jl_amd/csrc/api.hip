@@ -284,13 +284,26 @@ int64_t mrhip_outputlength(const mrhip_filter *f, int64_t n)
     return -1;
 }
 
+// FIRArbitrary: evaluate (or reuse) the phase schedule for a call of x_len samples from the current state
+static int64_t arb_schedule(mrhip_filter *f, int64_t x_len, ArbState *end_state)
+{
+    if (!(f->sched_cached && f->sched_xlen == x_len && f->sched_acc0 == f->phiAcc && f->sched_deficit0 == f->inputDeficit)) {
+        if (f->sched_in_flight) { (void)hipEventSynchronize(f->sched_copied); f->sched_in_flight = false; }
+        ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
+        f->sched_acc0 = f->phiAcc; f->sched_deficit0 = f->inputDeficit; f->sched_xlen = x_len;
+        f->sched_count = run_arbitrary_schedule(st, f->delta, f->Nphi, x_len, &f->sched_n, &f->sched_acc);
+        f->sched_end = st;
+        f->sched_cached = true;
+    }
+    if (end_state) *end_state = f->sched_end;
+    return f->sched_count;
+}
+
 int64_t mrhip_next_output_count(const mrhip_filter *f, int64_t n)
 {
     if (!f || n < 0) return -1;
-    if (f->kind == MRHIP_FIR_ARBITRARY) {
-        ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
-        return run_arbitrary_schedule(st, f->delta, f->Nphi, n, nullptr, nullptr);
-    }
+    if (f->kind == MRHIP_FIR_ARBITRARY)   // the schedule is cached for the filt call that normally follows
+        return arb_schedule(const_cast<mrhip_filter *>(f), n, nullptr);
     return plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, n).n_out;
 }
 
@@ -444,9 +457,9 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
 
     int64_t n_out = 0;
     if (f->kind == MRHIP_FIR_ARBITRARY) {
-        ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
+        ArbState st;
+        n_out = arb_schedule(f, x_len, &st);
         if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
-        n_out = run_arbitrary_schedule(st, f->delta, f->Nphi, x_len, &f->sched_n, &f->sched_acc);
         if (n_out > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
         if (n_out > 0) {
             if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
@@ -478,6 +491,7 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
         // commit the post-call state (Filters.jl:731-735)
         f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;
         f->inputDeficit = st.inputDeficit;
+        f->sched_cached = false;
     } else {
         const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len);
         n_out = p.n_out;

@@ -99,11 +99,18 @@ int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t
         return 0;
     }
     const double N = static_cast<double>(Nphi);
+    const bool n_pow2 = (Nphi & (Nphi - 1)) == 0;
+    const double invN = 1.0 / N;               // exact when Nphi is a power of two
     double acc = st.acc;
     int64_t xIdx = st.inputDeficit;        // :715
     int64_t count = 0;
     if (n_idx) n_idx->clear();
     if (acc_out) acc_out->clear();
+    {   // one allocation up front: about (xLen - deficit + 1) * rate outputs (rate = Nphi / delta)
+        const double est = static_cast<double>(xLen - xIdx + 1) * (N / delta) + 16.0;
+        if (n_idx && est < 4e9) n_idx->reserve(static_cast<size_t>(est));
+        if (acc_out && est < 4e9) acc_out->reserve(static_cast<size_t>(est));
+    }
     while (xIdx <= xLen) {                 // :717
         if (n_idx) n_idx->push_back(static_cast<int32_t>(xIdx));
         if (acc_out) acc_out->push_back(acc);
@@ -111,8 +118,17 @@ int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t
         acc += delta;                      // update(), :664
         if (acc > N) {                     // :666-669
             const double am1 = acc - 1.0;
-            xIdx += static_cast<int64_t>(std::floor(am1 / N));
-            acc = std::fmod(am1, N) + 1.0;
+            // xIdx += ifloor(am1 / N): the reference rounds the quotient before flooring; a power-of-two
+            // N makes the division an exact scaling, otherwise a true division is kept for fidelity
+            const double qd = n_pow2 ? am1 * invN : am1 / N;
+            xIdx += static_cast<int64_t>(std::floor(qd));
+            // acc = mod(am1, N) + 1: for positive operands the remainder is exact; am1 - k*N by repeated
+            // subtraction is exact at every step (the difference of a multiple of ulp(am1) and an integer
+            // that is no larger than am1) and is the same number fmod returns, at a fraction of its cost
+            double r = am1;
+            if (am1 < 4.0 * N) { while (r >= N) r -= N; }
+            else r = std::fmod(am1, N);        // very low rates: many periods per step
+            acc = r + 1.0;
         }
     }
     st.acc = acc;

@@ -221,6 +221,13 @@ struct mrhip_filter {
     // FIRArbitrary schedule staging
     std::vector<int32_t> sched_n;
     std::vector<double> sched_acc;
+    // schedule cache: valid when computed from exactly this (state, x_len); lets next_output_count and
+    // the filt call that follows share one evaluation of the serial recurrence
+    bool sched_cached = false;
+    int64_t sched_xlen = -1, sched_count = 0;
+    double sched_acc0 = 0.0;
+    int64_t sched_deficit0 = 0;
+    mrhip::ArbState sched_end;
     void *pin_n = nullptr, *pin_acc = nullptr;   // pinned host
     size_t pin_cap = 0;
     void *d_sched_n = nullptr, *d_sched_acc = nullptr;
