@@ -219,10 +219,22 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
 #pragma unroll
         for (int i = 0; i < T; ++i) taps[s][i] = tp[i];
     }
-    // both positions produce an output => the outputs are consecutive (t, t+1): one 8-byte store
-    const bool both = act[0] && act[1];
-    const unsigned t_first = static_cast<unsigned>(act[0] ? t_out[0] : t_out[1]);
-    const bool any = act[0] || act[1];
+    // Output staging.  A wave's 128 positions produce one contiguous run of outputs [t_lo, t_hi) of the
+    // step (about 128*L/M of them), scattered over its lanes' two accumulators with gaps where a position
+    // has no output.  The lanes drop their results into a 512-byte LDS strip at (t - t_lo) and read the
+    // strip back two per lane, so every step ends in ONE dense 8-byte-per-lane store instead of an
+    // 8-byte store with holes plus a 4-byte store for the odd ones (half the write requests to L2).
+    auto first_output_at = [&](long long p) -> long long {   // first output whose position is >= p
+        const long long num = p * a.L - a.u0;
+        return num <= 0 ? 0 : (num + a.M - 1) / a.M;
+    };
+    const long long t_lo_ll = first_output_at(128LL * wave);
+    const long long t_hi_ll = first_output_at(128LL * (wave + 1));
+    const unsigned t_lo = static_cast<unsigned>(t_lo_ll < pa.P ? t_lo_ll : pa.P);
+    const unsigned n_w = static_cast<unsigned>((t_hi_ll < pa.P ? t_hi_ll : pa.P)) - t_lo;   // outputs of this wave per step
+    float *const strip = reinterpret_cast<float *>(smem + 3 * static_cast<size_t>(pa.stage_bytes) + static_cast<size_t>(wave) * 512);
+    const unsigned sidx0 = static_cast<unsigned>(t_out[0]) - t_lo, sidx1 = static_cast<unsigned>(t_out[1]) - t_lo;
+    const unsigned my_pair = 2u * static_cast<unsigned>(lane);               // outputs my_pair, my_pair+1 of the strip
     const unsigned lane_win = static_cast<unsigned>(tid) * 8u;           // byte offset of sample 2*tid inside a stage
 
     int s = 0;
@@ -269,20 +281,22 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
                     if constexpr (2 * r < T) { if constexpr (r == 0) acc1 = taps[1][0] * whi; else acc1 = macf<FUSED>(taps[1][2 * r], whi, acc1); }
                 });
                 // byte offsets from the (wave-uniform) tile base stay 32-bit: scalar base + VGPR offset stores
-                const unsigned kj = static_cast<unsigned>(j) * static_cast<unsigned>(pa.P);
+                const unsigned kj = static_cast<unsigned>(j) * static_cast<unsigned>(pa.P) + t_lo;
                 char *const ybytes = reinterpret_cast<char *>(yc);
                 if (pa.ablate & 2) {   // timing experiments only: keep the arithmetic live, drop the stores
-                    if (acc0 == 1.2345e30f || acc1 == 1.2345e30f) *reinterpret_cast<float *>(ybytes + (kj + t_first) * 4u) = acc0 + acc1;
-                } else if (FULL || static_cast<long long>(kj) + t_first + (both ? 1 : 0) < remaining) {
-                    if (both) {
-                        const float pair[2] = {acc0, acc1};
-                        __builtin_memcpy(ybytes + (kj + t_first) * 4u, pair, 8);     // 4-byte aligned 8-byte store
-                    } else if (any) {
-                        *reinterpret_cast<float *>(ybytes + (kj + t_first) * 4u) = act[0] ? acc0 : acc1;
-                    }
+                    if (acc0 == 1.2345e30f || acc1 == 1.2345e30f) *reinterpret_cast<float *>(ybytes + (kj + my_pair) * 4u) = acc0 + acc1;
                 } else {
-                    if (act[0] && static_cast<long long>(kj) + t_out[0] < remaining) *reinterpret_cast<float *>(ybytes + (kj + t_out[0]) * 4u) = acc0;
-                    if (act[1] && static_cast<long long>(kj) + t_out[1] < remaining) *reinterpret_cast<float *>(ybytes + (kj + t_out[1]) * 4u) = acc1;
+                    if (act[0]) strip[sidx0] = acc0;
+                    if (act[1]) strip[sidx1] = acc1;
+                    const float2 v = reinterpret_cast<const float2 *>(strip)[lane];   // same wave: LDS ops are in order
+                    const unsigned lim = FULL ? n_w
+                                              : static_cast<unsigned>(remaining - kj > static_cast<long long>(n_w) ? n_w
+                                                                      : (remaining > static_cast<long long>(kj) ? remaining - kj : 0));
+                    if (my_pair + 1 < lim) {
+                        __builtin_memcpy(ybytes + (kj + my_pair) * 4u, &v, 8);        // 4-byte aligned 8-byte store
+                    } else if (my_pair < lim) {
+                        *reinterpret_cast<float *>(ybytes + (kj + my_pair) * 4u) = v.x;
+                    }
                 }
             }
         };
@@ -394,7 +408,7 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     tile_len = (tile_len + 3) / 4 * 4;
     const long long nslots = (tile_len / 4 + 63) / 64;
     const size_t stage_bytes = static_cast<size_t>(nslots) * 1024;
-    if (nslots > 32 || 3 * stage_bytes > 150 * 1024) return false;
+    if (nslots > 32 || 3 * stage_bytes + static_cast<size_t>(nwaves) * 512 > 150 * 1024) return false;
     const long long need_rounds = nslots;
     PairArgs pa{};
     pa.c = c; pa.P = static_cast<int>(static_cast<long long>(c) * a.L); pa.cM = static_cast<int>(cM);
@@ -411,7 +425,7 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     pa.total_tiles = pa.tiles_per_channel * a.nch;
     *out = pa;
     *block = dim3(static_cast<unsigned>(padded + 64));   // + the loader wave
-    *lds = 3 * stage_bytes;   // three pipeline stages
+    *lds = 3 * stage_bytes + static_cast<size_t>(nwaves) * 512;   // three pipeline stages + one output strip per compute wave
     return true;
 }
 

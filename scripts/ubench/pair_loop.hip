@@ -13,6 +13,9 @@ template <int N, typename V> __device__ __forceinline__ void lgkm_wait(V &r)
 { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N < 15 ? N : 15)); }
 
 constexpr int T = 24, NPR = 13;
+#ifndef TAPS_VGPR
+#define TAPS_VGPR 0
+#endif
 // MODE 0: strict mul+add two chains; 1: fused; 2: LDS only; 3: math only (strict); 4: strict, chains kept scalar via asm fence
 template <int MODE>
 __global__ __launch_bounds__(512) void k(float *out, const float *in, int steps, int cM)
@@ -24,7 +27,7 @@ __global__ __launch_bounds__(512) void k(float *out, const float *in, int steps,
     const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     float taps[2][T];
 #pragma unroll
-    for (int i = 0; i < T; ++i) { taps[0][i] = in[i]; taps[1][i] = in[32 + i]; }
+    for (int i = 0; i < T; ++i) { taps[0][i] = in[i + (TAPS_VGPR ? (threadIdx.x & 63) : 0)]; taps[1][i] = in[32 + i + (TAPS_VGPR ? (threadIdx.x & 63) : 0)]; }
     float sum = 0.f;
     const unsigned wbase = lds_base + threadIdx.x * 8u;
     for (int j = 0; j < steps; ++j) {
