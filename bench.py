@@ -149,7 +149,10 @@ def main():
         fo = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
         yo = fo.filt(x[nch - 1, :200_000].cpu().numpy())
         got = y[nch - 1, :len(yo)].cpu().numpy()
-        assert np.array_equal(got.view(np.uint32), yo.view(np.uint32)), "bench output differs from oracle"
+        if args.numerics == "strict":
+            assert np.array_equal(got.view(np.uint32), yo.view(np.uint32)), "bench output differs from oracle"
+        else:   # FUSED: one rounding per tap instead of two -- close to, not equal to, the strict oracle
+            assert np.allclose(got, yo, rtol=0, atol=24 * 2.0 ** -23 * float(np.abs(h).max()) * 24), "fused output far from oracle"
 
     total_in = float(nch) * n * args.steps * world
     ms_per_step = elapsed / args.steps * 1e3

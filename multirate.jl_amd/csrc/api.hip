@@ -112,8 +112,9 @@ int check_create_args(const void *h, int64_t hLen, int th, int tx, int64_t nch, 
 // Kernel selection for the rational family.  Tuned kernels are tried first; the universal
 // one-thread-per-output kernel accepts everything.
 hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s,
-                       const char **kname)
+                       const char **kname, bool *did_shiftin)
 {
+    *did_shiftin = false;
     if (!f->force_generic) {
         if (a.L == 1) {
             DirectArgs da;
@@ -125,8 +126,10 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
             PairArgs pa;
             dim3 block;
             size_t lds = 0;
-            if (plan_rational_pair(tk, a, f->num_cus, &pa, &block, &lds))
+            if (plan_rational_pair(tk, a, f->num_cus, &pa, &block, &lds)) {
+                *did_shiftin = a.H > 0;          // its loader waves write the call-end history themselves
                 return launch_rational_pair(fused, a, pa, block, lds, s, kname, f->num_cus);
+            }
         }
         TileArgs ta;
         dim3 grid, block;
@@ -456,6 +459,7 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
     if (x_len == 0) return MRHIP_OK;   // nothing to do: zero outputs, history and state unchanged
 
     int64_t n_out = 0;
+    bool did_shiftin = false;
     if (f->kind == MRHIP_FIR_ARBITRARY) {
         ArbState st;
         n_out = arb_schedule(f, x_len, &st);
@@ -501,7 +505,7 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
             if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
             PolyArgs a{};
-            a.x = x; a.y = y; a.hist = f->d_hist[f->hist_cur]; a.taps = f->d_taps;
+            a.x = x; a.y = y; a.hist = f->d_hist[f->hist_cur]; a.hist_new = f->d_hist[f->hist_cur ^ 1]; a.taps = f->d_taps;
             a.x_stride = x_stride; a.y_stride = y_stride; a.x_len = x_len; a.n_out = n_out;
             a.u0 = p.phi0 - 1; a.d0 = p.d0;
             a.zero_start_below = f->kind == MRHIP_FIR_STANDARD ? f->hLen + 1
@@ -510,7 +514,7 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H);
             a.nch = static_cast<int>(f->nch);
             if (int rc = timing_mark(f, stream)) return rc;
-            MRHIP_CHECK_HIP(launch_poly(f, tk, fused, a, stream, &f->last_kernel));
+            MRHIP_CHECK_HIP(launch_poly(f, tk, fused, a, stream, &f->last_kernel, &did_shiftin));
             if (int rc = timing_mark(f, stream)) return rc;
         }
         f->phiIdx = p.phi_end;
@@ -518,7 +522,9 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
     }
 
     // history <- last H samples of [history ; x]   (shiftin!, support.jl:61-80), ping-pong buffers
-    if (f->H > 0) {
+    if (f->H > 0 && did_shiftin) {
+        f->hist_cur ^= 1;
+    } else if (f->H > 0) {
         HistArgs ha{};
         ha.x = x; ha.hist_old = f->d_hist[f->hist_cur]; ha.hist_new = f->d_hist[f->hist_cur ^ 1];
         ha.x_stride = x_stride; ha.x_len = x_len; ha.H = static_cast<int>(f->H); ha.nch = static_cast<int>(f->nch);

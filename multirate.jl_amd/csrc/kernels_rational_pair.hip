@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "mrhip_internal.h"
 
@@ -69,10 +70,30 @@ __device__ __forceinline__ v2u_t lds_read_b64(unsigned byte_addr)
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
     return v;
 }
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+// two aligned pairs (pair P0 and P0+1 of the window at byte_addr) in one LDS instruction
+template <int P0>
+__device__ __forceinline__ v4u_t lds_read2_b64(unsigned byte_addr)
+{
+    v4u_t v;
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(byte_addr), "n"(P0), "n"(P0 + 1));
+    return v;
+}
 template <int N, typename V>
 __device__ __forceinline__ void lgkm_wait(V &reg)
 {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(N < 15 ? N : 15));
+}
+
+__device__ __forceinline__ unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+template <typename V>
+__device__ __forceinline__ void pin(V &reg)   // orders every later use of reg after the preceding volatile asm
+{
+    asm volatile("" : "+v"(reg));
+}
+__device__ __forceinline__ void lds_write_b32(unsigned byte_addr, float v)
+{
+    asm volatile("ds_write_b32 %0, %1" ::"v"(byte_addr), "v"(v));
 }
 
 __device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
@@ -89,7 +110,10 @@ __device__ __forceinline__ void wait_vmcnt_le(int n)
         MRHIP_W(0) MRHIP_W(1) MRHIP_W(2) MRHIP_W(3) MRHIP_W(4) MRHIP_W(5) MRHIP_W(6) MRHIP_W(7) MRHIP_W(8) MRHIP_W(9)
         MRHIP_W(10) MRHIP_W(11) MRHIP_W(12) MRHIP_W(13) MRHIP_W(14) MRHIP_W(15) MRHIP_W(16) MRHIP_W(17) MRHIP_W(18) MRHIP_W(19)
         MRHIP_W(20) MRHIP_W(21) MRHIP_W(22) MRHIP_W(23) MRHIP_W(24) MRHIP_W(25) MRHIP_W(26) MRHIP_W(27) MRHIP_W(28) MRHIP_W(29)
-        MRHIP_W(30) MRHIP_W(31) MRHIP_W(32)
+        MRHIP_W(30) MRHIP_W(31) MRHIP_W(32) MRHIP_W(33) MRHIP_W(34) MRHIP_W(35) MRHIP_W(36) MRHIP_W(37) MRHIP_W(38) MRHIP_W(39)
+        MRHIP_W(40) MRHIP_W(41) MRHIP_W(42) MRHIP_W(43) MRHIP_W(44) MRHIP_W(45) MRHIP_W(46) MRHIP_W(47) MRHIP_W(48) MRHIP_W(49)
+        MRHIP_W(50) MRHIP_W(51) MRHIP_W(52) MRHIP_W(53) MRHIP_W(54) MRHIP_W(55) MRHIP_W(56) MRHIP_W(57) MRHIP_W(58) MRHIP_W(59)
+        MRHIP_W(60)
 #undef MRHIP_W
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
@@ -102,6 +126,32 @@ __device__ __forceinline__ float macf(float t, float x, float acc)
     else { const float p = t * x; return acc + p; }
 }
 
+// ---- compile-time bookkeeping of the ring pipeline (see run_steps in the kernel) ----
+// virtual group p of a step issues a read iff p + K names a pair of this step (< NPR) or of the next one (>= NPRV)
+constexpr int ring_nprv(int npr, int k) { return (npr + k - 1) / k * k; }
+constexpr bool ring_issues(int p, int npr, int k) { return p + k < npr || p + k >= ring_nprv(npr, k); }
+constexpr int ring_reads_upto(int p_last, int npr, int k)      // reads issued at virtual groups 0..p_last
+{
+    int n = 0;
+    for (int p = 0; p <= p_last; ++p) n += ring_issues(p, npr, k) ? 1 : 0;
+    return n;
+}
+// LDS operations a wave issues between the read of pair v and "use v" (steady state; the first step of a tile,
+// whose pairs 0..K-1 come from the prologue, gives the same numbers), capped at 14
+constexpr int ring_younger(int v, int npr, int k)
+{
+    const int nprv = ring_nprv(npr, k);
+    int n = 0;
+    if (v >= k) {                                   // issued at virtual group v-k of the same step
+        for (int p = v - k + 1; p <= v - 1; ++p) n += ring_issues(p, npr, k) ? 1 : 0;
+    } else {                                        // issued at virtual group v + nprv - k of the previous step
+        for (int p = v + nprv - k + 1; p <= nprv - 1; ++p) n += ring_issues(p, npr, k) ? 1 : 0;
+        n += 3;                                     // W W S
+        for (int p = 0; p <= v - 1; ++p) n += ring_issues(p, npr, k) ? 1 : 0;
+    }
+    return n < 14 ? n : 14;
+}
+
 #ifdef MRHIP_PAIR_WPE   /* optional VGPR cap: waves per SIMD the register allocator must leave room for */
 #define MRHIP_PAIR_BOUNDS __launch_bounds__(kPairMaxThreads + 64, MRHIP_PAIR_WPE)
 #else
@@ -111,37 +161,46 @@ template <int T, bool FUSED>
 __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
 {
     constexpr int NPR = (T + 2) / 2;           // aligned 8-byte reads per lane per step: T+1 samples, rounded up
-#ifdef MRHIP_PAIR_TWO_BATCH
-    constexpr int NA = NPR > 8 ? (NPR + 1) / 2 : NPR;   // first read batch
-#else
-    constexpr int NA = NPR;                               // all reads up front
-#endif
-    constexpr int R1 = NA > 2 ? NA - 2 : NA;             // second batch is issued when pair R1 is about to be consumed
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave index as a scalar
     const int ncw = (blockDim.x >> 6) - 1;      // compute waves; the last wave of the workgroup is the loader
 
-    // ---- tile walk shared by both roles: tile -> (channel, tile-in-channel) without per-tile divisions
-    long long tile = blockIdx.x;
-    int ch = static_cast<int>(tile / pa.tiles_per_channel);
-    long long tau = tile - static_cast<long long>(ch) * pa.tiles_per_channel;
+    // ---- tile walk shared by both roles.  The launch is a sequence of STEPS (one period of c*M input positions
+    // each), numbered channel-major: g = channel * steps_per_channel + step.  Workgroup b owns the contiguous
+    // range [b*S, (b+1)*S) with S = ceil(total_steps / gridDim.x), so every workgroup does the same number of
+    // steps to within one (a round-robin split of whole tiles left 7 % of the grid idle for the last tile:
+    // MRHIP_PAIR_PROBE=1).  A range is cut into tiles of up to J steps that never cross a channel boundary;
+    // loader and compute waves derive the same tile sequence independently.
+    const unsigned spc = static_cast<unsigned>(pa.steps_per_channel);
+    const unsigned g_end = umin(pa.steps_per_wg * (blockIdx.x + 1u), pa.total_steps);
+    struct TileAt { int ch, st, jt; };                      // channel, first step within the channel, steps
+    auto tile_at = [&](unsigned g) -> TileAt {              // g < g_end; multiply-high by floor(2^32/spc) + fix-ups
+        unsigned q = __umulhi(g, pa.spc_magic);
+        unsigned r = g - q * spc;
+        if (r >= spc) { ++q; r -= spc; }
+        if (r >= spc) { ++q; r -= spc; }
+        const unsigned jt = umin(umin(static_cast<unsigned>(pa.J), spc - r), g_end - g);
+        return TileAt{static_cast<int>(q), static_cast<int>(r), static_cast<int>(jt)};
+    };
 
     if (wave == ncw) {
         // ================= loader wave: HBM -> LDS, one tile ahead of the compute waves =================
         // It is the only wave that waits on vmcnt, so the compute waves' output stores stay in flight
         // across tiles (their barrier carries no memory wait).
-        const int nchunks = pa.tile_len / 4;
-        const int nslots = (nchunks + 63) >> 6;          // 1 KiB LDS slots per stage
         // Stages one tile; returns the number of LDS-DMA operations it left in flight (0 for the
         // checked register path, which drains everything before returning).
-        auto stage_tile = [&](int sch, long long stau, int stage) -> int {
+        auto stage_tile = [&](const TileAt &ta, int stage) -> int {
+            const int sch = ta.ch;
+            const int tlen = (ta.jt * pa.cM + T + 2 + 3) & ~3;          // samples this tile needs, multiple of 4
+            const int nchunks = tlen / 4;
+            const int nslots = (nchunks + 63) >> 6;                     // 1 KiB LDS slots
             const float *__restrict__ xc = static_cast<const float *>(a.x) + static_cast<long long>(sch) * a.x_stride;
-            const long long o = pa.o0 + stau * pa.tile_in;                   // x index of LDS sample 0 (may be < 0)
+            const long long o = pa.o0 + static_cast<long long>(ta.st) * pa.cM;   // x index of LDS sample 0 (may be < 0)
             unsigned char *st = smem + static_cast<size_t>(stage) * pa.stage_bytes;
-            const bool interior = o >= 0 && o + pa.tile_len <= a.x_len;      // wave-uniform
+            const bool interior = o >= 0 && o + tlen <= a.x_len;             // wave-uniform
             if (interior) {
                 const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o);
                 for (int slot = 0; slot < nslots; ++slot) {
@@ -170,32 +229,54 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             return 0;
         };
-        auto advance = [&](long long &tl, int &c2, long long &ta2) {
-            tl += gridDim.x;
-            c2 += pa.grid_div;
-            ta2 += pa.grid_mod;
-            if (ta2 >= pa.tiles_per_channel) { ta2 -= pa.tiles_per_channel; ++c2; }
+        // pa.ns LDS stages, the DMA runs ns-1 tiles ahead: while the compute waves work on tile i the loader
+        // has tiles i+1 .. i+ns-2 landing and tile i+ns-1 being issued, so the HBM stream never pauses and a
+        // tile has ns-2 tile times to arrive (HBM latency under load is several microseconds; a tile is 1-2).
+        // `pg` walks ahead of `g`.  `hist` is a shift register of the LDS-DMA operation counts of the tiles
+        // issued so far (6 bits each, newest in the low bits): tile i+1 has landed once no more operations are
+        // outstanding than the ns-2 newest tiles own.
+        unsigned g = pa.steps_per_wg * blockIdx.x, pg = g;
+        unsigned long long hist = 0;
+        auto newest_ops = [&](int ntiles) -> int {
+            int n = 0;
+            for (int k = 0; k < ntiles; ++k) n += static_cast<int>((hist >> (6 * k)) & 63u);
+            return n < 60 ? n : 60;               // the counter itself holds at most 63
         };
-        // Three LDS stages, the DMA runs two tiles ahead: while the compute waves work on tile i the
-        // loader has tile i+1 landing and tile i+2 being issued, so the HBM stream never pauses.
-        // `ptile` walks two tiles ahead of `tile`.
-        long long ptile = tile;
-        int pch = ch;
-        long long ptau = tau;
-        int in_flight_newest = 0;
-        if (ptile < pa.total_tiles) { (void)stage_tile(pch, ptau, 0); advance(ptile, pch, ptau); }
-        if (ptile < pa.total_tiles && !(pa.ablate & 1)) { in_flight_newest = stage_tile(pch, ptau, 1); advance(ptile, pch, ptau); }
-        wait_vmcnt_le(in_flight_newest);          // tile 0 has landed (only tile 1's operations may remain)
-        int pstage = 2;
-        for (; tile < pa.total_tiles; tile += gridDim.x) {
-            if (!(pa.ablate & 4)) __builtin_amdgcn_s_barrier();   // tile `tile` is published; the stage of tile-1 is free again
-            in_flight_newest = 0;
-            if (ptile < pa.total_tiles && !(pa.ablate & 1)) {
-                in_flight_newest = stage_tile(pch, ptau, pstage);
-                advance(ptile, pch, ptau);
-                pstage = pstage == 2 ? 0 : pstage + 1;
+        int staged = 0;
+        for (; staged < pa.ns - 1 && pg < g_end; ++staged) {
+            if (staged > 0 && (pa.ablate & 1)) break;
+            const TileAt ta = tile_at(pg);
+            hist = (hist << 6) | static_cast<unsigned>(stage_tile(ta, staged));
+            pg += ta.jt;
+        }
+        wait_vmcnt_le(newest_ops(staged - 1));    // tile 0 has landed (only the later tiles' operations may remain)
+        int pstage = pa.ns - 1;
+        while (g < g_end) {
+            g += tile_at(g).jt;
+            __builtin_amdgcn_s_barrier();         // this tile is published; the stage of the tile before it is free again
+            if (pg < g_end && !(pa.ablate & 1)) {
+                const TileAt ta = tile_at(pg);
+                hist = (hist << 6) | static_cast<unsigned>(stage_tile(ta, pstage));
+                pg += ta.jt;
+                pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
+            } else {
+                hist <<= 6;                       // nothing issued: one tile fewer in flight
             }
-            wait_vmcnt_le(in_flight_newest);      // everything older than the tile just issued has landed
+            wait_vmcnt_le(newest_ops(pa.ns - 2)); // everything older than the ns-2 newest tiles has landed
+        }
+        // shiftin! (support.jl:61-80), fused: hist_new <- last H samples of [hist ; x] for the channels this
+        // workgroup is responsible for (round-robin); hist_new is the other ping-pong buffer, nobody reads it
+        // during this launch.  Saves one kernel launch per filt! call.
+        if (a.H > 0) {
+            const float *__restrict__ xin = static_cast<const float *>(a.x);
+            const float *__restrict__ hold = static_cast<const float *>(a.hist);
+            float *__restrict__ hnew = static_cast<float *>(a.hist_new);
+            for (int c2 = blockIdx.x; c2 < a.nch; c2 += gridDim.x)
+                for (int i = lane; i < a.H; i += 64) {
+                    const long long e = static_cast<long long>(i) + a.x_len;          // index into [hist ; x]
+                    hnew[static_cast<long long>(c2) * a.H + i] =
+                        e < a.H ? hold[static_cast<long long>(c2) * a.H + e] : xin[static_cast<long long>(c2) * a.x_stride + (e - a.H)];
+                }
         }
         return;
     }
@@ -207,14 +288,16 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
     float taps[2][T];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const long long p = 2LL * tid + s;                               // position inside the c*M period
-        const long long num = p * a.L - a.u0;
-        const long long tt = num <= 0 ? 0 : (num + a.M - 1) / a.M;       // first output at or after p
-        const long long u = a.u0 + tt * a.M;
-        const long long qq = u / a.L;
+        // 32-bit: plan_rational_pair guarantees c*M <= 1024 and L < M, so every product below is < 2^21
+        const int p = 2 * tid + s;                                       // position inside the c*M period
+        const int L = static_cast<int>(a.L), M = static_cast<int>(a.M), u0 = static_cast<int>(a.u0);
+        const int num = p * L - u0;
+        const int tt = num <= 0 ? 0 : (num + M - 1) / M;                 // first output at or after p
+        const int u = u0 + tt * M;
+        const int qq = u / L;
         act[s] = p < pa.cM && tt < pa.P && qq == p;
-        t_out[s] = static_cast<int>(tt);
-        const int phi = static_cast<int>(u - qq * a.L);
+        t_out[s] = tt;
+        const int phi = u - qq * L;
         const float *__restrict__ tp = static_cast<const float *>(a.taps) + static_cast<long long>(act[s] ? phi : 0) * T;
 #pragma unroll
         for (int i = 0; i < T; ++i) taps[s][i] = tp[i];
@@ -224,86 +307,147 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
     // has no output.  The lanes drop their results into a 512-byte LDS strip at (t - t_lo) and read the
     // strip back two per lane, so every step ends in ONE dense 8-byte-per-lane store instead of an
     // 8-byte store with holes plus a 4-byte store for the odd ones (half the write requests to L2).
-    auto first_output_at = [&](long long p) -> long long {   // first output whose position is >= p
-        const long long num = p * a.L - a.u0;
-        return num <= 0 ? 0 : (num + a.M - 1) / a.M;
+    auto first_output_at = [&](int p) -> int {   // first output whose position is >= p
+        const int num = p * static_cast<int>(a.L) - static_cast<int>(a.u0);
+        return num <= 0 ? 0 : (num + static_cast<int>(a.M) - 1) / static_cast<int>(a.M);
     };
-    const long long t_lo_ll = first_output_at(128LL * wave);
-    const long long t_hi_ll = first_output_at(128LL * (wave + 1));
+    const int t_lo_ll = first_output_at(128 * wave);
+    const int t_hi_ll = first_output_at(128 * (wave + 1));
     const unsigned t_lo = static_cast<unsigned>(t_lo_ll < pa.P ? t_lo_ll : pa.P);
     const unsigned n_w = static_cast<unsigned>((t_hi_ll < pa.P ? t_hi_ll : pa.P)) - t_lo;   // outputs of this wave per step
-    float *const strip = reinterpret_cast<float *>(smem + 3 * static_cast<size_t>(pa.stage_bytes) + static_cast<size_t>(wave) * 512);
-    const unsigned sidx0 = static_cast<unsigned>(t_out[0]) - t_lo, sidx1 = static_cast<unsigned>(t_out[1]) - t_lo;
+    // strip: 1 KiB per compute wave = 128 output slots + 2 x 64 dump slots for the accumulators of positions
+    // that produce no output (the writes are unconditional: no exec masking in the step loop)
+    const unsigned strip_base = lds_base + static_cast<unsigned>(pa.ns) * static_cast<unsigned>(pa.stage_bytes) + static_cast<unsigned>(wave) * 1024u;
+    const unsigned strip_w0 = strip_base + 4u * (act[0] ? static_cast<unsigned>(t_out[0]) - t_lo : 128u + static_cast<unsigned>(lane));
+    const unsigned strip_w1 = strip_base + 4u * (act[1] ? static_cast<unsigned>(t_out[1]) - t_lo : 192u + static_cast<unsigned>(lane));
+    const unsigned strip_r = strip_base + 8u * static_cast<unsigned>(lane);
     const unsigned my_pair = 2u * static_cast<unsigned>(lane);               // outputs my_pair, my_pair+1 of the strip
+    const bool st8_full = my_pair + 1 < n_w, st4_full = my_pair + 1 == n_w;  // store predicates of a full tile
     const unsigned lane_win = static_cast<unsigned>(tid) * 8u;           // byte offset of sample 2*tid inside a stage
 
-    int s = 0;
-    for (; tile < pa.total_tiles; s = (s == 2 ? 0 : s + 1)) {
-        const long long ntile = tile + gridDim.x;
-        int nch = ch + pa.grid_div;
-        long long ntau = tau + pa.grid_mod;
-        if (ntau >= pa.tiles_per_channel) { ntau -= pa.tiles_per_channel; ++nch; }
-
+    // The compute waves' tile walk is 32-bit and scalar (plan_rational_pair guarantees n_out and total_tiles
+    // < 2^31): 64-bit compares would park wave-uniform values in VGPRs for the life of the kernel.
+    const int n_out = static_cast<int>(a.n_out);
+    unsigned long long probe_c0 = 0, probe_r0 = 0;
+    if (pa.probe) { probe_c0 = __builtin_amdgcn_s_memtime(); probe_r0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned g = pa.steps_per_wg * blockIdx.x;
+    for (int s = 0; g < g_end; s = (s + 1 == pa.ns ? 0 : s + 1)) {
+        const TileAt ta = tile_at(g);
+        const int ch = ta.ch, J = ta.jt;
+        g += ta.jt;
         // One barrier per tile and no memory wait: the loader wave arrives only after this tile's
-        // data has landed; all compute waves arriving proves the other stage is no longer read.
-        if (!(pa.ablate & 4)) __builtin_amdgcn_s_barrier();   // (ablate bit 2: timing experiments without the barrier)
+        // data has landed; all compute waves arriving proves the oldest stage is no longer read.
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
-        float *__restrict__ yc = static_cast<float *>(a.y) + static_cast<long long>(ch) * a.y_stride + tau * pa.tile_out;
-        const long long remaining = a.n_out - tau * pa.tile_out;          // outputs of this channel from this tile on
-        const bool full = remaining >= pa.tile_out;                       // wave-uniform
+        float *__restrict__ yc = static_cast<float *>(a.y) + static_cast<long long>(ch) * a.y_stride + static_cast<long long>(ta.st) * pa.P;
+        const int remaining = n_out - ta.st * pa.P;                       // outputs of this channel from this tile on
+        const bool full = remaining >= J * pa.P;                          // wave-uniform
         const unsigned wbase = lds_base + static_cast<unsigned>(s) * pa.stage_bytes + lane_win;
 
+        // Ring-buffered software pipeline.  All LDS traffic of the compute waves is hand-issued asm, so the order
+        // of a wave's LDS operations is exactly the program order below and the counted waits hold.
+        //
+        // What bounds this loop on gfx950 is INSTRUCTION ISSUE: a SIMD issues about one instruction per 2.3
+        // cycles whatever its kind (VALU, LDS, SALU, s_waitcnt ...; scripts/ubench/valu_bank.hip and the
+        // ablation runs recorded in DESIGN.md), so the step is written for the fewest instructions around the
+        // 4*T-2 multiply/adds of its two dot products:
+        //   * window reads are ds_read2_b64 (a "quad" = two aligned pairs = four samples per instruction);
+        //   * a quad is fetched into slot q % K of a K-quad register ring K quads (16 VALU instructions each)
+        //     before it is consumed, and the slot is re-targeted as soon as it has fed its eight
+        //     multiply-adds: one counted wait per quad, few registers, no burst of LDS reads;
+        //   * the output path is three LDS operations and one store per step (see below).
+        // A step is padded to NQV = a multiple of K virtual quads so that slot numbers repeat every step:
+        //   per step:  W W S  [use 0, read 0+K] [use 1, read 1+K] ... ; virtual quads >= NQ only issue reads;
+        //   a read index >= NQV is quad (index - NQV) of the NEXT step's window.
+        //   W W = the previous step's two accumulators -> output strip, S = strip read-back (two dense outputs
+        //   per lane), stored to HBM mid-step.  ring_younger(q) counts the LDS operations issued between the
+        //   read of quad q and its use (compile time).
         auto run_steps = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
+            constexpr int NQ = (NPR + 1) / 2;
+            constexpr int K = NQ < 3 ? NQ : 3;
+            constexpr int NQV = (NQ + K - 1) / K * K;
+            constexpr int QS = NQ / 2;                        // the strip read-back is consumed after quad QS
+            v4u_t ring[K];
+            v2u_t sv = {0u, 0u};
+            char *const ybytes = reinterpret_cast<char *>(yc);
+            auto store_step = [&](int j, v2u_t v) {
+                // byte offsets from the (wave-uniform) tile base stay 32-bit: scalar base + VGPR offset stores
+                const unsigned kj = static_cast<unsigned>(j) * static_cast<unsigned>(pa.P) + t_lo;
+                if (pa.ablate & 2) {   // timing experiments only: keep the arithmetic live, drop the stores
+                    if (v.x == 0x7f123456u) *reinterpret_cast<unsigned *>(ybytes + (kj + my_pair) * 4u) = v.y;
+                    return;
+                }
+                if constexpr (FULL) {
+                    if (st8_full) __builtin_memcpy(ybytes + (kj + my_pair) * 4u, &v, 8);        // 4-byte aligned 8-byte store
+                    if (st4_full) *reinterpret_cast<unsigned *>(ybytes + (kj + my_pair) * 4u) = v.x;
+                } else {
+                    const unsigned rem_j = static_cast<unsigned>(remaining) > kj ? static_cast<unsigned>(remaining) - kj : 0u;
+                    const unsigned lim = rem_j > n_w ? n_w : rem_j;
+                    if (my_pair + 1 < lim) {
+                        __builtin_memcpy(ybytes + (kj + my_pair) * 4u, &v, 8);
+                    } else if (my_pair < lim) {
+                        *reinterpret_cast<unsigned *>(ybytes + (kj + my_pair) * 4u) = v.x;
+                    }
+                }
+            };
+            static_for<0, K>([&](auto I) { ring[decltype(I)::value] = lds_read2_b64<decltype(I)::value * 2>(wbase); });
+            float pacc0 = 0.f, pacc1 = 0.f;                   // step -1 "results": written to the strip, never stored
 #pragma unroll 1
-            for (int j = 0; j < pa.J; ++j) {
-                const unsigned waddr = wbase + static_cast<unsigned>(j) * pa.cM * 4u;
-                // The T+2 samples are fetched in two batches (pairs [0,NA) up front, pairs [NA,NPR) once R1
-                // pairs have been consumed) so that at most max(NA, NPR-R1) pairs are live at a time.
-                v2u_t pr[NPR];
-                static_for<0, NA>([&](auto I) { pr[decltype(I)::value] = lds_read_b64<decltype(I)::value * 8>(waddr); });
+            for (int j = 0; j < J; ++j) {
+                const int jn = j + 1 < J ? j + 1 : j;      // the last step re-reads its own window (never used)
+                const unsigned wcur = wbase + static_cast<unsigned>(j) * pa.cM * 4u;
+                const unsigned wnext = wbase + static_cast<unsigned>(jn) * pa.cM * 4u;
+                lds_write_b32(strip_w0, pacc0);
+                lds_write_b32(strip_w1, pacc1);
+                sv = lds_read_b64<0>(strip_r);                // same wave: LDS operations complete in order
                 float acc0 = 0.f, acc1 = 0.f;
-                // sample w[i] = pr[i/2][i%2]; output 0 uses w[i], output 1 uses w[i+1], i = 0..T-1.
+                // sample w[i]: output 0 uses w[i], output 1 uses w[i+1], i = 0..T-1; pair r = (w[2r], w[2r+1]).
                 // This file is compiled with -fno-slp-vectorize: hipcc would otherwise SLP-pack the two chains
-                // into v_pk_* (no faster per flop) and serialise both outputs into ONE dependent chain.
-                static_for<0, NPR>([&](auto I) {
-                    constexpr int r = decltype(I)::value;
-                    if constexpr (r == R1 && NA < NPR)
-                        static_for<NA, NPR>([&](auto Q) { pr[decltype(Q)::value] = lds_read_b64<decltype(Q)::value * 8>(waddr); });
-                    constexpr int issued = (r >= R1) ? NPR : NA;
-                    lgkm_wait<issued - 1 - r>(pr[r]);
-                    const float wlo = __uint_as_float(pr[r].x), whi = __uint_as_float(pr[r].y);
+                // into v_pk_* (no faster per flop on gfx950: scripts/ubench/valu_rate.hip) and serialise both
+                // outputs into ONE dependent chain.
+                auto pair_math = [&](auto r_tag, float wlo, float whi) {
+                    constexpr int r = decltype(r_tag)::value;
                     // w[2r] = wlo: output 0 tap 2r, output 1 tap 2r-1 ; w[2r+1] = whi: output 0 tap 2r+1, output 1 tap 2r
                     if constexpr (2 * r < T) { if constexpr (r == 0) acc0 = taps[0][0] * wlo; else acc0 = macf<FUSED>(taps[0][2 * r], wlo, acc0); }
                     if constexpr (2 * r - 1 >= 0 && 2 * r - 1 < T) acc1 = macf<FUSED>(taps[1][2 * r - 1], wlo, acc1);
                     if constexpr (2 * r + 1 < T) acc0 = macf<FUSED>(taps[0][2 * r + 1], whi, acc0);
                     if constexpr (2 * r < T) { if constexpr (r == 0) acc1 = taps[1][0] * whi; else acc1 = macf<FUSED>(taps[1][2 * r], whi, acc1); }
-                });
-                // byte offsets from the (wave-uniform) tile base stay 32-bit: scalar base + VGPR offset stores
-                const unsigned kj = static_cast<unsigned>(j) * static_cast<unsigned>(pa.P) + t_lo;
-                char *const ybytes = reinterpret_cast<char *>(yc);
-                if (pa.ablate & 2) {   // timing experiments only: keep the arithmetic live, drop the stores
-                    if (acc0 == 1.2345e30f || acc1 == 1.2345e30f) *reinterpret_cast<float *>(ybytes + (kj + my_pair) * 4u) = acc0 + acc1;
-                } else {
-                    if (act[0]) strip[sidx0] = acc0;
-                    if (act[1]) strip[sidx1] = acc1;
-                    const float2 v = reinterpret_cast<const float2 *>(strip)[lane];   // same wave: LDS ops are in order
-                    const unsigned lim = FULL ? n_w
-                                              : static_cast<unsigned>(remaining - kj > static_cast<long long>(n_w) ? n_w
-                                                                      : (remaining > static_cast<long long>(kj) ? remaining - kj : 0));
-                    if (my_pair + 1 < lim) {
-                        __builtin_memcpy(ybytes + (kj + my_pair) * 4u, &v, 8);        // 4-byte aligned 8-byte store
-                    } else if (my_pair < lim) {
-                        *reinterpret_cast<float *>(ybytes + (kj + my_pair) * 4u) = v.x;
+                };
+                static_for<0, NQV>([&](auto I) {
+                    constexpr int q = decltype(I)::value;
+                    constexpr int slot = q % K;
+                    if constexpr (q < NQ) {
+                        lgkm_wait<ring_younger(q, NQ, K)>(ring[slot]);
+                        pair_math(std::integral_constant<int, 2 * q>{}, __uint_as_float(ring[slot].x), __uint_as_float(ring[slot].y));
+                        if constexpr (2 * q + 1 < NPR)
+                            pair_math(std::integral_constant<int, 2 * q + 1>{}, __uint_as_float(ring[slot].z), __uint_as_float(ring[slot].w));
+                        pin(acc0); pin(acc1);                 // quad q is issued before its slot is re-targeted
                     }
-                }
+                    if constexpr (q + K < NQ) ring[slot] = lds_read2_b64<(q + K) * 2>(wcur);
+                    else if constexpr (q + K >= NQV) ring[slot] = lds_read2_b64<(q + K - NQV) * 2>(wnext);
+                    if constexpr (q == QS) {
+                        lgkm_wait<ring_reads_upto(QS, NQ, K)>(sv);    // only this step's reads are younger than S
+                        if (j > 0) store_step(j - 1, sv);     // wave-uniform
+                    }
+                });
+                pacc0 = acc0; pacc1 = acc1;
             }
+            lds_write_b32(strip_w0, pacc0);
+            lds_write_b32(strip_w1, pacc1);
+            sv = lds_read_b64<0>(strip_r);
+            lgkm_wait<0>(sv);                                 // also retires the last step's unused reads
+            static_for<0, K>([&](auto I) { pin(ring[decltype(I)::value]); });
+            store_step(J - 1, sv);
         };
         if (full) run_steps(std::true_type{});
         else run_steps(std::false_type{});
 
-        tile = ntile; ch = nch; tau = ntau;
+    }
+    if (pa.probe && tid == 0) {   // in-kernel clock = shader cycles / (100 MHz ticks) * 100 MHz (MI355X_MICROARCH.md, DVFS)
+        pa.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;
+        pa.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
     }
 }
 
@@ -325,10 +469,11 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
         if (per_cu < 1) per_cu = 1;                                                                 \
         if (blocks_per_cu_override > 0) per_cu = blocks_per_cu_override;                            \
         long long g = static_cast<long long>(num_cus) * per_cu;                                     \
-        if (g > pa.total_tiles) g = pa.total_tiles;                                                 \
+        if (g > static_cast<long long>(pa.total_steps)) g = pa.total_steps;                           \
         if (g < 1) g = 1;                                                                           \
-        pa.grid_div = static_cast<int>(g / pa.tiles_per_channel);                                   \
-        pa.grid_mod = static_cast<long long>(g % pa.tiles_per_channel);                             \
+        pa.steps_per_wg = static_cast<unsigned>((pa.total_steps + g - 1) / g);                      \
+        g = (pa.total_steps + pa.steps_per_wg - 1) / pa.steps_per_wg;   /* no empty workgroups */   \
+        if (g < 1) g = 1;                                                                           \
         if (pair_debug_once()) {                                                                    \
             hipFuncAttributes fa;                                                                   \
             (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kfn));                   \
@@ -336,7 +481,37 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
                          "tile_len=%d rounds=%d tiles=%lld\n", TT, g, block.x, lds, per_cu, fa.numRegs, pa.c, pa.P, pa.cM, \
                          pa.J, pa.tile_len, pa.dma_rounds, pa.total_tiles);                         \
         }                                                                                           \
+        static const int probe_on = pair_env_int("MRHIP_PAIR_PROBE", 0);                            \
+        static unsigned long long *probe_buf = nullptr;                                             \
+        static int probe_left = 6;                                                                  \
+        pa.probe = nullptr;                                                                         \
+        if (probe_on && probe_left > 0) {                                                           \
+            if (!probe_buf && hipMalloc(&probe_buf, sizeof(unsigned long long) * 2 * 65536) != hipSuccess) probe_buf = nullptr; \
+            if (g <= 65536) pa.probe = probe_buf;                                                   \
+        }                                                                                           \
         hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), block, lds, s, a, pa);              \
+        if (pa.probe) {                                                                             \
+            --probe_left;                                                                           \
+            std::vector<unsigned long long> hb(2 * static_cast<size_t>(g));                         \
+            (void)hipStreamSynchronize(s);                                                          \
+            (void)hipMemcpy(hb.data(), probe_buf, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost); \
+            std::vector<double> ghz, us;                                                            \
+            for (long long i = 0; i < g; ++i) if (hb[2 * i + 1]) { ghz.push_back(0.1 * hb[2 * i] / hb[2 * i + 1]); us.push_back(hb[2 * i + 1] * 0.01); } \
+            std::sort(ghz.begin(), ghz.end()); std::sort(us.begin(), us.end());                     \
+            if (!ghz.empty()) std::fprintf(stderr, "[mrhip] probe: in-kernel clock median %.3f GHz (min %.3f max %.3f); tile loop p10 %.1f median %.1f p90 %.1f max %.1f us\n", \
+                                           ghz[ghz.size() / 2], ghz.front(), ghz.back(), us[us.size() / 10], us[us.size() / 2], us[us.size() * 9 / 10], us.back()); \
+            if (probe_left == 0) {                                                                  \
+                for (int x = 0; x < 8; ++x) {                                                       \
+                    std::vector<double> u2, c2;                                                     \
+                    for (long long i = x; i < g; i += 8) if (hb[2 * i + 1]) { u2.push_back(hb[2 * i + 1] * 0.01); c2.push_back(0.1 * hb[2 * i] / hb[2 * i + 1]); } \
+                    std::sort(u2.begin(), u2.end()); std::sort(c2.begin(), c2.end());               \
+                    if (!u2.empty()) std::fprintf(stderr, "[mrhip] probe xcd %d: loop min %.1f median %.1f max %.1f us, clock median %.3f GHz\n", x, u2.front(), u2[u2.size() / 2], u2.back(), c2[c2.size() / 2]); \
+                }                                                                                   \
+                std::fprintf(stderr, "[mrhip] probe first 64 workgroups (us):");                    \
+                for (long long i = 0; i < 64 && i < g; ++i) std::fprintf(stderr, " %.0f", hb[2 * i + 1] * 0.01); \
+                std::fprintf(stderr, "\n");                                                         \
+            }                                                                                       \
+        }                                                                                           \
         return hipGetLastError();                                                                   \
     }
     switch (T) {
@@ -369,17 +544,19 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     if (!(a.M > a.L) || static_cast<double>(a.L) / a.M < 0.70) return false;
     if (a.zero_start_below > 0) return false;
     static const int env_c = pair_env_int("MRHIP_PAIR_C", 0), env_r = pair_env_int("MRHIP_PAIR_ROUNDS", 0);
-    // c: lanes = c*M/2 (c*M must be even), <= 512.  Measured on MI355X (147//160, 24 taps, scripts/
-    // exp_ps_matrix.sh): small workgroups (3-4 compute waves + the loader) beat larger ones that fill
-    // their last wave better -- more workgroups per CU smooth out the per-tile barrier -- so take the
-    // smallest c that gives at least 3 compute waves, falling back to the best lane utilisation.
+    static const int env_ns = pair_env_int("MRHIP_PAIR_NS", 0), env_j = pair_env_int("MRHIP_PAIR_J", 0);
+    const int ns = env_ns >= 3 && env_ns <= 10 ? env_ns : 3;
+    // c: lanes = c*M/2 (c*M must be even), <= 512.  Measured on MI355X (147//160, 24 taps; sweeps recorded in
+    // DESIGN.md): the loop is VALU-issue bound, so idle lanes in the last wave cost in proportion -- take the
+    // smallest c with at least 3 compute waves whose last wave is >= 90 % full (147//160: c = 3, 240 of 256
+    // lanes), falling back to the best lane utilisation.
     int best_c = 0;
     double best = -1.0;
     for (int c = 1; static_cast<long long>(c) * a.M / 2 <= kPairMaxThreads; ++c) {
         if ((static_cast<long long>(c) * a.M) % 2) continue;
         const int lanes = static_cast<int>(static_cast<long long>(c) * a.M / 2);
         const int padded = (lanes + 63) / 64 * 64;
-        if (padded >= 192 && static_cast<double>(lanes) / padded >= 0.75) { best_c = c; break; }
+        if (padded >= 192 && static_cast<double>(lanes) / padded >= 0.90) { best_c = c; break; }
         const double score = static_cast<double>(lanes) / padded * (padded < 192 ? 0.5 + 0.5 * padded / 192.0 : 1.0);
         if (score > best + 1e-9) { best = score; best_c = c; }
     }
@@ -392,15 +569,16 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     const int padded = (lanes + 63) / 64 * 64;
     const int nwaves = padded / 64;
     // tile: J steps; the stage is a whole number of 1 KiB DMA slots.  MRHIP_PAIR_ROUNDS (experiments) scales it.
-    const int stage_kib = env_r > 0 ? env_r * nwaves : 4 * nwaves;
+    const int stage_kib = env_r > 0 ? env_r * nwaves : 3 * nwaves;
     long long J = (static_cast<long long>(stage_kib) * 256 - a.T - 2) / cM;   // 256 samples per KiB
     if (J < 1) {
         J = 1;
     }
+    if (env_j > 0) J = env_j;
     if (J > 64) J = 64;
     // small problems (few channels, short calls): shrink the tile until there are enough tiles to give
     // every CU a few workgroups -- a launch that occupies a third of the chip is latency-bound
-    if (env_r <= 0) {
+    if (env_r <= 0 && env_j <= 0) {
         const long long want_tiles = 4LL * num_cus;
         while (J > 2 && ((a.n_out + J * c * a.L - 1) / (J * c * a.L)) * a.nch < want_tiles) J = (J + 1) / 2;
     }
@@ -408,7 +586,7 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     tile_len = (tile_len + 3) / 4 * 4;
     const long long nslots = (tile_len / 4 + 63) / 64;
     const size_t stage_bytes = static_cast<size_t>(nslots) * 1024;
-    if (nslots > 32 || 3 * stage_bytes + static_cast<size_t>(nwaves) * 512 > 150 * 1024) return false;
+    if (nslots > 32 || ns * stage_bytes + static_cast<size_t>(nwaves) * 1024 > 156 * 1024) return false;
     const long long need_rounds = nslots;
     PairArgs pa{};
     pa.c = c; pa.P = static_cast<int>(static_cast<long long>(c) * a.L); pa.cM = static_cast<int>(cM);
@@ -416,6 +594,7 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     pa.tile_len = static_cast<int>(tile_len);
     pa.dma_rounds = static_cast<int>(need_rounds);
     pa.stage_bytes = static_cast<int>(stage_bytes);
+    pa.ns = ns;
     pa.o0 = a.d0 - a.T;
     static const int env_ablate = pair_env_int("MRHIP_PS_ABLATE", 0);   // timing experiments: 1 = no staging, 2 = no stores
     pa.ablate = env_ablate;
@@ -423,15 +602,25 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     pa.tile_out = J * pa.P;
     pa.tiles_per_channel = (a.n_out + pa.tile_out - 1) / pa.tile_out;
     pa.total_tiles = pa.tiles_per_channel * a.nch;
+    if (a.n_out >= (1LL << 31) - pa.tile_out || pa.total_tiles >= (1LL << 31) - 65536) return false;   // 32-bit tile walk
     *out = pa;
     *block = dim3(static_cast<unsigned>(padded + 64));   // + the loader wave
-    *lds = 3 * stage_bytes + static_cast<size_t>(nwaves) * 512;   // three pipeline stages + one output strip per compute wave
+    {
+        const long long spc = (a.n_out + pa.P - 1) / pa.P;
+        if (spc * a.nch >= (1LL << 31)) return false;
+        pa.steps_per_channel = static_cast<unsigned>(spc);
+        pa.total_steps = static_cast<unsigned>(spc * a.nch);
+        pa.spc_magic = spc == 1 ? 0xffffffffu : static_cast<unsigned>((1ULL << 32) / static_cast<unsigned long long>(spc));
+    }
+    *out = pa;
+    *lds = ns * stage_bytes + static_cast<size_t>(nwaves) * 1024;   // the pipeline stages + one output strip per compute wave
     return true;
 }
 
-hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
+hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa_in, dim3 block, size_t lds, hipStream_t s,
                                 const char **kname, int num_cus)
 {
+    PairArgs pa = pa_in;
     *kname = "rational_pair_kernel";
     static const int bpc = pair_env_int("MRHIP_PAIR_BPC", 0);
     return fused ? launch_pair_T<true>(a.T, block, lds, s, a, pa, num_cus, bpc)

@@ -75,6 +75,8 @@ struct PolyArgs {            // rational family: STANDARD / DECIMATOR / INTERPOL
     const void *x;           // device, planar [ch][x_stride]
     void *y;                 // device, planar [ch][y_stride]
     const void *hist;        // device, [ch][H] samples of Tx (call-start history)
+    void *hist_new;          // device, [ch][H]: the other ping-pong buffer; a kernel that performs shiftin! itself
+                             // (support.jl:61-80) writes the call-end history here and reports it (*did_shiftin)
     const void *taps;        // device, R-typed, [Nphi][T] (column = phase, oldest-sample tap first)
     long long x_stride, y_stride;
     long long x_len;         // samples per channel in this call
@@ -134,15 +136,19 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     int J;                   // steps per tile
     int tile_len;            // samples staged per tile (multiple of 4)
     int dma_rounds;          // LDS-DMA instructions per wave per tile
-    int stage_bytes;         // LDS bytes per pipeline stage (three stages)
+    int stage_bytes;         // LDS bytes per pipeline stage
+    int ns;                  // pipeline stages (the DMA runs ns-1 tiles ahead of the compute waves)
     int ablate;              // timing experiments only (MRHIP_PS_ABLATE)
-    int grid_div;            // gridDim.x / tiles_per_channel   } so the tile -> (channel, tile-in-channel)
-    long long grid_mod;      // gridDim.x % tiles_per_channel   } walk needs no division per tile
+    unsigned steps_per_channel;   // ceil(n_out / P)
+    unsigned total_steps;         // steps_per_channel * channels
+    unsigned steps_per_wg;        // ceil(total_steps / grid): workgroup b owns steps [b*S, (b+1)*S)
+    unsigned spc_magic;           // floor(2^32 / steps_per_channel) (0xffffffff for 1): step number -> channel by multiply-high
     long long o0;            // d0 - T: x index of LDS sample 0 of tile 0 (negative => history)
     long long tile_in;       // J*c*M
     long long tile_out;      // J*c*L
     long long tiles_per_channel;
     long long total_tiles;
+    unsigned long long *probe;   // diagnostics (MRHIP_PAIR_PROBE=1): per-workgroup (shader cycles, 100 MHz ticks) of the tile loop
 };
 
 struct DirectArgs {          // tiling of the single-column kernel (kernels_fir_direct.hip)
@@ -179,7 +185,7 @@ hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, h
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
 bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
-                                const char **kname, int num_cus);
+                                const char **kname, int num_cus);   // also performs shiftin! into a.hist_new
 bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectArgs *out, size_t *lds);
 hipError_t launch_fir_direct(const TypeKey &tk, bool fused, const PolyArgs &a, const DirectArgs &da, size_t lds, hipStream_t s,
                              const char **kname, int num_cus);

@@ -1,0 +1,9 @@
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
+run() { echo "== $*"; env MRHIP_DEBUG=1 "$@" timeout 600 python bench.py --steps 3 --warmup 1 --samples 50000000 --no-cpu-baseline $EXTRA 2>&1 | grep -E "mrhip\]|metric|rror|differs" | sed -e 's/.*"achieved": \([0-9.]*\).*"avg_launch_ms": \([0-9.]*\).*/   GBps=\1 ms=\2/' | sed -e 's/.*occ.CU=\([0-9]*\) regs=\([0-9]*\).*J=\([0-9]*\).*/   occ=\1 regs=\2 J=\3/' | cut -c1-220; }
+{
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -5
+run A=1; run A=1
+run MRHIP_PAIR_ROUNDS=3; run MRHIP_PAIR_ROUNDS=5; run MRHIP_PAIR_C=4 MRHIP_PAIR_ROUNDS=3; run MRHIP_PAIR_C=6 MRHIP_PAIR_ROUNDS=2
+EXTRA="--no-check"; run MRHIP_PS_ABLATE=2; run MRHIP_PS_ABLATE=1; run MRHIP_PS_ABLATE=3
+EXTRA="--numerics fused --no-check"; run A=1
+} > gpurun_out/exp_pipe.log 2>&1

@@ -12,6 +12,30 @@ template <int OFF> __device__ __forceinline__ v2u_t lds_read_b64(unsigned a)
 template <int N, typename V> __device__ __forceinline__ void lgkm_wait(V &r)
 { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N < 15 ? N : 15)); }
 
+
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+// packed f32: lo = x.half(SEL) * t.lo ; hi = x.half(SEL) * t.hi
+template <int SEL> __device__ __forceinline__ v2f_t pk_mul_bcast(v2u_t x, v2f_t t)
+{
+    v2f_t d;
+    if constexpr (SEL == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(x), "v"(t));
+    else                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f_t pk_add(v2f_t a, v2f_t b)
+{
+    v2f_t d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <int SEL> __device__ __forceinline__ v2f_t pk_fma_bcast(v2u_t x, v2f_t t, v2f_t c)
+{
+    v2f_t d;
+    if constexpr (SEL == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(x), "v"(t), "v"(c));
+    else                    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(t), "v"(c));
+    return d;
+}
+
 constexpr int T = 24, NPR = 13;
 #ifndef TAPS_VGPR
 #define TAPS_VGPR 0
@@ -39,6 +63,38 @@ __global__ __launch_bounds__(512) void k(float *out, const float *in, int steps,
         } else {
             static_for<0, NPR>([&](auto I) { pr[decltype(I)::value] = v2u_t{__float_as_uint(sum + decltype(I)::value), __float_as_uint(sum)}; });
         }
+
+        if constexpr (MODE == 5 || MODE == 6) {
+            // skewed packed chains: step k uses sample w[k] for output-0 term k (lo) and output-1 term k-1 (hi)
+            v2f_t tp[T + 1];
+#pragma unroll
+            for (int kk = 0; kk <= T; ++kk) tp[kk] = v2f_t{kk < T ? taps[0][kk] : 0.f, kk >= 1 ? taps[1][kk - 1] : 0.f};
+            v2f_t acc;
+            static_for<0, NPR>([&](auto I) {
+                constexpr int r = decltype(I)::value;
+                lgkm_wait<NPR - 1 - r>(pr[r]);
+                if constexpr (r == 0) {
+                    acc.x = tp[0].x * __uint_as_float(pr[0].x);
+                    acc.y = -0.0f;
+                    if constexpr (MODE == 5) acc = pk_add(acc, pk_mul_bcast<1>(pr[0], tp[1]));
+                    else acc = pk_fma_bcast<1>(pr[0], tp[1], acc);
+                } else {
+                    if constexpr (2 * r < T) {
+                        if constexpr (MODE == 5) acc = pk_add(acc, pk_mul_bcast<0>(pr[r], tp[2 * r]));
+                        else acc = pk_fma_bcast<0>(pr[r], tp[2 * r], acc);
+                    } else if constexpr (2 * r == T) {
+                        float p = tp[T].y * __uint_as_float(pr[r].x); acc.y = acc.y + p;
+                    }
+                    if constexpr (2 * r + 1 < T) {
+                        if constexpr (MODE == 5) acc = pk_add(acc, pk_mul_bcast<1>(pr[r], tp[2 * r + 1]));
+                        else acc = pk_fma_bcast<1>(pr[r], tp[2 * r + 1], acc);
+                    } else if constexpr (2 * r + 1 == T) {
+                        float p = tp[T].y * __uint_as_float(pr[r].y); acc.y = acc.y + p;
+                    }
+                }
+            });
+            acc0 = acc.x; acc1 = acc.y;
+        } else
         static_for<0, NPR>([&](auto I) {
             constexpr int r = decltype(I)::value;
             if constexpr (MODE != 3) lgkm_wait<NPR - 1 - r>(pr[r]);
@@ -90,6 +146,8 @@ int main()
         run<1>("fused (compiler)", 512, bpc, p.multiProcessorCount, d, in);
         run<2>("LDS reads only", 512, bpc, p.multiProcessorCount, d, in);
         run<3>("math only strict", 512, bpc, p.multiProcessorCount, d, in);
+        run<5>("packed skewed strict", 512, bpc, p.multiProcessorCount, d, in);
+        run<6>("packed skewed fused", 512, bpc, p.multiProcessorCount, d, in);
     }
     return 0;
 }
