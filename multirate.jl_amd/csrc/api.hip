@@ -79,6 +79,8 @@ int alloc_common(mrhip_filter *f)
         MRHIP_CHECK_HIP(hipMalloc(&f->d_hist[i], hbytes));
         MRHIP_CHECK_HIP(hipMemset(f->d_hist[i], 0, hbytes));   // history = zeros(historyLen), Filters.jl:177
     }
+    MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_counters), 33 * 256));
+    MRHIP_CHECK_HIP(hipMemset(f->d_counters, 0, 33 * 256));
     {
         hipDeviceProp_t prop;
         MRHIP_CHECK_HIP(hipGetDeviceProperties(&prop, f->device));
@@ -128,7 +130,7 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
             size_t lds = 0;
             if (plan_rational_pair(tk, a, f->num_cus, &pa, &block, &lds)) {
                 *did_shiftin = a.H > 0;          // its loader waves write the call-end history themselves
-                return launch_rational_pair(fused, a, pa, block, lds, s, kname, f->num_cus);
+                return launch_rational_pair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
             }
         }
         TileArgs ta;
@@ -264,7 +266,7 @@ void mrhip_destroy(mrhip_filter *f)
     if (!f) return;
     DeviceGuard guard(f->device);
     (void)hipDeviceSynchronize();
-    for (void *p : {f->d_taps, f->d_dtaps, f->d_hist[0], f->d_hist[1], f->d_sched_n, f->d_sched_acc, f->d_xbuf, f->d_ybuf})
+    for (void *p : {f->d_taps, f->d_dtaps, f->d_hist[0], f->d_hist[1], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc, f->d_xbuf, f->d_ybuf})
         if (p) (void)hipFree(p);
     if (f->pin_n) (void)hipHostFree(f->pin_n);
     if (f->pin_acc) (void)hipHostFree(f->pin_acc);
@@ -379,6 +381,7 @@ int mrhip_reset(mrhip_filter *f)
     MRHIP_CHECK_HIP(hipDeviceSynchronize());
     const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
     if (bytes) MRHIP_CHECK_HIP(hipMemset(f->d_hist[f->hist_cur], 0, bytes));
+    MRHIP_CHECK_HIP(hipMemset(f->d_counters, 0, 33 * 256));
     f->phiIdx = 1; f->inputDeficit = 1; f->xIdx = 1; f->phiAcc = 1.0; f->alpha = 0.0;
     return MRHIP_OK;
 }

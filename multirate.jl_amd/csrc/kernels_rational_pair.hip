@@ -35,6 +35,7 @@ namespace mrhip {
 namespace {
 
 constexpr int kPairMaxThreads = 512;
+constexpr int kPairGroups = 32;         // scheduling groups (one step counter each); a multiple of the 8 XCDs
 
 inline bool pair_debug_once()
 {
@@ -169,22 +170,25 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
     const int ncw = (blockDim.x >> 6) - 1;      // compute waves; the last wave of the workgroup is the loader
 
     // ---- tile walk shared by both roles.  The launch is a sequence of STEPS (one period of c*M input positions
-    // each), numbered channel-major: g = channel * steps_per_channel + step.  Workgroup b owns the contiguous
-    // range [b*S, (b+1)*S) with S = ceil(total_steps / gridDim.x), so every workgroup does the same number of
-    // steps to within one (a round-robin split of whole tiles left 7 % of the grid idle for the last tile:
-    // MRHIP_PAIR_PROBE=1).  A range is cut into tiles of up to J steps that never cross a channel boundary;
-    // loader and compute waves derive the same tile sequence independently.
+    // each), numbered channel-major: g = channel * steps_per_channel + step.  Steps are handed out DYNAMICALLY in
+    // grabs of J: workgroups that share the CUs and the HBM run the same loop at speeds that differ by +-25 %
+    // (MRHIP_PAIR_PROBE=1: with equal static shares the first workgroup finished at 70 us, the last at 120 us),
+    // so a static split leaves a quarter of the machine idle at the end.  A single device-wide counter would
+    // serialise (~11 ns per same-address atomic x 22 000 grabs); instead the step range is cut into pa.ngroups
+    // contiguous group ranges, workgroup b draws from group b % ngroups (32 groups: an XCD-local set of ~32
+    // workgroups shares one counter, ~700 atomics per launch each).  The loader wave draws the grabs, cuts them
+    // into tiles (never across a channel boundary) and publishes each tile (first step, steps) through two
+    // LDS words per pipeline stage; the compute waves read them after the barrier that opens the tile.
     const unsigned spc = static_cast<unsigned>(pa.steps_per_channel);
-    const unsigned g_end = umin(pa.steps_per_wg * (blockIdx.x + 1u), pa.total_steps);
     struct TileAt { int ch, st, jt; };                      // channel, first step within the channel, steps
-    auto tile_at = [&](unsigned g) -> TileAt {              // g < g_end; multiply-high by floor(2^32/spc) + fix-ups
+    auto tile_at = [&](unsigned g, unsigned jt) -> TileAt {  // multiply-high by floor(2^32/spc) + fix-ups
         unsigned q = __umulhi(g, pa.spc_magic);
         unsigned r = g - q * spc;
         if (r >= spc) { ++q; r -= spc; }
         if (r >= spc) { ++q; r -= spc; }
-        const unsigned jt = umin(umin(static_cast<unsigned>(pa.J), spc - r), g_end - g);
-        return TileAt{static_cast<int>(q), static_cast<int>(r), static_cast<int>(jt)};
+        return TileAt{static_cast<int>(q), static_cast<int>(r), static_cast<int>(umin(jt, spc - r))};
     };
+    volatile unsigned *const tile_flag = reinterpret_cast<volatile unsigned *>(smem + pa.flags_off);   // [ns][2]: first step, steps (0 = end)
 
     if (wave == ncw) {
         // ================= loader wave: HBM -> LDS, one tile ahead of the compute waves =================
@@ -230,39 +234,66 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
             return 0;
         };
         // pa.ns LDS stages, the DMA runs ns-1 tiles ahead: while the compute waves work on tile i the loader
-        // has tiles i+1 .. i+ns-2 landing and tile i+ns-1 being issued, so the HBM stream never pauses and a
-        // tile has ns-2 tile times to arrive (HBM latency under load is several microseconds; a tile is 1-2).
-        // `pg` walks ahead of `g`.  `hist` is a shift register of the LDS-DMA operation counts of the tiles
-        // issued so far (6 bits each, newest in the low bits): tile i+1 has landed once no more operations are
-        // outstanding than the ns-2 newest tiles own.
-        unsigned g = pa.steps_per_wg * blockIdx.x, pg = g;
+        // has tiles i+1 .. i+ns-2 landing and tile i+ns-1 being issued, so the HBM stream never pauses.
+        // `hist` is a shift register of the LDS-DMA operation counts of the tiles issued so far (6 bits each,
+        // newest in the low bits): tile i+1 has landed once no more operations are outstanding than the ns-2
+        // newest tiles own.
+        const unsigned grp = blockIdx.x % static_cast<unsigned>(pa.ngroups);
+        const unsigned grp_lo = umin(grp * pa.steps_per_group, pa.total_steps);
+        const unsigned grp_hi = umin(grp_lo + pa.steps_per_group, pa.total_steps);
+        unsigned *const ctr = pa.counters + grp * 64u;            // one counter per 256 bytes
+        unsigned pend = 0;                                        // lane 0: the grab number drawn ahead of need
+        auto grab_issue = [&]() { if (lane == 0) pend = atomicAdd(ctr, 1u); };
+        unsigned ra = 0, rb = 0;                                  // the current grab's steps [ra, rb)
+        bool more = true;                                         // false after the first empty grab
+        auto grab_take = [&]() {                                  // the compiler waits for `pend` here (vmcnt(0))
+            const unsigned t = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(pend)));
+            const unsigned long long lo = static_cast<unsigned long long>(grp_lo) + static_cast<unsigned long long>(t) * pa.J;
+            if (lo < grp_hi) { ra = static_cast<unsigned>(lo); rb = umin(ra + pa.J, grp_hi); grab_issue(); }
+            else { more = false; ra = rb = 0; }
+        };
         unsigned long long hist = 0;
         auto newest_ops = [&](int ntiles) -> int {
             int n = 0;
             for (int k = 0; k < ntiles; ++k) n += static_cast<int>((hist >> (6 * k)) & 63u);
             return n < 60 ? n : 60;               // the counter itself holds at most 63
         };
-        int staged = 0;
-        for (; staged < pa.ns - 1 && pg < g_end; ++staged) {
-            if (staged > 0 && (pa.ablate & 1)) break;
-            const TileAt ta = tile_at(pg);
-            hist = (hist << 6) | static_cast<unsigned>(stage_tile(ta, staged));
-            pg += ta.jt;
-        }
-        wait_vmcnt_le(newest_ops(staged - 1));    // tile 0 has landed (only the later tiles' operations may remain)
-        int pstage = pa.ns - 1;
-        while (g < g_end) {
-            g += tile_at(g).jt;
-            __builtin_amdgcn_s_barrier();         // this tile is published; the stage of the tile before it is free again
-            if (pg < g_end && !(pa.ablate & 1)) {
-                const TileAt ta = tile_at(pg);
-                hist = (hist << 6) | static_cast<unsigned>(stage_tile(ta, pstage));
-                pg += ta.jt;
-                pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
-            } else {
-                hist <<= 6;                       // nothing issued: one tile fewer in flight
+        // next tile of the stream -> stage `stage`; returns false at the end of the stream (end marker published)
+        auto produce = [&](int stage) -> bool {
+            if (ra >= rb && more) grab_take();
+            if (ra >= rb) {
+                if (lane == 0) { tile_flag[2 * stage] = 0u; tile_flag[2 * stage + 1] = 0u; }
+                hist <<= 6;
+                return false;
             }
+            const TileAt ta = tile_at(ra, rb - ra);
+            if (lane == 0) { tile_flag[2 * stage] = ra; tile_flag[2 * stage + 1] = static_cast<unsigned>(ta.jt); }
+            hist = (hist << 6) | static_cast<unsigned>((pa.ablate & 1) ? 0 : stage_tile(ta, stage));
+            ra += static_cast<unsigned>(ta.jt);
+            return true;
+        };
+        grab_issue();
+        unsigned pipeline = 0;                    // bit k: the tile opened k barriers from now exists
+        for (int k = 0; k < pa.ns - 1; ++k)
+            if (produce(k)) pipeline |= 1u << k;  // after the end of the stream produce() keeps publishing end markers
+        wait_vmcnt_le(newest_ops(pa.ns - 2));     // tile 0 has landed (only the later tiles' operations may remain)
+        int pstage = pa.ns - 1;
+        for (;;) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the tile descriptors published so far are in LDS
+            __builtin_amdgcn_s_barrier();         // the next tile is published; the stage of the tile before it is free again
+            if (!(pipeline & 1u)) break;          // that was the end marker: every wave of the workgroup leaves
+            pipeline >>= 1;
+            if (produce(pstage)) pipeline |= 1u << (pa.ns - 2);
+            pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
             wait_vmcnt_le(newest_ops(pa.ns - 2)); // everything older than the ns-2 newest tiles has landed
+        }
+        // the last workgroup to finish re-arms the counters for the next launch (stream order makes it visible)
+        if (lane == 0) {
+            unsigned *const done = pa.counters + static_cast<unsigned>(pa.ngroups) * 64u;
+            if (atomicAdd(done, 1u) == gridDim.x - 1) {
+                for (int k = 0; k < pa.ngroups; ++k) pa.counters[k * 64] = 0u;
+                *done = 0u;
+            }
         }
         // shiftin! (support.jl:61-80), fused: hist_new <- last H samples of [hist ; x] for the channels this
         // workgroup is responsible for (round-robin); hist_new is the other ping-pong buffer, nobody reads it
@@ -330,15 +361,16 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
     const int n_out = static_cast<int>(a.n_out);
     unsigned long long probe_c0 = 0, probe_r0 = 0;
     if (pa.probe) { probe_c0 = __builtin_amdgcn_s_memtime(); probe_r0 = __builtin_amdgcn_s_memrealtime(); }
-    unsigned g = pa.steps_per_wg * blockIdx.x;
-    for (int s = 0; g < g_end; s = (s + 1 == pa.ns ? 0 : s + 1)) {
-        const TileAt ta = tile_at(g);
-        const int ch = ta.ch, J = ta.jt;
-        g += ta.jt;
-        // One barrier per tile and no memory wait: the loader wave arrives only after this tile's
-        // data has landed; all compute waves arriving proves the oldest stage is no longer read.
+    for (int s = 0;; s = (s + 1 == pa.ns ? 0 : s + 1)) {
+        // One barrier per tile and no memory wait: the loader wave arrives only after this tile's data has
+        // landed and its descriptor is in LDS; all compute waves arriving proves the oldest stage is no longer read.
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        const unsigned tg = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(tile_flag[2 * s])));
+        const unsigned tj = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(tile_flag[2 * s + 1])));
+        if (tj == 0u) break;                      // end marker
+        const TileAt ta = tile_at(tg, tj);
+        const int ch = ta.ch, J = ta.jt;
 
         float *__restrict__ yc = static_cast<float *>(a.y) + static_cast<long long>(ch) * a.y_stride + static_cast<long long>(ta.st) * pa.P;
         const int remaining = n_out - ta.st * pa.P;                       // outputs of this channel from this tile on
@@ -446,8 +478,9 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
 
     }
     if (pa.probe && tid == 0) {   // in-kernel clock = shader cycles / (100 MHz ticks) * 100 MHz (MI355X_MICROARCH.md, DVFS)
-        pa.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;
-        pa.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+        pa.probe[3 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;
+        pa.probe[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+        pa.probe[3 * blockIdx.x + 2] = probe_r0;
     }
 }
 
@@ -471,8 +504,8 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
         long long g = static_cast<long long>(num_cus) * per_cu;                                     \
         if (g > static_cast<long long>(pa.total_steps)) g = pa.total_steps;                           \
         if (g < 1) g = 1;                                                                           \
-        pa.steps_per_wg = static_cast<unsigned>((pa.total_steps + g - 1) / g);                      \
-        g = (pa.total_steps + pa.steps_per_wg - 1) / pa.steps_per_wg;   /* no empty workgroups */   \
+        pa.ngroups = static_cast<int>(g < kPairGroups ? g : kPairGroups);   /* every group needs a workgroup */ \
+        pa.steps_per_group = static_cast<unsigned>((pa.total_steps + pa.ngroups - 1) / pa.ngroups); \
         if (g < 1) g = 1;                                                                           \
         if (pair_debug_once()) {                                                                    \
             hipFuncAttributes fa;                                                                   \
@@ -486,31 +519,26 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
         static int probe_left = 6;                                                                  \
         pa.probe = nullptr;                                                                         \
         if (probe_on && probe_left > 0) {                                                           \
-            if (!probe_buf && hipMalloc(&probe_buf, sizeof(unsigned long long) * 2 * 65536) != hipSuccess) probe_buf = nullptr; \
+            if (!probe_buf && hipMalloc(&probe_buf, sizeof(unsigned long long) * 3 * 65536) != hipSuccess) probe_buf = nullptr; \
             if (g <= 65536) pa.probe = probe_buf;                                                   \
         }                                                                                           \
         hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), block, lds, s, a, pa);              \
         if (pa.probe) {                                                                             \
             --probe_left;                                                                           \
-            std::vector<unsigned long long> hb(2 * static_cast<size_t>(g));                         \
+            std::vector<unsigned long long> hb(3 * static_cast<size_t>(g));                         \
             (void)hipStreamSynchronize(s);                                                          \
             (void)hipMemcpy(hb.data(), probe_buf, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost); \
             std::vector<double> ghz, us;                                                            \
-            for (long long i = 0; i < g; ++i) if (hb[2 * i + 1]) { ghz.push_back(0.1 * hb[2 * i] / hb[2 * i + 1]); us.push_back(hb[2 * i + 1] * 0.01); } \
-            std::sort(ghz.begin(), ghz.end()); std::sort(us.begin(), us.end());                     \
+            std::vector<double> st, en;                                                             \
+            unsigned long long t0 = ~0ull;                                                          \
+            for (long long i = 0; i < g; ++i) if (hb[3 * i + 1] && hb[3 * i + 2] < t0) t0 = hb[3 * i + 2]; \
+            for (long long i = 0; i < g; ++i) if (hb[3 * i + 1]) { ghz.push_back(0.1 * hb[3 * i] / hb[3 * i + 1]); us.push_back(hb[3 * i + 1] * 0.01); \
+                st.push_back((hb[3 * i + 2] - t0) * 0.01); en.push_back((hb[3 * i + 2] - t0 + hb[3 * i + 1]) * 0.01); } \
+            std::sort(ghz.begin(), ghz.end()); std::sort(us.begin(), us.end()); std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end()); \
+            if (!st.empty()) std::fprintf(stderr, "[mrhip] probe: tile-loop START after first wg: median %.1f p90 %.1f max %.1f us; END: p10 %.1f median %.1f max %.1f us\n", \
+                                          st[st.size() / 2], st[st.size() * 9 / 10], st.back(), en[en.size() / 10], en[en.size() / 2], en.back()); \
             if (!ghz.empty()) std::fprintf(stderr, "[mrhip] probe: in-kernel clock median %.3f GHz (min %.3f max %.3f); tile loop p10 %.1f median %.1f p90 %.1f max %.1f us\n", \
                                            ghz[ghz.size() / 2], ghz.front(), ghz.back(), us[us.size() / 10], us[us.size() / 2], us[us.size() * 9 / 10], us.back()); \
-            if (probe_left == 0) {                                                                  \
-                for (int x = 0; x < 8; ++x) {                                                       \
-                    std::vector<double> u2, c2;                                                     \
-                    for (long long i = x; i < g; i += 8) if (hb[2 * i + 1]) { u2.push_back(hb[2 * i + 1] * 0.01); c2.push_back(0.1 * hb[2 * i] / hb[2 * i + 1]); } \
-                    std::sort(u2.begin(), u2.end()); std::sort(c2.begin(), c2.end());               \
-                    if (!u2.empty()) std::fprintf(stderr, "[mrhip] probe xcd %d: loop min %.1f median %.1f max %.1f us, clock median %.3f GHz\n", x, u2.front(), u2[u2.size() / 2], u2.back(), c2[c2.size() / 2]); \
-                }                                                                                   \
-                std::fprintf(stderr, "[mrhip] probe first 64 workgroups (us):");                    \
-                for (long long i = 0; i < 64 && i < g; ++i) std::fprintf(stderr, " %.0f", hb[2 * i + 1] * 0.01); \
-                std::fprintf(stderr, "\n");                                                         \
-            }                                                                                       \
         }                                                                                           \
         return hipGetLastError();                                                                   \
     }
@@ -546,20 +574,21 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     static const int env_c = pair_env_int("MRHIP_PAIR_C", 0), env_r = pair_env_int("MRHIP_PAIR_ROUNDS", 0);
     static const int env_ns = pair_env_int("MRHIP_PAIR_NS", 0), env_j = pair_env_int("MRHIP_PAIR_J", 0);
     const int ns = env_ns >= 3 && env_ns <= 10 ? env_ns : 3;
-    // c: lanes = c*M/2 (c*M must be even), <= 512.  Measured on MI355X (147//160, 24 taps; sweeps recorded in
-    // DESIGN.md): the loop is VALU-issue bound, so idle lanes in the last wave cost in proportion -- take the
-    // smallest c with at least 3 compute waves whose last wave is >= 90 % full (147//160: c = 3, 240 of 256
-    // lanes), falling back to the best lane utilisation.
+    // c: lanes = c*M/2 (c*M must be even), <= 512.  The loop is VALU-issue bound, so idle lanes in the last
+    // wave cost in proportion: among the sizes with 3..5 compute waves take the fullest (147//160: c = 4, 320
+    // lanes = 5 full waves; measured 4.02 TB/s vs 3.88 for c = 3 and 3.68 for c = 2 on the same box); if there
+    // is none (large M), the best lane utilisation overall.
     int best_c = 0;
     double best = -1.0;
-    for (int c = 1; static_cast<long long>(c) * a.M / 2 <= kPairMaxThreads; ++c) {
-        if ((static_cast<long long>(c) * a.M) % 2) continue;
-        const int lanes = static_cast<int>(static_cast<long long>(c) * a.M / 2);
-        const int padded = (lanes + 63) / 64 * 64;
-        if (padded >= 192 && static_cast<double>(lanes) / padded >= 0.90) { best_c = c; break; }
-        const double score = static_cast<double>(lanes) / padded * (padded < 192 ? 0.5 + 0.5 * padded / 192.0 : 1.0);
-        if (score > best + 1e-9) { best = score; best_c = c; }
-    }
+    for (int pass = 0; pass < 2 && !best_c; ++pass)
+        for (int c = 1; static_cast<long long>(c) * a.M / 2 <= kPairMaxThreads; ++c) {
+            if ((static_cast<long long>(c) * a.M) % 2) continue;
+            const int lanes = static_cast<int>(static_cast<long long>(c) * a.M / 2);
+            const int padded = (lanes + 63) / 64 * 64;
+            if (pass == 0 && (padded < 192 || padded > 320)) continue;
+            const double score = static_cast<double>(lanes) / padded * (padded < 192 ? 0.5 + 0.5 * padded / 192.0 : 1.0);
+            if (score > best + 1e-9) { best = score; best_c = c; }
+        }
     if (env_c > 0 && (static_cast<long long>(env_c) * a.M) % 2 == 0 && static_cast<long long>(env_c) * a.M / 2 <= kPairMaxThreads)
         best_c = env_c;
     if (!best_c) return false;
@@ -568,8 +597,11 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     const int lanes = static_cast<int>(cM / 2);
     const int padded = (lanes + 63) / 64 * 64;
     const int nwaves = padded / 64;
-    // tile: J steps; the stage is a whole number of 1 KiB DMA slots.  MRHIP_PAIR_ROUNDS (experiments) scales it.
-    const int stage_kib = env_r > 0 ? env_r * nwaves : 3 * nwaves;
+    // tile: J steps; the stage is a whole number of 1 KiB DMA slots, sized so that FOUR workgroups fit the CU's
+    // 160 KiB of LDS (ns stages + 1 KiB strip per compute wave + the tile descriptors).  MRHIP_PAIR_ROUNDS
+    // (experiments) sets the stage size directly.
+    const long long budget_kib = (160 * 1024 / 4 - 64 - static_cast<long long>(nwaves) * 1024) / ns / 1024;
+    const int stage_kib = env_r > 0 ? env_r * nwaves : static_cast<int>(budget_kib > 1 ? budget_kib : 1);
     long long J = (static_cast<long long>(stage_kib) * 256 - a.T - 2) / cM;   // 256 samples per KiB
     if (J < 1) {
         J = 1;
@@ -613,14 +645,18 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
         pa.spc_magic = spc == 1 ? 0xffffffffu : static_cast<unsigned>((1ULL << 32) / static_cast<unsigned long long>(spc));
     }
     *out = pa;
-    *lds = ns * stage_bytes + static_cast<size_t>(nwaves) * 1024;   // the pipeline stages + one output strip per compute wave
+    pa.flags_off = static_cast<int>(ns * stage_bytes + static_cast<size_t>(nwaves) * 1024);
+    *out = pa;
+    *lds = ns * stage_bytes + static_cast<size_t>(nwaves) * 1024 + 8 * ns;   // the pipeline stages + one output strip per compute wave + tile descriptors
     return true;
 }
 
 hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa_in, dim3 block, size_t lds, hipStream_t s,
-                                const char **kname, int num_cus)
+                                const char **kname, int num_cus, unsigned *counters)
 {
+    if (!counters) return hipErrorInvalidValue;
     PairArgs pa = pa_in;
+    pa.counters = counters;
     *kname = "rational_pair_kernel";
     static const int bpc = pair_env_int("MRHIP_PAIR_BPC", 0);
     return fused ? launch_pair_T<true>(a.T, block, lds, s, a, pa, num_cus, bpc)

@@ -141,7 +141,10 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     int ablate;              // timing experiments only (MRHIP_PS_ABLATE)
     unsigned steps_per_channel;   // ceil(n_out / P)
     unsigned total_steps;         // steps_per_channel * channels
-    unsigned steps_per_wg;        // ceil(total_steps / grid): workgroup b owns steps [b*S, (b+1)*S)
+    unsigned steps_per_group;     // ceil(total_steps / ngroups): group g owns steps [g*S, (g+1)*S)
+    int ngroups;                  // scheduling groups; workgroup b draws grabs of J steps from group b % ngroups
+    int flags_off;                // LDS byte offset of the per-stage tile descriptors
+    unsigned *counters;           // device: [g*64] next grab of group g, [ngroups*64] workgroups finished (re-arms all)
     unsigned spc_magic;           // floor(2^32 / steps_per_channel) (0xffffffff for 1): step number -> channel by multiply-high
     long long o0;            // d0 - T: x index of LDS sample 0 of tile 0 (negative => history)
     long long tile_in;       // J*c*M
@@ -185,7 +188,7 @@ hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, h
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
 bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
-                                const char **kname, int num_cus);   // also performs shiftin! into a.hist_new
+                                const char **kname, int num_cus, unsigned *counters);   // also performs shiftin! into a.hist_new
 bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectArgs *out, size_t *lds);
 hipError_t launch_fir_direct(const TypeKey &tk, bool fused, const PolyArgs &a, const DirectArgs &da, size_t lds, hipStream_t s,
                              const char **kname, int num_cus);
@@ -216,6 +219,7 @@ struct mrhip_filter {
     // device memory
     void *d_taps = nullptr, *d_dtaps = nullptr;
     void *d_hist[2] = {nullptr, nullptr};
+    unsigned *d_counters = nullptr;   // pair kernel's dynamic scheduling: 33 counters, 256 bytes apart, zero between launches
     int hist_cur = 0;
     // host copies of the taps in tap dtype (for get_taps)
     std::vector<unsigned char> h_taps, h_dtaps;
