@@ -57,7 +57,8 @@ typedef enum {
     MRHIP_FIR_DECIMATOR = 1,    /* FIRDecimator    src/Filters.jl:45-58   */
     MRHIP_FIR_INTERPOLATOR = 2, /* FIRInterpolator src/Filters.jl:28-41   */
     MRHIP_FIR_RATIONAL = 3,     /* FIRRational     src/Filters.jl:62-80   */
-    MRHIP_FIR_ARBITRARY = 4     /* FIRArbitrary    src/Filters.jl:91-117  */
+    MRHIP_FIR_ARBITRARY = 4,    /* FIRArbitrary    src/Filters.jl:91-117  */
+    MRHIP_FIR_FARROW = 5        /* FIRFarrow       src/Filters.jl:123-147 */
 } mrhip_kind;
 
 /* Arithmetic contract for the tap dot product (src/support.jl:5-55).
@@ -111,6 +112,10 @@ int64_t mrhip_outputlength_ratio(int64_t inputlength, int64_t interpolation, int
 /* replaces inputlength(outputlength, ratio, initial𝜙), src/Filters.jl:396-401 */
 int64_t mrhip_inputlength_ratio(int64_t outputlength, int64_t interpolation, int64_t decimation,
                                 int64_t initialPhi);
+/* replaces polyfit(y, polyorder), src/support.jl:85-88: least-squares polynomial through (x = 1..n, y[x]);
+ * coef receives polyorder+1 coefficients, ascending powers (Poly.a).  Returns 0, or MRHIP_ERR_INVALID_ARG when
+ * n < polyorder+1.  Float64 throughout (Julia's A \\ y promotes to Float64). */
+int mrhip_polyfit(const double *y, int64_t n, int64_t polyorder, double *coef);
 /* promote_type(Th, Tx) as used by every filt wrapper, e.g. src/Filters.jl:581 */
 int mrhip_output_dtype(int tap_dtype, int sample_dtype);
 
@@ -126,6 +131,25 @@ int mrhip_create_rational(const void *h, int64_t hLen, int tap_dtype, int64_t nu
  * MRHIP_ERR_INVALID_ARG ("rate must be greater than 0", :184). */
 int mrhip_create_arbitrary(const void *h, int64_t hLen, int tap_dtype, double rate, int64_t Nphi,
                            int sample_dtype, int64_t nchannels, int device, mrhip_filter **out);
+/* replaces FIRFilter(h::Vector, rate::FloatingPoint, Nphi::Integer, polyorder::Integer),
+ * src/Filters.jl:192-198 (+ FIRFarrow(h, rate, Nphi, polyorder), :138-147, pfb2pnfb :311-321 and
+ * polyfit, src/support.jl:85-88): every ROW of the tapsPerPhi x Nphi filter bank is replaced by its
+ * least-squares polynomial of degree polyorder over x = 1..Nphi, stored in the tap type; the taps of an
+ * output are those polynomials evaluated at its Float64 phase.  The fit (Julia: A \ y, LAPACK QR) is
+ * done on the host in Float64 by a Householder QR. */
+int mrhip_create_farrow(const void *h, int64_t hLen, int tap_dtype, double rate, int64_t Nphi, int64_t polyorder,
+                        int sample_dtype, int64_t nchannels, int device, mrhip_filter **out);
+/* same, with the polynomial filter bank supplied by the caller: pnfb[tapsPerPhi][polyorder+1] Float64,
+ * ascending powers (the layout of Poly.a), tapsPerPhi = ceil(hLen/Nphi); values are rounded to the tap type
+ * as the reference's Poly{T} storage does.  Lets a caller fit with its own least-squares routine (the
+ * reference pins no bits of the fit) and lets tests hand oracle and GPU the same coefficients. */
+int mrhip_create_farrow_pnfb(const double *pnfb, int64_t hLen, int tap_dtype, double rate, int64_t Nphi,
+                             int64_t polyorder, int sample_dtype, int64_t nchannels, int device, mrhip_filter **out);
+/* the polynomial filter bank in use, [tapsPerPhi][polyorder+1] Float64 (pfb2pnfb's result) */
+int mrhip_get_pnfb(const mrhip_filter *f, double *host_out);
+/* replaces tapsforphase(kernel::FIRFarrow, phase), src/Filters.jl:764-775: tapsPerPhi taps of tap_dtype
+ * for a phase in [0, Nphi+1] (host evaluation; MRHIP_ERR_INVALID_ARG outside the range like :765) */
+int mrhip_farrow_tapsforphase(const mrhip_filter *f, double phase, void *host_out);
 void mrhip_destroy(mrhip_filter *f);
 
 /* ---- bookkeeping ---------------------------------------------------------------------- */

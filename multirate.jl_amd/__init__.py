@@ -27,14 +27,17 @@ from .host import (  # noqa: F401
     load_library,
     nextphase,
     outputlength,
+    polyfit,
     reset,
+    setphase,
     taps2pfb,
+    tapsforphase,
 )
 from .design import firdes, kaiserlength  # noqa: F401
 from .sharding import ChannelShardedFilter, shard_channels  # noqa: F401
 
 __all__ = [
     "FIRFilter", "filt", "filt_", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
-    "firdes", "kaiserlength", "ChannelShardedFilter", "shard_channels", "load_library",
+    "setphase", "tapsforphase", "polyfit", "firdes", "kaiserlength", "ChannelShardedFilter", "shard_channels", "load_library",
     "library_path", "MultirateHIPError", "NUMERICS_STRICT", "NUMERICS_FUSED",
 ]

@@ -261,12 +261,109 @@ int mrhip_create_arbitrary(const void *h, int64_t hLen, int th, double rate, int
     return MRHIP_OK;
 }
 
+static int create_farrow_common(const std::vector<double> &pnfb_in, int64_t hLen, int th, double rate, int64_t Nphi,
+                                int64_t polyorder, int tx, int64_t nch, int device, mrhip_filter **out)
+{
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
+    auto *f = new mrhip_filter();
+    f->kind = MRHIP_FIR_FARROW;
+    f->th = th; f->tx = tx; f->ty = mrhip_output_dtype(th, tx);
+    f->nc = dtype_is_complex(tx) ? 2 : 1;
+    f->r_f64 = dtype_is_f64(f->ty);
+    f->nch = nch; f->hLen = hLen; f->L = Nphi; f->M = 1; f->Nphi = Nphi; f->device = device;
+    f->rate = rate;
+    f->delta = static_cast<double>(Nphi) / rate;   // Δ = N𝜙/rate, Filters.jl:143
+    f->polyorder = polyorder;
+    f->T = (hLen + Nphi - 1) / Nphi;
+    f->H = f->T - 1;
+    f->h_pnfb = pnfb_in;
+    // Poly{T} storage: coefficients live in the tap type (Filters.jl:313 Array(Poly{T}, ...))
+    if (th == MRHIP_F32) for (double &c : f->h_pnfb) c = static_cast<double>(static_cast<float>(c));
+    int rc = MRHIP_OK;
+    if (hipMalloc(reinterpret_cast<void **>(&f->d_pnfb), f->h_pnfb.size() * sizeof(double)) != hipSuccess ||
+        hipMemcpy(f->d_pnfb, f->h_pnfb.data(), f->h_pnfb.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(MRHIP_ERR_HIP, "uploading the polynomial filter bank failed");
+    if (!rc) rc = alloc_common(f);
+    if (rc) { mrhip_destroy(f); return rc; }
+    *out = f;
+    return MRHIP_OK;
+}
+
+int mrhip_create_farrow(const void *h, int64_t hLen, int th, double rate, int64_t Nphi, int64_t polyorder, int tx,
+                        int64_t nch, int device, mrhip_filter **out)
+{
+    if (int rc = check_create_args(h, hLen, th, tx, nch, device, out)) return rc;
+    if (!(rate > 0.0)) return fail(MRHIP_ERR_INVALID_ARG, "rate must be greater than 0");
+    if (Nphi < 1 || Nphi > 0x7fffffff || hLen > 0x7fffffff) return fail(MRHIP_ERR_INVALID_ARG, "bad Nphi");
+    if (polyorder < 0 || polyorder > 32 || polyorder + 1 > Nphi)
+        return fail(MRHIP_ERR_INVALID_ARG, "polyorder must be in 0..min(32, Nphi-1)");
+    // pfb = taps2pfb(h, Nphi); one polynomial per ROW (Filters.jl:139-140, :315-318)
+    const size_t es = dtype_scalar_size(th);
+    const int64_t T = taps2pfb(h, hLen, th, Nphi, nullptr);
+    std::vector<unsigned char> pfb(static_cast<size_t>(T) * Nphi * es);
+    taps2pfb(h, hLen, th, Nphi, pfb.data());
+    std::vector<double> pn(static_cast<size_t>(T) * (polyorder + 1)), row(static_cast<size_t>(Nphi));
+    for (int64_t i = 0; i < T; ++i) {
+        for (int64_t c = 0; c < Nphi; ++c)          // element (row i, column c) of the column-major bank
+            row[static_cast<size_t>(c)] = th == MRHIP_F32 ? static_cast<double>(reinterpret_cast<const float *>(pfb.data())[c * T + i])
+                                                          : reinterpret_cast<const double *>(pfb.data())[c * T + i];
+        if (!polyfit_rows(row.data(), Nphi, static_cast<int>(polyorder), &pn[static_cast<size_t>(i) * (polyorder + 1)]))
+            return fail(MRHIP_ERR_INVALID_ARG, "polynomial fit is rank deficient");
+    }
+    return create_farrow_common(pn, hLen, th, rate, Nphi, polyorder, tx, nch, device, out);
+}
+
+int mrhip_create_farrow_pnfb(const double *pnfb, int64_t hLen, int th, double rate, int64_t Nphi, int64_t polyorder,
+                             int tx, int64_t nch, int device, mrhip_filter **out)
+{
+    if (int rc = check_create_args(pnfb, hLen, th, tx, nch, device, out)) return rc;
+    if (!(rate > 0.0)) return fail(MRHIP_ERR_INVALID_ARG, "rate must be greater than 0");
+    if (Nphi < 1 || Nphi > 0x7fffffff || hLen > 0x7fffffff) return fail(MRHIP_ERR_INVALID_ARG, "bad Nphi");
+    if (polyorder < 0 || polyorder > 32) return fail(MRHIP_ERR_INVALID_ARG, "polyorder must be in 0..32");
+    const int64_t T = (hLen + Nphi - 1) / Nphi;
+    std::vector<double> pn(pnfb, pnfb + static_cast<size_t>(T) * (polyorder + 1));
+    return create_farrow_common(pn, hLen, th, rate, Nphi, polyorder, tx, nch, device, out);
+}
+
+int mrhip_polyfit(const double *y, int64_t n, int64_t polyorder, double *coef)
+{
+    if (!y || !coef || polyorder < 0 || polyorder > 64) return fail(MRHIP_ERR_INVALID_ARG, "bad polyfit arguments");
+    if (!polyfit_rows(y, n, static_cast<int>(polyorder), coef)) return fail(MRHIP_ERR_INVALID_ARG, "polynomial fit is rank deficient");
+    return MRHIP_OK;
+}
+
+int mrhip_get_pnfb(const mrhip_filter *f, double *host_out)
+{
+    if (!f || !host_out) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    if (f->kind != MRHIP_FIR_FARROW) return fail(MRHIP_ERR_INVALID_ARG, "not a FIRFarrow filter");
+    std::memcpy(host_out, f->h_pnfb.data(), f->h_pnfb.size() * sizeof(double));
+    return MRHIP_OK;
+}
+
+int mrhip_farrow_tapsforphase(const mrhip_filter *f, double phase, void *host_out)
+{
+    if (!f || !host_out) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    if (f->kind != MRHIP_FIR_FARROW) return fail(MRHIP_ERR_INVALID_ARG, "not a FIRFarrow filter");
+    if (!(phase >= 0.0 && phase <= static_cast<double>(f->Nphi) + 1.0))
+        return fail(MRHIP_ERR_INVALID_ARG, "phase must be >= 0 and <= Nphi+1");      // Filters.jl:765
+    const int64_t P = f->polyorder;
+    for (int64_t i = 0; i < f->T; ++i) {
+        const double *c = &f->h_pnfb[static_cast<size_t>(i) * (P + 1)];
+        double yv = c[P];
+        for (int64_t j = P - 1; j >= 0; --j) { const double t = phase * yv; yv = c[j] + t; }
+        if (f->th == MRHIP_F32) static_cast<float *>(host_out)[i] = static_cast<float>(yv);
+        else static_cast<double *>(host_out)[i] = yv;
+    }
+    return MRHIP_OK;
+}
+
 void mrhip_destroy(mrhip_filter *f)
 {
     if (!f) return;
     DeviceGuard guard(f->device);
     (void)hipDeviceSynchronize();
-    for (void *p : {f->d_taps, f->d_dtaps, f->d_hist[0], f->d_hist[1], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc, f->d_xbuf, f->d_ybuf})
+    for (void *p : {f->d_taps, f->d_dtaps, static_cast<void *>(f->d_pnfb), f->d_hist[0], f->d_hist[1], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc, f->d_xbuf, f->d_ybuf})
         if (p) (void)hipFree(p);
     if (f->pin_n) (void)hipHostFree(f->pin_n);
     if (f->pin_acc) (void)hipHostFree(f->pin_acc);
@@ -285,6 +382,7 @@ int64_t mrhip_outputlength(const mrhip_filter *f, int64_t n)
     case MRHIP_FIR_DECIMATOR: return outputlength_ratio(n - f->inputDeficit + 1, 1, f->M, 1);   // :367
     case MRHIP_FIR_RATIONAL: return outputlength_ratio(n - f->inputDeficit + 1, f->L, f->M, f->phiIdx); // :371
     case MRHIP_FIR_ARBITRARY: return static_cast<int64_t>(std::ceil(static_cast<double>(n - f->inputDeficit + 1) * f->rate)); // :375
+    case MRHIP_FIR_FARROW: return static_cast<int64_t>(std::ceil(static_cast<double>(n - f->inputDeficit + 1) * f->rate));    // :379
     }
     return -1;
 }
@@ -307,7 +405,7 @@ static int64_t arb_schedule(mrhip_filter *f, int64_t x_len, ArbState *end_state)
 int64_t mrhip_next_output_count(const mrhip_filter *f, int64_t n)
 {
     if (!f || n < 0) return -1;
-    if (f->kind == MRHIP_FIR_ARBITRARY)   // the schedule is cached for the filt call that normally follows
+    if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW)   // the schedule is cached for the filt call that normally follows
         return arb_schedule(const_cast<mrhip_filter *>(f), n, nullptr);
     return plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, n).n_out;
 }
@@ -340,7 +438,7 @@ int mrhip_set_state(mrhip_filter *f, int64_t phiIdx, int64_t inputDeficit, doubl
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
     if (inputDeficit < 1) return fail(MRHIP_ERR_INVALID_ARG, "inputDeficit must be >= 1");
-    if (f->kind == MRHIP_FIR_ARBITRARY) {
+    if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {
         if (!(phiAccumulator >= 1.0) || !(phiAccumulator < static_cast<double>(f->Nphi) + 1.0))
             return fail(MRHIP_ERR_INVALID_ARG, "phiAccumulator must be in [1, Nphi+1)");
         f->phiAcc = phiAccumulator;
@@ -463,9 +561,9 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
 
     int64_t n_out = 0;
     bool did_shiftin = false;
-    if (f->kind == MRHIP_FIR_ARBITRARY) {
+    if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {
         ArbState st;
-        n_out = arb_schedule(f, x_len, &st);
+        n_out = arb_schedule(f, x_len, &st);   // update(::FIRFarrow), Filters.jl:780-788, is the same recurrence
         if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
         if (n_out > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
         if (n_out > 0) {
@@ -478,6 +576,17 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_sched_acc, f->pin_acc, static_cast<size_t>(n_out) * sizeof(double), hipMemcpyHostToDevice, stream));
             MRHIP_CHECK_HIP(hipEventRecord(f->sched_copied, stream));
             f->sched_in_flight = true;
+            if (f->kind == MRHIP_FIR_FARROW) {
+                FarrowArgs fa{};
+                fa.x = x; fa.y = y; fa.hist = f->d_hist[f->hist_cur]; fa.pnfb = f->d_pnfb;
+                fa.n_idx = static_cast<const int *>(f->d_sched_n); fa.acc = static_cast<const double *>(f->d_sched_acc);
+                fa.x_stride = x_stride; fa.y_stride = y_stride; fa.x_len = x_len; fa.n_out = n_out;
+                fa.T = static_cast<int>(f->T); fa.H = static_cast<int>(f->H); fa.polyorder = static_cast<int>(f->polyorder);
+                fa.tap_f32 = f->th == MRHIP_F32; fa.nch = static_cast<int>(f->nch);
+                if (int rc = timing_mark(f, stream)) return rc;
+                MRHIP_CHECK_HIP(launch_farrow(tk, fused, fa, stream, &f->last_kernel));
+                if (int rc = timing_mark(f, stream)) return rc;
+            } else {
             ArbArgs a{};
             a.x = x; a.y = y; a.hist = f->d_hist[f->hist_cur]; a.taps = f->d_taps; a.dtaps = f->d_dtaps;
             a.n_idx = static_cast<const int *>(f->d_sched_n); a.acc = static_cast<const double *>(f->d_sched_acc);
@@ -494,6 +603,7 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
                     MRHIP_CHECK_HIP(launch_arb_generic(tk, fused, a, stream, &f->last_kernel));
             }
             if (int rc = timing_mark(f, stream)) return rc;
+            }
         }
         // commit the post-call state (Filters.jl:731-735)
         f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;

@@ -5,6 +5,7 @@
 // reading back from the device.
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "mrhip_internal.h"
 
@@ -137,6 +138,53 @@ int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t
     st.xIdx = xIdx;
     st.inputDeficit = xIdx - xLen;         // :734
     return count;
+}
+
+// polyfit(y, polyorder), src/support.jl:85-88: A = [x^p for x in 1:n, p = 0:polyorder]; coefficients = A \ y,
+// i.e. the least-squares solution Julia computes by a QR factorisation of A in Float64.  Restated as a
+// Householder QR (the reference pins no bits here: SURVEY.md 8c -- LAPACK's blocked QR and this one agree
+// to rounding).  Returns false when the system is rank deficient (n < polyorder+1).
+bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef)
+{
+    const int m = polyorder + 1;
+    if (n < m || m < 1) return false;
+    std::vector<double> A(static_cast<size_t>(n) * m), b(y, y + n);
+    for (int64_t r = 0; r < n; ++r) {
+        double v = 1.0;
+        for (int c = 0; c < m; ++c) { A[static_cast<size_t>(r) * m + c] = v; v *= static_cast<double>(r + 1); }
+    }
+    for (int c = 0; c < m; ++c) {                     // Householder reflections, column by column
+        double norm = 0.0;
+        for (int64_t r = c; r < n; ++r) norm += A[static_cast<size_t>(r) * m + c] * A[static_cast<size_t>(r) * m + c];
+        norm = std::sqrt(norm);
+        if (norm == 0.0) return false;
+        const double akk = A[static_cast<size_t>(c) * m + c];
+        const double alpha = akk > 0 ? -norm : norm;
+        std::vector<double> v(static_cast<size_t>(n - c));
+        v[0] = akk - alpha;
+        for (int64_t r = c + 1; r < n; ++r) v[static_cast<size_t>(r - c)] = A[static_cast<size_t>(r) * m + c];
+        double vnorm2 = 0.0;
+        for (double t : v) vnorm2 += t * t;
+        if (vnorm2 == 0.0) continue;
+        for (int cc = c; cc < m; ++cc) {
+            double dot = 0.0;
+            for (int64_t r = c; r < n; ++r) dot += v[static_cast<size_t>(r - c)] * A[static_cast<size_t>(r) * m + cc];
+            const double f = 2.0 * dot / vnorm2;
+            for (int64_t r = c; r < n; ++r) A[static_cast<size_t>(r) * m + cc] -= f * v[static_cast<size_t>(r - c)];
+        }
+        double dot = 0.0;
+        for (int64_t r = c; r < n; ++r) dot += v[static_cast<size_t>(r - c)] * b[static_cast<size_t>(r)];
+        const double f = 2.0 * dot / vnorm2;
+        for (int64_t r = c; r < n; ++r) b[static_cast<size_t>(r)] -= f * v[static_cast<size_t>(r - c)];
+    }
+    for (int c = m - 1; c >= 0; --c) {                // back substitution on the upper-triangular R
+        double sacc = b[static_cast<size_t>(c)];
+        for (int cc = c + 1; cc < m; ++cc) sacc -= A[static_cast<size_t>(c) * m + cc] * coef[cc];
+        const double d = A[static_cast<size_t>(c) * m + c];
+        if (d == 0.0) return false;
+        coef[c] = sacc / d;
+    }
+    return true;
 }
 
 }  // namespace mrhip

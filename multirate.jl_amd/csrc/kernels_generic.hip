@@ -133,6 +133,59 @@ __global__ __launch_bounds__(256) void arb_generic_kernel(ArbArgs a)
     }
 }
 
+// FIRFarrow (src/Filters.jl:123-147, 764-839): the taps of every output are polynomials in the Float64
+// phase 𝜙Idx evaluated by Horner in Float64 (Polynomials.jl polyval: y = p[end]; y = p[i] + x*y), stored
+// into currentTaps::Vector{Th} (rounded to Th), then one Vector unsafedot (support.jl:33-55, start from
+// zero on the seam, :46).  One thread per output: it evaluates its tapsPerPhi taps ONCE into an LDS
+// column (the taps depend on the output, not on the channel) and reuses them for every channel it
+// visits; CACHE = false recomputes them per channel when the bank does not fit LDS.  (n, phase) per
+// output come from the host-evaluated recurrence of update() (:780-788), shared with FIRArbitrary.
+template <typename TX, typename R, int NC, bool FUSED, bool CACHE>
+__global__ __launch_bounds__(256) void farrow_kernel(FarrowArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char farrow_smem[];
+    R *const tl = reinterpret_cast<R *>(farrow_smem);
+    const int tid = threadIdx.x, bs = blockDim.x;
+    const long long k = static_cast<long long>(blockIdx.x) * bs + tid;
+    if (k >= a.n_out) return;                      // no barriers below: each thread only reads its own LDS column
+    const long long n = a.n_idx[k];
+    const double phase = a.acc[k];
+    const int P = a.polyorder;
+    auto tap = [&](int i) -> R {
+        const double *__restrict__ c = a.pnfb + static_cast<long long>(i) * (P + 1);
+        double yv = c[P];
+        for (int j = P - 1; j >= 0; --j) { const double t = phase * yv; yv = c[j] + t; }
+        return a.tap_f32 ? static_cast<R>(static_cast<float>(yv)) : static_cast<R>(yv);
+    };
+    if constexpr (CACHE)
+        for (int i = 0; i < a.T; ++i) tl[i * bs + tid] = tap(i);
+    const long long base = n - a.T;
+    const bool seam = n < a.T;                     // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818
+    for (int ch = blockIdx.y; ch < a.nch; ch += gridDim.y) {
+        const TX *__restrict__ xc = static_cast<const TX *>(a.x) + static_cast<long long>(ch) * a.x_stride * NC;
+        const TX *__restrict__ hc = static_cast<const TX *>(a.hist) + static_cast<long long>(ch) * a.H * NC;
+        R *__restrict__ yc = static_cast<R *>(a.y) + static_cast<long long>(ch) * a.y_stride * NC;
+        TX v[NC];
+        R acc[NC];
+        load_sample<TX, NC>(xc, hc, a.H, base, v);
+        const R t0 = CACHE ? tl[tid] : tap(0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = t0 * static_cast<R>(v[c]);
+        if (seam) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = static_cast<R>(0) + acc[c];
+        }
+        for (int i = 1; i < a.T; ++i) {
+            load_sample<TX, NC>(xc, hc, a.H, base + i, v);
+            const R t = CACHE ? tl[i * bs + tid] : tap(i);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = mac<R, FUSED>(t, static_cast<R>(v[c]), acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) yc[k * NC + c] = acc[c];
+    }
+}
+
 // shiftin!: hist_new <- last H samples of [hist_old ; x]   (src/support.jl:61-80)
 template <typename TX, int NC>
 __global__ __launch_bounds__(256) void shiftin_kernel(HistArgs a)
@@ -189,6 +242,43 @@ hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, h
     return dispatch_types(tk, [&]<typename TX, typename R, int NC>() -> hipError_t {
         if (fused) hipLaunchKernelGGL((arb_generic_kernel<TX, R, NC, true>), grid_for(a.n_out, a.nch), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((arb_generic_kernel<TX, R, NC, false>), grid_for(a.n_out, a.nch), dim3(256), 0, s, a);
+        return hipGetLastError();
+    });
+}
+
+hipError_t launch_farrow(const TypeKey &tk, bool fused, const FarrowArgs &a, hipStream_t s, const char **kname)
+{
+    if (a.n_out <= 0) return hipSuccess;
+    *kname = "farrow_kernel";
+    return dispatch_types(tk, [&]<typename TX, typename R, int NC>() -> hipError_t {
+        // block size: as many outputs as keep one LDS column of T taps per thread within 64 KiB
+        const long long per_thread = static_cast<long long>(a.T) * static_cast<long long>(sizeof(R));
+        int bs = static_cast<int>(65536 / per_thread) / 64 * 64;
+        const bool cache = bs >= 64;
+        if (bs > 256) bs = 256;
+        if (!cache) bs = 256;
+        const size_t lds = cache ? static_cast<size_t>(per_thread) * bs : 0;
+        const long long bx = (a.n_out + bs - 1) / bs;
+        if (bx > 0x7fffffffLL) return hipErrorInvalidValue;
+        // channels are split over blockIdx.y only as far as needed to fill the machine: the taps are
+        // evaluated once per (output, blockIdx.y)
+        long long by = 1;
+        while (by < a.nch && bx * by < 2048) by *= 2;
+        if (by > a.nch) by = a.nch;
+        const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(by), 1);
+#define MRHIP_FARROW_LAUNCH(F, C)                                                                         \
+        {                                                                                                 \
+            auto kfn = farrow_kernel<TX, R, NC, F, C>;                                                    \
+            if (lds > 48 * 1024) {                                                                        \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                   \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+                if (e != hipSuccess) return e;                                                            \
+            }                                                                                             \
+            hipLaunchKernelGGL(kfn, grid, dim3(bs), lds, s, a);                                           \
+        }
+        if (fused) { if (cache) MRHIP_FARROW_LAUNCH(true, true) else MRHIP_FARROW_LAUNCH(true, false) }
+        else { if (cache) MRHIP_FARROW_LAUNCH(false, true) else MRHIP_FARROW_LAUNCH(false, false) }
+#undef MRHIP_FARROW_LAUNCH
         return hipGetLastError();
     });
 }

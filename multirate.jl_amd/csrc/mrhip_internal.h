@@ -104,6 +104,21 @@ struct ArbArgs {             // FIRArbitrary
     int nch;
 };
 
+struct FarrowArgs {          // FIRFarrow
+    const void *x;
+    void *y;
+    const void *hist;
+    const double *pnfb;      // device, [T][polyorder+1] ascending powers (values representable in Th)
+    const int *n_idx;        // device, per output: 1-based input index
+    const double *acc;       // device, per output: the Float64 phase 𝜙Idx
+    long long x_stride, y_stride;
+    long long x_len;
+    long long n_out;
+    int T, H, polyorder;
+    int tap_f32;             // currentTaps is a Vector{Float32}: round every evaluated tap to Float32
+    int nch;
+};
+
 struct HistArgs {            // shiftin! (src/support.jl:61-80) for every channel
     const void *x;
     const void *hist_old;
@@ -185,7 +200,10 @@ struct TypeKey {
 // ---------------------------------------------------------------------------------------
 hipError_t launch_poly_generic(const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, hipStream_t s, const char **kname);
+hipError_t launch_farrow(const TypeKey &tk, bool fused, const FarrowArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
+// least-squares polynomial fit of y[0..n) at x = 1..n (support.jl:85-88); coef receives polyorder+1 ascending powers
+bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef);
 bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                                 const char **kname, int num_cus, unsigned *counters);   // also performs shiftin! into a.hist_new
@@ -218,6 +236,9 @@ struct mrhip_filter {
 
     // device memory
     void *d_taps = nullptr, *d_dtaps = nullptr;
+    double *d_pnfb = nullptr;              // FIRFarrow: polynomial filter bank on the device
+    std::vector<double> h_pnfb;            // ... and on the host, [T][polyorder+1]
+    int64_t polyorder = 0;
     void *d_hist[2] = {nullptr, nullptr};
     unsigned *d_counters = nullptr;   // pair kernel's dynamic scheduling: 33 counters, 256 bytes apart, zero between launches
     int hist_cur = 0;

@@ -30,9 +30,9 @@ except Exception:  # pragma: no cover - torch is optional for pure-numpy use
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 F32, F64, C64, C128 = 0, 1, 2, 3
-STANDARD, DECIMATOR, INTERPOLATOR, RATIONAL, ARBITRARY = 0, 1, 2, 3, 4
+STANDARD, DECIMATOR, INTERPOLATOR, RATIONAL, ARBITRARY, FARROW = 0, 1, 2, 3, 4, 5
 KIND_NAMES = {STANDARD: "FIRStandard", DECIMATOR: "FIRDecimator", INTERPOLATOR: "FIRInterpolator",
-              RATIONAL: "FIRRational", ARBITRARY: "FIRArbitrary"}
+              RATIONAL: "FIRRational", ARBITRARY: "FIRArbitrary", FARROW: "FIRFarrow"}
 NUMERICS_STRICT, NUMERICS_FUSED = 0, 1
 
 _NP2DT = {np.dtype(np.float32): F32, np.dtype(np.float64): F64,
@@ -68,9 +68,14 @@ ABI = [
     ("mrhip_nextphase", _i64, [_i64, _i64, _i64]),
     ("mrhip_outputlength_ratio", _i64, [_i64, _i64, _i64, _i64]),
     ("mrhip_inputlength_ratio", _i64, [_i64, _i64, _i64, _i64]),
+    ("mrhip_polyfit", _i, [_vp, _i64, _i64, _vp]),
     ("mrhip_output_dtype", _i, [_i, _i]),
     ("mrhip_create_rational", _i, [_vp, _i64, _i, _i64, _i64, _i, _i64, _i, C.POINTER(_vp)]),
     ("mrhip_create_arbitrary", _i, [_vp, _i64, _i, _d, _i64, _i, _i64, _i, C.POINTER(_vp)]),
+    ("mrhip_create_farrow", _i, [_vp, _i64, _i, _d, _i64, _i64, _i, _i64, _i, C.POINTER(_vp)]),
+    ("mrhip_create_farrow_pnfb", _i, [_vp, _i64, _i, _d, _i64, _i64, _i, _i64, _i, C.POINTER(_vp)]),
+    ("mrhip_get_pnfb", _i, [_vp, _vp]),
+    ("mrhip_farrow_tapsforphase", _i, [_vp, _d, _vp]),
     ("mrhip_destroy", None, [_vp]),
     ("mrhip_outputlength", _i64, [_vp, _i64]),
     ("mrhip_next_output_count", _i64, [_vp, _i64]),
@@ -164,6 +169,14 @@ def taps2pfb(h, Nphi: int) -> np.ndarray:
     return out.reshape(Nphi, T).T.copy()
 
 
+def polyfit(y, polyorder: int) -> np.ndarray:
+    """polyfit(y, polyorder), src/support.jl:85-88: coefficients in ascending powers (Poly.a)."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.zeros(polyorder + 1, dtype=np.float64)
+    _check(load_library().mrhip_polyfit(_ptr(y), len(y), polyorder, _ptr(out)))
+    return out
+
+
 def nextphase(currentphase: int, ratio) -> int:
     """nextphase(currentphase, ratio), src/Filters.jl:433-439."""
     r = Fraction(ratio)
@@ -172,7 +185,8 @@ def nextphase(currentphase: int, ratio) -> int:
 
 # ---- the filter object ------------------------------------------------------------------------
 class FIRFilter:
-    """FIRFilter(h, ratio::Rational = 1//1)  or  FIRFilter(h, rate::Float, N𝜙 = 32).
+    """FIRFilter(h, ratio::Rational = 1//1)  or  FIRFilter(h, rate::Float, N𝜙 = 32)
+    or  FIRFilter(h, rate::Float, N𝜙, polyorder)  (FIRFarrow, src/Filters.jl:192-198).
 
     Mirrors src/Filters.jl:158-189: a ``Fraction``/int/(num, den) ratio selects FIRStandard,
     FIRDecimator, FIRInterpolator or FIRRational exactly as the reference does; a ``float`` selects
@@ -181,8 +195,8 @@ class FIRFilter:
     the sample dtype and the number of channels are known.
     """
 
-    def __init__(self, h, ratio=Fraction(1, 1), Nphi: int = 32, *, device: int = 0,
-                 numerics: int = NUMERICS_STRICT):
+    def __init__(self, h, ratio=Fraction(1, 1), Nphi: int = 32, polyorder=None, *, device: int = 0,
+                 numerics: int = NUMERICS_STRICT, pnfb=None):
         self._lib = load_library()
         self.h = _as_taps(h).copy()
         if len(self.h) < 1:
@@ -192,13 +206,18 @@ class FIRFilter:
         self._handle = None
         self._tx = None
         self._nch = None
+        self.polyorder = None
+        self._pnfb_in = None
         if isinstance(ratio, (float, np.floating)):
             if not ratio > 0.0:
                 raise MultirateHIPError(1, "rate must be greater than 0")  # Filters.jl:184
             self.rate = float(ratio)
             self.ratio = None
             self.Nphi = int(Nphi)
-            self.kind = ARBITRARY
+            self.kind = ARBITRARY if polyorder is None else FARROW
+            self.polyorder = None if polyorder is None else int(polyorder)
+            # optional caller-fitted polynomial bank (tapsPerPhi x (polyorder+1), ascending powers)
+            self._pnfb_in = None if pnfb is None else np.ascontiguousarray(pnfb, dtype=np.float64)
             self.interpolation, self.decimation = self.Nphi, 1
             self.tapsPerPhi = -(-len(self.h) // self.Nphi)
             self.historyLen = self.tapsPerPhi - 1
@@ -234,7 +253,13 @@ class FIRFilter:
         if tx not in _NP2DT:
             raise MultirateHIPError(1, f"unsupported sample dtype {tx}")
         out = C.c_void_p()
-        if self.kind == ARBITRARY:
+        if self.kind == FARROW and self._pnfb_in is not None:
+            rc = self._lib.mrhip_create_farrow_pnfb(_ptr(self._pnfb_in), len(self.h), _NP2DT[self.h.dtype], self.rate,
+                                                    self.Nphi, self.polyorder, _NP2DT[tx], nch, self.device, C.byref(out))
+        elif self.kind == FARROW:
+            rc = self._lib.mrhip_create_farrow(_ptr(self.h), len(self.h), _NP2DT[self.h.dtype], self.rate, self.Nphi,
+                                               self.polyorder, _NP2DT[tx], nch, self.device, C.byref(out))
+        elif self.kind == ARBITRARY:
             rc = self._lib.mrhip_create_arbitrary(_ptr(self.h), len(self.h), _NP2DT[self.h.dtype], self.rate,
                                                   self.Nphi, _NP2DT[tx], nch, self.device, C.byref(out))
         else:
@@ -314,6 +339,49 @@ class FIRFilter:
         _check(self._lib.mrhip_get_taps(self._handle, which, _ptr(out)))
         return out.reshape(self.Nphi, self.tapsPerPhi).T.copy()
 
+    def pnfb(self) -> np.ndarray:
+        """FIRFarrow.pnfb (src/Filters.jl:126): tapsPer𝜙 polynomials, ascending powers, shape (tapsPer𝜙, polyorder+1)."""
+        if self._handle is None or self.kind != FARROW:
+            raise MultirateHIPError(1, "pnfb() needs a bound FIRFarrow filter")
+        out = np.zeros((self.tapsPerPhi, self.polyorder + 1), dtype=np.float64)
+        _check(self._lib.mrhip_get_pnfb(self._handle, _ptr(out)))
+        return out
+
+    def tapsforphase(self, phase: float) -> np.ndarray:
+        """tapsforphase(kernel::FIRFarrow, phase), src/Filters.jl:764-775."""
+        if self._handle is None or self.kind != FARROW:
+            raise MultirateHIPError(1, "tapsforphase() needs a bound FIRFarrow filter")
+        out = np.zeros(self.tapsPerPhi, dtype=self.h.dtype)
+        _check(self._lib.mrhip_farrow_tapsforphase(self._handle, float(phase), _ptr(out)))
+        return out
+
+    def setphase(self, phi: float):
+        """setphase(self::FIRFilter, 𝜙), src/Filters.jl:210-235, 𝜙 in [0, 1].  The reference's methods for
+        FIRInterpolator/FIRRational use an undefined variable (:212); the evident intent -- the phase index that
+        corresponds to the fraction 𝜙 of one input sample -- is implemented: 𝜙Idx = floor(𝜙*N𝜙) + 1, clipped to
+        N𝜙.  FIRArbitrary: (α, 𝜙Idx) = modf(𝜙*N𝜙) as written (:217-222), stored as 𝜙Accumulator = 𝜙Idx + α clipped
+        to [1, N𝜙+1).  FIRFarrow: 𝜙Idx = 𝜙*(N𝜙-1)+1 (:226)."""
+        if not 0.0 <= phi <= 1.0:
+            raise MultirateHIPError(1, "phase must be in [0, 1]")            # @assert, :211
+        if self._handle is None:
+            raise MultirateHIPError(1, "setphase needs a bound filter (call filt once, or bind())")
+        st = self.state
+        if self.kind in (INTERPOLATOR, RATIONAL):
+            idx = min(int(phi * self.Nphi) + 1, self.Nphi)
+            self.set_state(idx, st.inputDeficit, 1.0)
+            return idx
+        if self.kind == ARBITRARY:
+            import math
+            alpha, idx = math.modf(phi * self.Nphi)
+            acc = min(max(idx + alpha, 1.0), math.nextafter(self.Nphi + 1.0, 0.0))
+            self.set_state(1, st.inputDeficit, acc)
+            return idx, alpha
+        if self.kind == FARROW:
+            acc = phi * (self.Nphi - 1) + 1
+            self.set_state(1, st.inputDeficit, acc)
+            return acc
+        raise MultirateHIPError(5, f"setphase is not defined for {self.kernel_name}")
+
     def set_timing(self, enabled: bool = True):
         _check(self._lib.mrhip_set_timing(self._handle, 1 if enabled else 0))
 
@@ -334,7 +402,7 @@ class FIRFilter:
                 return inputlength
             if self.kind == INTERPOLATOR:
                 return self.interpolation * inputlength
-            if self.kind == ARBITRARY:
+            if self.kind in (ARBITRARY, FARROW):
                 import math
                 return int(math.ceil((inputlength - self_state.inputDeficit + 1) * self.rate))
             return self._lib.mrhip_outputlength_ratio(inputlength, self.interpolation, self.decimation, 1)
@@ -342,7 +410,7 @@ class FIRFilter:
 
     def inputlength(self, outputlength: int) -> int:
         if self._handle is None:
-            if self.kind == ARBITRARY:
+            if self.kind in (ARBITRARY, FARROW):
                 raise MultirateHIPError(5, "inputlength is not defined for FIRArbitrary in the reference")
             return self._lib.mrhip_inputlength_ratio(outputlength, self.interpolation, self.decimation, 1)
         n = self._lib.mrhip_inputlength(self._handle, outputlength)
@@ -430,13 +498,14 @@ class FIRFilter:
 
 
 # ---- free functions with the reference's names -------------------------------------------------
-def filt(a, x, ratio=Fraction(1, 1), Nphi: int = 32, **kw):
-    """filt(self::FIRFilter, x)                      src/Filters.jl:475,519,577,633,744
-       filt(h::Vector, x::Vector, ratio::Rational)   src/Filters.jl:858-861
-       filt(h::Vector, x::Vector, rate::Float, N𝜙)   src/Filters.jl:864-867"""
+def filt(a, x, ratio=Fraction(1, 1), Nphi: int = 32, polyorder=None, **kw):
+    """filt(self::FIRFilter, x)                                  src/Filters.jl:475,519,577,633,744,841
+       filt(h::Vector, x::Vector, ratio::Rational)               src/Filters.jl:858-861
+       filt(h::Vector, x::Vector, rate::Float, N𝜙)               src/Filters.jl:864-867
+       filt(h::Vector, x::Vector, rate::Float, N𝜙, polyorder)    src/Filters.jl:870-873"""
     if isinstance(a, FIRFilter):
         return a.filt(x)
-    f = FIRFilter(a, ratio, Nphi, **kw)
+    f = FIRFilter(a, ratio, Nphi, polyorder, **kw)
     try:
         return f.filt(x)
     finally:
@@ -464,3 +533,13 @@ def inputlength(self: FIRFilter, outputlength: int) -> int:
 def reset(self: FIRFilter) -> FIRFilter:
     """reset(self::FIRFilter), src/Filters.jl:256-260."""
     return self.reset()
+
+
+def setphase(self: FIRFilter, phi: float):
+    """setphase(self::FIRFilter, 𝜙), src/Filters.jl:235."""
+    return self.setphase(phi)
+
+
+def tapsforphase(self: FIRFilter, phase: float) -> np.ndarray:
+    """tapsforphase(kernel::FIRFarrow, phase), src/Filters.jl:775."""
+    return self.tapsforphase(phase)

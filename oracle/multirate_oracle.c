@@ -18,6 +18,9 @@
  *   src/Filters.jl:396-422  inputlength
  *   src/Filters.jl:433-439  nextphase
  *   src/Filters.jl:450-752  the five filt!/filt state machines + update()
+ *   src/Filters.jl:123-147, 764-846  FIRFarrow: constructor, tapsforphase!, update, filt!/filt
+ *       (the polynomial fit itself, pfb2pnfb/polyfit :311-321 + support.jl:85-88, is restated in
+ *        oracle/oracle.py with numpy's least squares and handed to mro_create_farrow)
  *
  * Pinning status.  The reference is Julia-0.3 source; no Julia exists in the
  * build image and no modern Julia parses it, so it cannot be executed here.
@@ -65,6 +68,9 @@ struct mro_filter {
     long historyLen;
     void *taps;        /* flipped h (Standard/Decimator) or pfb, column-major tapsPerPhi x Nphi */
     void *dtaps;       /* dpfb (Arbitrary) */
+    double *pnfb;      /* Farrow: tapsPerPhi x (polyorder+1) coefficients, ascending powers */
+    long polyorder;
+    void *currentTaps; /* Farrow: tapsPerPhi taps of Th, Filters.jl:128 */
     void *history;     /* historyLen samples of Tx */
     /* streaming state */
     long phiIdx;       /* 1-based */
@@ -223,10 +229,75 @@ mro_filter *mro_create_arbitrary(const void *h, long hLen, int th, double rate, 
     return f;
 }
 
+/* Polynomials.jl polyval(p::Poly{T}, x::Number): R = promote_type(T, typeof(x)) = Float64 here;
+ * y = p[end]; for i = end-1:-1:0  y = p[i] + x*y  (separately rounded multiply and add). */
+double mro_polyval(const double *c, long polyorder, double x)
+{
+    double y = c[polyorder];
+    for (long i = polyorder - 1; i >= 0; --i) {
+        double t = x * y;
+        y = c[i] + t;
+    }
+    return y;
+}
+
+/* currentTaps[tapIdx] = polyval(pnfb[tapIdx], phiIdx), stored into Vector{Th} (Filters.jl:144, :790-792) */
+static void farrow_taps(mro_filter *f, double phase)
+{
+    for (long i = 0; i < f->tapsPerPhi; ++i) {
+        double v = mro_polyval(f->pnfb + i * (f->polyorder + 1), f->polyorder, phase);
+        if (f->th == MRO_F32) ((float *)f->currentTaps)[i] = (float)v;
+        else ((double *)f->currentTaps)[i] = v;
+    }
+}
+
+/* reference: src/Filters.jl:192-198 FIRFilter(h, rate, Nphi, polyorder) and :138-147 FIRFarrow(...) */
+mro_filter *mro_create_farrow(long hLen, int th, double rate, long Nphi, long polyorder, const double *pnfb, int tx)
+{
+    if (!(rate > 0.0)) return NULL;                       /* "rate must be greater than 0", :193 */
+    if (hLen < 1 || Nphi < 1 || polyorder < 0 || dtype_is_complex(th) || !pnfb) return NULL;
+    mro_filter *f = (mro_filter *)calloc(1, sizeof *f);
+    f->kind = MRO_FARROW;
+    f->th = th; f->tx = tx; f->nc = dtype_is_complex(tx) ? 2 : 1;
+    f->hLen = hLen; f->L = Nphi; f->M = 1; f->Nphi = Nphi; f->rate = rate;
+    f->tapsPerPhi = (hLen + Nphi - 1) / Nphi;
+    f->polyorder = polyorder;
+    f->pnfb = (double *)malloc((size_t)f->tapsPerPhi * (polyorder + 1) * sizeof(double));
+    memcpy(f->pnfb, pnfb, (size_t)f->tapsPerPhi * (polyorder + 1) * sizeof(double));
+    f->currentTaps = calloc((size_t)f->tapsPerPhi, dtype_scalar_size(th));
+    f->phiAccumulator = 1.0;                              /* 𝜙Idx = 1.0 (a Float64 for this kernel), :142 */
+    f->phiIdx = 1; f->alpha = 0.0;
+    f->delta = (double)Nphi / rate;                       /* :143 */
+    f->inputDeficit = 1; f->xIdx = 1;
+    farrow_taps(f, f->phiAccumulator);                    /* :146 */
+    f->historyLen = f->tapsPerPhi - 1;
+    f->history = calloc((size_t)(f->historyLen > 0 ? f->historyLen : 1) * f->nc, dtype_scalar_size(tx));
+    return f;
+}
+
+/* reference: src/Filters.jl:780-793  update(kernel::FIRFarrow) */
+void mro_update_farrow(mro_filter *k)
+{
+    double Nphi = (double)k->Nphi;
+    k->phiAccumulator += k->delta;
+    if (k->phiAccumulator > Nphi) {
+        k->xIdx += (long)floor((k->phiAccumulator - 1.0) / Nphi);
+        k->phiAccumulator = fmod(k->phiAccumulator - 1.0, Nphi) + 1.0;
+    }
+    farrow_taps(k, k->phiAccumulator);
+    k->phiIdx = (long)floor(k->phiAccumulator);           /* bookkeeping only (state snapshots) */
+    k->alpha = k->phiAccumulator - (double)k->phiIdx;
+}
+
+void mro_get_current_taps(const mro_filter *f, void *out)
+{
+    if (f->currentTaps) memcpy(out, f->currentTaps, (size_t)f->tapsPerPhi * dtype_scalar_size(f->th));
+}
+
 void mro_destroy(mro_filter *f)
 {
     if (!f) return;
-    free(f->taps); free(f->dtaps); free(f->history); free(f);
+    free(f->taps); free(f->dtaps); free(f->pnfb); free(f->currentTaps); free(f->history); free(f);
 }
 
 /* reference: src/Filters.jl:663-673  update(kernel::FIRArbitrary)
@@ -252,6 +323,7 @@ long mro_outputlength(const mro_filter *f, long inputlength)
     case MRO_DECIMATOR: return mro_outputlength_ratio(inputlength - f->inputDeficit + 1, 1, f->M, 1); /* :367 */
     case MRO_RATIONAL: return mro_outputlength_ratio(inputlength - f->inputDeficit + 1, f->L, f->M, f->phiIdx); /* :371 */
     case MRO_ARBITRARY: return (long)ceil((double)(inputlength - f->inputDeficit + 1) * f->rate); /* :375 */
+    case MRO_FARROW: return (long)ceil((double)(inputlength - f->inputDeficit + 1) * f->rate);    /* :379 */
     }
     return -1;
 }
@@ -324,6 +396,7 @@ long mro_filt_sched(mro_filter *f, const void *x, long xLen, void *y, long ycap,
     case MRO_RATIONAL: return filt_rational_##SUF(f, (const TXT *)x, xLen, (RT *)y, ycap);       \
     case MRO_DECIMATOR: return filt_decimator_##SUF(f, (const TXT *)x, xLen, (RT *)y, ycap);     \
     case MRO_ARBITRARY: return filt_arbitrary_##SUF(f, (const TXT *)x, xLen, (RT *)y, ycap, sched); \
+    case MRO_FARROW: return filt_farrow_##SUF(f, (const TXT *)x, xLen, (RT *)y, ycap, sched);       \
     }
     if (!hd && !xd) { DISPATCH(ff, float, float) }
     else if (!hd && xd) { DISPATCH(fd, double, double) }
@@ -350,10 +423,11 @@ void mro_get_state(const mro_filter *f, mro_state *s)
 void mro_set_state(mro_filter *f, long phiIdx, long inputDeficit, double phiAccumulator)
 {
     f->phiIdx = phiIdx; f->inputDeficit = inputDeficit;
-    if (f->kind == MRO_ARBITRARY) {
+    if (f->kind == MRO_ARBITRARY || f->kind == MRO_FARROW) {
         f->phiAccumulator = phiAccumulator;
         f->phiIdx = (long)floor(phiAccumulator);
         f->alpha = phiAccumulator - (double)f->phiIdx;
+        if (f->kind == MRO_FARROW) farrow_taps(f, phiAccumulator);
     }
 }
 
@@ -383,4 +457,5 @@ void mro_reset(mro_filter *f)
 {
     memset(f->history, 0, (size_t)f->historyLen * f->nc * dtype_scalar_size(f->tx));
     f->phiIdx = 1; f->inputDeficit = 1; f->phiAccumulator = 1.0; f->alpha = 0.0; f->xIdx = 1;
+    if (f->kind == MRO_FARROW) farrow_taps(f, 1.0);
 }

@@ -13,7 +13,8 @@ extern "C" {
 
 typedef enum { MRO_F32 = 0, MRO_F64 = 1, MRO_C64 = 2, MRO_C128 = 3 } mro_dtype;
 typedef enum {
-    MRO_STANDARD = 0, MRO_DECIMATOR = 1, MRO_INTERPOLATOR = 2, MRO_RATIONAL = 3, MRO_ARBITRARY = 4
+    MRO_STANDARD = 0, MRO_DECIMATOR = 1, MRO_INTERPOLATOR = 2, MRO_RATIONAL = 3, MRO_ARBITRARY = 4,
+    MRO_FARROW = 5
 } mro_kind;
 
 typedef struct mro_filter mro_filter;
@@ -40,6 +41,14 @@ long mro_taps2pfb(const void *h, long hLen, int th, long Nphi, void *out);
 
 mro_filter *mro_create_rational(const void *h, long hLen, int th, long num, long den, int tx);
 mro_filter *mro_create_arbitrary(const void *h, long hLen, int th, double rate, long Nphi, int tx);
+/* FIRFarrow (src/Filters.jl:123-147): `pnfb` holds the polynomial filter bank the caller fitted
+ * (pfb2pnfb/polyfit, :311-321, support.jl:85-88): tapsPerPhi polynomials of polyorder+1 coefficients,
+ * ascending powers, each already rounded to the tap type.  tapsPerPhi is ceil(hLen/Nphi). */
+mro_filter *mro_create_farrow(long hLen, int th, double rate, long Nphi, long polyorder, const double *pnfb, int tx);
+void mro_update_farrow(mro_filter *k);
+/* polyval(p::Poly{T}, x::Float64) as Polynomials.jl evaluates it: Horner from the highest power in Float64 */
+double mro_polyval(const double *coeffs, long polyorder, double x);
+void mro_get_current_taps(const mro_filter *f, void *out);
 void mro_destroy(mro_filter *f);
 void mro_update_arbitrary(mro_filter *k);
 

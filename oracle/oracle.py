@@ -64,6 +64,11 @@ def lib():
         L.mro_create_rational.argtypes = [vp, cl, ci, cl, cl, ci]
         L.mro_create_arbitrary.restype = vp
         L.mro_create_arbitrary.argtypes = [vp, cl, ci, cd, cl, ci]
+        L.mro_create_farrow.restype = vp
+        L.mro_create_farrow.argtypes = [cl, ci, cd, cl, cl, vp, ci]
+        L.mro_polyval.restype = cd
+        L.mro_polyval.argtypes = [vp, cl, cd]
+        L.mro_get_current_taps.argtypes = [vp, vp]
         L.mro_destroy.argtypes = [vp]
         L.mro_outputlength.restype = cl
         L.mro_outputlength.argtypes = [vp, cl]
@@ -120,18 +125,60 @@ def shiftin(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     return a
 
 
+def polyfit(y, polyorder: int) -> np.ndarray:
+    """src/support.jl:85-88: A = [x^p for x in 1:length(y), p = 0:polyorder]; Poly(A \\ y).
+    Julia's `\\` on a tall matrix is a QR least-squares solve in Float64; restated with LAPACK's
+    Householder QR (numpy.linalg.qr) and a triangular solve.  Different QR implementations agree to
+    rounding (amplified by the conditioning of the Vandermonde matrix), not bit for bit -- the reference
+    pins nothing here -- so the fit is done ONCE on the caller's side and the same
+    coefficients are handed to oracle and GPU.  Returns coefficients in ascending powers, Float64."""
+    y = np.asarray(y, dtype=np.float64)
+    xs = np.arange(1, len(y) + 1, dtype=np.float64)
+    A = np.vander(xs, polyorder + 1, increasing=True)
+    Q, R = np.linalg.qr(A)
+    import scipy.linalg
+    return scipy.linalg.solve_triangular(R, Q.T @ y)
+
+
+def pfb2pnfb(pfb: np.ndarray, polyorder: int) -> np.ndarray:
+    """src/Filters.jl:311-321: one polynomial per ROW of the tapsPerPhi x Nphi filter bank.  The result
+    is stored as Poly{T} (T = tap type), i.e. the Float64 fit rounded to T.  Shape (tapsPerPhi, polyorder+1),
+    ascending powers, dtype float64 holding T-representable values."""
+    T = pfb.shape[0]
+    out = np.empty((T, polyorder + 1), dtype=np.float64)
+    for i in range(T):
+        out[i] = polyfit(pfb[i, :], polyorder).astype(pfb.dtype).astype(np.float64)
+    return out
+
+
+def polyval(coeffs, x: float) -> float:
+    c = np.ascontiguousarray(coeffs, dtype=np.float64)
+    return lib().mro_polyval(_ptr(c), len(c) - 1, float(x))
+
+
 class FIRFilter:
     """Oracle-side FIRFilter.  ``ratio`` may be a Fraction / (num, den) tuple / int (rational
     family, Filters.jl:158) or a float (FIRArbitrary, Filters.jl:183, with ``Nphi``)."""
 
-    def __init__(self, h, ratio=Fraction(1, 1), Nphi: int = 32, tx=np.float32):
+    def __init__(self, h, ratio=Fraction(1, 1), Nphi: int = 32, tx=np.float32, polyorder=None, pnfb=None):
+        """``polyorder`` (with a float ``ratio``) selects FIRFarrow, src/Filters.jl:192-198; ``pnfb`` overrides
+        the fitted polynomial bank (tapsPerPhi x (polyorder+1), ascending powers)."""
         h = np.ascontiguousarray(h)
         if h.dtype not in (np.float32, np.float64):
             raise TypeError("taps must be float32 or float64")
         self.th = h.dtype
         self.tx = np.dtype(tx)
         L = lib()
-        if isinstance(ratio, float):
+        self.pnfb = None
+        if isinstance(ratio, float) and polyorder is not None:
+            if pnfb is None:
+                pnfb = pfb2pnfb(taps2pfb(h, Nphi), polyorder)
+            self.pnfb = np.ascontiguousarray(pnfb, dtype=np.float64)
+            assert self.pnfb.shape == (-(-len(h) // Nphi), polyorder + 1), self.pnfb.shape
+            self._h = L.mro_create_farrow(len(h), _NP2DT[h.dtype], ratio, Nphi, polyorder, _ptr(self.pnfb), _NP2DT[self.tx])
+            if not self._h:
+                raise ValueError("rate must be greater than 0")
+        elif isinstance(ratio, float):
             self._h = L.mro_create_arbitrary(_ptr(h), len(h), _NP2DT[h.dtype], ratio, Nphi, _NP2DT[self.tx])
             if not self._h:
                 raise ValueError("rate must be greater than 0")
@@ -183,6 +230,12 @@ class FIRFilter:
         lib().mro_get_taps(self._h, which, _ptr(out))
         return out.reshape(s.Nphi, s.tapsPerPhi).T.copy()
 
+    def current_taps(self) -> np.ndarray:
+        """FIRFarrow.currentTaps (src/Filters.jl:128)"""
+        out = np.zeros(self.state.tapsPerPhi, dtype=self.th)
+        lib().mro_get_current_taps(self._h, _ptr(out))
+        return out
+
     def outputlength(self, xlen: int) -> int:
         return lib().mro_outputlength(self._h, xlen)
 
@@ -210,7 +263,8 @@ class FIRFilter:
         return y
 
 
-def filt(h, x, ratio=Fraction(1, 1), Nphi: int = 32):
-    """Stateless filt(h, x, ratio) / filt(h, x, rate, Nphi): src/Filters.jl:858-867."""
+def filt(h, x, ratio=Fraction(1, 1), Nphi: int = 32, polyorder=None):
+    """Stateless filt(h, x, ratio) / filt(h, x, rate, Nphi) / filt(h, x, rate, Nphi, polyorder):
+    src/Filters.jl:858-873."""
     x = np.ascontiguousarray(x)
-    return FIRFilter(h, ratio, Nphi, tx=x.dtype).filt(x)
+    return FIRFilter(h, ratio, Nphi, tx=x.dtype, polyorder=polyorder).filt(x)

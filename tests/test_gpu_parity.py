@@ -337,3 +337,68 @@ def test_arbitrary_tuned_and_generic_agree(pkg, torch_cuda, monkeypatch):
         assert g.last_kernel_name() == "arb_generic_kernel"
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         assert_bit_equal(y_t, y_g, f"arb tuned vs generic Nphi={Nphi} T={T} rate={rate} {th} {tx}")
+
+
+def test_farrow_sweep_bit_exact_with_shared_polynomials(pkg, O, torch_cuda):
+    """FIRFarrow (src/Filters.jl:123-147, 764-846): the polynomial bank is fitted once (the reference pins no
+    bits of A \\ y) and handed to both sides; everything downstream -- Float64 Horner per tap, rounding to the
+    tap type, the Vector unsafedot incl. the seam start-from-zero, the phase recurrence -- must then agree
+    bit for bit, for every dtype, chunking and channel count."""
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    for trial in range(12):
+        Nphi = int(rng.choice([8, 32, 12]))
+        T = int(rng.integers(2, 36))
+        order = int(rng.integers(0, 7))
+        th = rng.choice([np.float32, np.float64])
+        tx = rng.choice([np.float32, np.float64, np.complex64, np.complex128])
+        h = (pkg.firdes(T * Nphi - int(rng.integers(0, Nphi)), 0.45 / Nphi, beta=7.0) * Nphi).astype(th)
+        rate = float(rng.choice([math.pi / 3, 0.1234, 1.0, 2.5, 31.7, 1 / 2.123456789]))
+        nch = int(rng.integers(1, 4))
+        n = 600
+        x = _rand(rng, (nch, n), tx)
+        sizes = [n] if trial % 3 == 0 else ([1] * 40 + [n - 40] if trial % 3 == 1 else [13] * (n // 13) + [n % 13])
+        pn = O.pfb2pnfb(O.taps2pfb(h, Nphi), order)
+        f = pkg.FIRFilter(h, rate, Nphi, order, pnfb=pn)
+        outs = [o.cpu().numpy() for o in _run_chunks(f, torch.from_numpy(x).cuda(), sizes)]
+        y = np.concatenate(outs, axis=1)
+        assert f.last_kernel_name() == "farrow_kernel" and f.kernel_name == "FIRFarrow"
+        assert np.array_equal(f.pnfb(), pn)
+        for c in range(nch):
+            fo = O.FIRFilter(h, rate, Nphi, tx=tx, polyorder=order, pnfb=pn)
+            yo = np.concatenate(_run_chunks(fo, x[c], sizes))
+            assert_bit_equal(y[c], yo, f"farrow rate={rate} Nphi={Nphi} T={T} order={order} {th} {tx}")
+        assert f.state.phiAccumulator == fo.state.phiAccumulator
+        assert f.state.inputDeficit == fo.state.inputDeficit
+        # tapsforphase (Filters.jl:764-775) == the oracle's polyval, rounded to the tap type
+        ph = float(rng.uniform(0, Nphi + 1))
+        assert np.array_equal(f.tapsforphase(ph), np.array([O.polyval(r, ph) for r in pn]).astype(th))
+        with pytest.raises(pkg.MultirateHIPError):
+            f.tapsforphase(Nphi + 1.5)
+        f.close()
+
+
+def test_farrow_own_fit_and_setphase(pkg, O, torch_cuda):
+    """The library's own least-squares fit (Householder QR, Float64) against numpy's: coefficients agree to
+    rounding and the filtered output to ~1e-12 relative; setphase semantics (Filters.jl:210-235)."""
+    rng = np.random.default_rng(4)
+    h = pkg.firdes(32 * 32, 0.45 / 32, beta=7.8562) * 32
+    x = rng.random(5000)
+    f = pkg.FIRFilter(h, float(math.pi / 3), 32, 4)
+    y = f.filt(x)
+    pn = O.pfb2pnfb(O.taps2pfb(h, 32), 4)
+    A = np.vander(np.arange(1.0, 33.0), 5, increasing=True)
+    assert np.abs(f.pnfb() @ A.T - pn @ A.T).max() <= 1e-9 * np.abs(h).max()     # same fitted filter bank
+    yo = O.FIRFilter(h, float(math.pi / 3), 32, tx=np.float64, polyorder=4, pnfb=pn).filt(x)
+    assert y.shape == yo.shape and np.abs(y - yo).max() <= 1e-10 * np.abs(yo).max()
+    # stateless form filt(h, x, rate, Nphi, polyorder), Filters.jl:870-873
+    assert np.array_equal(pkg.filt(h, x, float(math.pi / 3), 32, 4), y)
+    # setphase: FIRFarrow 𝜙Idx = 𝜙*(N𝜙-1)+1 (:226); FIRArbitrary (α, 𝜙Idx) = modf(𝜙*N𝜙) (:219)
+    assert f.setphase(0.5) == 0.5 * 31 + 1 and f.state.phiAccumulator == 16.5
+    fa = pkg.FIRFilter(h, 0.9, 32).bind(np.float64)
+    idx, alpha = fa.setphase(0.3)
+    assert (idx, alpha) == math.modf(0.3 * 32)[::-1] and fa.state.phiIdx == 9
+    fr = pkg.FIRFilter(h, Fraction(32, 5)).bind(np.float64)
+    assert fr.setphase(0.5) == 17 and fr.state.phiIdx == 17
+    with pytest.raises(pkg.MultirateHIPError):
+        fr.setphase(1.5)

@@ -155,3 +155,43 @@ def test_golden_vectors_frozen(O, golden):
         st = f.state
         assert [st.phiIdx, st.inputDeficit] == data[k + "_state"].tolist()
         assert_bit_equal(f.history, data[k + "_hist"], k + " history")
+
+
+def test_farrow_oracle_properties(O, pkg):
+    """FIRFarrow restatement (src/Filters.jl:123-147, 764-846).  The reference holds no asserted test for it
+    (test/farrowtest.jl only prints), so the oracle is checked through properties: polyfit is the
+    least-squares fit numpy.polyfit also finds; polyval is Horner; chunked == unchunked bit for bit;
+    counts and state follow FIRArbitrary's (same recurrence); a high-order Farrow filter approaches
+    FIRArbitrary's output (both interpolate the same filter bank)."""
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal(32)
+    for order in (0, 1, 3, 4, 7):
+        c = O.polyfit(y, order)
+        ref = np.polyfit(np.arange(1, 33), y, order)[::-1]
+        # the Vandermonde matrix over 1..32 is ill-conditioned at high order: compare the FITTED VALUES
+        A = np.vander(np.arange(1.0, 33.0), order + 1, increasing=True)
+        assert np.abs(A @ c - A @ ref).max() <= 1e-5 * np.abs(y).max()      # noise data: error ~ cond^2 * eps * |residual|
+        x0 = 3.25
+        assert abs(O.polyval(c, x0) - np.polyval(c[::-1], x0)) <= 1e-12 * max(1.0, abs(np.polyval(c[::-1], x0)))
+        # the library's own Householder fit agrees with LAPACK's to rounding
+        assert np.abs(A @ pkg.polyfit(y, order) - A @ c).max() <= 1e-6 * np.abs(y).max()
+    h = (pkg.firdes(32 * 32, 0.45 / 32, beta=7.8562) * 32)
+    rate = float(np.pi / 3)
+    for th, tx in ((np.float64, np.float64), (np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float32)):
+        x = _rand(rng, 3000, tx)
+        ht = h.astype(th)
+        fa = O.FIRFilter(ht, rate, 32, tx=tx)
+        ff = O.FIRFilter(ht, rate, 32, tx=tx, polyorder=6)
+        ya, yf = fa.filt(x), ff.filt(x)
+        assert len(ya) == len(yf) and yf.dtype == ya.dtype
+        assert np.abs(ya - yf).max() < 2e-3 * np.abs(ya).max()
+        assert ff.state.inputDeficit == fa.state.inputDeficit and ff.state.phiAccumulator == fa.state.phiAccumulator
+        f2 = O.FIRFilter(ht, rate, 32, tx=tx, polyorder=6)
+        yc = np.concatenate([f2.filt(x[i:i + 7]) for i in range(0, len(x), 7)])
+        assert np.array_equal(yc, yf)
+        # initial taps are the polynomials at phase 1.0 (Filters.jl:142-146)
+        t1 = np.array([O.polyval(r, 1.0) for r in ff.pnfb]).astype(th)
+        f3 = O.FIRFilter(ht, rate, 32, tx=tx, polyorder=6)
+        assert np.array_equal(f3.current_taps(), t1)
+    with pytest.raises(ValueError):
+        O.FIRFilter(h, -0.5, 32, polyorder=3)
