@@ -402,3 +402,23 @@ def test_farrow_own_fit_and_setphase(pkg, O, torch_cuda):
     assert fr.setphase(0.5) == 17 and fr.state.phiIdx == 17
     with pytest.raises(pkg.MultirateHIPError):
         fr.setphase(1.5)
+
+
+def test_farrow_golden_vectors_on_gpu(pkg, torch_cuda):
+    """GPU vs the committed FIRFarrow fixtures (no oracle involved at run time)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_farrow_v1.npz"))
+    for k in g["names"]:
+        Nphi, order = (int(v) for v in g[k + "_par"])
+        x = g[k + "_x"]
+        f = pkg.FIRFilter(g[k + "_h"], float(g[k + "_rate"]), Nphi, order, pnfb=g[k + "_pnfb"])
+        outs, pos = [], 0
+        for s in g[k + "_sizes"]:
+            outs.append(f.filt(x[pos:pos + int(s)]))
+            pos += int(s)
+        assert_bit_equal(np.concatenate(outs), g[k + "_y"], k)
+        assert [len(o) for o in outs] == g[k + "_counts"].tolist()
+        st = f.state
+        assert st.inputDeficit == int(g[k + "_state"][0]) and st.phiAccumulator == float(g[k + "_acc"])
+        assert_bit_equal(f.history, g[k + "_hist"], k + " history")
+        f.close()

@@ -87,6 +87,32 @@ def test_firdes_and_kaiserlength(pkg):
     assert h.shape == (3528,) and np.allclose(h, h[::-1]) and abs(h.sum() - 1) < 1e-3
 
 
+def test_firdes_all_responses_match_windowed_sinc(pkg):
+    """src/FIRDesign.jl:47-95: the four FIRResponse prototypes times a Kaiser window, against scipy's
+    independent windowed-sinc design (firwin, unscaled): equal to rounding.  F is in cycles/sample
+    (the reference's convention), firwin's cutoff is relative to Nyquist."""
+    import scipy.signal as sg
+    from multirate_jl_amd import design as D
+    beta = 6.3
+    assert np.abs(pkg.firdes(101, 0.2, beta=beta) - sg.firwin(101, 0.4, window=("kaiser", beta), scale=False)).max() < 1e-15
+    hb = D.firdes(101, [0.3, 0.1], response=D.BANDPASS, beta=beta)      # 2(F1 sinc - F2 sinc): pass band F2..F1
+    assert np.abs(hb - sg.firwin(101, [0.2, 0.6], window=("kaiser", beta), pass_zero=False, scale=False)).max() < 1e-15
+    hs = D.firdes(101, [0.1, 0.3], response=D.BANDSTOP, beta=beta)      # 2(F2 sinc - F1 sinc), FIRDesign.jl:59
+    assert np.abs(hs + sg.firwin(101, [0.2, 0.6], window=("kaiser", beta), pass_zero=False, scale=False)).max() < 1e-15
+    hh = D.firdes(100, 0.2, response=D.HIGHPASS, beta=beta)             # even numtaps -> one more tap (:55)
+    assert len(hh) == 101
+    assert np.abs(hh - sg.firwin(101, 0.4, window=("kaiser", beta), pass_zero=False, scale=False)).max() < 1e-15
+    # firdes(cutoff, transitionwidth, attenuation): length and beta from kaiserlength (:90-95)
+    n, b = pkg.kaiserlength(0.05, 80.0)
+    h2 = D.firdes(0.1, 0.05, 80.0)
+    assert len(h2) == n and np.array_equal(h2, D.firdes(n, 0.1, beta=b))
+    assert D.firdes(0.1, 0.05, samplerate=2.0).shape == (pkg.kaiserlength(0.05, 60.0, samplerate=2.0)[0],)
+    with pytest.raises(ValueError):
+        D.firprototype(11, 0.1, response=7)
+    # custom window function (FIRDesign.jl:85)
+    assert np.array_equal(D.firdes(21, 0.1, np.hanning), D.firprototype(21, 0.1) * np.hanning(21))
+
+
 def test_product_path_fails_loudly_without_gpu(pkg):
     """No CPU fallback: on a box without a gfx950 device constructing the device object raises."""
     import torch

@@ -195,3 +195,25 @@ def test_farrow_oracle_properties(O, pkg):
         assert np.array_equal(f3.current_taps(), t1)
     with pytest.raises(ValueError):
         O.FIRFilter(h, -0.5, 32, polyorder=3)
+
+
+def _farrow_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_farrow_v1.npz"))
+
+
+def test_farrow_golden_vectors_frozen(O):
+    """The committed FIRFarrow fixtures (tests/golden/make_golden_farrow.py) freeze the oracle's bits."""
+    g = _farrow_golden()
+    for k in g["names"]:
+        Nphi, order = (int(v) for v in g[k + "_par"])
+        x = g[k + "_x"]
+        f = O.FIRFilter(g[k + "_h"], float(g[k + "_rate"]), Nphi, tx=x.dtype, polyorder=order, pnfb=g[k + "_pnfb"])
+        outs, pos = [], 0
+        for s in g[k + "_sizes"]:
+            outs.append(f.filt(x[pos:pos + int(s)]))
+            pos += int(s)
+        assert_bit_equal(np.concatenate(outs), g[k + "_y"], k)
+        assert [len(o) for o in outs] == g[k + "_counts"].tolist()
+        assert f.state.inputDeficit == int(g[k + "_state"][0]) and f.state.phiAccumulator == float(g[k + "_acc"])
+        assert_bit_equal(f.history, g[k + "_hist"], k + " history")
