@@ -97,8 +97,10 @@ def test_firdes_all_responses_match_windowed_sinc(pkg):
     assert np.abs(pkg.firdes(101, 0.2, beta=beta) - sg.firwin(101, 0.4, window=("kaiser", beta), scale=False)).max() < 1e-15
     hb = D.firdes(101, [0.3, 0.1], response=D.BANDPASS, beta=beta)      # 2(F1 sinc - F2 sinc): pass band F2..F1
     assert np.abs(hb - sg.firwin(101, [0.2, 0.6], window=("kaiser", beta), pass_zero=False, scale=False)).max() < 1e-15
-    hs = D.firdes(101, [0.1, 0.3], response=D.BANDSTOP, beta=beta)      # 2(F2 sinc - F1 sinc), FIRDesign.jl:59
-    assert np.abs(hs + sg.firwin(101, [0.2, 0.6], window=("kaiser", beta), pass_zero=False, scale=False)).max() < 1e-15
+    # BANDSTOP as the reference writes it, 2(F2 sinc - F1 sinc) (FIRDesign.jl:59), has no unit impulse: it is the
+    # BANDPASS formula with the pair swapped -- reproduced as written (a reference quirk, not "fixed" here)
+    hs = D.firdes(101, [0.1, 0.3], response=D.BANDSTOP, beta=beta)
+    assert np.abs(hs - sg.firwin(101, [0.2, 0.6], window=("kaiser", beta), pass_zero=False, scale=False)).max() < 1e-15
     hh = D.firdes(100, 0.2, response=D.HIGHPASS, beta=beta)             # even numtaps -> one more tap (:55)
     assert len(hh) == 101
     assert np.abs(hh - sg.firwin(101, 0.4, window=("kaiser", beta), pass_zero=False, scale=False)).max() < 1e-15
