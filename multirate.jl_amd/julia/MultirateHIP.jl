@@ -1,8 +1,8 @@
 # MultirateHIP.jl -- thin Julia binding of libmultirate_hip.so (include/multirate_hip.h).
 #
 # Drop-in for the hot path of Multirate.jl's src/Filters.jl: same type and function names
-# (FIRFilter, FIRStandard/FIRDecimator/FIRInterpolator/FIRRational/FIRArbitrary, filt, filt!,
-# taps2pfb, outputlength, inputlength, reset, nextphase), same argument meaning, same return values,
+# (FIRFilter, FIRStandard/FIRDecimator/FIRInterpolator/FIRRational/FIRArbitrary/FIRFarrow, filt, filt!,
+# taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, polyfit), same argument meaning, same return values,
 # same errors -- every method body is a ccall.  Modern Julia (>= 1.6) syntax; the reference is
 # Julia-0.3 source and cannot be loaded by a current Julia, so this module stands beside it rather
 # than patching it.  See INTEGRATION.md for how a maintainer wires it into Multirate.jl.
@@ -12,8 +12,8 @@
 # ../host.py exercises symbol by symbol in tests/).
 module MultirateHIP
 
-export FIRFilter, FIRKernel, FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary,
-       filt, filt!, taps2pfb, outputlength, inputlength, reset, nextphase
+export FIRFilter, FIRKernel, FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary, FIRFarrow,
+       filt, filt!, taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, polyfit
 
 const libmr = get(ENV, "MRHIP_LIB_PATH", joinpath(@__DIR__, "..", "libmultirate_hip.so"))
 
@@ -32,7 +32,8 @@ struct FIRDecimator <: FIRKernel end
 struct FIRInterpolator <: FIRKernel end
 struct FIRRational <: FIRKernel end
 struct FIRArbitrary <: FIRKernel end
-const KINDS = (FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary)
+struct FIRFarrow <: FIRKernel end
+const KINDS = (FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary, FIRFarrow)
 
 struct MRHIPState                      # mirror of `mrhip_state`
     kind::Int32; tap_dtype::Int32; sample_dtype::Int32; output_dtype::Int32
@@ -52,6 +53,7 @@ mutable struct FIRFilter{Tk<:FIRKernel}
     ratio::Union{Rational{Int},Nothing}
     rate::Float64
     Nphi::Int
+    polyorder::Int                    # FIRFarrow only (-1 otherwise)
     device::Int
     handle::Ptr{Cvoid}
     Tx::Union{DataType,Nothing}
@@ -66,13 +68,19 @@ end
 # FIRFilter(h, resampleRatio::Rational = 1//1)            src/Filters.jl:158-180
 function FIRFilter(h::Vector{Th}, ratio::Rational = 1//1; device::Integer = 0) where {Th<:Union{Float32,Float64}}
     r = Rational{Int}(ratio)
-    f = FIRFilter{kindof(r)}(copy(h), r, 0.0, 0, device, C_NULL, nothing, 0)
+    f = FIRFilter{kindof(r)}(copy(h), r, 0.0, 0, -1, device, C_NULL, nothing, 0)
     finalizer(destroy!, f)
 end
 # FIRFilter(h, rate::AbstractFloat, Nphi = 32)            src/Filters.jl:183-189
 function FIRFilter(h::Vector{Th}, rate::AbstractFloat, Nphi::Integer = 32; device::Integer = 0) where {Th<:Union{Float32,Float64}}
     rate > 0.0 || error("rate must be greater than 0")
-    f = FIRFilter{FIRArbitrary}(copy(h), nothing, Float64(rate), Nphi, device, C_NULL, nothing, 0)
+    f = FIRFilter{FIRArbitrary}(copy(h), nothing, Float64(rate), Nphi, -1, device, C_NULL, nothing, 0)
+    finalizer(destroy!, f)
+end
+# FIRFilter(h, rate::AbstractFloat, Nphi, polyorder)      src/Filters.jl:192-198  (FIRFarrow)
+function FIRFilter(h::Vector{Th}, rate::AbstractFloat, Nphi::Integer, polyorder::Integer; device::Integer = 0) where {Th<:Union{Float32,Float64}}
+    rate > 0.0 || error("rate must be greater than 0")
+    f = FIRFilter{FIRFarrow}(copy(h), nothing, Float64(rate), Nphi, polyorder, device, C_NULL, nothing, 0)
     finalizer(destroy!, f)
 end
 
@@ -89,7 +97,11 @@ function bind!(f::FIRFilter, ::Type{Tx}, nch::Integer) where {Tx}
     end
     out = Ref{Ptr{Cvoid}}(C_NULL)
     Th = eltype(f.h)
-    if f.ratio === nothing
+    if f.ratio === nothing && f.polyorder >= 0
+        check(ccall((:mrhip_create_farrow, libmr), Cint,
+                    (Ptr{Cvoid}, Int64, Cint, Cdouble, Int64, Int64, Cint, Int64, Cint, Ptr{Ptr{Cvoid}}),
+                    f.h, length(f.h), dtypecode(Th), f.rate, f.Nphi, f.polyorder, dtypecode(Tx), nch, f.device, out))
+    elseif f.ratio === nothing
         check(ccall((:mrhip_create_arbitrary, libmr), Cint,
                     (Ptr{Cvoid}, Int64, Cint, Cdouble, Int64, Cint, Int64, Cint, Ptr{Ptr{Cvoid}}),
                     f.h, length(f.h), dtypecode(Th), f.rate, f.Nphi, dtypecode(Tx), nch, f.device, out))
@@ -130,12 +142,47 @@ function reset(f::FIRFilter)
     f
 end
 
+# polyfit(y, polyorder)                                    src/support.jl:85-88 (coefficients, ascending powers)
+function polyfit(y::AbstractVector, polyorder::Integer)
+    yd = Vector{Float64}(y)
+    coef = Vector{Float64}(undef, polyorder + 1)
+    check(ccall((:mrhip_polyfit, libmr), Cint, (Ptr{Cdouble}, Int64, Int64, Ptr{Cdouble}), yd, length(yd), polyorder, coef))
+    coef
+end
+# tapsforphase(kernel::FIRFarrow, phase)                   src/Filters.jl:764-775
+function tapsforphase(f::FIRFilter{FIRFarrow}, phase::Real)
+    f.handle == C_NULL && error("tapsforphase needs a bound filter (call filt once)")
+    taps = Vector{eltype(f.h)}(undef, state(f).tapsPerPhi)
+    check(ccall((:mrhip_farrow_tapsforphase, libmr), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Cvoid}), f.handle, Float64(phase), taps))
+    taps
+end
+# setphase(self::FIRFilter, 𝜙), 𝜙 in [0, 1]                src/Filters.jl:210-235.  The reference's methods for
+# FIRInterpolator/FIRRational read an undefined variable (:212); implemented with the evident intent
+# (𝜙Idx = floor(𝜙*N𝜙)+1 clipped to N𝜙); FIRArbitrary and FIRFarrow as written (:217-229).
+setstate!(f::FIRFilter, phiIdx::Integer, deficit::Integer, acc::Real) =
+    check(ccall((:mrhip_set_state, libmr), Cint, (Ptr{Cvoid}, Int64, Int64, Cdouble), f.handle, phiIdx, deficit, Float64(acc)))
+function setphase(f::FIRFilter{Tk}, phi::Real) where {Tk<:Union{FIRInterpolator,FIRRational}}
+    @assert 0 <= phi <= 1
+    st = state(f); idx = min(floor(Int, phi * st.Nphi) + 1, st.Nphi)
+    setstate!(f, idx, st.inputDeficit, 1.0); idx
+end
+function setphase(f::FIRFilter{FIRArbitrary}, phi::Real)
+    @assert 0 <= phi <= 1
+    st = state(f); (alpha, idx) = modf(phi * st.Nphi)
+    setstate!(f, 1, st.inputDeficit, clamp(idx + alpha, 1.0, prevfloat(st.Nphi + 1.0))); (idx, alpha)
+end
+function setphase(f::FIRFilter{FIRFarrow}, phi::Real)
+    @assert 0 <= phi <= 1
+    st = state(f); acc = phi * (st.Nphi - 1) + 1
+    setstate!(f, 1, st.inputDeficit, acc); acc
+end
+
 # ---- the hot path --------------------------------------------------------------------------------
 promote_out(::Type{Th}, ::Type{Tx}) where {Th,Tx} = promote_type(Th, Tx)   # Filters.jl:476,522,581,636,746
 
 # filt!(buffer, self, x): one channel (Vector) or one channel per column (Matrix), host memory.
 # Returns `buffer` for FIRStandard / FIRInterpolator (:472,:516) and the number of samples written for
-# FIRRational / FIRDecimator / FIRArbitrary (:574,:630,:741), exactly like the reference.
+# FIRRational / FIRDecimator / FIRArbitrary / FIRFarrow (:574,:630,:741,:838), exactly like the reference.
 function filt!(buffer::VecOrMat{Tb}, f::FIRFilter{Tk}, x::VecOrMat{Tx}) where {Tb,Tk,Tx}
     nch = size(x, 2)
     bind!(f, Tx, nch)
@@ -157,9 +204,10 @@ function filt(f::FIRFilter, x::VecOrMat{Tx}) where {Tx}
     buffer
 end
 
-# stateless forms, src/Filters.jl:858-867
+# stateless forms, src/Filters.jl:858-873
 filt(h::Vector, x::VecOrMat, ratio::Rational = 1//1) = filt(FIRFilter(h, ratio), x)
 filt(h::Vector, x::VecOrMat, rate::AbstractFloat, Nphi::Integer = 32) = filt(FIRFilter(h, rate, Nphi), x)
+filt(h::Vector, x::VecOrMat, rate::AbstractFloat, Nphi::Integer, polyorder::Integer) = filt(FIRFilter(h, rate, Nphi, polyorder), x)
 
 # Device-resident data (e.g. AMDGPU.jl ROCArray): pass raw device pointers and a HIP stream.
 # x and y are (n x nchannels) column-major on the filter's device; returns the per-channel output count.
