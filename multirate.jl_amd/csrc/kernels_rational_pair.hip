@@ -34,6 +34,9 @@
 namespace mrhip {
 namespace {
 
+#ifndef MRHIP_PAIR_READ2
+#define MRHIP_PAIR_READ2 0   /* window reads: 1 = ds_read2_b64 quads (fewer instructions), 0 = ds_read_b64 pairs (cheaper per byte; measured +1.5-2 %) */
+#endif
 constexpr int kPairMaxThreads = 512;
 constexpr int kPairGroups = 32;         // scheduling groups (one step counter each); a multiple of the 8 XCDs
 
@@ -243,7 +246,14 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
         const unsigned grp_hi = umin(grp_lo + pa.steps_per_group, pa.total_steps);
         unsigned *const ctr = pa.counters + grp * 64u;            // one counter per 256 bytes
         unsigned pend = 0;                                        // lane 0: the grab number drawn ahead of need
-        auto grab_issue = [&]() { if (lane == 0) pend = atomicAdd(ctr, 1u); };
+        // small launches (at most a couple of grabs per workgroup) skip the atomics: grab numbers are dealt
+        // round-robin from the workgroup number, which costs nothing and balances just as well
+        unsigned static_next = blockIdx.x / static_cast<unsigned>(pa.ngroups);
+        const unsigned static_stride = (gridDim.x + static_cast<unsigned>(pa.ngroups) - 1u - grp) / static_cast<unsigned>(pa.ngroups);
+        auto grab_issue = [&]() {
+            if (pa.static_grabs) { pend = static_next; static_next += static_stride; }
+            else if (lane == 0) pend = atomicAdd(ctr, 1u);
+        };
         unsigned ra = 0, rb = 0;                                  // the current grab's steps [ra, rb)
         bool more = true;                                         // false after the first empty grab
         auto grab_take = [&]() {                                  // the compiler waits for `pend` here (vmcnt(0))
@@ -288,7 +298,7 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
             wait_vmcnt_le(newest_ops(pa.ns - 2)); // everything older than the ns-2 newest tiles has landed
         }
         // the last workgroup to finish re-arms the counters for the next launch (stream order makes it visible)
-        if (lane == 0) {
+        if (lane == 0 && !pa.static_grabs) {
             unsigned *const done = pa.counters + static_cast<unsigned>(pa.ngroups) * 64u;
             if (atomicAdd(done, 1u) == gridDim.x - 1) {
                 for (int k = 0; k < pa.ngroups; ++k) pa.counters[k * 64] = 0u;
@@ -424,6 +434,7 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
                     }
                 }
             };
+#if MRHIP_PAIR_READ2
             static_for<0, K>([&](auto I) { ring[decltype(I)::value] = lds_read2_b64<decltype(I)::value * 2>(wbase); });
             float pacc0 = 0.f, pacc1 = 0.f;                   // step -1 "results": written to the strip, never stored
 #pragma unroll 1
@@ -473,6 +484,53 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
             static_for<0, K>([&](auto I) { pin(ring[decltype(I)::value]); });
             store_step(J - 1, sv);
         };
+#else
+            // ---- variant: plain ds_read_b64 pairs (181 B/clk/CU vs 120 for ds_read2_b64, scripts/ubench/lds_rate.hip),
+            // ring of KP pairs; twice the LDS instructions and waits of the read2 variant
+            constexpr int KP = NPR < 5 ? NPR : 5;
+            constexpr int NPRV = (NPR + KP - 1) / KP * KP;
+            constexpr int RS = NPR / 2;
+            v2u_t pring[KP];
+            static_for<0, KP>([&](auto I) { pring[decltype(I)::value] = lds_read_b64<decltype(I)::value * 8>(wbase); });
+            float pacc0 = 0.f, pacc1 = 0.f;
+#pragma unroll 1
+            for (int j = 0; j < J; ++j) {
+                const int jn = j + 1 < J ? j + 1 : j;
+                const unsigned wcur = wbase + static_cast<unsigned>(j) * pa.cM * 4u;
+                const unsigned wnext = wbase + static_cast<unsigned>(jn) * pa.cM * 4u;
+                lds_write_b32(strip_w0, pacc0);
+                lds_write_b32(strip_w1, pacc1);
+                sv = lds_read_b64<0>(strip_r);
+                float acc0 = 0.f, acc1 = 0.f;
+                static_for<0, NPRV>([&](auto I) {
+                    constexpr int r = decltype(I)::value;
+                    constexpr int slot = r % KP;
+                    if constexpr (r < NPR) {
+                        lgkm_wait<ring_younger(r, NPR, KP)>(pring[slot]);
+                        const float wlo = __uint_as_float(pring[slot].x), whi = __uint_as_float(pring[slot].y);
+                        if constexpr (2 * r < T) { if constexpr (r == 0) acc0 = taps[0][0] * wlo; else acc0 = macf<FUSED>(taps[0][2 * r], wlo, acc0); }
+                        if constexpr (2 * r - 1 >= 0 && 2 * r - 1 < T) acc1 = macf<FUSED>(taps[1][2 * r - 1], wlo, acc1);
+                        if constexpr (2 * r + 1 < T) acc0 = macf<FUSED>(taps[0][2 * r + 1], whi, acc0);
+                        if constexpr (2 * r < T) { if constexpr (r == 0) acc1 = taps[1][0] * whi; else acc1 = macf<FUSED>(taps[1][2 * r], whi, acc1); }
+                        pin(acc0); pin(acc1);
+                    }
+                    if constexpr (r + KP < NPR) pring[slot] = lds_read_b64<(r + KP) * 8>(wcur);
+                    else if constexpr (r + KP >= NPRV) pring[slot] = lds_read_b64<(r + KP - NPRV) * 8>(wnext);
+                    if constexpr (r == RS) {
+                        lgkm_wait<ring_reads_upto(RS, NPR, KP)>(sv);
+                        if (j > 0) store_step(j - 1, sv);
+                    }
+                });
+                pacc0 = acc0; pacc1 = acc1;
+            }
+            lds_write_b32(strip_w0, pacc0);
+            lds_write_b32(strip_w1, pacc1);
+            sv = lds_read_b64<0>(strip_r);
+            lgkm_wait<0>(sv);
+            static_for<0, KP>([&](auto I) { pin(pring[decltype(I)::value]); });
+            store_step(J - 1, sv);
+        };
+#endif
         if (full) run_steps(std::true_type{});
         else run_steps(std::false_type{});
 
@@ -506,6 +564,7 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
         if (g < 1) g = 1;                                                                           \
         pa.ngroups = static_cast<int>(g < kPairGroups ? g : kPairGroups);   /* every group needs a workgroup */ \
         pa.steps_per_group = static_cast<unsigned>((pa.total_steps + pa.ngroups - 1) / pa.ngroups); \
+        pa.static_grabs = (static_cast<long long>(pa.total_steps) + pa.J - 1) / pa.J <= 3 * g;      \
         if (g < 1) g = 1;                                                                           \
         if (pair_debug_once()) {                                                                    \
             hipFuncAttributes fa;                                                                   \

@@ -159,6 +159,7 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     unsigned steps_per_group;     // ceil(total_steps / ngroups): group g owns steps [g*S, (g+1)*S)
     int ngroups;                  // scheduling groups; workgroup b draws grabs of J steps from group b % ngroups
     int flags_off;                // LDS byte offset of the per-stage tile descriptors
+    int static_grabs;             // 1: grabs are dealt round-robin without atomics (small launches)
     unsigned *counters;           // device: [g*64] next grab of group g, [ngroups*64] workgroups finished (re-arms all)
     unsigned spc_magic;           // floor(2^32 / steps_per_channel) (0xffffffff for 1): step number -> channel by multiply-high
     long long o0;            // d0 - T: x index of LDS sample 0 of tile 0 (negative => history)
