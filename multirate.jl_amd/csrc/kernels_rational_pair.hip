@@ -8,16 +8,16 @@
 // the same phase, so the lane keeps TWO tap columns in VGPRs for its whole life and runs two
 // independent accumulation chains (ILP hides the dependent-add latency of a single dot product).
 // The two windows overlap in T-1 samples: one aligned run of T+1 (rounded to T+2) samples, fetched
-// with (T+2)/2 ds_read_b64, feeds both outputs -- half the LDS read traffic of one-output-per-lane,
-// and because every lane's run starts on an even sample index the reads are 8-byte aligned and the 32
-// lanes of a half-wave cover 64 consecutive banks: conflict-free at 256 B/clk/CU with a single copy
-// of the data in LDS.
+// with (T+2)/2 ds_read_b64 through a small register ring (see run_steps), feeds both outputs -- half the
+// LDS read traffic of one-output-per-lane, and because every lane's run starts on an even sample index
+// the reads are 8-byte aligned and conflict-free with a single copy of the data in LDS.
 //
-// Staging.  A tile is J steps: J*c*M + T + 1 input samples of one channel, brought HBM -> LDS by
+// Staging.  A tile is up to J steps: J*c*M + T + 2 input samples of one channel, brought HBM -> LDS by
 // LDS-DMA (global_load_lds_dwordx4, 16 B per lane, no VGPRs; the source only needs 4-byte alignment,
-// scripts/ubench/dma_test.hip), double buffered: the DMA for tile i+1 is issued right after the one
-// barrier that opens tile i and lands while tile i is computed.  The first/last tile of a channel
-// (history seam, end of input) is staged through a checked register path into the same buffer.
+// scripts/ubench/dma_test.hip) by a dedicated loader wave, pa.ns (3) stages deep: the DMA for tile i+2 is
+// issued right after the one barrier that opens tile i.  The first/last tile of a channel (history seam,
+// end of input) is staged through a checked register path into the same buffer.  The loader also draws
+// the work (grouped dynamic scheduling, see the kernel) and performs shiftin! at the end of the launch.
 //
 // Arithmetic: exactly the generic kernel's (STRICT: separately rounded multiply and add, oldest sample
 // first, first product initialises the accumulator; FUSED: explicit fma) => bit-identical results.
@@ -390,21 +390,18 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
         // Ring-buffered software pipeline.  All LDS traffic of the compute waves is hand-issued asm, so the order
         // of a wave's LDS operations is exactly the program order below and the counted waits hold.
         //
-        // What bounds this loop on gfx950 is INSTRUCTION ISSUE: a SIMD issues about one instruction per 2.3
-        // cycles whatever its kind (VALU, LDS, SALU, s_waitcnt ...; scripts/ubench/valu_bank.hip and the
-        // ablation runs recorded in DESIGN.md), so the step is written for the fewest instructions around the
-        // 4*T-2 multiply/adds of its two dot products:
-        //   * window reads are ds_read2_b64 (a "quad" = two aligned pairs = four samples per instruction);
-        //   * a quad is fetched into slot q % K of a K-quad register ring K quads (16 VALU instructions each)
-        //     before it is consumed, and the slot is re-targeted as soon as it has fed its eight
-        //     multiply-adds: one counted wait per quad, few registers, no burst of LDS reads;
-        //   * the output path is three LDS operations and one store per step (see below).
-        // A step is padded to NQV = a multiple of K virtual quads so that slot numbers repeat every step:
-        //   per step:  W W S  [use 0, read 0+K] [use 1, read 1+K] ... ; virtual quads >= NQ only issue reads;
-        //   a read index >= NQV is quad (index - NQV) of the NEXT step's window.
+        // A wave issues at most one instruction every ~6 cycles and a SIMD needs 3-4 resident waves to keep its
+        // VALU busy (scripts/ubench/valu_bank.hip), so registers are the budget: the T+2 window samples never
+        // sit in registers all at once.  A "unit" (one ds_read_b64 pair by default; one ds_read2_b64 quad with
+        // MRHIP_PAIR_READ2=1) is fetched into slot u % K of a K-unit register ring K units before it is
+        // consumed, and the slot is re-targeted as soon as it has fed its multiply-adds: LDS reads are spread
+        // evenly through the arithmetic instead of arriving as a burst the in-order wave must push through the
+        // shared LDS queue.  A step is padded to a multiple of K virtual units so that slot numbers repeat:
+        //   per step:  W W S  [use 0, read 0+K] [use 1, read 1+K] ... ; virtual units past the window only
+        //   issue reads; a read index past the padded step is a unit of the NEXT step's window.
         //   W W = the previous step's two accumulators -> output strip, S = strip read-back (two dense outputs
-        //   per lane), stored to HBM mid-step.  ring_younger(q) counts the LDS operations issued between the
-        //   read of quad q and its use (compile time).
+        //   per lane), stored to HBM mid-step.  ring_younger(u) counts the LDS operations issued between the
+        //   read of unit u and its use (compile time; verified for every T by simulation).
         auto run_steps = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
             constexpr int NQ = (NPR + 1) / 2;
