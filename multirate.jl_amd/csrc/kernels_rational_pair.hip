@@ -34,9 +34,6 @@
 namespace mrhip {
 namespace {
 
-#ifndef MRHIP_PAIR_READ2
-#define MRHIP_PAIR_READ2 0   /* window reads: 1 = ds_read2_b64 quads (fewer instructions), 0 = ds_read_b64 pairs (cheaper per byte; measured +1.5-2 %) */
-#endif
 constexpr int kPairMaxThreads = 512;
 constexpr int kPairGroups = 32;         // scheduling groups (one step counter each); a multiple of the 8 XCDs
 
@@ -83,6 +80,13 @@ __device__ __forceinline__ v4u_t lds_read2_b64(unsigned byte_addr)
     asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(byte_addr), "n"(P0), "n"(P0 + 1));
     return v;
 }
+template <int OFF>
+__device__ __forceinline__ v4u_t lds_read_b128(unsigned byte_addr)   // byte_addr + OFF must be 16-byte aligned
+{
+    v4u_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+    return v;
+}
 template <int N, typename V>
 __device__ __forceinline__ void lgkm_wait(V &reg)
 {
@@ -98,6 +102,11 @@ __device__ __forceinline__ void pin(V &reg)   // orders every later use of reg a
 __device__ __forceinline__ void lds_write_b32(unsigned byte_addr, float v)
 {
     asm volatile("ds_write_b32 %0, %1" ::"v"(byte_addr), "v"(v));
+}
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_write_b64(unsigned byte_addr, v2f_t v)   // 8-byte aligned
+{
+    asm volatile("ds_write_b64 %0, %1" ::"v"(byte_addr), "v"(v));
 }
 
 __device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
@@ -161,9 +170,15 @@ constexpr int ring_younger(int v, int npr, int k)
 #else
 #define MRHIP_PAIR_BOUNDS __launch_bounds__(kPairMaxThreads + 64)
 #endif
-template <int T, bool FUSED>
-__global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
+// NC = 1: Float32 samples; NC = 2: ComplexF32 samples (interleaved re, im) with real taps = two independent real
+// dots per output (SURVEY.md Appendix A "Types").  A sample is ES = 4*NC bytes; a lane's pair of samples is one
+// ds_read_b64 (NC = 1) or one 16-byte aligned ds_read_b128 (NC = 2).
+template <int T, bool FUSED, int NC>
+__global__ __launch_bounds__(kPairMaxThreads + 64)
+void rational_pair_kernel(PolyArgs a, PairArgs pa)
 {
+    constexpr unsigned ES = 4u * NC;            // bytes per sample
+    using pair_t = std::conditional_t<NC == 1, v2u_t, v4u_t>;   // two consecutive samples
     constexpr int NPR = (T + 2) / 2;           // aligned 8-byte reads per lane per step: T+1 samples, rounded up
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -201,15 +216,16 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
         // checked register path, which drains everything before returning).
         auto stage_tile = [&](const TileAt &ta, int stage) -> int {
             const int sch = ta.ch;
-            const int tlen = (ta.jt * pa.cM + T + 2 + 3) & ~3;          // samples this tile needs, multiple of 4
-            const int nchunks = tlen / 4;
+            constexpr int EPC = 4 / NC;                                 // samples per 16-byte DMA chunk
+            const int tlen = (ta.jt * pa.cM + T + 2 + EPC - 1) / EPC * EPC;   // samples this tile needs, whole chunks
+            const int nchunks = tlen / EPC;
             const int nslots = (nchunks + 63) >> 6;                     // 1 KiB LDS slots
-            const float *__restrict__ xc = static_cast<const float *>(a.x) + static_cast<long long>(sch) * a.x_stride;
+            const float *__restrict__ xc = static_cast<const float *>(a.x) + static_cast<long long>(sch) * a.x_stride * NC;
             const long long o = pa.o0 + static_cast<long long>(ta.st) * pa.cM;   // x index of LDS sample 0 (may be < 0)
             unsigned char *st = smem + static_cast<size_t>(stage) * pa.stage_bytes;
             const bool interior = o >= 0 && o + tlen <= a.x_len;             // wave-uniform
             if (interior) {
-                const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o);
+                const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
                 for (int slot = 0; slot < nslots; ++slot) {
                     const int ci = slot * 64 + lane;
                     const int cis = ci < nchunks ? ci : 0;                   // padding lanes re-read chunk 0 into LDS padding
@@ -218,18 +234,21 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
                 return nslots;
             }
             // first / last tile of a channel: history seam and end of input, element-wise checked
-            const float *__restrict__ hc = static_cast<const float *>(a.hist) + static_cast<long long>(sch) * a.H;
+            const float *__restrict__ hc = static_cast<const float *>(a.hist) + static_cast<long long>(sch) * a.H * NC;
             float *l = reinterpret_cast<float *>(st);
             for (int ci = lane; ci < nchunks; ci += 64) {
                 float4 v;
                 float *pv = reinterpret_cast<float *>(&v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const long long gi = o + 4LL * ci + e;
-                    float val = 0.f;
-                    if (gi >= 0) { if (gi < a.x_len) val = xc[gi]; }
-                    else if (gi >= -static_cast<long long>(a.H)) val = hc[a.H + gi];
-                    pv[e] = val;
+                for (int e = 0; e < EPC; ++e) {
+                    const long long gi = o + static_cast<long long>(EPC) * ci + e;
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        float val = 0.f;
+                        if (gi >= 0) { if (gi < a.x_len) val = xc[gi * NC + cc]; }
+                        else if (gi >= -static_cast<long long>(a.H)) val = hc[(a.H + gi) * NC + cc];
+                        pv[e * NC + cc] = val;
+                    }
                 }
                 *reinterpret_cast<float4 *>(l + ci * 4) = v;
             }
@@ -315,8 +334,11 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
             for (int c2 = blockIdx.x; c2 < a.nch; c2 += gridDim.x)
                 for (int i = lane; i < a.H; i += 64) {
                     const long long e = static_cast<long long>(i) + a.x_len;          // index into [hist ; x]
-                    hnew[static_cast<long long>(c2) * a.H + i] =
-                        e < a.H ? hold[static_cast<long long>(c2) * a.H + e] : xin[static_cast<long long>(c2) * a.x_stride + (e - a.H)];
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc)
+                        hnew[(static_cast<long long>(c2) * a.H + i) * NC + cc] =
+                            e < a.H ? hold[(static_cast<long long>(c2) * a.H + e) * NC + cc]
+                                    : xin[(static_cast<long long>(c2) * a.x_stride + (e - a.H)) * NC + cc];
                 }
         }
         return;
@@ -358,13 +380,12 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
     const unsigned n_w = static_cast<unsigned>((t_hi_ll < pa.P ? t_hi_ll : pa.P)) - t_lo;   // outputs of this wave per step
     // strip: 1 KiB per compute wave = 128 output slots + 2 x 64 dump slots for the accumulators of positions
     // that produce no output (the writes are unconditional: no exec masking in the step loop)
-    const unsigned strip_base = lds_base + static_cast<unsigned>(pa.ns) * static_cast<unsigned>(pa.stage_bytes) + static_cast<unsigned>(wave) * 1024u;
-    const unsigned strip_w0 = strip_base + 4u * (act[0] ? static_cast<unsigned>(t_out[0]) - t_lo : 128u + static_cast<unsigned>(lane));
-    const unsigned strip_w1 = strip_base + 4u * (act[1] ? static_cast<unsigned>(t_out[1]) - t_lo : 192u + static_cast<unsigned>(lane));
-    const unsigned strip_r = strip_base + 8u * static_cast<unsigned>(lane);
-    const unsigned my_pair = 2u * static_cast<unsigned>(lane);               // outputs my_pair, my_pair+1 of the strip
-    const bool st8_full = my_pair + 1 < n_w, st4_full = my_pair + 1 == n_w;  // store predicates of a full tile
-    const unsigned lane_win = static_cast<unsigned>(tid) * 8u;           // byte offset of sample 2*tid inside a stage
+    const unsigned strip_base = lds_base + static_cast<unsigned>(pa.ns) * static_cast<unsigned>(pa.stage_bytes) + static_cast<unsigned>(wave) * 256u * ES;
+    const unsigned strip_w0 = strip_base + ES * (act[0] ? static_cast<unsigned>(t_out[0]) - t_lo : 128u + static_cast<unsigned>(lane));
+    const unsigned strip_w1 = strip_base + ES * (act[1] ? static_cast<unsigned>(t_out[1]) - t_lo : 192u + static_cast<unsigned>(lane));
+    const unsigned strip_r = strip_base + 2u * ES * static_cast<unsigned>(lane);
+    const unsigned my_pair_pre = 2u * static_cast<unsigned>(lane);           // outputs my_pair, my_pair+1 of the strip
+    const bool st8_full = my_pair_pre + 1 < n_w, st4_full = my_pair_pre + 1 == n_w;  // store predicates of a full tile
 
     // The compute waves' tile walk is 32-bit and scalar (plan_rational_pair guarantees n_out and total_tiles
     // < 2^31): 64-bit compares would park wave-uniform values in VGPRs for the life of the kernel.
@@ -382,9 +403,15 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
         const TileAt ta = tile_at(tg, tj);
         const int ch = ta.ch, J = ta.jt;
 
-        float *__restrict__ yc = static_cast<float *>(a.y) + static_cast<long long>(ch) * a.y_stride + static_cast<long long>(ta.st) * pa.P;
+        float *__restrict__ yc = static_cast<float *>(a.y) + (static_cast<long long>(ch) * a.y_stride + static_cast<long long>(ta.st) * pa.P) * NC;
         const int remaining = n_out - ta.st * pa.P;                       // outputs of this channel from this tile on
         const bool full = remaining >= J * pa.P;                          // wave-uniform
+        // Lane-constant addresses are re-derived per tile from a fresh lane id (opaque to the compiler): kept live
+        // across the tile loop they cost registers the step loop never uses (and, spilled, a vmcnt(0) per tile).
+        unsigned lane_t;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+        const unsigned my_pair = 2u * lane_t;
+        const unsigned lane_win = (static_cast<unsigned>(wave) * 64u + lane_t) * 2u * ES;   // byte offset of sample 2*tid inside a stage
         const unsigned wbase = lds_base + static_cast<unsigned>(s) * pa.stage_bytes + lane_win;
 
         // Ring-buffered software pipeline.  All LDS traffic of the compute waves is hand-issued asm, so the order
@@ -392,8 +419,8 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
         //
         // A wave issues at most one instruction every ~6 cycles and a SIMD needs 3-4 resident waves to keep its
         // VALU busy (scripts/ubench/valu_bank.hip), so registers are the budget: the T+2 window samples never
-        // sit in registers all at once.  A "unit" (one ds_read_b64 pair by default; one ds_read2_b64 quad with
-        // MRHIP_PAIR_READ2=1) is fetched into slot u % K of a K-unit register ring K units before it is
+        // sit in registers all at once.  A "unit" (one pair of samples: ds_read_b64, or ds_read_b128 for complex;
+        // ds_read2_b64 quads were 1.5-2 % slower) is fetched into slot u % K of a K-unit register ring K units before it is
         // consumed, and the slot is re-targeted as soon as it has fed its multiply-adds: LDS reads are spread
         // evenly through the arithmetic instead of arriving as a burst the in-order wave must push through the
         // shared LDS queue.  A step is padded to a multiple of K virtual units so that slot numbers repeat:
@@ -404,130 +431,92 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
         //   read of unit u and its use (compile time; verified for every T by simulation).
         auto run_steps = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
-            constexpr int NQ = (NPR + 1) / 2;
-            constexpr int K = NQ < 3 ? NQ : 3;
-            constexpr int NQV = (NQ + K - 1) / K * K;
-            constexpr int QS = NQ / 2;                        // the strip read-back is consumed after quad QS
-            v4u_t ring[K];
-            v2u_t sv = {0u, 0u};
+            constexpr int KP = NPR < (NC == 1 ? 5 : 3) ? NPR : (NC == 1 ? 5 : 3);   // ring: 5 pairs of 8 B or 3 pairs of 16 B
+            constexpr int NPRV = (NPR + KP - 1) / KP * KP;
+            constexpr int RS = NPR / 2;                       // the strip read-back is consumed after pair RS
+            pair_t pring[KP];
+            pair_t sv{};
             char *const ybytes = reinterpret_cast<char *>(yc);
-            auto store_step = [&](int j, v2u_t v) {
+            auto store_step = [&](int j, pair_t v) {
                 // byte offsets from the (wave-uniform) tile base stay 32-bit: scalar base + VGPR offset stores
                 const unsigned kj = static_cast<unsigned>(j) * static_cast<unsigned>(pa.P) + t_lo;
+                char *const dst = ybytes + (kj + my_pair) * ES;                       // ES-byte aligned
                 if (pa.ablate & 2) {   // timing experiments only: keep the arithmetic live, drop the stores
-                    if (v.x == 0x7f123456u) *reinterpret_cast<unsigned *>(ybytes + (kj + my_pair) * 4u) = v.y;
+                    if (v.x == 0x7f123456u) *reinterpret_cast<unsigned *>(dst) = v.y;
                     return;
                 }
                 if constexpr (FULL) {
-                    if (st8_full) __builtin_memcpy(ybytes + (kj + my_pair) * 4u, &v, 8);        // 4-byte aligned 8-byte store
-                    if (st4_full) *reinterpret_cast<unsigned *>(ybytes + (kj + my_pair) * 4u) = v.x;
+                    if (st8_full) __builtin_memcpy(dst, &v, 2 * ES);                  // two dense outputs
+                    if (st4_full) __builtin_memcpy(dst, &v, ES);                      // the odd last one
                 } else {
                     const unsigned rem_j = static_cast<unsigned>(remaining) > kj ? static_cast<unsigned>(remaining) - kj : 0u;
                     const unsigned lim = rem_j > n_w ? n_w : rem_j;
-                    if (my_pair + 1 < lim) {
-                        __builtin_memcpy(ybytes + (kj + my_pair) * 4u, &v, 8);
-                    } else if (my_pair < lim) {
-                        *reinterpret_cast<unsigned *>(ybytes + (kj + my_pair) * 4u) = v.x;
-                    }
+                    if (my_pair + 1 < lim) __builtin_memcpy(dst, &v, 2 * ES);
+                    else if (my_pair < lim) __builtin_memcpy(dst, &v, ES);
                 }
             };
-#if MRHIP_PAIR_READ2
-            static_for<0, K>([&](auto I) { ring[decltype(I)::value] = lds_read2_b64<decltype(I)::value * 2>(wbase); });
-            float pacc0 = 0.f, pacc1 = 0.f;                   // step -1 "results": written to the strip, never stored
+            auto read_pair = [&](auto off_tag, unsigned addr) -> pair_t {
+                constexpr int OFFP = decltype(off_tag)::value;                        // pair index inside the window
+                if constexpr (NC == 1) return lds_read_b64<OFFP * 8>(addr);
+                else return lds_read_b128<OFFP * 16>(addr);
+            };
+            auto strip_write = [&](unsigned addr, const float (&acc)[NC]) {
+                if constexpr (NC == 1) lds_write_b32(addr, acc[0]);
+                else lds_write_b64(addr, v2f_t{acc[0], acc[1]});
+            };
+            static_for<0, KP>([&](auto I) { pring[decltype(I)::value] = read_pair(I, wbase); });
+            float pacc0[NC] = {}, pacc1[NC] = {};             // step -1 "results": written to the strip, never stored
 #pragma unroll 1
             for (int j = 0; j < J; ++j) {
-                const int jn = j + 1 < J ? j + 1 : j;      // the last step re-reads its own window (never used)
-                const unsigned wcur = wbase + static_cast<unsigned>(j) * pa.cM * 4u;
-                const unsigned wnext = wbase + static_cast<unsigned>(jn) * pa.cM * 4u;
-                lds_write_b32(strip_w0, pacc0);
-                lds_write_b32(strip_w1, pacc1);
-                sv = lds_read_b64<0>(strip_r);                // same wave: LDS operations complete in order
-                float acc0 = 0.f, acc1 = 0.f;
-                // sample w[i]: output 0 uses w[i], output 1 uses w[i+1], i = 0..T-1; pair r = (w[2r], w[2r+1]).
-                // This file is compiled with -fno-slp-vectorize: hipcc would otherwise SLP-pack the two chains
-                // into v_pk_* (no faster per flop on gfx950: scripts/ubench/valu_rate.hip) and serialise both
-                // outputs into ONE dependent chain.
-                auto pair_math = [&](auto r_tag, float wlo, float whi) {
-                    constexpr int r = decltype(r_tag)::value;
-                    // w[2r] = wlo: output 0 tap 2r, output 1 tap 2r-1 ; w[2r+1] = whi: output 0 tap 2r+1, output 1 tap 2r
-                    if constexpr (2 * r < T) { if constexpr (r == 0) acc0 = taps[0][0] * wlo; else acc0 = macf<FUSED>(taps[0][2 * r], wlo, acc0); }
-                    if constexpr (2 * r - 1 >= 0 && 2 * r - 1 < T) acc1 = macf<FUSED>(taps[1][2 * r - 1], wlo, acc1);
-                    if constexpr (2 * r + 1 < T) acc0 = macf<FUSED>(taps[0][2 * r + 1], whi, acc0);
-                    if constexpr (2 * r < T) { if constexpr (r == 0) acc1 = taps[1][0] * whi; else acc1 = macf<FUSED>(taps[1][2 * r], whi, acc1); }
-                };
-                static_for<0, NQV>([&](auto I) {
-                    constexpr int q = decltype(I)::value;
-                    constexpr int slot = q % K;
-                    if constexpr (q < NQ) {
-                        lgkm_wait<ring_younger(q, NQ, K)>(ring[slot]);
-                        pair_math(std::integral_constant<int, 2 * q>{}, __uint_as_float(ring[slot].x), __uint_as_float(ring[slot].y));
-                        if constexpr (2 * q + 1 < NPR)
-                            pair_math(std::integral_constant<int, 2 * q + 1>{}, __uint_as_float(ring[slot].z), __uint_as_float(ring[slot].w));
-                        pin(acc0); pin(acc1);                 // quad q is issued before its slot is re-targeted
-                    }
-                    if constexpr (q + K < NQ) ring[slot] = lds_read2_b64<(q + K) * 2>(wcur);
-                    else if constexpr (q + K >= NQV) ring[slot] = lds_read2_b64<(q + K - NQV) * 2>(wnext);
-                    if constexpr (q == QS) {
-                        lgkm_wait<ring_reads_upto(QS, NQ, K)>(sv);    // only this step's reads are younger than S
-                        if (j > 0) store_step(j - 1, sv);     // wave-uniform
-                    }
-                });
-                pacc0 = acc0; pacc1 = acc1;
-            }
-            lds_write_b32(strip_w0, pacc0);
-            lds_write_b32(strip_w1, pacc1);
-            sv = lds_read_b64<0>(strip_r);
-            lgkm_wait<0>(sv);                                 // also retires the last step's unused reads
-            static_for<0, K>([&](auto I) { pin(ring[decltype(I)::value]); });
-            store_step(J - 1, sv);
-        };
-#else
-            // ---- variant: plain ds_read_b64 pairs (181 B/clk/CU vs 120 for ds_read2_b64, scripts/ubench/lds_rate.hip),
-            // ring of KP pairs; twice the LDS instructions and waits of the read2 variant
-            constexpr int KP = NPR < 5 ? NPR : 5;
-            constexpr int NPRV = (NPR + KP - 1) / KP * KP;
-            constexpr int RS = NPR / 2;
-            v2u_t pring[KP];
-            static_for<0, KP>([&](auto I) { pring[decltype(I)::value] = lds_read_b64<decltype(I)::value * 8>(wbase); });
-            float pacc0 = 0.f, pacc1 = 0.f;
-#pragma unroll 1
-            for (int j = 0; j < J; ++j) {
-                const int jn = j + 1 < J ? j + 1 : j;
-                const unsigned wcur = wbase + static_cast<unsigned>(j) * pa.cM * 4u;
-                const unsigned wnext = wbase + static_cast<unsigned>(jn) * pa.cM * 4u;
-                lds_write_b32(strip_w0, pacc0);
-                lds_write_b32(strip_w1, pacc1);
-                sv = lds_read_b64<0>(strip_r);
-                float acc0 = 0.f, acc1 = 0.f;
+                const int jn = j + 1 < J ? j + 1 : j;         // the last step re-reads its own window (never used)
+                const unsigned wcur = wbase + static_cast<unsigned>(j) * pa.cM * ES;
+                const unsigned wnext = wbase + static_cast<unsigned>(jn) * pa.cM * ES;
+                strip_write(strip_w0, pacc0);
+                strip_write(strip_w1, pacc1);
+                sv = read_pair(std::integral_constant<int, 0>{}, strip_r);   // same wave: LDS operations complete in order
+                float acc0[NC] = {}, acc1[NC] = {};
+                // pair r = (w[2r], w[2r+1]); output 0 uses w[i], output 1 uses w[i+1], i = 0..T-1: w[2r] feeds tap 2r of
+                // output 0 and tap 2r-1 of output 1, w[2r+1] feeds tap 2r+1 of output 0 and tap 2r of output 1.
+                // This file is compiled with -fno-slp-vectorize: hipcc would otherwise SLP-pack the chains into
+                // v_pk_* (no faster per flop on gfx950: scripts/ubench/valu_rate.hip) and serialise them.
                 static_for<0, NPRV>([&](auto I) {
                     constexpr int r = decltype(I)::value;
                     constexpr int slot = r % KP;
                     if constexpr (r < NPR) {
                         lgkm_wait<ring_younger(r, NPR, KP)>(pring[slot]);
-                        const float wlo = __uint_as_float(pring[slot].x), whi = __uint_as_float(pring[slot].y);
-                        if constexpr (2 * r < T) { if constexpr (r == 0) acc0 = taps[0][0] * wlo; else acc0 = macf<FUSED>(taps[0][2 * r], wlo, acc0); }
-                        if constexpr (2 * r - 1 >= 0 && 2 * r - 1 < T) acc1 = macf<FUSED>(taps[1][2 * r - 1], wlo, acc1);
-                        if constexpr (2 * r + 1 < T) acc0 = macf<FUSED>(taps[0][2 * r + 1], whi, acc0);
-                        if constexpr (2 * r < T) { if constexpr (r == 0) acc1 = taps[1][0] * whi; else acc1 = macf<FUSED>(taps[1][2 * r], whi, acc1); }
-                        pin(acc0); pin(acc1);
+                        float wlo[NC], whi[NC];
+                        if constexpr (NC == 1) { wlo[0] = __uint_as_float(pring[slot].x); whi[0] = __uint_as_float(pring[slot].y); }
+                        else {
+                            wlo[0] = __uint_as_float(pring[slot].x); wlo[1] = __uint_as_float(pring[slot].y);
+                            whi[0] = __uint_as_float(pring[slot].z); whi[1] = __uint_as_float(pring[slot].w);
+                        }
+#pragma unroll
+                        for (int cc = 0; cc < NC; ++cc) {
+                            if constexpr (2 * r < T) { if constexpr (r == 0) acc0[cc] = taps[0][0] * wlo[cc]; else acc0[cc] = macf<FUSED>(taps[0][2 * r], wlo[cc], acc0[cc]); }
+                            if constexpr (2 * r - 1 >= 0 && 2 * r - 1 < T) acc1[cc] = macf<FUSED>(taps[1][2 * r - 1], wlo[cc], acc1[cc]);
+                            if constexpr (2 * r + 1 < T) acc0[cc] = macf<FUSED>(taps[0][2 * r + 1], whi[cc], acc0[cc]);
+                            if constexpr (2 * r < T) { if constexpr (r == 0) acc1[cc] = taps[1][0] * whi[cc]; else acc1[cc] = macf<FUSED>(taps[1][2 * r], whi[cc], acc1[cc]); }
+                        }
+#pragma unroll
+                        for (int cc = 0; cc < NC; ++cc) { pin(acc0[cc]); pin(acc1[cc]); }   // pair r is issued before its slot is re-targeted
                     }
-                    if constexpr (r + KP < NPR) pring[slot] = lds_read_b64<(r + KP) * 8>(wcur);
-                    else if constexpr (r + KP >= NPRV) pring[slot] = lds_read_b64<(r + KP - NPRV) * 8>(wnext);
+                    if constexpr (r + KP < NPR) pring[slot] = read_pair(std::integral_constant<int, r + KP>{}, wcur);
+                    else if constexpr (r + KP >= NPRV) pring[slot] = read_pair(std::integral_constant<int, r + KP - NPRV>{}, wnext);
                     if constexpr (r == RS) {
-                        lgkm_wait<ring_reads_upto(RS, NPR, KP)>(sv);
-                        if (j > 0) store_step(j - 1, sv);
+                        lgkm_wait<ring_reads_upto(RS, NPR, KP)>(sv);   // only this step's reads are younger than S
+                        if (j > 0) store_step(j - 1, sv);     // wave-uniform
                     }
                 });
-                pacc0 = acc0; pacc1 = acc1;
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) { pacc0[cc] = acc0[cc]; pacc1[cc] = acc1[cc]; }
             }
-            lds_write_b32(strip_w0, pacc0);
-            lds_write_b32(strip_w1, pacc1);
-            sv = lds_read_b64<0>(strip_r);
-            lgkm_wait<0>(sv);
+            strip_write(strip_w0, pacc0);
+            strip_write(strip_w1, pacc1);
+            sv = read_pair(std::integral_constant<int, 0>{}, strip_r);
+            lgkm_wait<0>(sv);                                 // also retires the last step's unused reads
             static_for<0, KP>([&](auto I) { pin(pring[decltype(I)::value]); });
             store_step(J - 1, sv);
         };
-#endif
         if (full) run_steps(std::true_type{});
         else run_steps(std::false_type{});
 
@@ -539,13 +528,13 @@ __global__ MRHIP_PAIR_BOUNDS void rational_pair_kernel(PolyArgs a, PairArgs pa)
     }
 }
 
-template <bool FUSED>
+template <bool FUSED, int NC>
 hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, PairArgs pa, int num_cus,
                          int blocks_per_cu_override)
 {
 #define MRHIP_CASE(TT)                                                                              \
     case TT: {                                                                                      \
-        auto kfn = rational_pair_kernel<TT, FUSED>;                                                 \
+        auto kfn = rational_pair_kernel<TT, FUSED, NC>;                                                \
         if (lds > 48 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
@@ -614,13 +603,15 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
 
 }  // namespace
 
-// Covers: Float32 samples and taps (R = Float32), M > L with L/M >= 0.7, tapsPerPhi <= 32, no zero-start
+// Covers: Float32 or ComplexF32 samples with Float32 taps (R = Float32), M > L with L/M >= 0.7, tapsPerPhi <= 32, no zero-start
 // quirk (i.e. a pfb kernel: FIRRational).  Returns false otherwise (caller tries the next kernel).
 bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {
     static const int enabled = pair_env_int("MRHIP_PAIR", 1);
     if (!enabled) return false;
-    if (tk.x_f64 || tk.r_f64 || tk.complex_x) return false;
+    if (tk.x_f64 || tk.r_f64) return false;
+    const int nc = tk.complex_x ? 2 : 1;
+    const long long es = 4 * nc;                      // bytes per sample
 #ifdef MRHIP_PS_FAST_BUILD
     if (a.T != 24) return false;
 #endif
@@ -641,7 +632,7 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
             if ((static_cast<long long>(c) * a.M) % 2) continue;
             const int lanes = static_cast<int>(static_cast<long long>(c) * a.M / 2);
             const int padded = (lanes + 63) / 64 * 64;
-            if (pass == 0 && (padded < 192 || padded > 320)) continue;
+            if (pass == 0 && (padded < 192 || padded > (nc == 1 ? 320 : 256))) continue;   // complex: 4 compute waves (measured: c=3, J=3)
             const double score = static_cast<double>(lanes) / padded * (padded < 192 ? 0.5 + 0.5 * padded / 192.0 : 1.0);
             if (score > best + 1e-9) { best = score; best_c = c; }
         }
@@ -656,9 +647,11 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     // tile: J steps; the stage is a whole number of 1 KiB DMA slots, sized so that FOUR workgroups fit the CU's
     // 160 KiB of LDS (ns stages + 1 KiB strip per compute wave + the tile descriptors).  MRHIP_PAIR_ROUNDS
     // (experiments) sets the stage size directly.
-    const long long budget_kib = (160 * 1024 / 4 - 64 - static_cast<long long>(nwaves) * 1024) / ns / 1024;
+    // Complex samples double every buffer: three workgroups per CU there.
+    const long long strip_bytes = static_cast<long long>(nwaves) * 256 * es;
+    const long long budget_kib = (160 * 1024 / (nc == 1 ? 4 : 3) - 64 - strip_bytes) / ns / 1024;
     const int stage_kib = env_r > 0 ? env_r * nwaves : static_cast<int>(budget_kib > 1 ? budget_kib : 1);
-    long long J = (static_cast<long long>(stage_kib) * 256 - a.T - 2) / cM;   // 256 samples per KiB
+    long long J = (static_cast<long long>(stage_kib) * 1024 / es - a.T - 2) / cM;
     if (J < 1) {
         J = 1;
     }
@@ -672,9 +665,9 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     }
     long long tile_len = J * cM + a.T + 2;
     tile_len = (tile_len + 3) / 4 * 4;
-    const long long nslots = (tile_len / 4 + 63) / 64;
+    const long long nslots = (tile_len * es / 16 + 63) / 64;
     const size_t stage_bytes = static_cast<size_t>(nslots) * 1024;
-    if (nslots > 32 || ns * stage_bytes + static_cast<size_t>(nwaves) * 1024 > 156 * 1024) return false;
+    if (nslots > 60 / (ns - 2) || ns * stage_bytes + static_cast<size_t>(strip_bytes) > 156 * 1024) return false;
     const long long need_rounds = nslots;
     PairArgs pa{};
     pa.c = c; pa.P = static_cast<int>(static_cast<long long>(c) * a.L); pa.cM = static_cast<int>(cM);
@@ -701,9 +694,10 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
         pa.spc_magic = spc == 1 ? 0xffffffffu : static_cast<unsigned>((1ULL << 32) / static_cast<unsigned long long>(spc));
     }
     *out = pa;
-    pa.flags_off = static_cast<int>(ns * stage_bytes + static_cast<size_t>(nwaves) * 1024);
+    pa.flags_off = static_cast<int>(ns * stage_bytes + static_cast<size_t>(strip_bytes));
+    pa.nc = nc;
     *out = pa;
-    *lds = ns * stage_bytes + static_cast<size_t>(nwaves) * 1024 + 8 * ns;   // the pipeline stages + one output strip per compute wave + tile descriptors
+    *lds = ns * stage_bytes + static_cast<size_t>(strip_bytes) + 8 * ns;   // the pipeline stages + one output strip per compute wave + tile descriptors
     return true;
 }
 
@@ -715,8 +709,11 @@ hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &p
     pa.counters = counters;
     *kname = "rational_pair_kernel";
     static const int bpc = pair_env_int("MRHIP_PAIR_BPC", 0);
-    return fused ? launch_pair_T<true>(a.T, block, lds, s, a, pa, num_cus, bpc)
-                 : launch_pair_T<false>(a.T, block, lds, s, a, pa, num_cus, bpc);
+    if (pa.nc == 2)
+        return fused ? launch_pair_T<true, 2>(a.T, block, lds, s, a, pa, num_cus, bpc)
+                     : launch_pair_T<false, 2>(a.T, block, lds, s, a, pa, num_cus, bpc);
+    return fused ? launch_pair_T<true, 1>(a.T, block, lds, s, a, pa, num_cus, bpc)
+                 : launch_pair_T<false, 1>(a.T, block, lds, s, a, pa, num_cus, bpc);
 }
 
 }  // namespace mrhip

@@ -153,6 +153,7 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     int dma_rounds;          // LDS-DMA instructions per wave per tile
     int stage_bytes;         // LDS bytes per pipeline stage
     int ns;                  // pipeline stages (the DMA runs ns-1 tiles ahead of the compute waves)
+    int nc;                  // components per sample: 1 = Float32, 2 = ComplexF32
     int ablate;              // timing experiments only (MRHIP_PS_ABLATE)
     unsigned steps_per_channel;   // ceil(n_out / P)
     unsigned total_steps;         // steps_per_channel * channels

@@ -23,9 +23,9 @@ def rand(shape, dtype):
     return torch.rand(shape, device=dev, dtype=dtype)
 
 
-def run(name, h, ratio, nphi, nch, n, dtype, bytes_per_in, reps=5, chunk=None):
+def run(name, h, ratio, nphi, nch, n, dtype, bytes_per_in, reps=5, chunk=None, polyorder=None):
     x = rand((nch, n), dtype)
-    f = pkg.FIRFilter(h, ratio, nphi, device=0)
+    f = pkg.FIRFilter(h, ratio, nphi, polyorder, device=0)
     chunk = chunk or n
     f.filt(x[:, :chunk])                       # warm-up + bind
     f.reset()
@@ -56,7 +56,7 @@ h147 = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
 h128 = pkg.firdes(128, 0.5 / 4, beta=7.8562).astype(np.float32)
 harb = pkg.firdes(32 * 32, 0.45 / 32, beta=7.8562) * 32
 
-which = sys.argv[1:] or ["c1", "c2", "c3a", "c3b", "c4", "c5"]
+which = sys.argv[1:] or ["c1", "c2", "c3a", "c3b", "c4", "c4f", "c5"]
 if "c1" in which:
     run("C1 rational 147//160 f32 1ch x 1e6 (one call)", h147, Fraction(147, 160), 32, 1, 1_000_000, torch.float32, 7.675)
 if "c2" in which:
@@ -67,5 +67,7 @@ if "c3b" in which:
     run("C3b decimator 1//4 128 taps c64 256ch x 1e6", h128, Fraction(1, 4), 32, 256, 1_000_000, torch.complex64, 10.0)
 if "c4" in which:
     run("C4 arbitrary pi/3 32x32 taps f64 64ch x 1e7", harb, float(math.pi / 3), 32, 64, 10_000_000, torch.float64, 8 + 8 * math.pi / 3, reps=2)
+if "c4f" in which:
+    run("C4f farrow pi/3 32x32 taps polyorder 4 f64 64ch x 1e7", harb, float(math.pi / 3), 32, 64, 10_000_000, torch.float64, 8 + 8 * math.pi / 3, reps=2, polyorder=4)
 if "c5" in which:
     run("C5 rational 147//160 c64 512ch x 1e6 (one GPU's shard of 4096)", h147, Fraction(147, 160), 32, 512, 1_000_000, torch.complex64, 15.35)

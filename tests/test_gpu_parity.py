@@ -294,7 +294,8 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
              (7, 5, 100, np.float64, np.float32), (160, 147, 1000, np.float64, np.complex128),
              (1, 3, 31, np.float32, np.float32), (1, 1, 17, np.float32, np.float64), (5, 2, 160, np.float32, np.float32),
              (9, 10, 200, np.float32, np.float32), (31, 32, 31 * 7, np.float32, np.float32), (5, 7, 33, np.float32, np.float32),
-             (146, 147, 146 * 32, np.float32, np.float32), (1, 4, 128, np.float32, np.complex64), (1, 1, 300, np.float64, np.float64),
+             (146, 147, 146 * 32, np.float32, np.float32), (147, 160, 147 * 24, np.float32, np.complex64),
+             (9, 10, 200, np.float32, np.complex64), (5, 7, 33, np.float32, np.complex64), (1, 4, 128, np.float32, np.complex64), (1, 1, 300, np.float64, np.float64),
              (1, 7, 129, np.float64, np.complex128), (1, 32, 1, np.float32, np.float32), (1, 5, 64, np.float64, np.float32)]
     tuned_seen = set()
     for (L, M, hl, th, tx) in cases:
@@ -422,3 +423,24 @@ def test_farrow_golden_vectors_on_gpu(pkg, torch_cuda):
         assert st.inputDeficit == int(g[k + "_state"][0]) and st.phiAccumulator == float(g[k + "_acc"])
         assert_bit_equal(f.history, g[k + "_hist"], k + " history")
         f.close()
+
+
+def test_config4_farrow_vs_naive_tolerance(pkg, torch_cuda):
+    """BASELINE config 4 names "FIRArbitrary (Farrow)": the Farrow form on the same shape (pi/3, 32 taps x 32
+    filters, Float64, 64 channels).  A degree-4 polynomial per tap row approximates the filter bank, so the
+    stated tolerance vs NaiveResamplers' algorithm is the fit error, 5e-3 of the peak output, far above the
+    FIRArbitrary bound (|h[end]|*max|x|); counts are identical to FIRArbitrary's."""
+    from oracle import naive as N
+    torch = torch_cuda
+    h = pkg.firdes(1024, 0.45 / 32, beta=7.8562) * 32
+    rng = np.random.default_rng(11)
+    x = rng.random((64, 3000))
+    f = pkg.FIRFilter(h, float(math.pi / 3), 32, 4)
+    y = f.filt(torch.from_numpy(x).cuda()).cpu().numpy()
+    ya = pkg.FIRFilter(h, float(math.pi / 3), 32).filt(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert y.shape == ya.shape
+    for c in (0, 31, 63):
+        ref = N.naive_arbitrary(h, x[c], float(math.pi / 3), 32)
+        n = min(len(ref), y.shape[1])
+        assert abs(len(ref) - y.shape[1]) <= 1
+        assert np.abs(y[c, :n] - ref[:n]).max() <= 5e-3 * np.abs(ref).max()
