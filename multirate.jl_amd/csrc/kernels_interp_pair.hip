@@ -1,0 +1,415 @@
+// kernels_interp_pair.hip -- FIRInterpolator (L//1), Float32 taps, Float32 or ComplexF32 samples,
+// tapsPerPhi <= 32: TWO PHASES per lane.
+//
+// reference: src/Filters.jl:489-517 (filt!), dot: src/support.jl:5-31 (matrix unsafedot, no start-from-zero).
+//
+// Every input position p produces the L outputs p*L .. p*L+L-1 (phases 1..L), all from the SAME window of
+// tapsPerPhi samples ending at p.  A lane owns one position of the step and two adjacent phases (2q, 2q+1):
+// it keeps two tap columns in VGPRs for its whole life (the phase of a lane never changes, whatever the
+// step stride) and feeds both dot products from one fetch of the window -- half the LDS reads per output of
+// the one-output-per-lane kernel (kernels_phase_stationary.hip), which is what bounded it: at 128 VALU
+// operations and 32 LDS reads per ComplexF32 output neither pipe had room to hide the other.  The lanes of a
+// position read identical LDS addresses (broadcast), consecutive positions consecutive samples: conflict-free.
+// Consecutive lanes own consecutive output pairs, so results go straight from the accumulators to one
+// dense 2-sample store per lane (no staging through LDS).
+//
+// Everything around the dot products is the machinery of kernels_rational_pair.hip: a loader wave streams
+// tiles HBM -> LDS with LDS-DMA three stages deep, hands out the work in dynamically drawn grabs of J steps
+// (32 XCD-local counters), publishes tiles through LDS, and performs shiftin! at the end of the launch; the
+// compute waves fetch the window through a small register ring with compile-time wait counts.
+//
+// Arithmetic: exactly the generic kernel's (STRICT: separately rounded multiply and add, oldest sample first,
+// first product initialises the accumulator; FUSED: explicit fma) => bit-identical results.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "mrhip_internal.h"
+#include "pair_device.h"
+
+#pragma clang fp contract(off)
+
+namespace mrhip {
+namespace {
+
+using namespace dev;
+
+constexpr int kIntMaxThreads = 512;
+constexpr int kIntGroups = 32;
+
+inline int int_env_int(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+inline bool int_debug_once()
+{
+    static int state = -1;
+    if (state < 0) { const char *v = std::getenv("MRHIP_DEBUG"); state = (v && v[0] == '1') ? 1 : 0; }
+    if (state == 1) { state = 0; return true; }
+    return false;
+}
+
+// PairArgs is reused with these meanings: cM = positions per step (CP), c = lanes per position (LP = ceil(L/2)),
+// P = outputs per step (CP*L); the scheduling fields are identical.
+template <int T, bool FUSED, int NC>
+__global__ __launch_bounds__(kIntMaxThreads + 64)
+void interp_pair_kernel(PolyArgs a, PairArgs pa)
+{
+    constexpr unsigned ES = 4u * NC;            // bytes per sample
+    using samp_t = std::conditional_t<NC == 1, unsigned, v2u_t>;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int ncw = (blockDim.x >> 6) - 1;      // compute waves; the last wave of the workgroup is the loader
+    const int CP = pa.cM, LP = pa.c, L = a.L;
+
+    // ---- tile walk shared by both roles (see kernels_rational_pair.hip): steps of CP positions, numbered
+    // channel-major, drawn in grabs of J from 32 group counters by the loader wave, published through LDS
+    const unsigned spc = static_cast<unsigned>(pa.steps_per_channel);
+    struct TileAt { int ch, st, jt; };
+    auto tile_at = [&](unsigned g, unsigned jt) -> TileAt {
+        unsigned q = __umulhi(g, pa.spc_magic);
+        unsigned r = g - q * spc;
+        if (r >= spc) { ++q; r -= spc; }
+        if (r >= spc) { ++q; r -= spc; }
+        return TileAt{static_cast<int>(q), static_cast<int>(r), static_cast<int>(umin(jt, spc - r))};
+    };
+    volatile unsigned *const tile_flag = reinterpret_cast<volatile unsigned *>(smem + pa.flags_off);   // [ns][2]
+
+    if (wave == ncw) {
+        // ================= loader wave =================
+        auto stage_tile = [&](const TileAt &ta, int stage) -> int {
+            constexpr int EPC = 4 / NC;                                 // samples per 16-byte DMA chunk
+            const int tlen = (ta.jt * CP + T - 1 + EPC - 1) / EPC * EPC;  // samples this tile needs, whole chunks
+            const int nchunks = tlen / EPC;
+            const int nslots = (nchunks + 63) >> 6;                     // 1 KiB LDS slots
+            const float *__restrict__ xc = static_cast<const float *>(a.x) + static_cast<long long>(ta.ch) * a.x_stride * NC;
+            // x index (0-based) of LDS sample 0: the oldest sample of the tile's first position
+            const long long o = static_cast<long long>(ta.st) * CP - (T - 1);
+            unsigned char *st = smem + static_cast<size_t>(stage) * pa.stage_bytes;
+            const bool interior = o >= 0 && o + tlen <= a.x_len;        // wave-uniform
+            if (interior) {
+                const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
+                for (int slot = 0; slot < nslots; ++slot) {
+                    const int ci = slot * 64 + lane;
+                    const int cis = ci < nchunks ? ci : 0;              // padding lanes re-read chunk 0 into LDS padding
+                    dma16(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
+                }
+                return nslots;
+            }
+            // first / last tile of a channel: history seam and end of input, element-wise checked
+            const float *__restrict__ hc = static_cast<const float *>(a.hist) + static_cast<long long>(ta.ch) * a.H * NC;
+            float *l = reinterpret_cast<float *>(st);
+            for (int ci = lane; ci < nchunks; ci += 64) {
+                float4 v;
+                float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const long long gi = o + static_cast<long long>(EPC) * ci + e;
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        float val = 0.f;
+                        if (gi >= 0) { if (gi < a.x_len) val = xc[gi * NC + cc]; }
+                        else if (gi >= -static_cast<long long>(a.H)) val = hc[(a.H + gi) * NC + cc];
+                        pv[e * NC + cc] = val;
+                    }
+                }
+                *reinterpret_cast<float4 *>(l + ci * 4) = v;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            return 0;
+        };
+        const unsigned grp = blockIdx.x % static_cast<unsigned>(pa.ngroups);
+        const unsigned grp_lo = umin(grp * pa.steps_per_group, pa.total_steps);
+        const unsigned grp_hi = umin(grp_lo + pa.steps_per_group, pa.total_steps);
+        unsigned *const ctr = pa.counters + grp * 64u;
+        unsigned pend = 0;
+        unsigned static_next = blockIdx.x / static_cast<unsigned>(pa.ngroups);
+        const unsigned static_stride = (gridDim.x + static_cast<unsigned>(pa.ngroups) - 1u - grp) / static_cast<unsigned>(pa.ngroups);
+        auto grab_issue = [&]() {
+            if (pa.static_grabs) { pend = static_next; static_next += static_stride; }
+            else if (lane == 0) pend = atomicAdd(ctr, 1u);
+        };
+        unsigned ra = 0, rb = 0;
+        bool more = true;
+        auto grab_take = [&]() {
+            const unsigned t = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(pend)));
+            const unsigned long long lo = static_cast<unsigned long long>(grp_lo) + static_cast<unsigned long long>(t) * pa.J;
+            if (lo < grp_hi) { ra = static_cast<unsigned>(lo); rb = umin(ra + pa.J, grp_hi); grab_issue(); }
+            else { more = false; ra = rb = 0; }
+        };
+        unsigned long long hist = 0;
+        auto newest_ops = [&](int ntiles) -> int {
+            int n = 0;
+            for (int k = 0; k < ntiles; ++k) n += static_cast<int>((hist >> (6 * k)) & 63u);
+            return n < 60 ? n : 60;
+        };
+        auto produce = [&](int stage) -> bool {
+            if (ra >= rb && more) grab_take();
+            if (ra >= rb) {
+                if (lane == 0) { tile_flag[2 * stage] = 0u; tile_flag[2 * stage + 1] = 0u; }
+                hist <<= 6;
+                return false;
+            }
+            const TileAt ta = tile_at(ra, rb - ra);
+            if (lane == 0) { tile_flag[2 * stage] = ra; tile_flag[2 * stage + 1] = static_cast<unsigned>(ta.jt); }
+            hist = (hist << 6) | static_cast<unsigned>(stage_tile(ta, stage));
+            ra += static_cast<unsigned>(ta.jt);
+            return true;
+        };
+        grab_issue();
+        unsigned pipeline = 0;
+        for (int k = 0; k < pa.ns - 1; ++k)
+            if (produce(k)) pipeline |= 1u << k;
+        wait_vmcnt_le(newest_ops(pa.ns - 2));
+        int pstage = pa.ns - 1;
+        for (;;) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!(pipeline & 1u)) break;
+            pipeline >>= 1;
+            if (produce(pstage)) pipeline |= 1u << (pa.ns - 2);
+            pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
+            wait_vmcnt_le(newest_ops(pa.ns - 2));
+        }
+        if (lane == 0 && !pa.static_grabs) {
+            unsigned *const done = pa.counters + static_cast<unsigned>(pa.ngroups) * 64u;
+            if (atomicAdd(done, 1u) == gridDim.x - 1) {
+                for (int k = 0; k < pa.ngroups; ++k) pa.counters[k * 64] = 0u;
+                *done = 0u;
+            }
+        }
+        // shiftin! (support.jl:61-80), fused
+        if (a.H > 0) {
+            const float *__restrict__ xin = static_cast<const float *>(a.x);
+            const float *__restrict__ hold = static_cast<const float *>(a.hist);
+            float *__restrict__ hnew = static_cast<float *>(a.hist_new);
+            for (int c2 = blockIdx.x; c2 < a.nch; c2 += gridDim.x)
+                for (int i = lane; i < a.H; i += 64) {
+                    const long long e = static_cast<long long>(i) + a.x_len;
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc)
+                        hnew[(static_cast<long long>(c2) * a.H + i) * NC + cc] =
+                            e < a.H ? hold[(static_cast<long long>(c2) * a.H + e) * NC + cc]
+                                    : xin[(static_cast<long long>(c2) * a.x_stride + (e - a.H)) * NC + cc];
+                }
+        }
+        return;
+    }
+
+    // ================= compute waves =================
+    // lane -> (position within the step, phase pair)
+    const int posl = tid / LP, q = tid - posl * LP;
+    const bool lane_act = posl < CP;
+    const int ph0 = 2 * q, ph1 = 2 * q + 1;
+    const bool has1 = ph1 < L;
+    float taps[2][T];
+    {
+        const float *__restrict__ t0 = static_cast<const float *>(a.taps) + static_cast<long long>(ph0 < L ? ph0 : 0) * T;
+        const float *__restrict__ t1 = static_cast<const float *>(a.taps) + static_cast<long long>(has1 ? ph1 : 0) * T;
+#pragma unroll
+        for (int i = 0; i < T; ++i) { taps[0][i] = t0[i]; taps[1][i] = t1[i]; }
+    }
+    const int x_len = static_cast<int>(a.x_len);
+    // outputs of one position are contiguous: y[(p*L + ph)]; this lane's first output inside a step
+    const unsigned out_in_step = static_cast<unsigned>(posl) * static_cast<unsigned>(L) + static_cast<unsigned>(ph0);
+
+    for (int s = 0;; s = (s + 1 == pa.ns ? 0 : s + 1)) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned tg = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(tile_flag[2 * s])));
+        const unsigned tj = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(tile_flag[2 * s + 1])));
+        if (tj == 0u) break;
+        const TileAt ta = tile_at(tg, tj);
+        const int J = ta.jt;
+        const int p0 = ta.st * CP;                                       // first position (0-based) of the tile
+        float *__restrict__ yc = static_cast<float *>(a.y) + (static_cast<long long>(ta.ch) * a.y_stride + static_cast<long long>(p0) * L) * NC;
+        char *const ybytes = reinterpret_cast<char *>(yc);
+        const int npos = x_len - p0;                                     // positions of this channel from this tile on
+        const unsigned wbase = lds_base + static_cast<unsigned>(s) * pa.stage_bytes + static_cast<unsigned>(posl) * ES;
+
+        // Ring-pipelined window: sample i of the window is read K samples before it is consumed; a step is
+        // padded to TV = a multiple of K virtual samples so that slot numbers repeat (no strip operations here:
+        // ring_younger(.., strip_ops = 0)).
+        constexpr int K = T < 6 ? T : 6;
+        constexpr int TV = (T + K - 1) / K * K;
+        samp_t ring[K];
+        auto read_samp = [&](auto off_tag, unsigned addr) -> samp_t {
+            constexpr int OFF = decltype(off_tag)::value;
+            if constexpr (NC == 1) return lds_read_b32<OFF * 4>(addr);
+            else return lds_read_b64<OFF * 8>(addr);
+        };
+        static_for<0, K>([&](auto I) { ring[decltype(I)::value] = read_samp(I, wbase); });
+#pragma unroll 1
+        for (int j = 0; j < J; ++j) {
+            const int jn = j + 1 < J ? j + 1 : j;
+            const unsigned wcur = wbase + static_cast<unsigned>(j) * CP * ES;
+            const unsigned wnext = wbase + static_cast<unsigned>(jn) * CP * ES;
+            float acc0[NC] = {}, acc1[NC] = {};
+            static_for<0, TV>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                constexpr int slot = i % K;
+                if constexpr (i < T) {
+                    lgkm_wait<ring_younger(i, T, K, 0)>(ring[slot]);
+                    float w[NC];
+                    if constexpr (NC == 1) w[0] = __uint_as_float(ring[slot]);
+                    else { w[0] = __uint_as_float(ring[slot].x); w[1] = __uint_as_float(ring[slot].y); }
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        if constexpr (i == 0) { acc0[cc] = taps[0][0] * w[cc]; acc1[cc] = taps[1][0] * w[cc]; }
+                        else { acc0[cc] = macf<FUSED>(taps[0][i], w[cc], acc0[cc]); acc1[cc] = macf<FUSED>(taps[1][i], w[cc], acc1[cc]); }
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) { pin(acc0[cc]); pin(acc1[cc]); }
+                }
+                if constexpr (i + K < T) ring[slot] = read_samp(std::integral_constant<int, i + K>{}, wcur);
+                else if constexpr (i + K >= TV) ring[slot] = read_samp(std::integral_constant<int, i + K - TV>{}, wnext);
+            });
+            // store: outputs (position j*CP + posl, phases ph0, ph1) are adjacent in y
+            const int pi = j * CP + posl;
+            if (lane_act && pi < npos && !(pa.ablate & 2)) {
+                char *const dst = ybytes + (static_cast<unsigned>(j) * static_cast<unsigned>(pa.P) + out_in_step) * ES;
+                if (has1) {
+                    float o2[2 * NC];
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) { o2[cc] = acc0[cc]; o2[NC + cc] = acc1[cc]; }
+                    __builtin_memcpy(dst, o2, 2 * ES);
+                } else {
+                    __builtin_memcpy(dst, acc0, ES);
+                }
+            } else if (pa.ablate & 2) {
+                if (acc0[0] == 1.2345e30f) *reinterpret_cast<float *>(ybytes) = acc1[0];
+            }
+        }
+        // retire the last step's unused look-ahead reads before the stage can be overwritten
+        lgkm_wait<0>(ring[0]);
+        static_for<1, K>([&](auto I) { pin(ring[decltype(I)::value]); });
+    }
+}
+
+template <bool FUSED, int NC>
+hipError_t launch_interp_T(int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, PairArgs pa, int num_cus)
+{
+#define MRHIP_CASE(TT)                                                                              \
+    case TT: {                                                                                      \
+        auto kfn = interp_pair_kernel<TT, FUSED, NC>;                                               \
+        if (lds > 48 * 1024) {                                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+            if (e != hipSuccess) return e;                                                          \
+        }                                                                                           \
+        int per_cu = 0;                                                                             \
+        hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, static_cast<int>(block.x), lds); \
+        if (eo != hipSuccess) return eo;                                                            \
+        if (per_cu < 1) per_cu = 1;                                                                 \
+        long long g = static_cast<long long>(num_cus) * per_cu;                                     \
+        if (g > static_cast<long long>(pa.total_steps)) g = pa.total_steps;                         \
+        if (g < 1) g = 1;                                                                           \
+        pa.ngroups = static_cast<int>(g < kIntGroups ? g : kIntGroups);                             \
+        pa.steps_per_group = static_cast<unsigned>((pa.total_steps + pa.ngroups - 1) / pa.ngroups); \
+        pa.static_grabs = (static_cast<long long>(pa.total_steps) + pa.J - 1) / pa.J <= 3 * g;      \
+        if (int_debug_once()) {                                                                     \
+            hipFuncAttributes fa;                                                                   \
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kfn));                   \
+            std::fprintf(stderr, "[mrhip] interp_pair T=%d L=%d grid=%lld block=%u lds=%zu occ/CU=%d regs=%d CP=%d LP=%d J=%d steps=%u\n", \
+                         TT, a.L, g, block.x, lds, per_cu, fa.numRegs, pa.cM, pa.c, pa.J, pa.total_steps); \
+        }                                                                                           \
+        hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), block, lds, s, a, pa);              \
+        return hipGetLastError();                                                                   \
+    }
+    switch (T) {
+#ifdef MRHIP_PS_FAST_BUILD
+        MRHIP_CASE(32)
+#else
+        MRHIP_CASE(1) MRHIP_CASE(2) MRHIP_CASE(3) MRHIP_CASE(4) MRHIP_CASE(5) MRHIP_CASE(6) MRHIP_CASE(7) MRHIP_CASE(8)
+        MRHIP_CASE(9) MRHIP_CASE(10) MRHIP_CASE(11) MRHIP_CASE(12) MRHIP_CASE(13) MRHIP_CASE(14) MRHIP_CASE(15) MRHIP_CASE(16)
+        MRHIP_CASE(17) MRHIP_CASE(18) MRHIP_CASE(19) MRHIP_CASE(20) MRHIP_CASE(21) MRHIP_CASE(22) MRHIP_CASE(23) MRHIP_CASE(24)
+        MRHIP_CASE(25) MRHIP_CASE(26) MRHIP_CASE(27) MRHIP_CASE(28) MRHIP_CASE(29) MRHIP_CASE(30) MRHIP_CASE(31) MRHIP_CASE(32)
+#endif
+    default: return hipErrorInvalidValue;
+    }
+#undef MRHIP_CASE
+}
+
+}  // namespace
+
+// Covers FIRInterpolator (M == 1, L >= 2), Float32 taps, Float32 / ComplexF32 samples, tapsPerPhi <= 32.
+bool plan_interp_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
+{
+    static const int enabled = int_env_int("MRHIP_INTERP", 1);
+    if (!enabled) return false;
+    if (tk.x_f64 || tk.r_f64) return false;
+    if (a.M != 1 || a.L < 2 || a.T < 1 || a.T > 32 || a.zero_start_below > 0) return false;
+#ifdef MRHIP_PS_FAST_BUILD
+    if (a.T != 32) return false;
+#endif
+    if (a.x_len >= (1LL << 31) / (a.L + 1) || a.n_out >= (1LL << 31)) return false;   // 32-bit walk
+    const int nc = tk.complex_x ? 2 : 1;
+    const long long es = 4 * nc;
+    const int LP = (a.L + 1) / 2;
+    if (LP > 256) return false;
+    static const int env_j = int_env_int("MRHIP_INTERP_J", 0), env_w = int_env_int("MRHIP_INTERP_WAVES", 0);
+    const int ns = 3;
+    // lanes: 4 compute waves by default; CP = positions per step
+    const int want_lanes = (env_w > 0 ? env_w : 4) * 64;
+    int CP = want_lanes / LP;
+    if (CP < 1) CP = 1;
+    const int lanes = CP * LP;
+    const int padded = (lanes + 63) / 64 * 64;
+    const int nwaves = padded / 64;
+    // stage sized for four workgroups per CU
+    const long long budget = (160 * 1024 / 4 - 64) / ns / 1024 * 1024;
+    long long J = (budget / es - (a.T - 1) - 4) / CP;
+    if (env_j > 0) J = env_j;
+    if (J < 1) J = 1;
+    if (J > 64) J = 64;
+    const long long spc = (a.x_len + CP - 1) / CP;                       // steps per channel
+    if (env_j <= 0) {
+        const long long want_tiles = 4LL * num_cus;
+        while (J > 1 && ((spc + J - 1) / J) * a.nch < want_tiles) J = (J + 1) / 2;
+    }
+    const long long tile_len = (J * CP + a.T - 1 + 3) / 4 * 4;
+    const long long nslots = (tile_len * es / 16 + 63) / 64;
+    const size_t stage_bytes = static_cast<size_t>(nslots) * 1024;
+    if (nslots > 60 / (ns - 2) || ns * stage_bytes > 150 * 1024) return false;
+    if (spc * a.nch >= (1LL << 31)) return false;
+    PairArgs pa{};
+    pa.c = LP; pa.cM = CP; pa.P = static_cast<int>(static_cast<long long>(CP) * a.L);
+    pa.J = static_cast<int>(J);
+    pa.tile_len = static_cast<int>(tile_len);
+    pa.dma_rounds = static_cast<int>(nslots);
+    pa.stage_bytes = static_cast<int>(stage_bytes);
+    pa.ns = ns; pa.nc = nc;
+    pa.o0 = -(a.T - 1);
+    static const int env_ablate = int_env_int("MRHIP_PS_ABLATE", 0);
+    pa.ablate = env_ablate;
+    pa.steps_per_channel = static_cast<unsigned>(spc);
+    pa.total_steps = static_cast<unsigned>(spc * a.nch);
+    pa.spc_magic = spc == 1 ? 0xffffffffu : static_cast<unsigned>((1ULL << 32) / static_cast<unsigned long long>(spc));
+    pa.flags_off = static_cast<int>(ns * stage_bytes);
+    *out = pa;
+    *block = dim3(static_cast<unsigned>(nwaves * 64 + 64));   // + the loader wave
+    *lds = ns * stage_bytes + 8 * ns;
+    return true;
+}
+
+hipError_t launch_interp_pair(bool fused, const PolyArgs &a, const PairArgs &pa_in, dim3 block, size_t lds, hipStream_t s,
+                              const char **kname, int num_cus, unsigned *counters)
+{
+    if (!counters) return hipErrorInvalidValue;
+    PairArgs pa = pa_in;
+    pa.counters = counters;
+    pa.probe = nullptr;
+    *kname = "interp_pair_kernel";
+    if (pa.nc == 2)
+        return fused ? launch_interp_T<true, 2>(a.T, block, lds, s, a, pa, num_cus)
+                     : launch_interp_T<false, 2>(a.T, block, lds, s, a, pa, num_cus);
+    return fused ? launch_interp_T<true, 1>(a.T, block, lds, s, a, pa, num_cus)
+                 : launch_interp_T<false, 1>(a.T, block, lds, s, a, pa, num_cus);
+}
+
+}  // namespace mrhip

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "mrhip_internal.h"
+#include "pair_device.h"
 
 #pragma clang fp contract(off)
 
@@ -50,126 +51,8 @@ inline int pair_env_int(const char *name, int dflt)
     return v && *v ? std::atoi(v) : dflt;
 }
 
-typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+using namespace dev;
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// ds_read_b64 as inline asm (hipcc would fuse neighbours into the half-rate ds_read2_b64); the wait
-// is issued by hand: LDS operations of a wave return in order, so with reads r_0..r_{n-1} issued back
-// to back, waiting for lgkmcnt <= n-1-i guarantees r_i has landed.  "+v" pins uses after the wait.
-template <int OFF>
-__device__ __forceinline__ v2u_t lds_read_b64(unsigned byte_addr)
-{
-    v2u_t v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
-    return v;
-}
-typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-// two aligned pairs (pair P0 and P0+1 of the window at byte_addr) in one LDS instruction
-template <int P0>
-__device__ __forceinline__ v4u_t lds_read2_b64(unsigned byte_addr)
-{
-    v4u_t v;
-    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(byte_addr), "n"(P0), "n"(P0 + 1));
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ v4u_t lds_read_b128(unsigned byte_addr)   // byte_addr + OFF must be 16-byte aligned
-{
-    v4u_t v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
-    return v;
-}
-template <int N, typename V>
-__device__ __forceinline__ void lgkm_wait(V &reg)
-{
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(N < 15 ? N : 15));
-}
-
-__device__ __forceinline__ unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
-template <typename V>
-__device__ __forceinline__ void pin(V &reg)   // orders every later use of reg after the preceding volatile asm
-{
-    asm volatile("" : "+v"(reg));
-}
-__device__ __forceinline__ void lds_write_b32(unsigned byte_addr, float v)
-{
-    asm volatile("ds_write_b32 %0, %1" ::"v"(byte_addr), "v"(v));
-}
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void lds_write_b64(unsigned byte_addr, v2f_t v)   // 8-byte aligned
-{
-    asm volatile("ds_write_b64 %0, %1" ::"v"(byte_addr), "v"(v));
-}
-
-__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction only takes an immediate)
-__device__ __forceinline__ void wait_vmcnt_le(int n)
-{
-    switch (n) {
-#define MRHIP_W(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
-        MRHIP_W(0) MRHIP_W(1) MRHIP_W(2) MRHIP_W(3) MRHIP_W(4) MRHIP_W(5) MRHIP_W(6) MRHIP_W(7) MRHIP_W(8) MRHIP_W(9)
-        MRHIP_W(10) MRHIP_W(11) MRHIP_W(12) MRHIP_W(13) MRHIP_W(14) MRHIP_W(15) MRHIP_W(16) MRHIP_W(17) MRHIP_W(18) MRHIP_W(19)
-        MRHIP_W(20) MRHIP_W(21) MRHIP_W(22) MRHIP_W(23) MRHIP_W(24) MRHIP_W(25) MRHIP_W(26) MRHIP_W(27) MRHIP_W(28) MRHIP_W(29)
-        MRHIP_W(30) MRHIP_W(31) MRHIP_W(32) MRHIP_W(33) MRHIP_W(34) MRHIP_W(35) MRHIP_W(36) MRHIP_W(37) MRHIP_W(38) MRHIP_W(39)
-        MRHIP_W(40) MRHIP_W(41) MRHIP_W(42) MRHIP_W(43) MRHIP_W(44) MRHIP_W(45) MRHIP_W(46) MRHIP_W(47) MRHIP_W(48) MRHIP_W(49)
-        MRHIP_W(50) MRHIP_W(51) MRHIP_W(52) MRHIP_W(53) MRHIP_W(54) MRHIP_W(55) MRHIP_W(56) MRHIP_W(57) MRHIP_W(58) MRHIP_W(59)
-        MRHIP_W(60)
-#undef MRHIP_W
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
-template <bool FUSED>
-__device__ __forceinline__ float macf(float t, float x, float acc)
-{
-    if constexpr (FUSED) return __builtin_fmaf(t, x, acc);
-    else { const float p = t * x; return acc + p; }
-}
-
-// ---- compile-time bookkeeping of the ring pipeline (see run_steps in the kernel) ----
-// virtual group p of a step issues a read iff p + K names a pair of this step (< NPR) or of the next one (>= NPRV)
-constexpr int ring_nprv(int npr, int k) { return (npr + k - 1) / k * k; }
-constexpr bool ring_issues(int p, int npr, int k) { return p + k < npr || p + k >= ring_nprv(npr, k); }
-constexpr int ring_reads_upto(int p_last, int npr, int k)      // reads issued at virtual groups 0..p_last
-{
-    int n = 0;
-    for (int p = 0; p <= p_last; ++p) n += ring_issues(p, npr, k) ? 1 : 0;
-    return n;
-}
-// LDS operations a wave issues between the read of pair v and "use v" (steady state; the first step of a tile,
-// whose pairs 0..K-1 come from the prologue, gives the same numbers), capped at 14
-constexpr int ring_younger(int v, int npr, int k)
-{
-    const int nprv = ring_nprv(npr, k);
-    int n = 0;
-    if (v >= k) {                                   // issued at virtual group v-k of the same step
-        for (int p = v - k + 1; p <= v - 1; ++p) n += ring_issues(p, npr, k) ? 1 : 0;
-    } else {                                        // issued at virtual group v + nprv - k of the previous step
-        for (int p = v + nprv - k + 1; p <= nprv - 1; ++p) n += ring_issues(p, npr, k) ? 1 : 0;
-        n += 3;                                     // W W S
-        for (int p = 0; p <= v - 1; ++p) n += ring_issues(p, npr, k) ? 1 : 0;
-    }
-    return n < 14 ? n : 14;
-}
-
-#ifdef MRHIP_PAIR_WPE   /* optional VGPR cap: waves per SIMD the register allocator must leave room for */
-#define MRHIP_PAIR_BOUNDS __launch_bounds__(kPairMaxThreads + 64, MRHIP_PAIR_WPE)
-#else
-#define MRHIP_PAIR_BOUNDS __launch_bounds__(kPairMaxThreads + 64)
-#endif
 // NC = 1: Float32 samples; NC = 2: ComplexF32 samples (interleaved re, im) with real taps = two independent real
 // dots per output (SURVEY.md Appendix A "Types").  A sample is ES = 4*NC bytes; a lane's pair of samples is one
 // ds_read_b64 (NC = 1) or one 16-byte aligned ds_read_b128 (NC = 2).

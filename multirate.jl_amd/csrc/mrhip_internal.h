@@ -209,6 +209,9 @@ bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef);
 bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                                 const char **kname, int num_cus, unsigned *counters);   // also performs shiftin! into a.hist_new
+bool plan_interp_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
+hipError_t launch_interp_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
+                              const char **kname, int num_cus, unsigned *counters);   // FIRInterpolator, two phases per lane; also performs shiftin!
 bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectArgs *out, size_t *lds);
 hipError_t launch_fir_direct(const TypeKey &tk, bool fused, const PolyArgs &a, const DirectArgs &da, size_t lds, hipStream_t s,
                              const char **kname, int num_cus);
