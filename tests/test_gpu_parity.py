@@ -297,6 +297,8 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
              (146, 147, 146 * 32, np.float32, np.float32), (147, 160, 147 * 24, np.float32, np.complex64),
              (9, 10, 200, np.float32, np.complex64), (5, 7, 33, np.float32, np.complex64), (1, 4, 128, np.float32, np.complex64), (1, 1, 300, np.float64, np.float64),
              (1, 7, 129, np.float64, np.complex128), (1, 32, 1, np.float32, np.float32), (1, 5, 64, np.float64, np.float32),
+             (1, 4, 128, np.float32, np.float32), (1, 1, 64, np.float32, np.complex64), (1, 2, 200, np.float32, np.float32),
+             (1, 8, 131, np.float32, np.complex64), (1, 1, 300, np.float32, np.float32), (1, 4, 509, np.float32, np.complex64),
              (5, 1, 160, np.float32, np.float32), (3, 1, 17, np.float32, np.complex64), (7, 1, 50, np.float32, np.float32),
              (2, 1, 64, np.float32, np.complex64), (33, 1, 33 * 32, np.float32, np.float32), (6, 1, 100, np.float64, np.float64)]
     tuned_seen = set()
@@ -308,7 +310,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, Fraction(L, M))
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_pair_kernel", "interp_pair_kernel", "fir_direct_kernel"), (L, M, hl)
+        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_pair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"), (L, M, hl)
         tuned_seen.add(f.last_kernel_name())
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, Fraction(L, M))
@@ -317,7 +319,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         assert_bit_equal(y_t, y_g, f"tuned vs generic L={L} M={M} hLen={hl} {th} {tx}")
         assert_bit_equal(f.history, g.history, "history")
-    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_pair_kernel", "interp_pair_kernel", "fir_direct_kernel"}, tuned_seen
+    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_pair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"}, tuned_seen
 
 
 def test_arbitrary_tuned_and_generic_agree(pkg, torch_cuda, monkeypatch):
