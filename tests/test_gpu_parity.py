@@ -448,3 +448,30 @@ def test_config4_farrow_vs_naive_tolerance(pkg, torch_cuda):
         n = min(len(ref), y.shape[1])
         assert abs(len(ref) - y.shape[1]) <= 1
         assert np.abs(y[c, :n] - ref[:n]).max() <= 5e-3 * np.abs(ref).max()
+
+
+def test_dynamic_scheduling_paths_match_generic_at_scale(pkg, torch_cuda, monkeypatch):
+    """Launches large enough that the loader waves draw their work from the group counters (more than three
+    grabs per workgroup; smaller launches are dealt statically): complex pair kernel and the interpolator kernel,
+    chunked so that the counters are re-armed between launches, against the universal kernel bit for bit."""
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(77)
+    nch, n = 32, 300_000
+    xr = torch.rand((nch, n, 2), generator=g, device="cuda", dtype=torch.float32) - 0.5
+    xc = torch.view_as_complex(xr)
+    rng = np.random.default_rng(3)
+    for (L, M, hl, kname) in [(147, 160, 147 * 24, "rational_pair_kernel"), (4, 1, 128, "interp_pair_kernel"),
+                              (13, 16, 13 * 9, "rational_pair_kernel"), (3, 1, 3 * 20, "interp_pair_kernel")]:
+        h = rng.standard_normal(hl).astype(np.float32)
+        sizes = [120_001, 7, 179_992]
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        f = pkg.FIRFilter(h, Fraction(L, M))
+        y_t = torch.cat(_run_chunks(f, xc, sizes), dim=-1)
+        assert f.last_kernel_name() == kname
+        monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+        gf = pkg.FIRFilter(h, Fraction(L, M))
+        y_g = torch.cat(_run_chunks(gf, xc, sizes), dim=-1)
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        assert y_t.shape == y_g.shape
+        assert torch.equal(torch.view_as_real(y_t).view(torch.int32), torch.view_as_real(y_g).view(torch.int32)), (L, M)
+        assert_bit_equal(f.history, gf.history, "history")
