@@ -79,6 +79,11 @@ struct mro_filter {
     long xIdx;
 };
 
+/* 0 = STRICT (default, the reference's arithmetic), 1 = FUSED: checker for the library's opt-in
+ * MRHIP_NUMERICS_FUSED mode (same order, one fma per tap).  Process-wide, test use only. */
+static int g_mro_fused = 0;
+void mro_set_fused(int fused) { g_mro_fused = fused ? 1 : 0; }
+
 static size_t dtype_scalar_size(int dt) { return (dt == MRO_F32 || dt == MRO_C64) ? 4 : 8; }
 static int dtype_is_complex(int dt) { return dt == MRO_C64 || dt == MRO_C128; }
 static int dtype_is_f64(int dt) { return dt == MRO_F64 || dt == MRO_C128; }

@@ -70,6 +70,7 @@ def lib():
         L.mro_polyval.argtypes = [vp, cl, cd]
         L.mro_get_current_taps.argtypes = [vp, vp]
         L.mro_destroy.argtypes = [vp]
+        L.mro_set_fused.argtypes = [ci]
         L.mro_outputlength.restype = cl
         L.mro_outputlength.argtypes = [vp, cl]
         L.mro_inputlength.restype = cl
@@ -97,6 +98,12 @@ def lib():
         L.mro_shiftin.argtypes = [vp, cl, vp, cl, C.c_size_t]
         _lib = L
     return _lib
+
+
+def set_fused(fused: bool):
+    """Process-wide: True makes every dot product use one fma per tap (checker for the library's opt-in
+    NUMERICS_FUSED mode); False (default) is the reference's separately rounded multiply and add."""
+    lib().mro_set_fused(1 if fused else 0)
 
 
 def _ptr(a: np.ndarray):

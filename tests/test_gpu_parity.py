@@ -475,3 +475,28 @@ def test_dynamic_scheduling_paths_match_generic_at_scale(pkg, torch_cuda, monkey
         assert y_t.shape == y_g.shape
         assert torch.equal(torch.view_as_real(y_t).view(torch.int32), torch.view_as_real(y_g).view(torch.int32)), (L, M)
         assert_bit_equal(f.history, gf.history, "history")
+
+
+def test_fused_numerics_bit_exact_vs_fused_oracle(pkg, O, torch_cuda):
+    """NUMERICS_FUSED (opt-in): same order, one fma per tap.  Against the oracle in its fused mode the results are
+    bit-identical for every kernel family (the tuned kernels use explicit fma in the same places)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(123)
+    cases = [(Fraction(147, 160), 147 * 24, np.float32, np.float32), (Fraction(147, 160), 147 * 24, np.float32, np.complex64),
+             (Fraction(4, 1), 128, np.float32, np.complex64), (Fraction(1, 4), 128, np.float32, np.complex64),
+             (Fraction(1, 1), 100, np.float64, np.float64), (Fraction(7, 5), 90, np.float64, np.float32),
+             (float(math.pi / 3), 32 * 32, np.float64, np.float64), (0.37, 32 * 10, np.float32, np.complex64)]
+    O.set_fused(True)
+    try:
+        for (ratio, hl, th, tx) in cases:
+            h = (rng.standard_normal(hl) if not isinstance(ratio, float) else pkg.firdes(hl, 0.45 / 32, beta=7.0) * 32).astype(th)
+            x = _rand(rng, (2, 30_000), tx) - 0.5
+            f = pkg.FIRFilter(h, ratio, 32, numerics=pkg.NUMERICS_FUSED)
+            sizes = [10_007, 3, 19_990]
+            y = torch.cat(_run_chunks(f, torch.from_numpy(x).cuda(), sizes), dim=-1).cpu().numpy()
+            for c in range(2):
+                fo = O.FIRFilter(h, ratio, 32, tx=tx)
+                yo = np.concatenate(_run_chunks(fo, x[c], sizes))
+                assert_bit_equal(y[c], yo, f"fused {ratio} {th} {tx} kernel={f.last_kernel_name()}")
+    finally:
+        O.set_fused(False)
