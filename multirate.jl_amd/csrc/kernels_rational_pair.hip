@@ -275,10 +275,14 @@ void rational_pair_kernel(PolyArgs a, PairArgs pa)
     const int n_out = static_cast<int>(a.n_out);
     unsigned long long probe_c0 = 0, probe_r0 = 0;
     if (pa.probe) { probe_c0 = __builtin_amdgcn_s_memtime(); probe_r0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned long long probe_bar = 0;             // cycles this wave spends at the tile barrier (diagnostics)
     for (int s = 0;; s = (s + 1 == pa.ns ? 0 : s + 1)) {
         // One barrier per tile and no memory wait: the loader wave arrives only after this tile's data has
         // landed and its descriptor is in LDS; all compute waves arriving proves the oldest stage is no longer read.
+        unsigned long long probe_b0 = 0;
+        if (pa.probe) probe_b0 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
+        if (pa.probe) probe_bar += __builtin_amdgcn_s_memtime() - probe_b0;
         asm volatile("" ::: "memory");
         const unsigned tg = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(tile_flag[2 * s])));
         const unsigned tj = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(tile_flag[2 * s + 1])));
@@ -409,6 +413,11 @@ void rational_pair_kernel(PolyArgs a, PairArgs pa)
         pa.probe[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
         pa.probe[3 * blockIdx.x + 2] = probe_r0;
     }
+    if (pa.probe && lane == 0 && wave < 8) {   // per-wave barrier cycles and SIMD id (HW_ID bits 5:4)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        pa.probe[4 * gridDim.x + 8 * blockIdx.x + wave] = (probe_bar << 8) | ((hwid >> 4) & 3u);
+    }
 }
 
 template <bool FUSED, int NC>
@@ -447,13 +456,13 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
         static int probe_left = 6;                                                                  \
         pa.probe = nullptr;                                                                         \
         if (probe_on && probe_left > 0) {                                                           \
-            if (!probe_buf && hipMalloc(&probe_buf, sizeof(unsigned long long) * 3 * 65536) != hipSuccess) probe_buf = nullptr; \
+            if (!probe_buf && hipMalloc(&probe_buf, sizeof(unsigned long long) * 12 * 65536) != hipSuccess) probe_buf = nullptr; \
             if (g <= 65536) pa.probe = probe_buf;                                                   \
         }                                                                                           \
         hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), block, lds, s, a, pa);              \
         if (pa.probe) {                                                                             \
             --probe_left;                                                                           \
-            std::vector<unsigned long long> hb(3 * static_cast<size_t>(g));                         \
+            std::vector<unsigned long long> hb(12 * static_cast<size_t>(g));                         \
             (void)hipStreamSynchronize(s);                                                          \
             (void)hipMemcpy(hb.data(), probe_buf, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost); \
             std::vector<double> ghz, us;                                                            \
@@ -465,6 +474,18 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
             std::sort(ghz.begin(), ghz.end()); std::sort(us.begin(), us.end()); std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end()); \
             if (!st.empty()) std::fprintf(stderr, "[mrhip] probe: tile-loop START after first wg: median %.1f p90 %.1f max %.1f us; END: p10 %.1f median %.1f max %.1f us\n", \
                                           st[st.size() / 2], st[st.size() * 9 / 10], st.back(), en[en.size() / 10], en[en.size() / 2], en.back()); \
+            {                                                                                       \
+                const int ncwv = static_cast<int>(block.x / 64) - 1;                                \
+                for (int w = 0; w < ncwv && w < 8; ++w) {                                           \
+                    std::vector<double> wf; int simd_hist[4] = {0, 0, 0, 0};                         \
+                    for (long long i = 0; i < g; ++i) if (hb[3 * i] > 1000) {                       \
+                        const unsigned long long v = hb[4 * g + 8 * i + w];                         \
+                        wf.push_back(static_cast<double>(v >> 8) / static_cast<double>(hb[3 * i])); ++simd_hist[v & 3]; } \
+                    std::sort(wf.begin(), wf.end());                                                \
+                    if (!wf.empty()) std::fprintf(stderr, "[mrhip] probe: wave %d spends %.3f of the tile loop at the barrier (median); SIMD histogram %d %d %d %d\n", \
+                                                  w, wf[wf.size() / 2], simd_hist[0], simd_hist[1], simd_hist[2], simd_hist[3]); \
+                }                                                                                   \
+            }                                                                                       \
             if (!ghz.empty()) std::fprintf(stderr, "[mrhip] probe: in-kernel clock median %.3f GHz (min %.3f max %.3f); tile loop p10 %.1f median %.1f p90 %.1f max %.1f us\n", \
                                            ghz[ghz.size() / 2], ghz.front(), ghz.back(), us[us.size() / 10], us[us.size() / 2], us[us.size() * 9 / 10], us.back()); \
         }                                                                                           \
