@@ -7,8 +7,10 @@
 //
 // A persistent workgroup keeps both polyphase banks in LDS (column pitch T+1 elements, so lanes with
 // different phases land on different banks) and, per tile of consecutive outputs of one channel,
-// stages the contiguous run of input samples those outputs touch.  One lane = one output; the sample
-// is read once per tap and feeds both dot products.
+// stages the contiguous run of input samples those outputs touch, for CPL channels at once.  One lane = one
+// output index of CPL channels: the phase schedule is shared by all channels, so the two taps read per
+// step feed 2*CPL dot products (LDS reads per output and tap: 1 + 2/CPL instead of 3 -- the kernel was
+// LDS-bound at three reads per tap); the sample is read once per tap and channel and feeds both dots.
 //
 // Arithmetic: identical to arb_generic_kernel (STRICT / FUSED) => bit-identical results.
 #include <algorithm>
@@ -37,7 +39,7 @@ __device__ __forceinline__ R mac(R t, R x, R acc)
     }
 }
 
-template <typename TX, typename R, int NC, bool FUSED>
+template <typename TX, typename R, int NC, bool FUSED, int CPL>
 __global__ __launch_bounds__(kArbThreads) void arb_tiled_kernel(ArbArgs a, ArbTileArgs ta)
 {
     struct alignas(sizeof(TX) * NC) Sample { TX c[NC]; };
@@ -61,27 +63,34 @@ __global__ __launch_bounds__(kArbThreads) void arb_tiled_kernel(ArbArgs a, ArbTi
     }
 
     for (long long tile = blockIdx.x; tile < ta.total_tiles; tile += gridDim.x) {
-        const int ch = static_cast<int>(tile / ta.tiles_per_channel);
-        const long long tau = tile - static_cast<long long>(ch) * ta.tiles_per_channel;
+        const int cg = static_cast<int>(tile / ta.tiles_per_channel);                  // channel group
+        const long long tau = tile - static_cast<long long>(cg) * ta.tiles_per_channel;
+        const int ch0 = cg * CPL;
+        const int nchl = a.nch - ch0 < CPL ? a.nch - ch0 : CPL;                         // channels of this group
         const long long k0 = tau * ta.tile_out;
         const long long klast = (k0 + ta.tile_out < a.n_out ? k0 + ta.tile_out : a.n_out) - 1;
-        const Sample *__restrict__ xc = static_cast<const Sample *>(a.x) + static_cast<long long>(ch) * a.x_stride;
-        const Sample *__restrict__ hc = static_cast<const Sample *>(a.hist) + static_cast<long long>(ch) * a.H;
-        R *__restrict__ yc = static_cast<R *>(a.y) + static_cast<long long>(ch) * a.y_stride * NC;
         // samples this tile touches: x[n_lo - T .. n_hi - 1] (0-based), n = 1-based newest-sample index
         const long long n_lo = a.n_idx[k0], n_hi = a.n_idx[klast];
         const long long o = n_lo - T;
         const int span = static_cast<int>(n_hi - n_lo) + T;
 
         __syncthreads();   // previous tile's reads are done (and, first time, the tap banks are written)
-        for (int s = tid; s < span; s += kArbThreads) {
-            const long long gi = o + s;
-            Sample v;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) v.c[c] = static_cast<TX>(0);
-            if (gi >= 0) { if (gi < a.x_len) v = xc[gi]; }
-            else if (gi >= -static_cast<long long>(a.H)) v = hc[a.H + gi];
-            lx[s] = v;
+        for (int cc = 0; cc < CPL; ++cc) {
+            if (cc < nchl) {
+                const Sample *__restrict__ xc = static_cast<const Sample *>(a.x) + static_cast<long long>(ch0 + cc) * a.x_stride;
+                const Sample *__restrict__ hc = static_cast<const Sample *>(a.hist) + static_cast<long long>(ch0 + cc) * a.H;
+                Sample *const lxc = lx + static_cast<size_t>(cc) * ta.max_span;
+                for (int s = tid; s < span; s += kArbThreads) {
+                    const long long gi = o + s;
+                    Sample v;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) v.c[c] = static_cast<TX>(0);
+                    if (gi >= 0) { if (gi < a.x_len) v = xc[gi]; }
+                    else if (gi >= -static_cast<long long>(a.H)) v = hc[a.H + gi];
+                    lxc[s] = v;
+                }
+            }
         }
         __syncthreads();
 
@@ -93,29 +102,41 @@ __global__ __launch_bounds__(kArbThreads) void arb_tiled_kernel(ArbArgs a, ArbTi
             const int phi = static_cast<int>(phif) - 1;     // 0-based column
             const R *tp = lpfb + phi * TP;
             const R *dp = ldpfb + phi * TP;
-            const Sample *wp = lx + (n - n_lo);             // oldest sample of this output's window
-            R lo[NC], up[NC];
+            const Sample *wp = lx + (n - n_lo);             // oldest sample of this output's window (channel 0 of the group)
+            R lo[CPL][NC], up[CPL][NC];
             {
-                const Sample v = wp[0];
                 const R t = tp[0], d = dp[0];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) { lo[c] = t * static_cast<R>(v.c[c]); up[c] = d * static_cast<R>(v.c[c]); }
+                for (int cc = 0; cc < CPL; ++cc) {
+                    const Sample v = wp[static_cast<size_t>(cc) * ta.max_span];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) { lo[cc][c] = t * static_cast<R>(v.c[c]); up[cc][c] = d * static_cast<R>(v.c[c]); }
+                }
             }
-#pragma unroll 8
+#pragma unroll 4
             for (int i = 1; i < T; ++i) {
-                const Sample v = wp[i];
                 const R t = tp[i], d = dp[i];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    lo[c] = mac<R, FUSED>(t, static_cast<R>(v.c[c]), lo[c]);
-                    up[c] = mac<R, FUSED>(d, static_cast<R>(v.c[c]), up[c]);
+                for (int cc = 0; cc < CPL; ++cc) {
+                    const Sample v = wp[static_cast<size_t>(cc) * ta.max_span + i];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        lo[cc][c] = mac<R, FUSED>(t, static_cast<R>(v.c[c]), lo[cc][c]);
+                        up[cc][c] = mac<R, FUSED>(d, static_cast<R>(v.c[c]), up[cc][c]);
+                    }
                 }
             }
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const double prod = static_cast<double>(up[c]) * alpha;      // Filters.jl:730, Float64 combine
-                const double sum = static_cast<double>(lo[c]) + prod;
-                yc[k * NC + c] = static_cast<R>(sum);
+            for (int cc = 0; cc < CPL; ++cc) {
+                if (cc < nchl) {
+                    R *__restrict__ yc = static_cast<R *>(a.y) + static_cast<long long>(ch0 + cc) * a.y_stride * NC;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const double prod = static_cast<double>(up[cc][c]) * alpha;      // Filters.jl:730, Float64 combine
+                        const double sum = static_cast<double>(lo[cc][c]) + prod;
+                        yc[k * NC + c] = static_cast<R>(sum);
+                    }
+                }
             }
         }
     }
@@ -149,7 +170,12 @@ hipError_t launch_arb(bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_
         hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, ta);
         return hipGetLastError();
     };
-    return fused ? go(arb_tiled_kernel<TX, R, NC, true>) : go(arb_tiled_kernel<TX, R, NC, false>);
+    switch (ta.cpl) {
+    case 8: return fused ? go(arb_tiled_kernel<TX, R, NC, true, 8>) : go(arb_tiled_kernel<TX, R, NC, false, 8>);
+    case 4: return fused ? go(arb_tiled_kernel<TX, R, NC, true, 4>) : go(arb_tiled_kernel<TX, R, NC, false, 4>);
+    case 2: return fused ? go(arb_tiled_kernel<TX, R, NC, true, 2>) : go(arb_tiled_kernel<TX, R, NC, false, 2>);
+    default: return fused ? go(arb_tiled_kernel<TX, R, NC, true, 1>) : go(arb_tiled_kernel<TX, R, NC, false, 1>);
+    }
 }
 
 }  // namespace
@@ -166,17 +192,24 @@ bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_ho
     const size_t bank_elems = static_cast<size_t>(a.Nphi) * TP;
     const size_t banks_bytes = (2 * bank_elems * rs + 15) / 16 * 16;
     if (banks_bytes > 96 * 1024) return false;
+    // channels per lane: the tap reads are shared by CPL channels (needs enough channels to keep the machine busy)
+    static const int env_cpl = [] { const char *v = std::getenv("MRHIP_ARB_CPL"); return v && *v ? std::atoi(v) : 0; }();
+    int cpl = a.nch >= 32 ? 4 : (a.nch >= 8 ? 2 : 1);
+    if (env_cpl == 1 || env_cpl == 2 || env_cpl == 4 || env_cpl == 8) cpl = env_cpl;
+    const long long groups = (a.nch + cpl - 1) / cpl;
     // tile: a multiple of 256 outputs whose sample span fits the remaining budget
-    long long tile_out = 1024;
+    static const int env_tile = [] { const char *v = std::getenv("MRHIP_ARB_TILE"); return v && *v ? std::atoi(v) : 0; }();
+    // (measured, config 4: with several channels per lane small tiles win -- 6 workgroups per CU)
+    long long tile_out = env_tile >= 256 ? env_tile / 256 * 256 : (cpl >= 4 ? 256 : 1024);
     const long long want_tiles = 4LL * num_cus;
-    while (tile_out > 256 && ((a.n_out + tile_out - 1) / tile_out) * a.nch < want_tiles) tile_out /= 2;
+    while (tile_out > 256 && ((a.n_out + tile_out - 1) / tile_out) * groups < want_tiles) tile_out /= 2;
     for (;;) {
         long long max_span = 0;
         for (long long k0 = 0; k0 < a.n_out; k0 += tile_out) {
             const long long kl = std::min<long long>(k0 + tile_out, a.n_out) - 1;
             max_span = std::max<long long>(max_span, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0] + a.T);
         }
-        const size_t total = banks_bytes + static_cast<size_t>(max_span) * sb;
+        const size_t total = banks_bytes + static_cast<size_t>(max_span) * sb * cpl;
         if (total <= 64 * 1024 || tile_out == 256) {
             if (total > 150 * 1024) return false;
             ArbTileArgs ta{};
@@ -186,7 +219,8 @@ bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_ho
             ta.max_span = static_cast<int>(max_span);
             ta.tile_out = tile_out;
             ta.tiles_per_channel = (a.n_out + tile_out - 1) / tile_out;
-            ta.total_tiles = ta.tiles_per_channel * a.nch;
+            ta.total_tiles = ta.tiles_per_channel * groups;
+            ta.cpl = cpl;
             *out = ta;
             *lds = total;
             return true;

@@ -181,6 +181,7 @@ struct DirectArgs {          // tiling of the single-column kernel (kernels_fir_
 };
 
 struct ArbTileArgs {         // tiling of the FIRArbitrary kernel (kernels_arbitrary.hip)
+    int cpl;                 // channels per lane (1, 2 or 4): a tile covers cpl channels
     int tap_pitch;           // elements between PFB columns in LDS (T + 1)
     int bank_elems;          // elements per tap bank in LDS
     int x_offset_bytes;      // byte offset of the sample tile in LDS
