@@ -571,7 +571,67 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
     int64_t n_out = 0;
     bool did_shiftin = false;
     if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {
+        // one range [k0, k0+cnt) of this call's outputs: schedule entries are already in the device buffers
+        const size_t yelt = dtype_scalar_size(f->ty) * static_cast<size_t>(f->nc);
+        auto launch_range = [&](int64_t k0, int64_t cnt, const int32_t *n_host) -> int {
+            void *yk = static_cast<unsigned char *>(y) + static_cast<size_t>(k0) * yelt;
+            if (f->kind == MRHIP_FIR_FARROW) {
+                FarrowArgs fa{};
+                fa.x = x; fa.y = yk; fa.hist = f->d_hist[f->hist_cur]; fa.pnfb = f->d_pnfb;
+                fa.n_idx = static_cast<const int *>(f->d_sched_n) + k0; fa.acc = static_cast<const double *>(f->d_sched_acc) + k0;
+                fa.x_stride = x_stride; fa.y_stride = y_stride; fa.x_len = x_len; fa.n_out = cnt;
+                fa.T = static_cast<int>(f->T); fa.H = static_cast<int>(f->H); fa.polyorder = static_cast<int>(f->polyorder);
+                fa.tap_f32 = f->th == MRHIP_F32; fa.nch = static_cast<int>(f->nch);
+                if (int rc = timing_mark(f, stream)) return rc;
+                MRHIP_CHECK_HIP(launch_farrow(tk, fused, fa, stream, &f->last_kernel));
+                return timing_mark(f, stream);
+            }
+            ArbArgs a{};
+            a.x = x; a.y = yk; a.hist = f->d_hist[f->hist_cur]; a.taps = f->d_taps; a.dtaps = f->d_dtaps;
+            a.n_idx = static_cast<const int *>(f->d_sched_n) + k0; a.acc = static_cast<const double *>(f->d_sched_acc) + k0;
+            a.x_stride = x_stride; a.y_stride = y_stride; a.x_len = x_len; a.n_out = cnt;
+            a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H); a.Nphi = static_cast<int>(f->Nphi);
+            a.nch = static_cast<int>(f->nch);
+            if (int rc = timing_mark(f, stream)) return rc;
+            ArbTileArgs ta;
+            size_t lds = 0;
+            if (!f->force_generic && plan_arb_tiled(tk, a, n_host, f->num_cus, &ta, &lds))
+                MRHIP_CHECK_HIP(launch_arb_tiled(tk, fused, a, ta, lds, stream, &f->last_kernel, f->num_cus));
+            else
+                MRHIP_CHECK_HIP(launch_arb_generic(tk, fused, a, stream, &f->last_kernel));
+            return timing_mark(f, stream);
+        };
         ArbState st;
+        // Upper bound of the output count (the reference's outputlength estimate, Filters.jl:375-381, + 2 for the
+        // rounding of its Float64 recurrence).  With room for it in y, the serial host recurrence is PIPELINED with
+        // the GPU: every piece of the schedule is uploaded and its kernel launched while the next piece is computed.
+        const int64_t est = x_len >= f->inputDeficit
+            ? static_cast<int64_t>(std::ceil(static_cast<double>(x_len - f->inputDeficit + 1) * f->rate)) + 2 : 0;
+        const bool cached = f->sched_cached && f->sched_xlen == x_len && f->sched_acc0 == f->phiAcc && f->sched_deficit0 == f->inputDeficit;
+        static const int64_t piece = [] { const char *v = std::getenv("MRHIP_SCHED_PIECE"); return v && *v ? std::atoll(v) : 262144LL; }();
+        if (!cached && est > 2 * piece && y && y_capacity >= est && (f->nch == 1 || y_stride >= est) && est < 0x7fffffffLL) {
+            if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
+            if (int rc = ensure_sched_capacity(f, static_cast<size_t>(est))) return rc;
+            st = ArbState{f->phiAcc, f->phiIdx, f->alpha, f->inputDeficit, f->inputDeficit};   // xIdx starts at inputDeficit (:715)
+            bool done = false;
+            int64_t k0 = 0;
+            while (!done) {
+                int32_t *pn = static_cast<int32_t *>(f->pin_n) + k0;
+                double *pa = static_cast<double *>(f->pin_acc) + k0;
+                const int64_t room = std::min<int64_t>(piece, est - k0);
+                if (room <= 0) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");   // cannot happen: est is an upper bound
+                const int64_t cnt = run_arbitrary_schedule_piece(st, f->delta, f->Nphi, x_len, pn, pa, room, &done);
+                if (cnt > 0) {
+                    MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<int32_t *>(f->d_sched_n) + k0, pn, static_cast<size_t>(cnt) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                    MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<double *>(f->d_sched_acc) + k0, pa, static_cast<size_t>(cnt) * sizeof(double), hipMemcpyHostToDevice, stream));
+                    if (int rc = launch_range(k0, cnt, pn)) return rc;
+                    k0 += cnt;
+                }
+            }
+            MRHIP_CHECK_HIP(hipEventRecord(f->sched_copied, stream));
+            f->sched_in_flight = true;
+            n_out = k0;
+        } else {
         n_out = arb_schedule(f, x_len, &st);   // update(::FIRFarrow), Filters.jl:780-788, is the same recurrence
         if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
         if (n_out > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
@@ -585,34 +645,8 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_sched_acc, f->pin_acc, static_cast<size_t>(n_out) * sizeof(double), hipMemcpyHostToDevice, stream));
             MRHIP_CHECK_HIP(hipEventRecord(f->sched_copied, stream));
             f->sched_in_flight = true;
-            if (f->kind == MRHIP_FIR_FARROW) {
-                FarrowArgs fa{};
-                fa.x = x; fa.y = y; fa.hist = f->d_hist[f->hist_cur]; fa.pnfb = f->d_pnfb;
-                fa.n_idx = static_cast<const int *>(f->d_sched_n); fa.acc = static_cast<const double *>(f->d_sched_acc);
-                fa.x_stride = x_stride; fa.y_stride = y_stride; fa.x_len = x_len; fa.n_out = n_out;
-                fa.T = static_cast<int>(f->T); fa.H = static_cast<int>(f->H); fa.polyorder = static_cast<int>(f->polyorder);
-                fa.tap_f32 = f->th == MRHIP_F32; fa.nch = static_cast<int>(f->nch);
-                if (int rc = timing_mark(f, stream)) return rc;
-                MRHIP_CHECK_HIP(launch_farrow(tk, fused, fa, stream, &f->last_kernel));
-                if (int rc = timing_mark(f, stream)) return rc;
-            } else {
-            ArbArgs a{};
-            a.x = x; a.y = y; a.hist = f->d_hist[f->hist_cur]; a.taps = f->d_taps; a.dtaps = f->d_dtaps;
-            a.n_idx = static_cast<const int *>(f->d_sched_n); a.acc = static_cast<const double *>(f->d_sched_acc);
-            a.x_stride = x_stride; a.y_stride = y_stride; a.x_len = x_len; a.n_out = n_out;
-            a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H); a.Nphi = static_cast<int>(f->Nphi);
-            a.nch = static_cast<int>(f->nch);
-            if (int rc = timing_mark(f, stream)) return rc;
-            {
-                ArbTileArgs ta;
-                size_t lds = 0;
-                if (!f->force_generic && plan_arb_tiled(tk, a, f->sched_n.data(), f->num_cus, &ta, &lds))
-                    MRHIP_CHECK_HIP(launch_arb_tiled(tk, fused, a, ta, lds, stream, &f->last_kernel, f->num_cus));
-                else
-                    MRHIP_CHECK_HIP(launch_arb_generic(tk, fused, a, stream, &f->last_kernel));
-            }
-            if (int rc = timing_mark(f, stream)) return rc;
-            }
+            if (int rc = launch_range(0, n_out, f->sched_n.data())) return rc;
+        }
         }
         // commit the post-call state (Filters.jl:731-735)
         f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;

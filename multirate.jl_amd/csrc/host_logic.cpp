@@ -140,6 +140,45 @@ int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t
     return count;
 }
 
+// The same recurrence, resumable: continues from (st.acc, st.xIdx) and writes at most `max_outputs` schedule
+// entries into raw buffers (the caller's pinned staging memory); *done is set once xIdx has passed xLen, at which
+// point st holds the call-end state exactly as run_arbitrary_schedule leaves it.  Lets filt! overlap the serial
+// host recurrence of one long call with the kernels of the pieces already scheduled.
+int64_t run_arbitrary_schedule_piece(ArbState &st, double delta, int64_t Nphi, int64_t xLen, int32_t *n_idx, double *acc_out,
+                                     int64_t max_outputs, bool *done)
+{
+    const double N = static_cast<double>(Nphi);
+    const bool n_pow2 = (Nphi & (Nphi - 1)) == 0;
+    const double invN = 1.0 / N;
+    double acc = st.acc;
+    int64_t xIdx = st.xIdx;
+    int64_t count = 0;
+    while (xIdx <= xLen && count < max_outputs) {
+        n_idx[count] = static_cast<int32_t>(xIdx);
+        acc_out[count] = acc;
+        ++count;
+        acc += delta;
+        if (acc > N) {
+            const double am1 = acc - 1.0;
+            const double qd = n_pow2 ? am1 * invN : am1 / N;
+            xIdx += static_cast<int64_t>(std::floor(qd));
+            double r = am1;
+            if (am1 < 4.0 * N) { while (r >= N) r -= N; }
+            else r = std::fmod(am1, N);
+            acc = r + 1.0;
+        }
+    }
+    st.acc = acc;
+    st.xIdx = xIdx;
+    *done = xIdx > xLen;
+    if (*done) {
+        st.phiIdx = static_cast<int64_t>(std::floor(acc));
+        st.alpha = acc - static_cast<double>(st.phiIdx);
+        st.inputDeficit = xIdx - xLen;
+    }
+    return count;
+}
+
 // polyfit(y, polyorder), src/support.jl:85-88: A = [x^p for x in 1:n, p = 0:polyorder]; coefficients = A \ y,
 // i.e. the least-squares solution Julia computes by a QR factorisation of A in Float64.  Restated as a
 // Householder QR (the reference pins no bits here: SURVEY.md 8c -- LAPACK's blocked QR and this one agree

@@ -67,6 +67,8 @@ struct ArbState {
 // Returns the number of outputs; `st` is advanced to the post-call state.
 int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t xLen,
                                std::vector<int32_t> *n_idx, std::vector<double> *acc_out);
+int64_t run_arbitrary_schedule_piece(ArbState &st, double delta, int64_t Nphi, int64_t xLen, int32_t *n_idx, double *acc_out,
+                                     int64_t max_outputs, bool *done);
 
 // ---------------------------------------------------------------------------------------
 // device-side parameter blocks
