@@ -194,11 +194,19 @@ function filt!(buffer::VecOrMat{Tb}, f::FIRFilter{Tk}, x::VecOrMat{Tx}) where {T
     (Tk === FIRStandard || Tk === FIRInterpolator) ? buffer : Int(nw[])
 end
 
-# filt(self, x): allocate, filt!, trim to the samples written (src/Filters.jl:475,519,577,633,744)
-function filt(f::FIRFilter, x::VecOrMat{Tx}) where {Tx}
+# filt(self, x): allocate, filt!, trim to the samples written (src/Filters.jl:475,519,577,633,744,841)
+function filt(f::FIRFilter{Tk}, x::VecOrMat{Tx}) where {Tk,Tx}
     bind!(f, Tx, size(x, 2))
-    n = max(nextoutputcount(f, size(x, 1)), 0)
     Tb = promote_out(eltype(f.h), Tx)
+    if Tk === FIRArbitrary || Tk === FIRFarrow
+        # like the reference (:744-752, :841-849): allocate the outputlength estimate (+2, it is only a guess there) and
+        # trim to the count filt! returns; the library pipelines the serial phase recurrence with the kernels
+        cap = max(outputlength(f, size(x, 1)), 0) + 2
+        buffer = x isa Vector ? Vector{Tb}(undef, cap) : Matrix{Tb}(undef, cap, size(x, 2))
+        n = size(x, 1) == 0 ? 0 : filt!(buffer, f, x)
+        return x isa Vector ? resize!(buffer, n) : buffer[1:n, :]
+    end
+    n = max(nextoutputcount(f, size(x, 1)), 0)
     buffer = x isa Vector ? Vector{Tb}(undef, n) : Matrix{Tb}(undef, n, size(x, 2))
     size(x, 1) == 0 || filt!(buffer, f, x)
     buffer
