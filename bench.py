@@ -18,8 +18,9 @@ reported value is all ranks' input samples / max-over-ranks time ("scaling": "we
 One JSON line is printed by rank 0.  `roofline.achieved` = algorithmic bytes per launch
 (7.675 B per input sample per channel = 4 B read + 0.91875 * 4 B written) x samples per
 launch / average launch duration of the dominant kernel, measured with HIP events recorded on the
-launch stream around every compute-kernel launch of the timed region (mrhip_set_timing /
-mrhip_timing_read).  `cpu_baseline` = the CPU oracle (a C port of the reference algorithm; the
+launch stream around every 4th compute-kernel launch of the timed region (mrhip_set_timing /
+mrhip_timing_read; the event records themselves cost a few microseconds of stream time per launch, so bracketing
+every launch would slow the very throughput being measured).  `cpu_baseline` = the CPU oracle (a C port of the reference algorithm; the
 reference itself is Julia-0.3 source and cannot run) on one core over a bounded sample.
 """
 from __future__ import annotations
@@ -71,6 +72,7 @@ def main():
     ap.add_argument("--samples", type=int, default=100_000_000, help="input samples per channel per step")
     ap.add_argument("--chunk", type=int, default=1_000_000, help="samples per channel per filt! call")
     ap.add_argument("--numerics", choices=["strict", "fused"], default="strict")
+    ap.add_argument("--time-every", type=int, default=4, help="bracket every n-th kernel launch of the timed region with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check (timing experiments)")
     args = ap.parse_args()
@@ -128,7 +130,7 @@ def main():
     for _ in range(args.warmup):
         produced = one_step()
     barrier()
-    filt.set_timing(True)
+    filt.set_timing(args.time_every)   # HIP events around every n-th launch (they cost stream time themselves)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         produced = one_step()

@@ -213,7 +213,9 @@ int mrhip_filt_once(const void *h, int64_t hLen, int tap_dtype, int64_t num, int
  * bracketed by a pair of HIP events recorded on the launch stream (the history-shift kernel and
  * the copies are outside the bracket).  Nothing synchronises until mrhip_timing_read, which waits
  * for the recorded events, returns how many launches were bracketed since the last read and the sum
- * of their durations in milliseconds, and clears the log.  bench.py uses it for roofline.achieved. */
+ * of their durations in milliseconds, and clears the log.  bench.py uses it for roofline.achieved.
+ * enabled = n > 1 brackets every n-th compute launch only (the two event records cost a few microseconds of
+ * stream time per launch, which a throughput measurement of back-to-back launches would otherwise include). */
 int mrhip_set_timing(mrhip_filter *f, int enabled);
 int mrhip_timing_read(mrhip_filter *f, int64_t *n_launches, double *total_ms);
 /* name of the device kernel the last filt call dispatched (for profiles / logs) */

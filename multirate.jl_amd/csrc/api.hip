@@ -518,6 +518,16 @@ int mrhip_get_taps(mrhip_filter *f, int which, void *host_out)
 static int timing_mark(mrhip_filter *f, hipStream_t stream)
 {
     if (!f->timing) return MRHIP_OK;
+    // called in pairs (before / after every compute launch); with a stride only every n-th launch is bracketed,
+    // because the event records themselves cost a few microseconds of stream time per launch
+    if (!f->timing_open) {
+        const bool take = (f->timing_launch++ % f->timing_stride) == 0;
+        if (!take) { f->timing_open = true; f->ev_skip = true; return MRHIP_OK; }
+        f->timing_open = true; f->ev_skip = false;
+    } else {
+        f->timing_open = false;
+        if (f->ev_skip) return MRHIP_OK;
+    }
     if (f->ev_used == f->ev_pool.size()) {
         hipEvent_t e = nullptr;
         MRHIP_CHECK_HIP(hipEventCreate(&e));
@@ -764,6 +774,8 @@ int mrhip_set_timing(mrhip_filter *f, int enabled)
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
     f->timing = enabled != 0;
+    f->timing_stride = enabled > 1 ? enabled : 1;     // enabled = n > 1: bracket every n-th compute launch
+    f->timing_launch = 0; f->timing_open = false; f->ev_skip = false;
     f->ev_used = 0;
     return MRHIP_OK;
 }

@@ -282,6 +282,10 @@ struct mrhip_filter {
 
     // measurement
     bool timing = false;
+    int timing_stride = 1;            // bracket every timing_stride-th compute launch (1 = all)
+    int64_t timing_launch = 0;        // compute launches seen since timing was enabled
+    bool timing_open = false;         // between the two marks of a launch
+    bool ev_skip = false;             // ... of a launch that is not bracketed
     std::vector<hipEvent_t> ev_pool;   // pairs: [2i] start, [2i+1] stop
     size_t ev_used = 0;                // events handed out since the last mrhip_timing_read
     const char *last_kernel = "";

@@ -382,8 +382,9 @@ class FIRFilter:
             return acc
         raise MultirateHIPError(5, f"setphase is not defined for {self.kernel_name}")
 
-    def set_timing(self, enabled: bool = True):
-        _check(self._lib.mrhip_set_timing(self._handle, 1 if enabled else 0))
+    def set_timing(self, enabled=True):
+        """True/False, or an int n > 1 to bracket every n-th compute launch only."""
+        _check(self._lib.mrhip_set_timing(self._handle, int(enabled)))
 
     def timing_read(self):
         """(number of compute-kernel launches since the last read, sum of their durations in ms)."""
