@@ -500,3 +500,30 @@ def test_fused_numerics_bit_exact_vs_fused_oracle(pkg, O, torch_cuda):
                 assert_bit_equal(y[c], yo, f"fused {ratio} {th} {tx} kernel={f.last_kernel_name()}")
     finally:
         O.set_fused(False)
+
+
+def test_config5_4096_channels_complex_one_gpu(pkg, torch_cuda, monkeypatch):
+    """BASELINE config 5's full channel count on ONE GPU (4096 x ComplexF32 147//160; per-channel length reduced):
+    channel offsets pass 4 GiB, so every 32-bit offset in the kernels is exercised.  Tuned == universal kernel bit
+    for bit on all channels (checksum) and element-wise on a few; channel independence (a channel of the batch ==
+    the same signal alone)."""
+    torch = torch_cuda
+    nch, n = 4096, 160_000
+    h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.view_as_complex(torch.rand((nch, n, 2), generator=g, device="cuda", dtype=torch.float32) - 0.5)
+    assert x.numel() * 8 > 2 ** 32
+    f = pkg.FIRFilter(h, Fraction(147, 160))
+    y = f.filt(x)
+    assert f.last_kernel_name() == "rational_pair_kernel" and y.shape == (nch, n * 147 // 160)
+    monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+    gf = pkg.FIRFilter(h, Fraction(147, 160))
+    yg = gf.filt(x)
+    monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+    assert gf.last_kernel_name() == "poly_generic_kernel"
+    a, b = torch.view_as_real(y).view(torch.int32), torch.view_as_real(yg).view(torch.int32)
+    assert torch.equal(a, b)
+    for c in (0, 2047, 4095):
+        y1 = pkg.FIRFilter(h, Fraction(147, 160)).filt(x[c].contiguous())
+        assert torch.equal(torch.view_as_real(y1).view(torch.int32), a[c])
+    assert_bit_equal(f.history[4095], gf.history[4095], "history")
