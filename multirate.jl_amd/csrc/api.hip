@@ -593,7 +593,12 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
                 fa.T = static_cast<int>(f->T); fa.H = static_cast<int>(f->H); fa.polyorder = static_cast<int>(f->polyorder);
                 fa.tap_f32 = f->th == MRHIP_F32; fa.nch = static_cast<int>(f->nch);
                 if (int rc = timing_mark(f, stream)) return rc;
-                MRHIP_CHECK_HIP(launch_farrow(tk, fused, fa, stream, &f->last_kernel));
+                ArbTileArgs fta;
+                size_t flds = 0;
+                if (!f->force_generic && plan_farrow_tiled(tk, fa, n_host, f->num_cus, &fta, &flds))
+                    MRHIP_CHECK_HIP(launch_farrow_tiled(tk, fused, fa, fta, flds, stream, &f->last_kernel, f->num_cus));
+                else
+                    MRHIP_CHECK_HIP(launch_farrow(tk, fused, fa, stream, &f->last_kernel));
                 return timing_mark(f, stream);
             }
             ArbArgs a{};

@@ -178,6 +178,127 @@ hipError_t launch_arb(bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_
     }
 }
 
+
+// ---- FIRFarrow, tiled --------------------------------------------------------------------------------------
+// Same staging as arb_tiled_kernel, for the Farrow filter (src/Filters.jl:764-839): a workgroup takes a tile of 256
+// consecutive output indices.  Every thread evaluates the T polynomial taps of ITS output once (Float64 Horner,
+// rounded to the tap type: Polynomials.jl polyval + the store into currentTaps::Vector{Th}) into an LDS column,
+// then the workgroup walks over ALL channels in groups of CPL: stage the contiguous sample run of the group,
+// one Vector dot per channel (start from zero on the seam, support.jl:46) with the taps read back from LDS.
+// The taps depend on the output index only, so they are evaluated once per 256 outputs x all channels.
+template <typename TX, typename R, int NC, bool FUSED, int CPL>
+__global__ __launch_bounds__(kArbThreads) void farrow_tiled_kernel(FarrowArgs a, ArbTileArgs ta)
+{
+    struct alignas(sizeof(TX) * NC) Sample { TX c[NC]; };
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R *const tl = reinterpret_cast<R *>(smem);                                  // taps: [T][256]
+    Sample *const lx = reinterpret_cast<Sample *>(smem + ta.x_offset_bytes);    // samples: [CPL][max_span]
+    const int tid = threadIdx.x;
+    const int T = a.T, P = a.polyorder;
+
+    for (long long tile = blockIdx.x; tile < ta.total_tiles; tile += gridDim.x) {
+        const long long k0 = tile * ta.tile_out;
+        const long long klast = (k0 + ta.tile_out < a.n_out ? k0 + ta.tile_out : a.n_out) - 1;
+        const long long n_lo = a.n_idx[k0], n_hi = a.n_idx[klast];
+        const long long o = n_lo - T;
+        const int span = static_cast<int>(n_hi - n_lo) + T;
+        const long long k = k0 + tid;
+        const bool have = k <= klast;
+        long long n = 0;
+        if (have) {
+            n = a.n_idx[k];
+            const double phase = a.acc[k];
+            for (int i = 0; i < T; ++i) {            // Horner in Float64, separately rounded multiply and add
+                const double *__restrict__ c = a.pnfb + static_cast<long long>(i) * (P + 1);
+                double yv = c[P];
+                for (int j = P - 1; j >= 0; --j) { const double t = phase * yv; yv = c[j] + t; }
+                tl[i * kArbThreads + tid] = a.tap_f32 ? static_cast<R>(static_cast<float>(yv)) : static_cast<R>(yv);
+            }
+        }
+        const bool seam = n < T;                      // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818
+        for (int ch0 = 0; ch0 < a.nch; ch0 += CPL) {
+            const int nchl = a.nch - ch0 < CPL ? a.nch - ch0 : CPL;
+            __syncthreads();   // the previous group's reads are done
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) {
+                if (cc < nchl) {
+                    const Sample *__restrict__ xc = static_cast<const Sample *>(a.x) + static_cast<long long>(ch0 + cc) * a.x_stride;
+                    const Sample *__restrict__ hc = static_cast<const Sample *>(a.hist) + static_cast<long long>(ch0 + cc) * a.H;
+                    Sample *const lxc = lx + static_cast<size_t>(cc) * ta.max_span;
+                    for (int s = tid; s < span; s += kArbThreads) {
+                        const long long gi = o + s;
+                        Sample v;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) v.c[c] = static_cast<TX>(0);
+                        if (gi >= 0) { if (gi < a.x_len) v = xc[gi]; }
+                        else if (gi >= -static_cast<long long>(a.H)) v = hc[a.H + gi];
+                        lxc[s] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            if (have) {
+                const Sample *wp = lx + (n - n_lo);
+                R acc[CPL][NC];
+                {
+                    const R t = tl[tid];
+#pragma unroll
+                    for (int cc = 0; cc < CPL; ++cc) {
+                        const Sample v = wp[static_cast<size_t>(cc) * ta.max_span];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            acc[cc][c] = t * static_cast<R>(v.c[c]);
+                            if (seam) acc[cc][c] = static_cast<R>(0) + acc[cc][c];
+                        }
+                    }
+                }
+#pragma unroll 4
+                for (int i = 1; i < T; ++i) {
+                    const R t = tl[i * kArbThreads + tid];
+#pragma unroll
+                    for (int cc = 0; cc < CPL; ++cc) {
+                        const Sample v = wp[static_cast<size_t>(cc) * ta.max_span + i];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) acc[cc][c] = mac<R, FUSED>(t, static_cast<R>(v.c[c]), acc[cc][c]);
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+                    if (cc < nchl) {
+                        R *__restrict__ yc = static_cast<R *>(a.y) + static_cast<long long>(ch0 + cc) * a.y_stride * NC;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) yc[k * NC + c] = acc[cc][c];
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the tap columns are rewritten by the next tile
+    }
+}
+
+template <typename TX, typename R, int NC>
+hipError_t launch_farrow_t(bool fused, const FarrowArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s, int num_cus)
+{
+    auto go = [&](auto kfn) -> hipError_t {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+        }
+        int per_cu = 0;
+        hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kArbThreads, lds);
+        if (eo != hipSuccess) return eo;
+        if (per_cu < 1) per_cu = 1;
+        long long g = static_cast<long long>(num_cus) * per_cu;
+        if (g > ta.total_tiles) g = ta.total_tiles;
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, ta);
+        return hipGetLastError();
+    };
+    if (ta.cpl == 4) return fused ? go(farrow_tiled_kernel<TX, R, NC, true, 4>) : go(farrow_tiled_kernel<TX, R, NC, false, 4>);
+    return fused ? go(farrow_tiled_kernel<TX, R, NC, true, 1>) : go(farrow_tiled_kernel<TX, R, NC, false, 1>);
+}
+
 }  // namespace
 
 // `n_idx_host` is the host copy of the per-output input indices (non-decreasing).  Returns false when
@@ -236,6 +357,47 @@ hipError_t launch_arb_tiled(const TypeKey &tk, bool fused, const ArbArgs &a, con
     if (!tk.x_f64 && !tk.r_f64) return tk.complex_x ? launch_arb<float, float, 2>(fused, a, ta, lds, s, num_cus) : launch_arb<float, float, 1>(fused, a, ta, lds, s, num_cus);
     if (!tk.x_f64 && tk.r_f64) return tk.complex_x ? launch_arb<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_arb<float, double, 1>(fused, a, ta, lds, s, num_cus);
     if (tk.x_f64 && tk.r_f64) return tk.complex_x ? launch_arb<double, double, 2>(fused, a, ta, lds, s, num_cus) : launch_arb<double, double, 1>(fused, a, ta, lds, s, num_cus);
+    return hipErrorInvalidValue;
+}
+
+// FIRFarrow: tap columns of 256 outputs (T*256 elements of R) plus the sample runs of CPL channels must fit LDS.
+bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_idx_host, int num_cus, ArbTileArgs *out, size_t *lds)
+{
+    static const int enabled = [] { const char *v = std::getenv("MRHIP_FARROW_TILED"); return !(v && v[0] == '0'); }();
+    (void)num_cus;
+    if (!enabled || a.n_out < 1) return false;
+    const size_t rs = tk.r_f64 ? 8 : 4;
+    const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
+    const size_t taps_bytes = (static_cast<size_t>(a.T) * kArbThreads * rs + 15) / 16 * 16;
+    if (taps_bytes > 96 * 1024) return false;
+    const int cpl = a.nch >= 4 ? 4 : 1;
+    const long long tile_out = kArbThreads;
+    long long max_span = 0;
+    for (long long k0 = 0; k0 < a.n_out; k0 += tile_out) {
+        const long long kl = std::min<long long>(k0 + tile_out, a.n_out) - 1;
+        max_span = std::max<long long>(max_span, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0] + a.T);
+    }
+    const size_t total = taps_bytes + static_cast<size_t>(max_span) * sb * cpl;
+    if (total > 150 * 1024) return false;
+    ArbTileArgs ta{};
+    ta.cpl = cpl;
+    ta.x_offset_bytes = static_cast<int>(taps_bytes);
+    ta.max_span = static_cast<int>(max_span);
+    ta.tile_out = tile_out;
+    ta.tiles_per_channel = (a.n_out + tile_out - 1) / tile_out;
+    ta.total_tiles = ta.tiles_per_channel;            // a tile covers all channels
+    *out = ta;
+    *lds = total;
+    return true;
+}
+
+hipError_t launch_farrow_tiled(const TypeKey &tk, bool fused, const FarrowArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
+                               const char **kname, int num_cus)
+{
+    *kname = "farrow_tiled_kernel";
+    if (!tk.x_f64 && !tk.r_f64) return tk.complex_x ? launch_farrow_t<float, float, 2>(fused, a, ta, lds, s, num_cus) : launch_farrow_t<float, float, 1>(fused, a, ta, lds, s, num_cus);
+    if (!tk.x_f64 && tk.r_f64) return tk.complex_x ? launch_farrow_t<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_farrow_t<float, double, 1>(fused, a, ta, lds, s, num_cus);
+    if (tk.x_f64 && tk.r_f64) return tk.complex_x ? launch_farrow_t<double, double, 2>(fused, a, ta, lds, s, num_cus) : launch_farrow_t<double, double, 1>(fused, a, ta, lds, s, num_cus);
     return hipErrorInvalidValue;
 }
 

@@ -207,6 +207,9 @@ struct TypeKey {
 hipError_t launch_poly_generic(const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_farrow(const TypeKey &tk, bool fused, const FarrowArgs &a, hipStream_t s, const char **kname);
+bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_idx_host, int num_cus, ArbTileArgs *out, size_t *lds);
+hipError_t launch_farrow_tiled(const TypeKey &tk, bool fused, const FarrowArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
+                               const char **kname, int num_cus);
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
 // least-squares polynomial fit of y[0..n) at x = 1..n (support.jl:85-88); coef receives polyorder+1 ascending powers
 bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef);
