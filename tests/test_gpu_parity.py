@@ -527,3 +527,42 @@ def test_config5_4096_channels_complex_one_gpu(pkg, torch_cuda, monkeypatch):
         y1 = pkg.FIRFilter(h, Fraction(147, 160)).filt(x[c].contiguous())
         assert torch.equal(torch.view_as_real(y1).view(torch.int32), a[c])
     assert_bit_equal(f.history[4095], gf.history[4095], "history")
+
+
+def test_farrow_errors_and_edge_cases(pkg, O, torch_cuda):
+    """Argument checks of the FIRFarrow entry points (reference: error("rate must be greater than 0"), Filters.jl:193;
+    tapsforphase range, :765) and the edge cases the other kernels are tested for: empty and short inputs,
+    one-sample pieces, polyorder 0, a bank with fewer columns than coefficients."""
+    h = (pkg.firdes(8 * 12, 0.45 / 8, beta=6.0) * 8).astype(np.float32)
+    with pytest.raises(pkg.MultirateHIPError):
+        pkg.FIRFilter(h, -1.0, 8, 3)
+    with pytest.raises(pkg.MultirateHIPError):
+        pkg.FIRFilter(h, 1.1, 8, 8).bind(np.float32)           # polyorder + 1 > Nphi: rank deficient fit
+    with pytest.raises(pkg.MultirateHIPError):
+        pkg.FIRFilter(h, 1.1, 8, -1).bind(np.float32)
+    fa = pkg.FIRFilter(h, 1.1, 8).bind(np.float32)
+    with pytest.raises(pkg.MultirateHIPError):
+        fa.tapsforphase(1.0)                                    # not a Farrow filter
+    with pytest.raises(pkg.MultirateHIPError):
+        fa.pnfb()
+    rng = np.random.default_rng(8)
+    x = rng.random(300).astype(np.float32)
+    for order in (0, 3):
+        pn = O.pfb2pnfb(O.taps2pfb(h, 8), order)
+        f = pkg.FIRFilter(h, 0.731, 8, order, pnfb=pn)
+        fo = O.FIRFilter(h, 0.731, 8, tx=np.float32, polyorder=order, pnfb=pn)
+        assert f.filt(x[:0]).shape == (0,)                     # empty input: nothing happens
+        outs, refs = [], []
+        for a, b in ((0, 1), (1, 2), (2, 3), (3, 3), (3, 40), (40, 41), (41, 300)):   # one-sample pieces, an empty one
+            outs.append(f.filt(x[a:b])); refs.append(fo.filt(x[a:b]))
+            assert outs[-1].shape == refs[-1].shape
+        assert_bit_equal(np.concatenate(outs), np.concatenate(refs), f"farrow pieces order {order}")
+        assert f.state.inputDeficit == fo.state.inputDeficit and f.state.phiAccumulator == fo.state.phiAccumulator
+        f.reset(); fo.reset()
+        assert_bit_equal(f.filt(x), fo.filt(x), "after reset")
+    # buffer too small: error before any work, state unchanged (the reference has no check; SURVEY a15)
+    f = pkg.FIRFilter(h, 2.5, 8, 2).bind(np.float32)
+    st0 = f.state.phiAccumulator
+    with pytest.raises(pkg.MultirateHIPError) as ei:
+        f.filt_into(np.empty(10, dtype=np.float32), x)
+    assert ei.value.code == 2 and f.state.phiAccumulator == st0
