@@ -194,6 +194,12 @@ int mrhip_get_taps(mrhip_filter *f, int which, void *host_out);
  * reduced, *n_written = 0 (:543-547, :638-643, :705-709). */
 int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
                       int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream);
+/* Streaming helper: exactly the sequence of filt!(buffer, self, x[a:a+chunk]) calls a caller would make
+ * over consecutive `chunk`-sample pieces of a device-resident signal, issued back to back by the library (one host
+ * call instead of x_len/chunk).  Output k of piece i lands right after the outputs of piece i-1 in y; *n_written is the
+ * total per channel.  State and history are carried from piece to piece on the device, bit-identical to the caller's own loop. */
+int mrhip_filt_device_chunked(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, int64_t chunk, void *y,
+                              int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream);
 /* same contract with HOST pointers: copies x in, runs mrhip_filt_device, copies y out,
  * synchronises.  Replaces filt!(buffer, self, x) for a caller whose data lives in host memory. */
 int mrhip_filt_host(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,

@@ -147,6 +147,12 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
         size_t lds = 0;
         if (plan_phase_stationary(tk, a, f->num_cus, &ta, &grid, &block, &lds))
             return launch_poly_phase_stationary(tk, fused, a, ta, grid, block, lds, s, kname, f->num_cus);
+        {   // any tapsPerPhi / any L: tap bank and sample tile in LDS
+            ArbTileArgs tt;
+            size_t tl = 0;
+            if (plan_poly_tiled(tk, a, f->num_cus, &tt, &tl))
+                return launch_poly_tiled(tk, fused, a, tt, tl, s, kname, f->num_cus);
+        }
     }
     return launch_poly_generic(tk, fused, a, s, kname);
 }
@@ -703,6 +709,28 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
         f->hist_cur ^= 1;
     }
     if (n_written) *n_written = n_out;
+    return MRHIP_OK;
+}
+
+int mrhip_filt_device_chunked(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, int64_t chunk, void *y,
+                              int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    if (n_written) *n_written = 0;
+    if (chunk < 1) return fail(MRHIP_ERR_INVALID_ARG, "chunk must be >= 1");
+    if (x_len < 0 || y_capacity < 0) return fail(MRHIP_ERR_INVALID_ARG, "negative length");
+    const size_t xelt = dtype_scalar_size(f->tx) * static_cast<size_t>(f->nc);
+    const size_t yelt = dtype_scalar_size(f->ty) * static_cast<size_t>(f->nc);
+    int64_t k = 0;
+    for (int64_t a = 0; a < x_len; a += chunk) {
+        const int64_t len = std::min<int64_t>(chunk, x_len - a);
+        int64_t got = 0;
+        const int rc = mrhip_filt_device(f, static_cast<const unsigned char *>(x) + static_cast<size_t>(a) * xelt, len, x_stride,
+                                         static_cast<unsigned char *>(y) + static_cast<size_t>(k) * yelt, y_capacity - k, y_stride, &got, stream);
+        if (rc) return rc;
+        k += got;
+    }
+    if (n_written) *n_written = k;
     return MRHIP_OK;
 }
 

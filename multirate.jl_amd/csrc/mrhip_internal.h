@@ -225,6 +225,9 @@ hipError_t launch_fir_direct(const TypeKey &tk, bool fused, const PolyArgs &a, c
 bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_host, int num_cus, ArbTileArgs *out, size_t *lds);
 hipError_t launch_arb_tiled(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
                             const char **kname, int num_cus);
+bool plan_poly_tiled(const TypeKey &tk, const PolyArgs &a, int num_cus, ArbTileArgs *out, size_t *lds);
+hipError_t launch_poly_tiled(const TypeKey &tk, bool fused, const PolyArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
+                             const char **kname, int num_cus);
 bool plan_phase_stationary(const TypeKey &tk, const PolyArgs &a, int num_cus, TileArgs *out, dim3 *grid, dim3 *block,
                            size_t *lds);
 hipError_t launch_poly_phase_stationary(const TypeKey &tk, bool fused, const PolyArgs &a, const TileArgs &ta, dim3 grid,

@@ -88,6 +88,7 @@ ABI = [
     ("mrhip_set_numerics", _i, [_vp, _i]),
     ("mrhip_get_taps", _i, [_vp, _i, _vp]),
     ("mrhip_filt_device", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
+    ("mrhip_filt_device_chunked", _i, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
     ("mrhip_filt_host", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64]),
     ("mrhip_synchronize", _i, [_vp, _vp]),
     ("mrhip_filt_once", _i, [_vp, _i64, _i, _i64, _i64, _d, _i64, _vp, _i64, _i, _vp, _i64, _pi64, _i]),
@@ -473,6 +474,27 @@ class FIRFilter:
             raise MultirateHIPError(1, f"buffer must be a C-contiguous numpy array of {self.output_dtype}")
         cap = buffer.shape[-1]
         _check(self._lib.mrhip_filt_host(self._handle, _ptr(x), n, n, _ptr(buffer), cap, cap, C.byref(nw)))
+        return nw.value
+
+    def filt_into_chunked(self, buffer, x, chunk: int) -> int:
+        """The loop ``for a in range(0, n, chunk): filt!(buffer[k:], self, x[a:a+chunk])`` issued by the library in one
+        call (torch device tensors only): streaming with the state carried on the device, bit-identical to the
+        caller's own loop, without its per-call host overhead.  Returns the total per-channel output count."""
+        if not _is_torch(x) or not x.is_cuda:
+            raise MultirateHIPError(1, "filt_into_chunked takes torch device tensors")
+        if x.stride(-1) != 1 or buffer.stride(-1) != 1:
+            raise MultirateHIPError(1, "x and buffer must be contiguous along time (planar channels)")
+        nch, n, _ = self._shape(x)
+        self._ensure(_torch_np_dtype(x.dtype), nch)
+        if _torch_np_dtype(buffer.dtype) != self.output_dtype:
+            raise MultirateHIPError(1, f"buffer dtype must be {self.output_dtype}")
+        cap = buffer.shape[-1]
+        xs = x.stride(0) if x.ndim == 2 and nch > 1 else n
+        ys = buffer.stride(0) if buffer.ndim == 2 and nch > 1 else cap
+        nw = C.c_int64(0)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(self._lib.mrhip_filt_device_chunked(self._handle, C.c_void_p(x.data_ptr()), n, xs, int(chunk),
+                                                   C.c_void_p(buffer.data_ptr()), cap, ys, C.byref(nw), C.c_void_p(stream)))
         return nw.value
 
     def filt(self, x):

@@ -33,8 +33,14 @@ def run(name, h, ratio, nphi, nch, n, dtype, bytes_per_in, reps=5, chunk=None, p
     import time
     torch.cuda.synchronize()
     t_wall = time.perf_counter()
+    ychunked = None
+    if chunk != n and os.environ.get("MRHIP_BENCH_CHUNKED", "1") == "1":      # streaming through the library's chunk loop
+        ychunked = torch.empty((nch, f.outputlength(n) + 8), dtype=torch.float32 if dtype == torch.float32 else dtype, device=dev)
     for _ in range(reps):
         f.reset()
+        if ychunked is not None:
+            f.filt_into_chunked(ychunked, x, chunk)
+            continue
         for a in range(0, n, chunk):
             f.filt(x[:, a:a + chunk])
     torch.cuda.synchronize()
@@ -71,3 +77,16 @@ if "c4f" in which:
     run("C4f farrow pi/3 32x32 taps polyorder 4 f64 64ch x 1e7", harb, float(math.pi / 3), 32, 64, 10_000_000, torch.float64, 8 + 8 * math.pi / 3, reps=2, polyorder=4)
 if "c5" in which:
     run("C5 rational 147//160 c64 512ch x 1e6 (one GPU's shard of 4096)", h147, Fraction(147, 160), 32, 512, 1_000_000, torch.complex64, 15.35)
+
+# extra shapes outside BASELINE.json (where the non-headline kernels stand)
+if "x160" in which:
+    h160 = pkg.firdes(24 * 160, 0.5 / 160, beta=7.8562).astype(np.float32)
+    run("X rational 160//147 (44.1k->48k) f32 64ch x 1e6", h160, Fraction(160, 147), 32, 64, 1_000_000, torch.float32, 4 + 4 * 160 / 147)
+if "xf64" in which:
+    run("X rational 147//160 f64 64ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 64, 1_000_000, torch.float64, 2 * 7.675)
+if "xstd" in which:
+    run("X standard 1//1 128 taps f32 64ch x 4e6", h128, Fraction(1, 1), 32, 64, 4_000_000, torch.float32, 8.0)
+if "x32" in which:
+    h32 = pkg.firdes(24 * 3, 0.5 / 3, beta=7.8562).astype(np.float32)
+    run("X rational 3//2 f32 64ch x 1e6", h32, Fraction(3, 2), 32, 64, 1_000_000, torch.float32, 4 + 6)
+    run("X rational 2//3 f32 64ch x 1e6", h32, Fraction(2, 3), 32, 64, 1_000_000, torch.float32, 4 + 8 / 3)

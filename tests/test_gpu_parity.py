@@ -566,3 +566,50 @@ def test_farrow_errors_and_edge_cases(pkg, O, torch_cuda):
     with pytest.raises(pkg.MultirateHIPError) as ei:
         f.filt_into(np.empty(10, dtype=np.float32), x)
     assert ei.value.code == 2 and f.state.phiAccumulator == st0
+
+
+def test_chunked_streaming_entry_matches_caller_loop(pkg, torch_cuda):
+    """mrhip_filt_device_chunked == the caller's own loop of filt! calls, bit for bit (rational and arbitrary)."""
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.rand((3, 250_000), generator=g, device="cuda", dtype=torch.float32)
+    h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    for ratio, nphi in ((Fraction(147, 160), 32), (0.9173, 32), (Fraction(1, 4), 32)):
+        hh = h if not isinstance(ratio, float) else (pkg.firdes(32 * 16, 0.45 / 32, beta=7.0) * 32).astype(np.float32)
+        f1 = pkg.FIRFilter(hh, ratio, nphi)
+        y1 = torch.cat([f1.filt(x[:, a:a + 9973]) for a in range(0, x.shape[1], 9973)], dim=1)
+        f2 = pkg.FIRFilter(hh, ratio, nphi).bind(np.float32, 3)
+        y2 = torch.empty((3, y1.shape[1] + 8), device="cuda", dtype=torch.float32)
+        n = f2.filt_into_chunked(y2, x, 9973)
+        assert n == y1.shape[1] and torch.equal(y1.view(torch.int32), y2[:, :n].view(torch.int32))
+        assert (f1.state.phiIdx, f1.state.inputDeficit, f1.state.phiAccumulator) == (f2.state.phiIdx, f2.state.inputDeficit, f2.state.phiAccumulator)
+
+
+def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
+    """Filters the register-resident kernels do not take (tapsPerPhi > 32, L > 512 phases, hLen > 512 single-rate /
+    decimating) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
+    across chunk seams, for every dtype combination, 1..35 channels (all channels-per-lane variants + ragged group)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    cases = [(2, 3, 72, np.float32, np.float32, 35), (3, 2, 200, np.float32, np.complex64, 9), (147, 160, 147 * 40, np.float32, np.float32, 33),
+             (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 3, 700, np.float32, np.float32, 5),
+             (1, 1, 600, np.float64, np.complex128, 2), (5, 64, 5 * 40, np.float64, np.float32, 32), (4, 7, 4 * 33, np.float32, np.float64, 1)]
+    for (L, M, hl, th, tx, nch) in cases:
+        h = rng.standard_normal(hl).astype(th)
+        x = _rand(rng, (nch, 30_000), tx) - 0.5
+        xd = torch.from_numpy(x).cuda()
+        sizes = [12_000, 1, 17, 17_982]
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        f = pkg.FIRFilter(h, Fraction(L, M))
+        y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+        assert f.last_kernel_name() == "poly_tiled_kernel", (L, M, hl, f.last_kernel_name())
+        monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+        g = pkg.FIRFilter(h, Fraction(L, M))
+        y_g = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
+        assert g.last_kernel_name() == "poly_generic_kernel"
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        assert_bit_equal(y_t, y_g, f"tiled vs generic L={L} M={M} hLen={hl} {th} {tx}")
+        assert_bit_equal(f.history, g.history, "history")
+        fo = O.FIRFilter(h, Fraction(L, M), tx=tx)
+        yo = np.concatenate([fo.filt(p) for p in np.split(x[nch - 1], np.cumsum(sizes)[:-1])])
+        assert_bit_equal(y_t[nch - 1], yo, f"tiled vs oracle L={L} M={M} hLen={hl}")
