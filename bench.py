@@ -88,13 +88,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  MRHIP_BENCH_BACKEND=gloo (plumbing check on a box with fewer GPUs than ranks: ranks then
+    # share devices round-robin and the one timing reduction goes through the host) is never used by the driver.
+    backend = os.environ.get("MRHIP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = ge.load_package()
     h = pkg.firdes(TAPS_PER_PHI * L, 0.5 / L, beta=7.8562).astype(np.float32)
@@ -107,7 +114,7 @@ def main():
         x[c].uniform_(0.0, 1.0, generator=gen)
     y = torch.empty((nch, n_out_total), dtype=torch.float32, device=dev)
 
-    filt = pkg.FIRFilter(h, Fraction(L, M), device=local_rank,
+    filt = pkg.FIRFilter(h, Fraction(L, M), device=dev_index,
                          numerics=pkg.NUMERICS_FUSED if args.numerics == "fused" else pkg.NUMERICS_STRICT)
     filt.bind(np.float32, nch)
 
@@ -141,7 +148,7 @@ def main():
     assert produced == n_out_total, (produced, n_out_total)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
