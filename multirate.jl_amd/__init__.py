@@ -17,6 +17,7 @@ from __future__ import annotations
 
 from .host import (  # noqa: F401
     FIRFilter,
+    FilterCascade,
     MultirateHIPError,
     NUMERICS_FUSED,
     NUMERICS_STRICT,
@@ -38,7 +39,7 @@ from .design import (BANDPASS, BANDSTOP, HIGHPASS, LOWPASS, firdes, firprototype
 from .sharding import ChannelShardedFilter, shard_channels  # noqa: F401
 
 __all__ = [
-    "FIRFilter", "filt", "filt_", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
+    "FIRFilter", "FilterCascade", "filt", "filt_", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
     "setphase", "tapsforphase", "polyfit", "firdes", "firprototype", "kaiserlength", "kaiser", "LOWPASS", "BANDPASS", "HIGHPASS", "BANDSTOP", "ChannelShardedFilter", "shard_channels", "load_library",
     "library_path", "MultirateHIPError", "NUMERICS_STRICT", "NUMERICS_FUSED",
 ]

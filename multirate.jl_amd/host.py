@@ -545,6 +545,38 @@ def filt(a, x, ratio=Fraction(1, 1), Nphi: int = 32, polyorder=None, **kw):
         f.close()
 
 
+class FilterCascade:
+    """Device-resident cascade (no reference counterpart): ``filt`` runs the stages back to back on
+    the current stream -- the intermediate signals never leave HBM and, because every output count is closed-form
+    on the host, nothing is read back between stages.  Each stage is an ordinary stateful FIRFilter, so chunked
+    calls continue the stream exactly like calling the stages by hand (e.g. decimate 1//4, then 147//160)."""
+
+    def __init__(self, *stages: "FIRFilter"):
+        if not stages or not all(isinstance(f, FIRFilter) for f in stages):
+            raise MultirateHIPError(1, "FilterCascade takes one or more FIRFilter stages")
+        self.stages = tuple(stages)
+
+    def filt(self, x):
+        for f in self.stages:
+            x = f.filt(x)
+        return x
+
+    def outputlength(self, inputlength: int) -> int:
+        n = int(inputlength)
+        for f in self.stages:
+            n = f.outputlength(n)
+        return n
+
+    def reset(self):
+        for f in self.stages:
+            f.reset()
+        return self
+
+    def close(self):
+        for f in self.stages:
+            f.close()
+
+
 def filt_(buffer, self: FIRFilter, x):
     """filt!(buffer, self, x).  Returns what the reference returns: ``buffer`` for FIRStandard /
     FIRInterpolator (src/Filters.jl:472,516), the number of samples written for FIRRational /

@@ -229,4 +229,16 @@ function filt_device!(f::FIRFilter, yptr::Ptr{Cvoid}, ycap::Integer, ystride::In
     Int(nw[])
 end
 
+# The streaming loop `for each chunk: filt!(view(y, k+1:...), f, view(x, a+1:a+chunk))` over a device-resident signal,
+# issued by the library in one call (mrhip_filt_device_chunked): same outputs, same end state.
+function filt_device_chunked!(f::FIRFilter, yptr::Ptr{Cvoid}, ycap::Integer, ystride::Integer, xptr::Ptr{Cvoid}, xlen::Integer,
+                              xstride::Integer, chunk::Integer, ::Type{Tx}, nch::Integer; stream::Ptr{Cvoid} = C_NULL) where {Tx}
+    bind!(f, Tx, nch)
+    nw = Ref{Int64}(0)
+    check(ccall((:mrhip_filt_device_chunked, libmr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Cvoid}),
+                f.handle, xptr, xlen, xstride, chunk, yptr, ycap, ystride, nw, stream))
+    Int(nw[])
+end
+
 end # module

@@ -613,3 +613,59 @@ def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
         fo = O.FIRFilter(h, Fraction(L, M), tx=tx)
         yo = np.concatenate([fo.filt(p) for p in np.split(x[nch - 1], np.cumsum(sizes)[:-1])])
         assert_bit_equal(y_t[nch - 1], yo, f"tiled vs oracle L={L} M={M} hLen={hl}")
+
+
+def test_hip_graph_capture_of_fixed_chunk_streaming(pkg, torch_cuda):
+    """filt! on a caller stream only enqueues kernels, so a fixed-chunk streaming loop can be captured
+    in a HIP graph.  With chunk % M == 0 the (phiIdx, inputDeficit) state is the same at every call and an even number
+    of calls returns the history ping-pong to its start, so every replay continues the stream exactly like the
+    plain loop would (history carried on the device)."""
+    torch = torch_cuda
+    L, M, chunk, ncalls, nch = 147, 160, 16_000, 4, 3
+    h = pkg.firdes(24 * L, 0.5 / L, beta=7.8562).astype(np.float32)
+    x = torch.rand((nch, chunk * ncalls), dtype=torch.float32, device="cuda") - 0.5
+    nout = chunk * L // M
+    f = pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nch)
+    y_g = torch.zeros((nch, nout * ncalls), dtype=torch.float32, device="cuda")
+
+    def loop(flt, y):
+        for i in range(ncalls):
+            assert flt.filt_into(y[:, i * nout:(i + 1) * nout], x[:, i * chunk:(i + 1) * chunk]) == nout
+
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=s):
+        loop(f, y_g)
+    ref = pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nch)
+    y_ref = torch.empty_like(y_g)
+    for replay in range(3):                      # pass 0 starts from the zero history, passes 1, 2 continue the stream
+        g.replay()
+        loop(ref, y_ref)
+        torch.cuda.synchronize()
+        assert torch.equal(y_g.view(torch.int32), y_ref.view(torch.int32)), f"replay {replay}"
+    assert f.last_kernel_name() == "rational_pair_kernel"
+
+
+def test_filter_cascade_device_resident(pkg, O, torch_cuda):
+    """Decimate 1//4 then resample 147//160 then an arbitrary-rate stage, chunked: equal to the oracle stages chained."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    h1 = rng.standard_normal(64).astype(np.float32)
+    h2 = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    h3 = (pkg.firdes(32 * 12, 0.45 / 32, beta=7.0) * 32).astype(np.float32)
+    x = (rng.random((2, 90_000), dtype=np.float32) - 0.5)
+    casc = pkg.FilterCascade(pkg.FIRFilter(h1, Fraction(1, 4)), pkg.FIRFilter(h2, Fraction(147, 160)), pkg.FIRFilter(h3, 1.2345, 32))
+    xd = torch.from_numpy(x).cuda()
+    sizes = [40_001, 3, 49_996]
+    y = torch.cat(_run_chunks(casc, xd, sizes), dim=-1).cpu().numpy()
+    for c in range(2):
+        stages = [O.FIRFilter(h1, Fraction(1, 4), tx=np.float32), O.FIRFilter(h2, Fraction(147, 160), tx=np.float32),
+                  O.FIRFilter(h3, 1.2345, 32, tx=np.float32)]
+        outs = []
+        for p in np.split(x[c], np.cumsum(sizes)[:-1]):
+            for st in stages:
+                p = st.filt(p)
+            outs.append(p)
+        assert_bit_equal(y[c], np.concatenate(outs), f"cascade ch {c}")
+    assert casc.reset().stages[1].state.phiIdx == 1
