@@ -436,6 +436,11 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
         hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, static_cast<int>(block.x), lds); \
         if (eo != hipSuccess) return eo;                                                            \
         if (per_cu < 1) per_cu = 1;                                                                 \
+        {   /* see plan_rational_pair: the fourth six-wave workgroup never fits next to three running ones; short */ \
+            /* launches (a tile or two per workgroup, static dealing) keep the full grid: slots free up at once */ \
+            const long long tiles = (static_cast<long long>(pa.total_steps) + pa.J - 1) / pa.J;     \
+            if (block.x == 6 * 64 && per_cu > 3 && tiles > 3LL * num_cus * per_cu) per_cu = 3;      \
+        }                                                                                           \
         if (blocks_per_cu_override > 0) per_cu = blocks_per_cu_override;                            \
         long long g = static_cast<long long>(num_cus) * per_cu;                                     \
         if (g > static_cast<long long>(pa.total_steps)) g = pa.total_steps;                           \
@@ -553,7 +558,12 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     // (experiments) sets the stage size directly.
     // Complex samples double every buffer: three workgroups per CU there.
     const long long strip_bytes = static_cast<long long>(nwaves) * 256 * es;
-    const long long budget_kib = (160 * 1024 / (nc == 1 ? 4 : 3) - 64 - strip_bytes) / ns / 1024;
+    // Six-wave workgroups (147//160: five compute waves + the loader): the occupancy query promises four per CU
+    // (24 waves = 6 per SIMD at 78 VGPRs), but a workgroup's waves land 2,2,1,1 on the four SIMDs and the fourth
+    // workgroup only fits when the first three happen to be rotated evenly -- MRHIP_PAIR_PROBE=1 shows a quarter of a
+    // 4-per-CU grid starting after the others have finished.  Plan for the three that are really resident.
+    const int wg_per_cu = (nc == 1 && nwaves + 1 != 6) ? 4 : 3;
+    const long long budget_kib = ((wg_per_cu == 3 ? 150 : 160) * 1024 / wg_per_cu - 64 - strip_bytes) / ns / 1024;   // three: LDS is granted in coarse granules, leave slack (3 x 54 296 B did not fit)
     const int stage_kib = env_r > 0 ? env_r * nwaves : static_cast<int>(budget_kib > 1 ? budget_kib : 1);
     long long J = (static_cast<long long>(stage_kib) * 1024 / es - a.T - 2) / cM;
     if (J < 1) {
