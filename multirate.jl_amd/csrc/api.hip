@@ -12,6 +12,7 @@
 
 namespace mrhip {
 
+thread_local LaunchEvents g_launch_events;
 static thread_local std::string g_last_error;
 
 void set_error(const std::string &msg) { g_last_error = msg; }
@@ -520,26 +521,47 @@ int mrhip_get_taps(mrhip_filter *f, int which, void *host_out)
 // ---------------------------------------------------------------------------------------
 // the hot path
 // ---------------------------------------------------------------------------------------
-// record the next event of the timing log on `stream` (no-op unless timing is enabled)
+// Timing log (no-op unless timing is enabled).  Called in pairs around every compute launch; with a stride only
+// every n-th launch is timed (timing costs stream time itself).  Two mechanisms:
+//  * default: hipEventRecord before and after the launch on the launch stream (two marker packets, ~6 us of stream
+//    time per timed launch; the interval reads ~5 us longer than the kernel's own begin/end timestamps in a
+//    rocprofv3 kernel trace of the same launch);
+//  * MRHIP_TIMING_ATTACH=1: the pair is attached to the kernel's own dispatch (launch_kernel() -> hipExtLaunchKernel).
+//    Measured on MI355X / ROCm 7.2: same interval as the bracket, but the runtime serialises around such a launch
+//    (8.8 us idle before, 4.8 us after in the kernel trace), so it disturbs the throughput more.  Kept for experiments.
 static int timing_mark(mrhip_filter *f, hipStream_t stream)
 {
     if (!f->timing) return MRHIP_OK;
-    // called in pairs (before / after every compute launch); with a stride only every n-th launch is bracketed,
-    // because the event records themselves cost a few microseconds of stream time per launch
+    static const bool attach = [] { const char *v = std::getenv("MRHIP_TIMING_ATTACH"); return v && v[0] == '1'; }();
     if (!f->timing_open) {
+        f->timing_open = true;
         const bool take = (f->timing_launch++ % f->timing_stride) == 0;
-        if (!take) { f->timing_open = true; f->ev_skip = true; return MRHIP_OK; }
-        f->timing_open = true; f->ev_skip = false;
+        f->ev_skip = !take;
+        if (!take) return MRHIP_OK;
+        while (f->ev_pool.size() < f->ev_used + 2) {
+            hipEvent_t e = nullptr;
+            MRHIP_CHECK_HIP(hipEventCreate(&e));
+            f->ev_pool.push_back(e);
+        }
+        if (attach) {
+            g_launch_events.start = f->ev_pool[f->ev_used];
+            g_launch_events.stop = f->ev_pool[f->ev_used + 1];
+        } else {
+            MRHIP_CHECK_HIP(hipEventRecord(f->ev_pool[f->ev_used], stream));
+        }
+        f->ev_used += 2;
     } else {
         f->timing_open = false;
         if (f->ev_skip) return MRHIP_OK;
+        if (attach) {
+            if (g_launch_events.start) {          // no kernel consumed the pair (nothing to launch)
+                g_launch_events = LaunchEvents{};
+                f->ev_used -= 2;
+            }
+        } else {
+            MRHIP_CHECK_HIP(hipEventRecord(f->ev_pool[f->ev_used - 1], stream));
+        }
     }
-    if (f->ev_used == f->ev_pool.size()) {
-        hipEvent_t e = nullptr;
-        MRHIP_CHECK_HIP(hipEventCreate(&e));
-        f->ev_pool.push_back(e);
-    }
-    MRHIP_CHECK_HIP(hipEventRecord(f->ev_pool[f->ev_used++], stream));
     return MRHIP_OK;
 }
 

@@ -167,7 +167,7 @@ hipError_t launch_arb(bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_
             std::fprintf(stderr, "[mrhip] arb_tiled T=%d Nphi=%d grid=%lld lds=%zu occ/CU=%d regs=%d tile_out=%lld max_span=%d tiles=%lld\n",
                          a.T, a.Nphi, g, lds, per_cu, fa.numRegs, ta.tile_out, ta.max_span, ta.total_tiles);
         }
-        hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, ta);
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, ta);
         return hipGetLastError();
     };
     switch (ta.cpl) {
@@ -292,7 +292,7 @@ hipError_t launch_farrow_t(bool fused, const FarrowArgs &a, const ArbTileArgs &t
         long long g = static_cast<long long>(num_cus) * per_cu;
         if (g > ta.total_tiles) g = ta.total_tiles;
         if (g < 1) g = 1;
-        hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, ta);
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, ta);
         return hipGetLastError();
     };
     if (ta.cpl == 4) return fused ? go(farrow_tiled_kernel<TX, R, NC, true, 4>) : go(farrow_tiled_kernel<TX, R, NC, false, 4>);

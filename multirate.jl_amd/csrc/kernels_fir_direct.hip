@@ -317,7 +317,7 @@ hipError_t launch_direct_pair(bool fused, const PolyArgs &a, DirectArgs da, size
             std::fprintf(stderr, "[mrhip] fir_direct_pair T=%d M=%d grid=%lld lds=%zu occ/CU=%d regs=%d J=%d tile_len=%d pitch=%d tiles=%lld\n",
                          a.T, a.M, g, lds, per_cu, fa.numRegs, da.J, da.tile_len, da.row_pitch, da.total_tiles);
         }
-        hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), dim3(kDirectThreads), lds, s, a, da);
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kDirectThreads), lds, s, a, da);
         return hipGetLastError();
     };
     const int nch = (a.T + a.M + 63) / 64;
@@ -363,7 +363,7 @@ hipError_t launch_direct(bool fused, const PolyArgs &a, DirectArgs da, size_t ld
             std::fprintf(stderr, "[mrhip] fir_direct T=%d M=%d grid=%lld lds=%zu occ/CU=%d regs=%d J=%d tile_len=%d pitch=%d tiles=%lld\n",
                          a.T, a.M, g, lds, per_cu, fa.numRegs, da.J, da.tile_len, da.row_pitch, da.total_tiles);
         }
-        hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), dim3(kDirectThreads), lds, s, a, da);
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kDirectThreads), lds, s, a, da);
         return hipGetLastError();
     };
     const int nch = (a.T + 63) / 64;

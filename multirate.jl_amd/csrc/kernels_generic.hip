@@ -228,8 +228,8 @@ hipError_t launch_poly_generic(const TypeKey &tk, bool fused, const PolyArgs &a,
     if ((a.n_out + 255) / 256 > 0x7fffffffLL) return hipErrorInvalidValue;
     *kname = "poly_generic_kernel";
     return dispatch_types(tk, [&]<typename TX, typename R, int NC>() -> hipError_t {
-        if (fused) hipLaunchKernelGGL((poly_generic_kernel<TX, R, NC, true>), grid_for(a.n_out, a.nch), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((poly_generic_kernel<TX, R, NC, false>), grid_for(a.n_out, a.nch), dim3(256), 0, s, a);
+        if (fused) launch_kernel(poly_generic_kernel<TX, R, NC, true>, grid_for(a.n_out, a.nch), dim3(256), 0, s, a);
+        else launch_kernel(poly_generic_kernel<TX, R, NC, false>, grid_for(a.n_out, a.nch), dim3(256), 0, s, a);
         return hipGetLastError();
     });
 }
@@ -240,8 +240,8 @@ hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, h
     if ((a.n_out + 255) / 256 > 0x7fffffffLL) return hipErrorInvalidValue;
     *kname = "arb_generic_kernel";
     return dispatch_types(tk, [&]<typename TX, typename R, int NC>() -> hipError_t {
-        if (fused) hipLaunchKernelGGL((arb_generic_kernel<TX, R, NC, true>), grid_for(a.n_out, a.nch), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((arb_generic_kernel<TX, R, NC, false>), grid_for(a.n_out, a.nch), dim3(256), 0, s, a);
+        if (fused) launch_kernel(arb_generic_kernel<TX, R, NC, true>, grid_for(a.n_out, a.nch), dim3(256), 0, s, a);
+        else launch_kernel(arb_generic_kernel<TX, R, NC, false>, grid_for(a.n_out, a.nch), dim3(256), 0, s, a);
         return hipGetLastError();
     });
 }
@@ -274,7 +274,7 @@ hipError_t launch_farrow(const TypeKey &tk, bool fused, const FarrowArgs &a, hip
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
                 if (e != hipSuccess) return e;                                                            \
             }                                                                                             \
-            hipLaunchKernelGGL(kfn, grid, dim3(bs), lds, s, a);                                           \
+            launch_kernel(kfn, grid, dim3(bs), lds, s, a);                                           \
         }
         if (fused) { if (cache) MRHIP_FARROW_LAUNCH(true, true) else MRHIP_FARROW_LAUNCH(true, false) }
         else { if (cache) MRHIP_FARROW_LAUNCH(false, true) else MRHIP_FARROW_LAUNCH(false, false) }

@@ -318,7 +318,7 @@ hipError_t launch_interp_T(int T, dim3 block, size_t lds, hipStream_t s, const P
             std::fprintf(stderr, "[mrhip] interp_pair T=%d L=%d grid=%lld block=%u lds=%zu occ/CU=%d regs=%d CP=%d LP=%d J=%d steps=%u\n", \
                          TT, a.L, g, block.x, lds, per_cu, fa.numRegs, pa.cM, pa.c, pa.J, pa.total_steps); \
         }                                                                                           \
-        hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), block, lds, s, a, pa);              \
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), block, lds, s, a, pa);              \
         return hipGetLastError();                                                                   \
     }
     switch (T) {

@@ -362,7 +362,7 @@ hipError_t launch_T(int T, dim3 grid, dim3 block, size_t lds, hipStream_t s, con
                          "bypos=%d tile_len=%d dma_rounds=%d tiles=%lld\n", TT, grid.x, block.x, lds, per_cu, fa.numRegs, \
                          ta.c, ta.P, ta.J, ta.by_position, ta.tile_len, ta.dma_rounds, ta.total_tiles); \
         }                                                                                           \
-        hipLaunchKernelGGL(kfn, grid, block, lds, s, a, ta);                                        \
+        launch_kernel(kfn, grid, block, lds, s, a, ta);                                        \
         return hipGetLastError();                                                                   \
     }
     switch (T) {

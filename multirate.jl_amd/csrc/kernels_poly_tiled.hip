@@ -165,7 +165,7 @@ hipError_t launch_tiled(bool fused, const PolyArgs &a, const ArbTileArgs &ta, si
             std::fprintf(stderr, "[mrhip] poly_tiled T=%d L=%d M=%d grid=%lld lds=%zu occ/CU=%d regs=%d cpl=%d tile_out=%lld max_span=%d tiles=%lld\n",
                          a.T, a.L, a.M, g, lds, per_cu, fa.numRegs, ta.cpl, ta.tile_out, ta.max_span, ta.total_tiles);
         }
-        hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), dim3(kTiledThreads), lds, s, a, ta);
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kTiledThreads), lds, s, a, ta);
         return hipGetLastError();
     };
     switch (ta.cpl) {

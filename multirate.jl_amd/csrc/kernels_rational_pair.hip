@@ -464,7 +464,7 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
             if (!probe_buf && hipMalloc(&probe_buf, sizeof(unsigned long long) * 12 * 65536) != hipSuccess) probe_buf = nullptr; \
             if (g <= 65536) pa.probe = probe_buf;                                                   \
         }                                                                                           \
-        hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(g)), block, lds, s, a, pa);              \
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), block, lds, s, a, pa);              \
         if (pa.probe) {                                                                             \
             --probe_left;                                                                           \
             std::vector<unsigned long long> hb(12 * static_cast<size_t>(g));                         \

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <string>
@@ -192,6 +193,23 @@ struct ArbTileArgs {         // tiling of the FIRArbitrary kernel (kernels_arbit
     long long tiles_per_channel;
     long long total_tiles;
 };
+
+// Every compute kernel is launched through launch_kernel().  Optional timing mode MRHIP_TIMING_ATTACH=1
+// (api.hip:timing_mark): a start/stop event pair armed by api.hip is attached to the next kernel's own dispatch
+// (hipExtLaunchKernel) instead of being recorded around it.
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+extern thread_local LaunchEvents g_launch_events;
+
+template <typename F, typename... Args>
+inline void launch_kernel(F kfn, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args)
+{
+    const LaunchEvents ev = g_launch_events;
+    g_launch_events = LaunchEvents{};
+    if (ev.start && ev.stop)
+        hipExtLaunchKernelGGL(kfn, grid, block, static_cast<std::uint32_t>(lds), s, ev.start, ev.stop, 0u, args...);
+    else
+        hipLaunchKernelGGL(kfn, grid, block, lds, s, args...);
+}
 
 // dtype combination a kernel is instantiated for
 struct TypeKey {
