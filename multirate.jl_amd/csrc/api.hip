@@ -4,6 +4,7 @@
 // every constructor fails with MRHIP_ERR_NO_DEVICE.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -658,19 +659,28 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             st = ArbState{f->phiAcc, f->phiIdx, f->alpha, f->inputDeficit, f->inputDeficit};   // xIdx starts at inputDeficit (:715)
             bool done = false;
             int64_t k0 = 0;
+            static const bool prof = [] { const char *v = std::getenv("MRHIP_DEBUG"); return v && v[0] == '2'; }();
+            double t_rec = 0, t_copy = 0, t_launch = 0;
+            auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
             while (!done) {
                 int32_t *pn = static_cast<int32_t *>(f->pin_n) + k0;
                 double *pa = static_cast<double *>(f->pin_acc) + k0;
                 const int64_t room = std::min<int64_t>(piece, est - k0);
                 if (room <= 0) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");   // cannot happen: est is an upper bound
+                const double t0 = prof ? now() : 0;
                 const int64_t cnt = run_arbitrary_schedule_piece(st, f->delta, f->Nphi, x_len, pn, pa, room, &done);
+                const double t1 = prof ? now() : 0;
                 if (cnt > 0) {
                     MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<int32_t *>(f->d_sched_n) + k0, pn, static_cast<size_t>(cnt) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
                     MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<double *>(f->d_sched_acc) + k0, pa, static_cast<size_t>(cnt) * sizeof(double), hipMemcpyHostToDevice, stream));
+                    const double t2 = prof ? now() : 0;
                     if (int rc = launch_range(k0, cnt, pn)) return rc;
+                    if (prof) { t_rec += t1 - t0; t_copy += t2 - t1; t_launch += now() - t2; }
                     k0 += cnt;
                 }
             }
+            if (prof) std::fprintf(stderr, "[mrhip] arbitrary schedule: recurrence %.2f ms, memcpy enqueue %.2f ms, plan+launch %.2f ms (%lld outputs)\n",
+                                   t_rec * 1e3, t_copy * 1e3, t_launch * 1e3, static_cast<long long>(k0));
             MRHIP_CHECK_HIP(hipEventRecord(f->sched_copied, stream));
             f->sched_in_flight = true;
             n_out = k0;

@@ -3,7 +3,9 @@
 // Everything here depends only on lengths and on the (phase, deficit) state, never on sample
 // values, so the host can size buffers, pick grids and advance the stream state without ever
 // reading back from the device.
+#include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <cstring>
 #include <vector>
 
@@ -89,9 +91,94 @@ CallPlan plan_rational(int kind, int64_t L, int64_t M, int64_t phiIdx, int64_t i
     return p;
 }
 
-// FIRArbitrary: the phase accumulator is a serial Float64 recurrence whose roundings the
-// reference's outputs depend on (src/Filters.jl:663-673), so it is evaluated here, in order,
-// with the same IEEE operations, once per call; every channel shares the result.
+// FIRArbitrary / FIRFarrow: the phase accumulator is a serial Float64 recurrence whose roundings the reference's
+// outputs depend on (src/Filters.jl:663-673), so it is evaluated here, in order, once per call; every channel shares
+// the result.  One step of update():  acc += delta; if acc > N: xIdx += ifloor((acc-1)/N); acc = mod(acc-1, N) + 1.
+//
+// The loop is bound by the LATENCY of that dependent Float64 chain (add, -1, -N, +1), so the chain is shortened
+// without changing a bit: with a1 = fl(acc + delta) and k = floor((a1-1)/N),
+//     fl(fl(fl(a1 - 1) - k*N) + 1) == a1 - k*N   exactly,
+// because 1 and N are multiples of ulp(a1) (a1 < 2^53), every intermediate is a multiple of ulp(a1) no larger in
+// magnitude than a1, hence representable, hence each of the three operations is exact; and k = #{j >= 1 : a1 >= j*N + 1}
+// (a1 - 1 >= j*N  <=>  a1 >= j*N + 1, both sides exact).  So the new accumulator is ONE exact subtraction away from a1,
+// selected among a1, a1-N, a1-2N, a1-3N by comparisons.  The index step keeps the reference's expression (quotient
+// rounded before the floor; for a power-of-two N it is exactly k).  Rates so low that a step spans four periods or
+// more take the reference's expressions one by one (slow_step), OUTSIDE the hot loop: a call in the loop body makes
+// the compiler keep the loop constants (and, through reference parameters, the accumulator) in memory -- 3x slower.
+// Checked: schedule-dependent outputs and end state == oracle (a plain restatement) bit for bit
+// (tests/test_gpu_parity.py::test_arbitrary_phase_recurrence_many_rates; 8e6 steps of a Python model of both forms).
+namespace {
+
+struct ArbConsts {
+    double delta, N, invN;
+    bool n_pow2;
+    ArbConsts(double delta_, int64_t Nphi) : delta(delta_), N(static_cast<double>(Nphi)), invN(1.0 / static_cast<double>(Nphi)),
+                                             n_pow2((Nphi & (Nphi - 1)) == 0) {}
+};
+
+struct SlowStep { double acc; int64_t dx; };
+__attribute__((noinline)) SlowStep arb_slow_step(double a1, double N, double invN, bool n_pow2)
+{
+    const double am1 = a1 - 1.0;
+    const double qd = n_pow2 ? am1 * invN : am1 / N;   // exact scaling for a power of two; else the reference's division
+    return SlowStep{std::fmod(am1, N) + 1.0,             // exact remainder of positive operands = mod()
+                    static_cast<int64_t>(std::floor(qd))};
+}
+
+// Runs until xIdx > xLen, `max_outputs` entries were written, or a step needs the slow path (returned in *slow_a1,
+// with the accumulator NOT yet advanced).  n_idx / acc_out may be null (count only).
+template <bool POW2>
+inline int64_t arb_hot_loop(const ArbConsts &c, double &acc_io, int64_t &xIdx_io, int64_t xLen, int32_t *n_idx, double *acc_out,
+                            int64_t max_outputs, bool *need_slow, double *slow_a1)
+{
+    const double delta = c.delta, N = c.N, N2 = 2.0 * N, N3 = 3.0 * N;
+    const double Np1 = N + 1.0, N2p1 = N2 + 1.0, N3p1 = N3 + 1.0, fast_limit = 4.0 * N + 1.0;
+    double acc = acc_io;
+    int64_t xIdx = xIdx_io, count = 0;
+    *need_slow = false;
+    while (xIdx <= xLen && count < max_outputs) {          // :717
+        if (n_idx) n_idx[count] = static_cast<int32_t>(xIdx);
+        if (acc_out) acc_out[count] = acc;
+        ++count;
+        const double a1 = acc + delta;                       // update(), :664
+        if (__builtin_expect(!(a1 < fast_limit), 0)) { *need_slow = true; *slow_a1 = a1; break; }
+        const double s1 = a1 - N, s2 = a1 - N2, s3 = a1 - N3;
+        const bool w1 = a1 >= Np1, w2 = a1 >= N2p1, w3 = a1 >= N3p1;
+        double nacc = a1;
+        nacc = w1 ? s1 : nacc;
+        nacc = w2 ? s2 : nacc;
+        nacc = w3 ? s3 : nacc;
+        if constexpr (POW2) xIdx += static_cast<int64_t>(w1) + static_cast<int64_t>(w2) + static_cast<int64_t>(w3);
+        else if (a1 > N) xIdx += static_cast<int64_t>((a1 - 1.0) / N);   // :667: quotient rounded first; positive, so the cast floors
+        acc = nacc;
+    }
+    acc_io = acc;
+    xIdx_io = xIdx;
+    return count;
+}
+
+// up to max_outputs schedule entries from (acc, xIdx); returns the number written
+int64_t arb_run(const ArbConsts &c, double &acc, int64_t &xIdx, int64_t xLen, int32_t *n_idx, double *acc_out, int64_t max_outputs)
+{
+    int64_t count = 0;
+    while (xIdx <= xLen && count < max_outputs) {
+        bool need_slow = false;
+        double a1 = 0.0;
+        int32_t *pn = n_idx ? n_idx + count : nullptr;
+        double *pa = acc_out ? acc_out + count : nullptr;
+        count += c.n_pow2 ? arb_hot_loop<true>(c, acc, xIdx, xLen, pn, pa, max_outputs - count, &need_slow, &a1)
+                          : arb_hot_loop<false>(c, acc, xIdx, xLen, pn, pa, max_outputs - count, &need_slow, &a1);
+        if (need_slow) {                                     // the entry was written; finish its update() the slow way
+            const SlowStep r = arb_slow_step(a1, c.N, c.invN, c.n_pow2);
+            acc = r.acc;
+            xIdx += r.dx;
+        }
+    }
+    return count;
+}
+
+}  // namespace
+
 int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t xLen,
                                std::vector<int32_t> *n_idx, std::vector<double> *acc_out)
 {
@@ -99,39 +186,20 @@ int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t
         st.inputDeficit -= xLen;
         return 0;
     }
-    const double N = static_cast<double>(Nphi);
-    const bool n_pow2 = (Nphi & (Nphi - 1)) == 0;
-    const double invN = 1.0 / N;               // exact when Nphi is a power of two
+    const ArbConsts c(delta, Nphi);
     double acc = st.acc;
     int64_t xIdx = st.inputDeficit;        // :715
     int64_t count = 0;
     if (n_idx) n_idx->clear();
     if (acc_out) acc_out->clear();
-    {   // one allocation up front: about (xLen - deficit + 1) * rate outputs (rate = Nphi / delta)
-        const double est = static_cast<double>(xLen - xIdx + 1) * (N / delta) + 16.0;
-        if (n_idx && est < 4e9) n_idx->reserve(static_cast<size_t>(est));
-        if (acc_out && est < 4e9) acc_out->reserve(static_cast<size_t>(est));
+    const int64_t chunk = 1 << 16;
+    while (xIdx <= xLen) {
+        if (n_idx) n_idx->resize(static_cast<size_t>(count + chunk));
+        if (acc_out) acc_out->resize(static_cast<size_t>(count + chunk));
+        count += arb_run(c, acc, xIdx, xLen, n_idx ? n_idx->data() + count : nullptr, acc_out ? acc_out->data() + count : nullptr, chunk);
     }
-    while (xIdx <= xLen) {                 // :717
-        if (n_idx) n_idx->push_back(static_cast<int32_t>(xIdx));
-        if (acc_out) acc_out->push_back(acc);
-        ++count;
-        acc += delta;                      // update(), :664
-        if (acc > N) {                     // :666-669
-            const double am1 = acc - 1.0;
-            // xIdx += ifloor(am1 / N): the reference rounds the quotient before flooring; a power-of-two
-            // N makes the division an exact scaling, otherwise a true division is kept for fidelity
-            const double qd = n_pow2 ? am1 * invN : am1 / N;
-            xIdx += static_cast<int64_t>(std::floor(qd));
-            // acc = mod(am1, N) + 1: for positive operands the remainder is exact; am1 - k*N by repeated
-            // subtraction is exact at every step (the difference of a multiple of ulp(am1) and an integer
-            // that is no larger than am1) and is the same number fmod returns, at a fraction of its cost
-            double r = am1;
-            if (am1 < 4.0 * N) { while (r >= N) r -= N; }
-            else r = std::fmod(am1, N);        // very low rates: many periods per step
-            acc = r + 1.0;
-        }
-    }
+    if (n_idx) n_idx->resize(static_cast<size_t>(count));
+    if (acc_out) acc_out->resize(static_cast<size_t>(count));
     st.acc = acc;
     st.phiIdx = static_cast<int64_t>(std::floor(acc));   // :671
     st.alpha = acc - static_cast<double>(st.phiIdx);     // :672
@@ -147,27 +215,10 @@ int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t
 int64_t run_arbitrary_schedule_piece(ArbState &st, double delta, int64_t Nphi, int64_t xLen, int32_t *n_idx, double *acc_out,
                                      int64_t max_outputs, bool *done)
 {
-    const double N = static_cast<double>(Nphi);
-    const bool n_pow2 = (Nphi & (Nphi - 1)) == 0;
-    const double invN = 1.0 / N;
+    const ArbConsts c(delta, Nphi);
     double acc = st.acc;
     int64_t xIdx = st.xIdx;
-    int64_t count = 0;
-    while (xIdx <= xLen && count < max_outputs) {
-        n_idx[count] = static_cast<int32_t>(xIdx);
-        acc_out[count] = acc;
-        ++count;
-        acc += delta;
-        if (acc > N) {
-            const double am1 = acc - 1.0;
-            const double qd = n_pow2 ? am1 * invN : am1 / N;
-            xIdx += static_cast<int64_t>(std::floor(qd));
-            double r = am1;
-            if (am1 < 4.0 * N) { while (r >= N) r -= N; }
-            else r = std::fmod(am1, N);
-            acc = r + 1.0;
-        }
-    }
+    const int64_t count = arb_run(c, acc, xIdx, xLen, n_idx, acc_out, max_outputs);
     st.acc = acc;
     st.xIdx = xIdx;
     *done = xIdx > xLen;

@@ -669,3 +669,27 @@ def test_filter_cascade_device_resident(pkg, O, torch_cuda):
             outs.append(p)
         assert_bit_equal(y[c], np.concatenate(outs), f"cascade ch {c}")
     assert casc.reset().stages[1].state.phiIdx == 1
+
+
+def test_arbitrary_phase_recurrence_many_rates(pkg, O, torch_cuda):
+    """The host evaluates FIRArbitrary's serial Float64 phase recurrence (Filters.jl:663-673) through an algebraically
+    shortened dependency chain (host_logic.cpp:ArbStepper); the oracle restates the reference's expressions one by
+    one.  Outputs (which depend on every accumulator value) and the end state must agree bit for bit for
+    power-of-two and other Nphi, rates from 1/300 (many periods per step: general path) to 40, long runs, chunked."""
+    torch = torch_cuda
+    rng = np.random.default_rng(123)
+    rates = [math.pi / 3, 1.0, 0.5, 2.0, 1 / 3, 0.999999, 1.000001, 7.77, 40.0, 0.26, 0.2499, 0.01, 1 / 300, 0.0333, 3.999]
+    for i, rate in enumerate(rates):
+        for Nphi in (32, 10, 7, 1, 64):
+            T = 3
+            h = rng.standard_normal(T * Nphi).astype(np.float32)
+            n = 60_000 if rate <= 2.0 else 8_000
+            x = rng.standard_normal(n).astype(np.float32)
+            sizes = [n // 3, 1, n - n // 3 - 1]
+            f = pkg.FIRFilter(h, rate, Nphi)
+            y = np.concatenate([o.cpu().numpy() for o in _run_chunks(f, torch.from_numpy(x).cuda(), sizes)])
+            fo = O.FIRFilter(h, rate, Nphi, tx=np.float32)
+            yo = np.concatenate(_run_chunks(fo, x, sizes))
+            assert_bit_equal(y, yo, f"rate={rate} Nphi={Nphi}")
+            assert f.state.phiAccumulator == fo.state.phiAccumulator and f.state.inputDeficit == fo.state.inputDeficit, (rate, Nphi)
+            f.close()
