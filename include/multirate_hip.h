@@ -197,7 +197,9 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
 /* Streaming helper: exactly the sequence of filt!(buffer, self, x[a:a+chunk]) calls a caller would make
  * over consecutive `chunk`-sample pieces of a device-resident signal, issued back to back by the library (one host
  * call instead of x_len/chunk).  Output k of piece i lands right after the outputs of piece i-1 in y; *n_written is the
- * total per channel.  State and history are carried from piece to piece on the device, bit-identical to the caller's own loop. */
+ * total per channel.  State and history are carried from piece to piece on the device, bit-identical to the caller's own loop.
+ * Like that loop, an error (e.g. MRHIP_ERR_BUFFER_TOO_SMALL for a later piece) leaves the pieces already issued applied:
+ * *n_written then holds the outputs produced so far and the filter stands at the start of the failing piece. */
 int mrhip_filt_device_chunked(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, int64_t chunk, void *y,
                               int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream);
 /* same contract with HOST pointers: copies x in, runs mrhip_filt_device, copies y out,

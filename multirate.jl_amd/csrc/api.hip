@@ -759,7 +759,7 @@ int mrhip_filt_device_chunked(mrhip_filter *f, const void *x, int64_t x_len, int
         int64_t got = 0;
         const int rc = mrhip_filt_device(f, static_cast<const unsigned char *>(x) + static_cast<size_t>(a) * xelt, len, x_stride,
                                          static_cast<unsigned char *>(y) + static_cast<size_t>(k) * yelt, y_capacity - k, y_stride, &got, stream);
-        if (rc) return rc;
+        if (rc) { if (n_written) *n_written = k; return rc; }
         k += got;
     }
     if (n_written) *n_written = k;

@@ -321,6 +321,7 @@ void rational_pair_kernel(PolyArgs a, PairArgs pa)
             constexpr int KP = NPR < (NC == 1 ? 5 : 3) ? NPR : (NC == 1 ? 5 : 3);   // ring: 5 pairs of 8 B or 3 pairs of 16 B
             constexpr int NPRV = (NPR + KP - 1) / KP * KP;
             constexpr int RS = NPR / 2;                       // the strip read-back is consumed after pair RS
+            constexpr bool PAIRED_WAITS = KP >= 5;   // the three-unit ring of the complex kernel keeps its full look-ahead
             pair_t pring[KP];
             pair_t sv{};
             char *const ybytes = reinterpret_cast<char *>(yc);
@@ -370,7 +371,12 @@ void rational_pair_kernel(PolyArgs a, PairArgs pa)
                     constexpr int r = decltype(I)::value;
                     constexpr int slot = r % KP;
                     if constexpr (r < NPR) {
-                        lgkm_wait<ring_younger(r, NPR, KP)>(pring[slot]);
+                        // one s_waitcnt per two units (the loop is bound by instruction issue, every kind counts)
+                        if constexpr (!PAIRED_WAITS) lgkm_wait<ring_younger(r, NPR, KP)>(pring[slot]);
+                        else if constexpr (r % 2 == 0) {
+                            if constexpr (r + 1 < NPR) lgkm_wait2<ring_younger_pair(r, NPR, KP)>(pring[slot], pring[(r + 1) % KP]);
+                            else lgkm_wait<ring_younger(r, NPR, KP)>(pring[slot]);
+                        }
                         float wlo[NC], whi[NC];
                         if constexpr (NC == 1) { wlo[0] = __uint_as_float(pring[slot].x); whi[0] = __uint_as_float(pring[slot].y); }
                         else {

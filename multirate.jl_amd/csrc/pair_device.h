@@ -55,6 +55,12 @@ __device__ __forceinline__ void lgkm_wait(V &reg)
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(N < 15 ? N : 15));
 }
 
+template <int N, typename V>
+__device__ __forceinline__ void lgkm_wait2(V &reg_a, V &reg_b)   // one wait that releases two ring slots
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(reg_a), "+v"(reg_b) : "n"(N < 15 ? N : 15));
+}
+
 __device__ __forceinline__ unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
 template <typename V>
 __device__ __forceinline__ void pin(V &reg)   // orders every later use of reg after the preceding volatile asm
@@ -127,6 +133,16 @@ constexpr int ring_younger(int v, int npr, int k, int strip_ops = 3)
     return n < 14 ? n : 14;
 }
 
+
+// One wait per TWO ring units: at "use v" (v even) unit v+1 must be back as well.  Its read was issued one group
+// later than unit v's, and the read of group v itself has not been issued yet at that point.
+constexpr int ring_younger_pair(int v, int npr, int k, int strip_ops = 3)
+{
+    const int a = ring_younger(v, npr, k, strip_ops);
+    int b = ring_younger(v + 1, npr, k, strip_ops) - (ring_issues(v, npr, k) ? 1 : 0);
+    if (b < 0) b = 0;
+    return a < b ? a : b;
+}
 
 template <int OFF>
 __device__ __forceinline__ unsigned lds_read_b32(unsigned byte_addr)
