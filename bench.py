@@ -5,9 +5,12 @@
 
 Workload (BASELINE.json metric "Msamples/s in (Float32, 147//160, 24*147 taps)"): FIRRational
 147//160, 3528 windowed-sinc x Kaiser(7.8562) taps (README.md:172-179 recipe), Float32 taps and
-samples, 64 independent channels x 1e8 samples per channel per GPU (the north-star roofline
-shape), STREAMED through one stateful FIRFilter in 1e6-sample chunks (configs[1]'s chunking):
-one step = one pass over the whole batch = 100 filt! calls, state and history carried on the device.
+samples, 64 independent channels x 1e8 samples per channel per GPU -- the shape BASELINE.json's north star
+quotes the roofline target on.  One step = one pass over the whole batch = ONE filt! call on a stateful
+FIRFilter (reset before every pass).  The same batch STREAMED in 1e6-sample chunks (configs[1]'s chunking
+applied to the 64-channel batch: 100 filt! calls per pass, state and history carried on the device; bit-identical
+outputs) is measured right after the timed region and reported in the extra object `streamed_1e6_chunks`
+(N = 1 only); `--chunk 1000000` makes it the timed workload instead.
 Inputs are synthetic uniform [0,1) samples generated on the device before the timed region and
 stay resident in HBM; outputs are written to a resident HBM buffer.
 
@@ -18,9 +21,9 @@ reported value is all ranks' input samples / max-over-ranks time ("scaling": "we
 One JSON line is printed by rank 0.  `roofline.achieved` = algorithmic bytes per launch
 (7.675 B per input sample per channel = 4 B read + 0.91875 * 4 B written) x samples per
 launch / average launch duration of the dominant kernel, measured with HIP events recorded on the
-launch stream around every 4th compute-kernel launch of the timed region (mrhip_set_timing /
-mrhip_timing_read; the event records themselves cost a few microseconds of stream time per launch, so bracketing
-every launch would slow the very throughput being measured).  `cpu_baseline` = the CPU oracle (a C port of the reference algorithm; the
+launch stream around the compute-kernel launches of the timed region (mrhip_set_timing / mrhip_timing_read; every
+launch when a pass is one call, every 4th in the chunked stream: the event records themselves cost a few
+microseconds of stream time per launch, so bracketing every 120 us launch would slow the very throughput being measured).  `cpu_baseline` = the CPU oracle (a C port of the reference algorithm; the
 reference itself is Julia-0.3 source and cannot run) on one core over a bounded sample.
 """
 from __future__ import annotations
@@ -67,13 +70,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=3)   # the clocks take a few 10 ms launches to settle (kernel trace: 12.7, 11.1, 10.5, 10.3, 10.2 ms)
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--samples", type=int, default=100_000_000, help="input samples per channel per step")
-    ap.add_argument("--chunk", type=int, default=1_000_000, help="samples per channel per filt! call")
+    ap.add_argument("--chunk", type=int, default=0, help="samples per channel per filt! call (0 = the whole batch in one call)")
     ap.add_argument("--numerics", choices=["strict", "fused"], default="strict")
-    ap.add_argument("--time-every", type=int, default=4, help="bracket every n-th kernel launch of the timed region with HIP events")
+    ap.add_argument("--time-every", type=int, default=0, help="bracket every n-th kernel launch of the timed region with HIP events "
+                    "(0 = every launch when a pass is one call, every 4th when it is chunked: the brackets cost stream time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the extra chunked passes reported as `streamed_1e6_chunks`")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check (timing experiments)")
     args = ap.parse_args()
 
@@ -105,7 +110,9 @@ def main():
 
     pkg = ge.load_package()
     h = pkg.firdes(TAPS_PER_PHI * L, 0.5 / L, beta=7.8562).astype(np.float32)
-    nch, n, chunk = args.channels, args.samples, args.chunk
+    nch, n = args.channels, args.samples
+    chunk = args.chunk if 0 < args.chunk < n else n
+    time_every = args.time_every if args.time_every > 0 else (1 if chunk == n else 4)
     n_out_total = (n * L + M - 1) // M
 
     gen = torch.Generator(device=dev).manual_seed(0x4D520000 + rank)
@@ -118,8 +125,8 @@ def main():
                          numerics=pkg.NUMERICS_FUSED if args.numerics == "fused" else pkg.NUMERICS_STRICT)
     filt.bind(np.float32, nch)
 
-    def one_step():
-        """one pass over the batch: stream n samples per channel through the filter in `chunk` pieces"""
+    def one_step(chunk=chunk):
+        """one pass over the batch: n samples per channel through the (reset) filter in pieces of `chunk`"""
         filt.reset()
         k = 0
         for a in range(0, n, chunk):
@@ -137,7 +144,7 @@ def main():
     for _ in range(args.warmup):
         produced = one_step()
     barrier()
-    filt.set_timing(args.time_every)   # HIP events around every n-th launch (they cost stream time themselves)
+    filt.set_timing(time_every)   # HIP events around every n-th launch (they cost stream time themselves)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         produced = one_step()
@@ -146,6 +153,26 @@ def main():
     n_launch, kern_ms = filt.timing_read()
     filt.set_timing(False)
     assert produced == n_out_total, (produced, n_out_total)
+
+    # The same batch streamed in 1e6-sample chunks (100 filt! calls per pass), reported next to the timed workload,
+    # never as `value`.  Outputs are bit-identical to the single call (chunked == unchunked is a tested invariant).
+    streamed = None
+    if world == 1 and chunk == n and n > 1_000_000 and not args.no_streamed:
+        sc = 1_000_000
+        one_step(sc); torch.cuda.synchronize(dev)
+        filt.set_timing(4)
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(sc)
+        torch.cuda.synchronize(dev)
+        el1 = time.perf_counter() - ts
+        nl1, ms1 = filt.timing_read()
+        filt.set_timing(False)
+        streamed = {"chunk": sc, "launches_per_step": (n + sc - 1) // sc,
+                    "Msamples_per_s": round(float(nch) * n * args.steps / el1 / 1e6, 3),
+                    "avg_launch_ms": round(ms1 / max(nl1, 1), 5), "launches_timed": nl1,
+                    "achieved_GBps": round(nch * sc * BYTES_PER_INPUT_SAMPLE / (ms1 / max(nl1, 1) / 1e3) / 1e9, 2)}
+        streamed["frac"] = round(streamed["achieved_GBps"] / HBM_PEAK_GBPS, 4)
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -170,9 +197,11 @@ def main():
     achieved = bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath):      # PMC-measured HBM bytes of a launch of THIS size (profiles/: separate --pmc passes)
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            for e in json.load(open(tpath)).get("entries", []):
+                if abs(e["algorithmic_bytes_per_launch"] - bytes_per_launch) <= 1e-3 * bytes_per_launch:
+                    traffic = e["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
 
@@ -184,8 +213,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"FIRRational 147//160, 3528 taps, Float32, {nch} channels x {n} samples per GPU, "
-                                   f"streamed in {chunk}-sample chunks through one stateful FIRFilter "
-                                   "(inputs and outputs resident in HBM)",
+                                   + ("one filt! call per pass" if chunk == n else f"streamed in {chunk}-sample chunks through one stateful FIRFilter")
+                                   + " (inputs and outputs resident in HBM)",
                        "channels_per_gpu": nch, "samples_per_channel": n, "chunk": chunk,
                        "numerics": args.numerics, "parallelism": f"channel-shard x{world}, no collective"},
             "output_msamples_s": round(value * L / M, 3),
@@ -196,6 +225,8 @@ def main():
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5), "launches_timed": n_launch,
                          "whole_step_GBps": round(nch * n * BYTES_PER_INPUT_SAMPLE / (ms_per_step / 1e3) / 1e9, 2)},
         }
+        if streamed is not None:
+            line["streamed_1e6_chunks"] = streamed
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(h)
         print(json.dumps(line), flush=True)

@@ -90,3 +90,7 @@ if "x32" in which:
     h32 = pkg.firdes(24 * 3, 0.5 / 3, beta=7.8562).astype(np.float32)
     run("X rational 3//2 f32 64ch x 1e6", h32, Fraction(3, 2), 32, 64, 1_000_000, torch.float32, 4 + 6)
     run("X rational 2//3 f32 64ch x 1e6", h32, Fraction(2, 3), 32, 64, 1_000_000, torch.float32, 4 + 8 / 3)
+if "xc32" in which:   # the headline's launch size (491 MB) on the ComplexF32 kernel: 32 complex channels x 1e6 per launch
+    os.environ["MRHIP_BENCH_CHUNKED"] = "0"
+    run("X rational 147//160 c64 32ch x 2e7 in 1e6 chunks", h147, Fraction(147, 160), 32, 32, 20_000_000, torch.complex64, 15.35, reps=3, chunk=1_000_000)
+    run("X rational 147//160 f32 64ch x 2e7 in 1e6 chunks", h147, Fraction(147, 160), 32, 64, 20_000_000, torch.float32, 7.675, reps=3, chunk=1_000_000)
