@@ -1,8 +1,9 @@
-# rocprofv3 kernel stats of the DEFAULT bench command (the one the driver runs), for the duration-agreement check
+# rocprofv3 kernel stats of the CHUNKED stream (bench.py --chunk 1000000; profiles/r01c), for the duration-agreement check.
+# The default (single-call) command is profiled by scripts/profile_headline.sh.
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out
 rm -rf $OUT/prof_full
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/prof_full -o full -- python3 $R/bench.py > $OUT/prof_full_bench.json 2> $OUT/prof_full.log
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/prof_full -o full -- python3 $R/bench.py --chunk 1000000 > $OUT/prof_full_bench.json 2> $OUT/prof_full.log
 cd $R && python3 - <<'PY'
 import csv, glob, json, statistics
 rows = list(csv.DictReader(open(glob.glob('gpurun_out/prof_full/**/full_kernel_trace.csv', recursive=True)[0])))
