@@ -47,13 +47,13 @@ def cpu_baseline(h, seconds_budget=20.0):
     """Time the oracle (port of the reference's filt, one thread) on a bounded sample of the workload."""
     import numpy as np
     from oracle import oracle as O
-    n = 20_000_000
+    n = 300_000_000                            # ~2.4 s per run on one core: ~10 s of CPU work in all
     x = np.random.default_rng(0).random(n, dtype=np.float32)
     f = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
     f.filt(x[:1_000_000])                     # warm-up
     times = []
     t_all = time.perf_counter()
-    while len(times) < 5 and (time.perf_counter() - t_all) < seconds_budget:
+    while len(times) < 3 and (time.perf_counter() - t_all) < seconds_budget:
         f = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
         t0 = time.perf_counter()
         f.filt(x)

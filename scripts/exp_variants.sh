@@ -1,12 +1,12 @@
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-run() { echo "== $*"; env MRHIP_DEBUG=1 "$@" timeout 300 python bench.py --steps 3 --warmup 2 --samples 50000000 --no-cpu-baseline $EXTRA 2>&1 | grep -E "metric|rror|fault|differs" | sed -e 's/.*"value": \([0-9.]*\).*"achieved": \([0-9.]*\).*"avg_launch_ms": \([0-9.]*\).*/   value=\1 GBps=\2 ms=\3/' | cut -c1-300 | tail -3; }
+run() { echo "== $*"; env MRHIP_DEBUG=1 "$@" timeout 300 python bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-streamed $EXTRA 2>&1 | grep -E "mrhip\] rational|metric|rror|fault|differs" | sed -e 's/.*"value": \([0-9.]*\).*"achieved": \([0-9.]*\).*"avg_launch_ms": \([0-9.]*\).*/   value=\1 GBps=\2 ms=\3/' | sed -e 's/.*grid=\([0-9]*\).*lds=\([0-9]*\).*occ.CU=\([0-9]*\) regs=\([0-9]*\).*J=\([0-9]*\).*/   grid=\1 lds=\2 occ=\3 regs=\4 J=\5/' | cut -c1-300 | tail -2; }
 {
-for i in 1 2; do
-run MRHIP_LIB_PATH=$R/build_exp/lib_paired.so
-run MRHIP_LIB_PATH=$R/build_exp/lib_single.so
-done
-run MRHIP_LIB_PATH=$R/build_exp/lib_paired.so MRHIP_PS_ABLATE=3
-run MRHIP_LIB_PATH=$R/build_exp/lib_single.so MRHIP_PS_ABLATE=3
-EXTRA="--numerics fused" run MRHIP_LIB_PATH=$R/build_exp/lib_paired.so
-EXTRA="--numerics fused" run MRHIP_LIB_PATH=$R/build_exp/lib_single.so
-} > gpurun_out/exp_waits.log 2>&1
+run MRHIP_PAIR=1
+run MRHIP_PAIR_J=4 MRHIP_PAIR_BPC=4
+run MRHIP_PAIR_J=4 MRHIP_PAIR_BPC=3
+run MRHIP_PAIR_NS=4 MRHIP_PAIR_J=4 MRHIP_PAIR_BPC=3
+run MRHIP_PAIR_J=5 MRHIP_PAIR_BPC=4
+run MRHIP_PAIR_C=5
+run MRHIP_PAIR_C=3
+run MRHIP_PAIR=1
+} > gpurun_out/exp_big_launch.log 2>&1
