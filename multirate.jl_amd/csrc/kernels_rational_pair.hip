@@ -535,7 +535,7 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     if (a.zero_start_below > 0) return false;
     static const int env_c = pair_env_int("MRHIP_PAIR_C", 0), env_r = pair_env_int("MRHIP_PAIR_ROUNDS", 0);
     static const int env_ns = pair_env_int("MRHIP_PAIR_NS", 0), env_j = pair_env_int("MRHIP_PAIR_J", 0);
-    const int ns = env_ns >= 3 && env_ns <= 10 ? env_ns : 3;
+    int ns = env_ns >= 2 && env_ns <= 10 ? env_ns : 3;
     // c: lanes = c*M/2 (c*M must be even), <= 512.  The loop is VALU-issue bound, so idle lanes in the last
     // wave cost in proportion: among the sizes with 3..5 compute waves take the fullest (147//160: c = 4, 320
     // lanes = 5 full waves; measured 4.02 TB/s vs 3.88 for c = 3 and 3.68 for c = 2 on the same box); if there
@@ -569,11 +569,25 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     // workgroup only fits when the first three happen to be rotated evenly -- MRHIP_PAIR_PROBE=1 shows a quarter of a
     // 4-per-CU grid starting after the others have finished.  Plan for the three that are really resident.
     const int wg_per_cu = (nc == 1 && nwaves + 1 != 6) ? 4 : 3;
-    const long long budget_kib = ((wg_per_cu == 3 ? 150 : 160) * 1024 / wg_per_cu - 64 - strip_bytes) / ns / 1024;   // three: LDS is granted in coarse granules, leave slack (3 x 54 296 B did not fit)
-    const int stage_kib = env_r > 0 ? env_r * nwaves : static_cast<int>(budget_kib > 1 ? budget_kib : 1);
-    long long J = (static_cast<long long>(stage_kib) * 1024 / es - a.T - 2) / cM;
-    if (J < 1) {
-        J = 1;
+    // J (steps per tile) from the LDS budget of `stages` pipeline stages
+    auto j_for = [&](int stages) -> long long {
+        // three per CU: LDS is granted in coarse granules, leave slack (3 x 54 296 B did not fit)
+        const long long budget_kib = ((wg_per_cu == 3 ? 150 : 160) * 1024 / wg_per_cu - 64 - strip_bytes) / stages / 1024;
+        const int stage_kib = env_r > 0 ? env_r * nwaves : static_cast<int>(budget_kib > 1 ? budget_kib : 1);
+        const long long j = (static_cast<long long>(stage_kib) * 1024 / es - a.T - 2) / cM;
+        return j < 1 ? 1 : j;
+    };
+    long long J = j_for(ns);
+    // Long launches: every tile costs ~1000 cycles of barrier skew, ring priming and drain (compute-only time follows
+    // 72 us + 68 us / J per 491 MB), so the LDS is better spent on TWO stages of larger tiles: the DMA then runs one
+    // tile (J steps, ~5 us) ahead, still far more than the HBM latency.  Measured, 64 ch x 1e8 in one call: J = 8 /
+    // two stages 4.87-4.89 TB/s vs 4.76 with J = 5 / three stages; a 491 MB launch (16 tiles per workgroup) loses 2 %
+    // to the coarser tail instead, so short launches keep three stages.
+    if (env_ns <= 0 && env_j <= 0 && env_r <= 0) {
+        const long long j2 = std::min<long long>(j_for(2), 64);
+        const long long nslots2 = (((j2 * cM + a.T + 2 + 3) / 4 * 4) * es / 16 + 63) / 64;
+        const long long tiles2 = ((a.n_out + j2 * c * a.L - 1) / (j2 * c * a.L)) * a.nch;
+        if (j2 > J && nslots2 <= 60 && tiles2 >= 48LL * num_cus * wg_per_cu) { ns = 2; J = j2; }
     }
     if (env_j > 0) J = env_j;
     if (J > 64) J = 64;
@@ -587,7 +601,7 @@ bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairA
     tile_len = (tile_len + 3) / 4 * 4;
     const long long nslots = (tile_len * es / 16 + 63) / 64;
     const size_t stage_bytes = static_cast<size_t>(nslots) * 1024;
-    if (nslots > 60 / (ns - 2) || ns * stage_bytes + static_cast<size_t>(strip_bytes) > 156 * 1024) return false;
+    if (nslots > 60 / (ns > 2 ? ns - 2 : 1) || ns * stage_bytes + static_cast<size_t>(strip_bytes) > 156 * 1024) return false;
     const long long need_rounds = nslots;
     PairArgs pa{};
     pa.c = c; pa.P = static_cast<int>(static_cast<long long>(c) * a.L); pa.cM = static_cast<int>(cM);

@@ -1,12 +1,7 @@
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-run() { echo "== $*"; env MRHIP_DEBUG=1 "$@" timeout 300 python bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-streamed $EXTRA 2>&1 | grep -E "mrhip\] rational|metric|rror|fault|differs" | sed -e 's/.*"value": \([0-9.]*\).*"achieved": \([0-9.]*\).*"avg_launch_ms": \([0-9.]*\).*/   value=\1 GBps=\2 ms=\3/' | sed -e 's/.*grid=\([0-9]*\).*lds=\([0-9]*\).*occ.CU=\([0-9]*\) regs=\([0-9]*\).*J=\([0-9]*\).*/   grid=\1 lds=\2 occ=\3 regs=\4 J=\5/' | cut -c1-300 | tail -2; }
 {
-run MRHIP_PAIR=1
-run MRHIP_PAIR_J=4 MRHIP_PAIR_BPC=4
-run MRHIP_PAIR_J=4 MRHIP_PAIR_BPC=3
-run MRHIP_PAIR_NS=4 MRHIP_PAIR_J=4 MRHIP_PAIR_BPC=3
-run MRHIP_PAIR_J=5 MRHIP_PAIR_BPC=4
-run MRHIP_PAIR_C=5
-run MRHIP_PAIR_C=3
-run MRHIP_PAIR=1
-} > gpurun_out/exp_big_launch.log 2>&1
+python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+MRHIP_DEBUG=1 python bench.py --no-cpu-baseline 2>&1 | grep -E "mrhip\]|metric" | cut -c1-1900
+python scripts/bench_c5_sharded.py 2>/dev/null
+python scripts/bench_configs.py c5 c1 2>/dev/null | cut -c1-330
+} > gpurun_out/exp_ns2_final.log 2>&1

@@ -693,3 +693,34 @@ def test_arbitrary_phase_recurrence_many_rates(pkg, O, torch_cuda):
             assert_bit_equal(y, yo, f"rate={rate} Nphi={Nphi}")
             assert f.state.phiAccumulator == fo.state.phiAccumulator and f.state.inputDeficit == fo.state.inputDeficit, (rate, Nphi)
             f.close()
+
+
+def test_long_launch_two_stage_tiles_match_generic(pkg, O, torch_cuda, monkeypatch):
+    """Long launches (>= 48 tiles per resident workgroup) switch the pair kernel to two LDS stages of larger tiles
+    (plan_rational_pair): Float32 64 ch x 3.3e6 and ComplexF32 96 ch x 1.5e6 in ragged pieces, against the universal
+    kernel bit for bit, plus oracle spot checks at the seams."""
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(5)
+    h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    for (nch, n, cplx) in ((64, 3_300_000, False), (96, 1_500_000, True)):
+        if cplx:
+            x = torch.view_as_complex(torch.rand((nch, n, 2), generator=g, device="cuda", dtype=torch.float32) - 0.5)
+        else:
+            x = torch.rand((nch, n), generator=g, device="cuda", dtype=torch.float32) - 0.5
+        sizes = [n - 200_003, 200_003]
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        f = pkg.FIRFilter(h, Fraction(147, 160))
+        y_t = torch.cat(_run_chunks(f, x, sizes), dim=-1)
+        assert f.last_kernel_name() == "rational_pair_kernel"
+        monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+        gf = pkg.FIRFilter(h, Fraction(147, 160))
+        y_g = torch.cat(_run_chunks(gf, x, sizes), dim=-1)
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        a = torch.view_as_real(y_t) if cplx else y_t
+        b = torch.view_as_real(y_g) if cplx else y_g
+        assert a.shape == b.shape and torch.equal(a.view(torch.int32), b.view(torch.int32)), (nch, n, cplx)
+        assert_bit_equal(f.history, gf.history, "history")
+        c = nch - 1
+        fo = O.FIRFilter(h, Fraction(147, 160), tx=np.complex64 if cplx else np.float32)
+        yo = fo.filt(x[c, :50_000].cpu().numpy())
+        assert_bit_equal(y_t[c, :len(yo)].cpu().numpy(), yo, "oracle spot check")
