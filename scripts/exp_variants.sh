@@ -1,10 +1,8 @@
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-run() { echo "== $*"; env MRHIP_DEBUG=1 "$@" timeout 300 python scripts/bench_configs.py c3a 2>&1 | grep -E "mrhip\]|config" | sed -e 's/.*"kernel_ms_per_pass": \([0-9.]*\).*"algorithmic_GBps": \([0-9.]*\).*/   kernel_ms=\1 GBps=\2/' | cut -c1-250; }
+run() { echo "== $*"; env MRHIP_DEBUG=1 "$@" timeout 300 python bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-streamed 2>&1 | grep -E "mrhip\] rational|metric|rror|fault|differs" | sed -e 's/.*"value": \([0-9.]*\).*"achieved": \([0-9.]*\).*"avg_launch_ms": \([0-9.]*\).*/   value=\1 GBps=\2 ms=\3/' | sed -e 's/.*grid=\([0-9]*\).*lds=\([0-9]*\).*occ.CU=\([0-9]*\) regs=\([0-9]*\).*J=\([0-9]*\).*/   grid=\1 lds=\2 occ=\3 regs=\4 J=\5/' | cut -c1-300 | tail -2; }
 {
-run MRHIP_INTERP=1
-run MRHIP_INTERP_NS=2
-run MRHIP_INTERP_NS=2 MRHIP_INTERP_J=12
-run MRHIP_INTERP_NS=2 MRHIP_INTERP_J=16
-run MRHIP_INTERP_J=4
-run MRHIP_INTERP=1
-} > gpurun_out/exp_interp_ns2.log 2>&1
+run MRHIP_PAIR=1
+run MRHIP_PAIR_NS=2 MRHIP_PAIR_J=9
+run MRHIP_PAIR=1
+run MRHIP_PAIR_NS=2 MRHIP_PAIR_J=9
+} > gpurun_out/exp_j9.log 2>&1
