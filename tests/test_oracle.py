@@ -217,3 +217,45 @@ def test_farrow_golden_vectors_frozen(O):
         assert [len(o) for o in outs] == g[k + "_counts"].tolist()
         assert f.state.inputDeficit == int(g[k + "_state"][0]) and f.state.phiAccumulator == float(g[k + "_acc"])
         assert_bit_equal(f.history, g[k + "_hist"], k + " history")
+
+
+def test_phase_recurrence_shortened_chain_is_exact():
+    """host_logic.cpp evaluates update() (src/Filters.jl:663-669) as  a1 = fl(acc + delta);  acc' = a1 - k*N  with
+    k = #{j >= 1 : a1 >= j*N + 1}  instead of  fl(mod(fl(a1 - 1), N) + 1): a Python model of both forms (IEEE doubles)
+    must agree bit for bit, step by step, for power-of-two and other N, rates from 1/100 to 30.  (The C++ itself is
+    checked on the GPU box against the oracle: test_arbitrary_phase_recurrence_many_rates.)"""
+    import random
+    import struct
+
+    def ref_step(acc, x, delta, N):
+        acc = acc + delta
+        if acc > N:
+            am1 = acc - 1.0
+            x += int(math.floor(am1 / N))
+            acc = math.fmod(am1, N) + 1.0
+        return acc, x
+
+    def new_step(acc, x, delta, N, pow2):
+        a1 = acc + delta
+        if a1 < 4.0 * N + 1.0:
+            w1, w2, w3 = a1 >= N + 1.0, a1 >= 2.0 * N + 1.0, a1 >= 3.0 * N + 1.0
+            n = a1 - 3.0 * N if w3 else (a1 - 2.0 * N if w2 else (a1 - N if w1 else a1))
+            if pow2:
+                x += int(w1) + int(w2) + int(w3)
+            elif a1 > N:
+                x += int((a1 - 1.0) / N)
+            return n, x
+        am1 = a1 - 1.0
+        return math.fmod(am1, N) + 1.0, x + int(math.floor(am1 / N))
+
+    rnd = random.Random(1)
+    for trial in range(60):
+        nphi = rnd.choice([32, 32, 16, 64, 7, 10, 33, 100, 3, 1, 2, 128])
+        rate = rnd.choice([math.pi / 3, rnd.uniform(0.05, 8.0), rnd.uniform(0.9, 1.1), 10 ** rnd.uniform(-2, 1.5), 1.0, 0.5, 2.0, 1 / 3])
+        delta, N = nphi / rate, float(nphi)
+        a = b = 1.0
+        xa = xb = 1
+        for i in range(4000):
+            a, xa = ref_step(a, xa, delta, N)
+            b, xb = new_step(b, xb, delta, N, (nphi & (nphi - 1)) == 0)
+            assert struct.pack("d", a) == struct.pack("d", b) and xa == xb, (nphi, rate, i)
