@@ -701,19 +701,22 @@ def test_long_launch_two_stage_tiles_match_generic(pkg, O, torch_cuda, monkeypat
     kernel bit for bit, plus oracle spot checks at the seams."""
     torch = torch_cuda
     g = torch.Generator(device="cuda").manual_seed(5)
-    h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
-    for (nch, n, cplx) in ((64, 3_300_000, False), (96, 1_500_000, True)):
+    rng = np.random.default_rng(8)
+    for (nch, n, cplx, L, M, hl) in ((64, 3_300_000, False, 147, 160, 147 * 24), (96, 1_500_000, True, 147, 160, 147 * 24),
+                                     (64, 4_000_000, False, 13, 16, 13 * 9), (64, 4_000_000, False, 31, 32, 31 * 7),
+                                     (48, 3_000_000, True, 9, 10, 9 * 20)):
+        h = rng.standard_normal(hl).astype(np.float32)
         if cplx:
             x = torch.view_as_complex(torch.rand((nch, n, 2), generator=g, device="cuda", dtype=torch.float32) - 0.5)
         else:
             x = torch.rand((nch, n), generator=g, device="cuda", dtype=torch.float32) - 0.5
         sizes = [n - 200_003, 200_003]
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
-        f = pkg.FIRFilter(h, Fraction(147, 160))
+        f = pkg.FIRFilter(h, Fraction(L, M))
         y_t = torch.cat(_run_chunks(f, x, sizes), dim=-1)
         assert f.last_kernel_name() == "rational_pair_kernel"
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
-        gf = pkg.FIRFilter(h, Fraction(147, 160))
+        gf = pkg.FIRFilter(h, Fraction(L, M))
         y_g = torch.cat(_run_chunks(gf, x, sizes), dim=-1)
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         a = torch.view_as_real(y_t) if cplx else y_t
@@ -721,6 +724,8 @@ def test_long_launch_two_stage_tiles_match_generic(pkg, O, torch_cuda, monkeypat
         assert a.shape == b.shape and torch.equal(a.view(torch.int32), b.view(torch.int32)), (nch, n, cplx)
         assert_bit_equal(f.history, gf.history, "history")
         c = nch - 1
-        fo = O.FIRFilter(h, Fraction(147, 160), tx=np.complex64 if cplx else np.float32)
+        fo = O.FIRFilter(h, Fraction(L, M), tx=np.complex64 if cplx else np.float32)
         yo = fo.filt(x[c, :50_000].cpu().numpy())
         assert_bit_equal(y_t[c, :len(yo)].cpu().numpy(), yo, "oracle spot check")
+        del x, y_t, y_g, a, b
+        torch.cuda.empty_cache()
