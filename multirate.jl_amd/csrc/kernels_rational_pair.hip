@@ -276,13 +276,15 @@ void rational_pair_kernel(PolyArgs a, PairArgs pa)
     unsigned long long probe_c0 = 0, probe_r0 = 0;
     if (pa.probe) { probe_c0 = __builtin_amdgcn_s_memtime(); probe_r0 = __builtin_amdgcn_s_memrealtime(); }
     unsigned long long probe_bar = 0;             // cycles this wave spends at the tile barrier (diagnostics)
+    unsigned long long probe_pre = 0;             // cycles between leaving the barrier and entering the step loop (descriptor read + address arithmetic)
     for (int s = 0;; s = (s + 1 == pa.ns ? 0 : s + 1)) {
         // One barrier per tile and no memory wait: the loader wave arrives only after this tile's data has
         // landed and its descriptor is in LDS; all compute waves arriving proves the oldest stage is no longer read.
         unsigned long long probe_b0 = 0;
         if (pa.probe) probe_b0 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
-        if (pa.probe) probe_bar += __builtin_amdgcn_s_memtime() - probe_b0;
+        unsigned long long probe_b1 = 0;
+        if (pa.probe) { probe_b1 = __builtin_amdgcn_s_memtime(); probe_bar += probe_b1 - probe_b0; }
         asm volatile("" ::: "memory");
         const unsigned tg = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(tile_flag[2 * s])));
         const unsigned tj = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(tile_flag[2 * s + 1])));
@@ -410,6 +412,7 @@ void rational_pair_kernel(PolyArgs a, PairArgs pa)
             static_for<0, KP>([&](auto I) { pin(pring[decltype(I)::value]); });
             store_step(J - 1, sv);
         };
+        if (pa.probe) { probe_pre += __builtin_amdgcn_s_memtime() - probe_b1; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         if (full) run_steps(std::true_type{});
         else run_steps(std::false_type{});
 
@@ -423,6 +426,7 @@ void rational_pair_kernel(PolyArgs a, PairArgs pa)
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         pa.probe[4 * gridDim.x + 8 * blockIdx.x + wave] = (probe_bar << 8) | ((hwid >> 4) & 3u);
+        if (wave == 0) pa.probe[4 * gridDim.x + 8 * blockIdx.x + 7] = probe_pre;   // slot 7 (no eighth compute wave): wave 0's pre-loop cycles
     }
 }
 
@@ -496,6 +500,12 @@ hipError_t launch_pair_T(int T, dim3 block, size_t lds, hipStream_t s, const Pol
                     if (!wf.empty()) std::fprintf(stderr, "[mrhip] probe: wave %d spends %.3f of the tile loop at the barrier (median); SIMD histogram %d %d %d %d\n", \
                                                   w, wf[wf.size() / 2], simd_hist[0], simd_hist[1], simd_hist[2], simd_hist[3]); \
                 }                                                                                   \
+            }                                                                                       \
+            {                                                                                       \
+                std::vector<double> pf;                                                             \
+                for (long long i = 0; i < g; ++i) if (hb[3 * i] > 1000) pf.push_back(static_cast<double>(hb[4 * g + 8 * i + 7]) / static_cast<double>(hb[3 * i])); \
+                std::sort(pf.begin(), pf.end());                                                    \
+                if (!pf.empty() && static_cast<int>(block.x / 64) - 1 < 8) std::fprintf(stderr, "[mrhip] probe: wave 0 spends %.3f of the tile loop between the barrier and the step loop (descriptor read, address arithmetic; median)\n", pf[pf.size() / 2]); \
             }                                                                                       \
             if (!ghz.empty()) std::fprintf(stderr, "[mrhip] probe: in-kernel clock median %.3f GHz (min %.3f max %.3f); tile loop p10 %.1f median %.1f p90 %.1f max %.1f us\n", \
                                            ghz[ghz.size() / 2], ghz.front(), ghz.back(), us[us.size() / 10], us[us.size() / 2], us[us.size() * 9 / 10], us.back()); \
