@@ -14,8 +14,9 @@
 //
 // Staging.  A tile is up to J steps: J*c*M + T + 2 input samples of one channel, brought HBM -> LDS by
 // LDS-DMA (global_load_lds_dwordx4, 16 B per lane, no VGPRs; the source only needs 4-byte alignment,
-// scripts/ubench/dma_test.hip) by a dedicated loader wave, pa.ns (3) stages deep: the DMA for tile i+2 is
-// issued right after the one barrier that opens tile i.  The first/last tile of a channel (history seam,
+// scripts/ubench/dma_test.hip) by a dedicated loader wave, pa.ns stages deep (three stages of J = 5 steps for short
+// launches: the DMA for tile i+2 is issued right after the one barrier that opens tile i; two stages of J = 8 steps for
+// long launches: one tile ahead, fewer tile boundaries -- see plan_rational_pair).  The first/last tile of a channel (history seam,
 // end of input) is staged through a checked register path into the same buffer.  The loader also draws
 // the work (grouped dynamic scheduling, see the kernel) and performs shiftin! at the end of the launch.
 //
