@@ -3,6 +3,7 @@ and the committed golden vectors.  Bar: BIT-EXACT for every dtype (both sides ev
 product in the order the reference source states, separately rounded multiply/add), which is
 inside the north star's "within 1 ULP" for Float32/Float64/ComplexF32."""
 import math
+import os
 from fractions import Fraction
 
 import numpy as np
@@ -729,3 +730,15 @@ def test_long_launch_two_stage_tiles_match_generic(pkg, O, torch_cuda, monkeypat
         assert_bit_equal(y_t[c, :len(yo)].cpu().numpy(), yo, "oracle spot check")
         del x, y_t, y_g, a, b
         torch.cuda.empty_cache()
+
+
+def test_randomised_stress_short(torch_cuda):
+    """scripts/stress_random.py (random kinds / ratios / tap counts / dtypes / channels / chunkings; every tuned kernel
+    against the universal kernel and the oracle, bit for bit) on a fixed seed, as a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_random.py"), "--cases", "160", "--seed", "11", "--seconds", "90"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout
