@@ -1,8 +1,10 @@
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
+run() { echo "== $*"; env MRHIP_DEBUG=1 "$@" timeout 300 python scripts/bench_configs.py x160 xf64 2>&1 | grep -E "mrhip\]|config" | sed -e 's/.*"kernel_ms_per_pass": \([0-9.]*\).*"algorithmic_GBps": \([0-9.]*\).*/   kernel_ms=\1 GBps=\2/' | cut -c1-200; }
 {
-for i in 1 2; do
-echo "== base"; python scripts/bench_configs.py c3b xstd 2>/dev/null | cut -c1-60,150-330
-echo "== scalar taps"; MRHIP_LIB_PATH=$R/build_exp/lib_scalar_taps.so python scripts/bench_configs.py c3b xstd 2>/dev/null | cut -c1-60,150-330
-done
-MRHIP_LIB_PATH=$R/build_exp/lib_scalar_taps.so timeout 600 python -m pytest tests -x -q -m gpu -k "tuned or config3 or sweep" 2>&1 | tail -2
-} > gpurun_out/exp_scalar_taps.log 2>&1
+run MRHIP_PS_J=0
+run MRHIP_PS_J=4
+run MRHIP_PS_J=12
+run MRHIP_PS_J=16
+run MRHIP_PS_BPC=2
+run MRHIP_PS_BPC=4
+} > gpurun_out/exp_ps.log 2>&1
