@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--big", action="store_true", help="long launches: 32-96 channels x 0.5-4e6 samples, ratios the pair kernels take "
+                    "(dynamic scheduling, two-stage tiles)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     tally, bad, t0 = {}, 0, time.time()
@@ -47,6 +49,14 @@ def main():
         nch = int(rng.choice([1, 2, 3, 5, 8, 31, 32, 33, 64, 70]))
         n = int(rng.choice([1, 7, 300, 5_000, 40_000, 150_000]))
         n = max(1, int(n * (0.5 + rng.random())))
+        if args.big:
+            arbitrary = False
+            th = np.float32
+            tx = rng.choice([np.float32, np.float32, np.complex64])
+            nch = int(rng.choice([32, 48, 64, 96]))
+            n = int(rng.choice([500_000, 1_500_000, 4_000_000]) * (0.6 + 0.4 * rng.random()))
+            if tx == np.complex64:
+                n //= 2
         cuts = sorted(set(int(c) for c in rng.integers(0, n + 1, size=int(rng.integers(0, 4)))))
         sizes = np.diff([0] + cuts + [n]).tolist()
         if arbitrary:
@@ -59,6 +69,8 @@ def main():
             desc = f"arbitrary rate={ratio} Nphi={nphi} hLen={len(h)}"
         else:
             kind = rng.choice(["rational", "rational", "near1", "interp", "decim", "standard", "h147"])
+            if args.big:
+                kind = rng.choice(["near1", "near1", "h147", "interp"])
             if kind == "h147":
                 L, M = 147, 160
             elif kind == "near1":
@@ -73,7 +85,7 @@ def main():
                 L, M = int(rng.integers(1, 40)), int(rng.integers(1, 40))
             fr = Fraction(L, M)
             L, M = fr.numerator, fr.denominator
-            tmax = 44 if L > 1 else 700
+            tmax = (33 if args.big else 44) if L > 1 else 700
             hl = max(2, int(rng.integers(1, tmax)) * L - int(rng.integers(0, L)))
             if L == 1:
                 hl = int(rng.integers(2, 700))
