@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X polyphase resampling engine.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config headline|c5]
 
-Workload (BASELINE.json metric "Msamples/s in (Float32, 147//160, 24*147 taps)"): FIRRational
+Workload `headline` (BASELINE.json metric "Msamples/s in (Float32, 147//160, 24*147 taps)"): FIRRational
 147//160, 3528 windowed-sinc x Kaiser(7.8562) taps (README.md:172-179 recipe), Float32 taps and
 samples, 64 independent channels x 1e8 samples per channel per GPU -- the shape BASELINE.json's north star
 quotes the roofline target on.  One step = one pass over the whole batch = ONE filt! call on a stateful
@@ -14,23 +14,36 @@ outputs) is measured right after the timed region and reported in the extra obje
 Inputs are synthetic uniform [0,1) samples generated on the device before the timed region and
 stay resident in HBM; outputs are written to a resident HBM buffer.
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank filters its own 64-channel
-shard -- channels are independent, so there is no data-path collective -- and the
-reported value is all ranks' input samples / max-over-ranks time ("scaling": "weak").
+Workload `c5` (BASELINE.json configs[4]): 4096 ComplexF32 channels x 1e6 samples, 147//160, sharded by channel over the
+N GPUs ("scaling": "strong": the total is fixed, rank r filters shard_channels(4096, N, r)).  `value` is the
+compute-only rate (no collective on the data path); the final gather of the outputs over RCCL/xGMI is timed
+separately, to rank 0 (`gather.root`) and as an all-gather (`gather.all`), and reported next to it.
+
+Multi-GPU: one process per GPU.  Under torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE in the environment)
+this process IS one rank.  Started directly as `python bench.py --gpus N` with N > 1 it is only a launcher: it
+makes NO GPU call, starts N fresh child processes of this script (one per GPU, rendezvous on 127.0.0.1) and
+exits with their status -- a process that has touched the GPU is never re-executed.  For `headline` every rank
+filters its own 64-channel shard -- channels are independent, so there is no data-path collective --
+and the reported value is all ranks' input samples / max-over-ranks time ("scaling": "weak").  `n_gpus` is the
+world size the process group actually formed (asserted equal to the all-reduced rank count).
 
 One JSON line is printed by rank 0.  `roofline.achieved` = algorithmic bytes per launch
-(7.675 B per input sample per channel = 4 B read + 0.91875 * 4 B written) x samples per
-launch / average launch duration of the dominant kernel, measured with HIP events recorded on the
+(7.675 B per input sample per channel = 4 B read + 0.91875 * 4 B written; 15.35 B for ComplexF32) x
+samples per launch / average launch duration of the dominant kernel, measured with HIP events recorded on the
 launch stream around the compute-kernel launches of the timed region (mrhip_set_timing / mrhip_timing_read; every
 launch when a pass is one call, every 4th in the chunked stream: the event records themselves cost a few
-microseconds of stream time per launch, so bracketing every 120 us launch would slow the very throughput being measured).  `cpu_baseline` = the CPU oracle (a C port of the reference algorithm; the
-reference itself is Julia-0.3 source and cannot run) on one core over a bounded sample.
+microseconds of stream time per launch, so bracketing every 120 us launch would slow the very throughput being
+measured).  `cpu_baseline` = the CPU oracle (a C port of the reference algorithm; the reference itself is
+Julia-0.3 source and cannot run) on ONE core (the reference is single-threaded), median of 5 runs over a bounded
+sample; `cpu_baseline_all_cores` = the same port with one channel per logical core.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from fractions import Fraction
@@ -41,76 +54,207 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 L, M, TAPS_PER_PHI = 147, 160, 24
 BYTES_PER_INPUT_SAMPLE = 4.0 + (L / M) * 4.0   # 7.675
+BYTES_PER_INPUT_SAMPLE_C64 = 2 * BYTES_PER_INPUT_SAMPLE   # 15.35
+METRIC = "Msamples/s in (Float32, 147//160, 24*147 taps) + achieved HBM GB/s vs roofline"
 
 
-def cpu_baseline(h, seconds_budget=20.0):
-    """Time the oracle (port of the reference's filt, one thread) on a bounded sample of the workload."""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (checker-side code: the only place outside tests/ and smoke() that touches oracle/)
+# ---------------------------------------------------------------------------------------------
+def host_description():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    return {"cpu_model": model, "logical_cores": logical, "usable_cores": usable}
+
+
+def cpu_baseline(h, seconds_budget=25.0):
+    """Time the oracle (port of the reference's filt) on a bounded sample of the workload: one thread (the
+    like-for-like figure: the reference is single-threaded), then one channel per usable core."""
+    import threading
+
     import numpy as np
     from oracle import oracle as O
-    n = 300_000_000                            # ~2.4 s per run on one core: ~10 s of CPU work in all
+    host = host_description()
+    n = 300_000_000                            # ~2.4 s per run on one core: ~12 s of CPU work for 5 runs
     x = np.random.default_rng(0).random(n, dtype=np.float32)
-    f = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
-    f.filt(x[:1_000_000])                     # warm-up
+    O.FIRFilter(h, Fraction(L, M), tx=np.float32).filt(x[:1_000_000])   # warm-up
     times = []
     t_all = time.perf_counter()
-    while len(times) < 3 and (time.perf_counter() - t_all) < seconds_budget:
+    while len(times) < 5 and (time.perf_counter() - t_all) < seconds_budget:
         f = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
         t0 = time.perf_counter()
         f.filt(x)
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(n / med / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"1 channel x {n} Float32 samples, 147//160, 3528 taps, median of {len(times)} runs of "
-                      "oracle/multirate_oracle.c (gcc -O3, strict order, no FMA); reference is Julia 0.3 and "
-                      "cannot run; README.md:172-193 quotes 17.56 Msamples/s on unnamed 2014 hardware"}
+    one = {"value": round(n / med / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "cpu_model": host["cpu_model"], "host_logical_cores": host["logical_cores"], "runs": len(times),
+           "sample": f"1 channel x {n} Float32 samples, 147//160, 3528 taps, median of {len(times)} runs of "
+                     "oracle/multirate_oracle.c (gcc -O3, strict order, no FMA) on one core; reference is Julia 0.3 and "
+                     "cannot run; README.md:172-193 quotes 17.56 Msamples/s (Float64 taps) on unnamed 2014 hardware"}
+
+    # all cores: one channel per usable core, one thread each (ctypes releases the GIL inside the C call)
+    cores = max(1, host["usable_cores"])
+    n2 = 20_000_000
+    xs = x[:n2]
+    mtimes = []
+    t_all = time.perf_counter()
+    while len(mtimes) < 5 and (time.perf_counter() - t_all) < 10.0:
+        filters = [O.FIRFilter(h, Fraction(L, M), tx=np.float32) for _ in range(cores)]
+        threads = [threading.Thread(target=f.filt, args=(xs,)) for f in filters]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        mtimes.append(time.perf_counter() - t0)
+    mtimes.sort()
+    mmed = mtimes[len(mtimes) // 2]
+    allc = {"value": round(cores * n2 / mmed / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "cpu_model": host["cpu_model"], "host_logical_cores": host["logical_cores"], "runs": len(mtimes),
+            "sample": f"{cores} channels x {n2} Float32 samples, one channel per core (one thread each), "
+                      f"median of {len(mtimes)} runs"}
+    return one, allc
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=3)   # the clocks take a few 10 ms launches to settle (kernel trace: 12.7, 11.1, 10.5, 10.3, 10.2 ms)
-    ap.add_argument("--channels", type=int, default=64)
-    ap.add_argument("--samples", type=int, default=100_000_000, help="input samples per channel per step")
-    ap.add_argument("--chunk", type=int, default=0, help="samples per channel per filt! call (0 = the whole batch in one call)")
-    ap.add_argument("--numerics", choices=["strict", "fused"], default="strict")
-    ap.add_argument("--time-every", type=int, default=0, help="bracket every n-th kernel launch of the timed region with HIP events "
-                    "(0 = every launch when a pass is one call, every 4th when it is chunked: the brackets cost stream time)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-streamed", action="store_true", help="skip the extra chunked passes reported as `streamed_1e6_chunks`")
-    ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check (timing experiments)")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` started directly (no torch.distributed.run around it)
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    import numpy as np
-    import torch
-    import __graft_entry__ as ge
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    # one rank per GPU.  MRHIP_BENCH_BACKEND=gloo (plumbing check on a box with fewer GPUs than ranks: ranks then
-    # share devices round-robin and the one timing reduction goes through the host) is never used by the driver.
+def launch_ranks(n):
+    """Start n child processes of this script, one per GPU, and return the worst exit status.  This process
+    makes no GPU call: torch.cuda.device_count() only counts (it does not create a context on this image), and
+    nothing that has initialised the GPU is ever exec'ed -- the ranks are ordinary fresh children."""
     backend = os.environ.get("MRHIP_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    if backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    worst = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in pending:        # one rank failed: the others would wait at the rendezvous forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
 
+
+# ---------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------
+class Rank:
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+        # one rank per GPU.  MRHIP_BENCH_BACKEND=gloo (plumbing check on a box with fewer GPUs than ranks: ranks then
+        # share devices round-robin and the collectives go through the host) is never used by the driver.
+        self.backend = os.environ.get("MRHIP_BENCH_BACKEND", "nccl")
+        self.dev_index = self.local_rank if self.backend == "nccl" else self.local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(self.dev_index)
+        self.dev = torch.device("cuda", self.dev_index)
+        self.dist = None
+        self.formed = 1
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+            # the number of ranks the communicator really has: every rank contributes 1
+            one = torch.ones(1, dtype=torch.int64, device=self.coll_device())
+            dist.all_reduce(one)
+            self.formed = int(one.item())
+            assert self.formed == dist.get_world_size() == self.world, (self.formed, self.world)
+
+    def coll_device(self):
+        return self.dev if self.backend == "nccl" else "cpu"
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, values):
+        if self.dist is None:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.coll_device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def traffic_for(bytes_per_launch):
+    """PMC-measured HBM bytes of a launch of THIS size (profiles/: separate --pmc passes), or None"""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            for e in json.load(open(tpath)).get("entries", []):
+                if abs(e["algorithmic_bytes_per_launch"] - bytes_per_launch) <= 1e-3 * bytes_per_launch:
+                    return e["hbm_bytes_per_launch"]
+        except Exception:
+            return None
+    return None
+
+
+def run_headline(args, R):
+    import numpy as np
+    import __graft_entry__ as ge
+    torch, dev, rank, world = R.torch, R.dev, R.rank, R.world
     pkg = ge.load_package()
     h = pkg.firdes(TAPS_PER_PHI * L, 0.5 / L, beta=7.8562).astype(np.float32)
-    nch, n = args.channels, args.samples
+    nch, n = args.channels or 64, args.samples or 100_000_000
     chunk = args.chunk if 0 < args.chunk < n else n
     time_every = args.time_every if args.time_every > 0 else (1 if chunk == n else 4)
     n_out_total = (n * L + M - 1) // M
@@ -121,7 +265,7 @@ def main():
         x[c].uniform_(0.0, 1.0, generator=gen)
     y = torch.empty((nch, n_out_total), dtype=torch.float32, device=dev)
 
-    filt = pkg.FIRFilter(h, Fraction(L, M), device=dev_index,
+    filt = pkg.FIRFilter(h, Fraction(L, M), device=R.dev_index,
                          numerics=pkg.NUMERICS_FUSED if args.numerics == "fused" else pkg.NUMERICS_STRICT)
     filt.bind(np.float32, nch)
 
@@ -136,19 +280,14 @@ def main():
             k += cnt
         return k
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
     for _ in range(args.warmup):
         produced = one_step()
-    barrier()
+    R.barrier()
     filt.set_timing(time_every)   # HIP events around every n-th launch (they cost stream time themselves)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         produced = one_step()
-    barrier()
+    R.barrier()
     elapsed = time.perf_counter() - t0
     n_launch, kern_ms = filt.timing_read()
     filt.set_timing(False)
@@ -173,11 +312,9 @@ def main():
                     "avg_launch_ms": round(ms1 / max(nl1, 1), 5), "launches_timed": nl1,
                     "achieved_GBps": round(nch * sc * BYTES_PER_INPUT_SAMPLE / (ms1 / max(nl1, 1) / 1e3) / 1e9, 2)}
         streamed["frac"] = round(streamed["achieved_GBps"] / HBM_PEAK_GBPS, 4)
+        streamed["whole_step_GBps"] = round(nch * n * BYTES_PER_INPUT_SAMPLE * args.steps / el1 / 1e9, 2)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = R.max_over_ranks([elapsed])[0]
 
     # light sanity check of the timed output against the oracle (checker only, after the timed region)
     if rank == 0 and not args.no_check:
@@ -195,32 +332,24 @@ def main():
     avg_launch_s = (kern_ms / 1e3) / max(n_launch, 1)
     bytes_per_launch = nch * min(chunk, n) * BYTES_PER_INPUT_SAMPLE
     achieved = bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):      # PMC-measured HBM bytes of a launch of THIS size (profiles/: separate --pmc passes)
-        try:
-            for e in json.load(open(tpath)).get("entries", []):
-                if abs(e["algorithmic_bytes_per_launch"] - bytes_per_launch) <= 1e-3 * bytes_per_launch:
-                    traffic = e["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
 
     if rank == 0:
         line = {
-            "metric": "Msamples/s in (Float32, 147//160, 24*147 taps) + achieved HBM GB/s vs roofline",
+            "metric": METRIC,
             "value": round(value, 3), "unit": "Msamples/s (input samples, all channels, all GPUs)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": R.formed, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"FIRRational 147//160, 3528 taps, Float32, {nch} channels x {n} samples per GPU, "
                                    + ("one filt! call per pass" if chunk == n else f"streamed in {chunk}-sample chunks through one stateful FIRFilter")
                                    + " (inputs and outputs resident in HBM)",
                        "channels_per_gpu": nch, "samples_per_channel": n, "chunk": chunk,
-                       "numerics": args.numerics, "parallelism": f"channel-shard x{world}, no collective"},
+                       "numerics": args.numerics, "parallelism": f"channel-shard x{world}, no collective",
+                       "backend": R.backend if world > 1 else None},
             "output_msamples_s": round(value * L / M, 3),
             "kernel": filt.last_kernel_name(),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_for(bytes_per_launch),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5), "launches_timed": n_launch,
                          "whole_step_GBps": round(nch * n * BYTES_PER_INPUT_SAMPLE / (ms_per_step / 1e3) / 1e9, 2)},
@@ -228,11 +357,136 @@ def main():
         if streamed is not None:
             line["streamed_1e6_chunks"] = streamed
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(h)
+            line["cpu_baseline"], line["cpu_baseline_all_cores"] = cpu_baseline(h)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+
+def run_c5(args, R):
+    """BASELINE.json configs[4]: 4096 ComplexF32 channels, 147//160, sharded by channel over the ranks (strong scaling)."""
+    import numpy as np
+    import __graft_entry__ as ge
+    torch, dev, rank, world = R.torch, R.dev, R.rank, R.world
+    pkg = ge.load_package()
+    h = pkg.firdes(TAPS_PER_PHI * L, 0.5 / L, beta=7.8562).astype(np.float32)
+    nch_total, n = args.channels or 4096, args.samples or 1_000_000
+    n_out = (n * L + M - 1) // M
+    sh = pkg.ChannelShardedFilter(h, Fraction(L, M), nch_total, rank=rank, world_size=world, device=R.dev_index)
+    x = torch.view_as_complex(torch.rand((sh.count, n, 2), dtype=torch.float32, device=dev,
+                                         generator=torch.Generator(device=dev).manual_seed(0xC5000000 + sh.start)))
+    y = torch.empty((sh.count, n_out), dtype=torch.complex64, device=dev)
+    if sh.filter is not None:
+        sh.filter.bind(np.complex64, sh.count)
+
+    def one_step():
+        if sh.filter is None:
+            return
+        sh.filter.reset()
+        got = sh.filter.filt_into(y, x)
+        assert got == n_out, (got, n_out)
+
+    for _ in range(args.warmup):
+        one_step()
+    R.barrier()
+    if sh.filter is not None:
+        sh.filter.set_timing(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    R.barrier()
+    t_compute = time.perf_counter() - t0
+    n_launch, kern_ms = sh.filter.timing_read() if sh.filter is not None else (0, 0.0)
+    if sh.filter is not None:
+        sh.filter.set_timing(False)
+
+    # the final gather, timed on its own: to rank 0, and as an all-gather (every rank ends with all 4096 channels)
+    gather = {}
+    out_bytes = float(nch_total) * n_out * 8
+    if world > 1 and not args.no_gather:
+        yc = y if R.backend == "nccl" else y.cpu()          # gloo plumbing check: collectives on host tensors
+        for kind, fn in (("root", sh.gather), ("all", sh.all_gather)):
+            g = fn(yc, n_out=n_out); del g                   # warm-up (communicator set-up, allocator)
+            R.barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                g = fn(yc, n_out=n_out); del g
+            R.barrier()
+            tg = R.max_over_ranks([(time.perf_counter() - t1) / args.steps])[0]
+            moved = out_bytes * (world - 1) / world          # bytes that cross a link: into the root / into each rank
+            gather[kind] = {"ms": round(tg * 1e3, 3), "GBps_into_one_gpu": round(moved / tg / 1e9, 1),
+                            "compute_plus_gather_Msamples_per_s": None}
+    t_compute = R.max_over_ranks([t_compute])[0]
+
+    # parity spot check against the oracle (checker only, after the timed region): rank 0's first and last channel
+    if rank == 0 and not args.no_check and sh.filter is not None:
+        from oracle import oracle as O
+        for c in sorted({0, sh.count - 1}):
+            yo = O.FIRFilter(h, Fraction(L, M), tx=np.complex64).filt(x[c, :100_000].cpu().numpy())
+            got = y[c, :len(yo)].cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), yo.view(np.uint32)), "bench output differs from oracle"
+
+    if rank == 0:
+        per_step = t_compute / args.steps
+        total_in = float(nch_total) * n
+        value = total_in / per_step / 1e6
+        for kind in gather:
+            gather[kind]["compute_plus_gather_Msamples_per_s"] = round(total_in / (per_step + gather[kind]["ms"] / 1e3) / 1e6, 3)
+        avg_launch_s = (kern_ms / 1e3) / max(n_launch, 1)
+        bytes_per_launch = sh.count * n * BYTES_PER_INPUT_SAMPLE_C64
+        achieved = bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
+        line = {
+            "metric": "Msamples/s in (ComplexF32, 147//160, 24*147 taps), 4096 channels sharded by channel + achieved HBM GB/s vs roofline",
+            "value": round(value, 3), "unit": "Msamples/s (input samples, all channels, all GPUs; compute only)",
+            "n_gpus": R.formed, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(per_step * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C5: FIRRational 147//160, 3528 taps, ComplexF32 samples x Float32 taps, {nch_total} channels x {n} "
+                                   f"samples in all, sharded by channel over {world} GPU(s); one filt! call per pass "
+                                   "(inputs and outputs resident in HBM)",
+                       "channels_total": nch_total, "channels_per_gpu": sh.count, "samples_per_channel": n,
+                       "parallelism": f"channel-shard x{world}, no data-path collective; final gather timed separately",
+                       "backend": R.backend if world > 1 else None},
+            "output_msamples_s": round(value * L / M, 3),
+            "kernel": sh.filter.last_kernel_name() if sh.filter is not None else None,
+            "gather": gather or None,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_for(bytes_per_launch),
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "avg_launch_ms": round(avg_launch_s * 1e3, 5), "launches_timed": n_launch,
+                         "note": "rank 0's kernel; per-GPU fraction (every rank runs the same shard size +-1 channel)"},
+        }
+        print(json.dumps(line), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=3)   # the clocks take a few 10 ms launches to settle (kernel trace: 12.7, 11.1, 10.5, 10.3, 10.2 ms)
+    ap.add_argument("--config", choices=["headline", "c5"], default="headline")
+    ap.add_argument("--channels", type=int, default=0, help="channels per GPU (headline, default 64) / in all (c5, default 4096)")
+    ap.add_argument("--samples", type=int, default=0, help="input samples per channel per step (default 1e8 headline, 1e6 c5)")
+    ap.add_argument("--chunk", type=int, default=0, help="samples per channel per filt! call (0 = the whole batch in one call)")
+    ap.add_argument("--numerics", choices=["strict", "fused"], default="strict")
+    ap.add_argument("--time-every", type=int, default=0, help="bracket every n-th kernel launch of the timed region with HIP events "
+                    "(0 = every launch when a pass is one call, every 4th when it is chunked: the brackets cost stream time)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the extra chunked passes reported as `streamed_1e6_chunks`")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check (timing experiments)")
+    ap.add_argument("--no-gather", action="store_true", help="c5: skip the gather timings")
+    args = ap.parse_args()
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        # started directly, not by torch.distributed.run: become the launcher (no GPU call in this process)
+        sys.exit(launch_ranks(args.gpus))
+
+    R = Rank(args)
+    if R.world != args.gpus and R.world > 1:
+        args.gpus = R.world
+    if args.config == "c5":
+        run_c5(args, R)
+    else:
+        run_headline(args, R)
+    R.finish()      # only on success: a rank that raised must not wait for the others at a barrier (the launcher ends them)
 
 
 if __name__ == "__main__":

@@ -119,6 +119,29 @@ int mrhip_polyfit(const double *y, int64_t n, int64_t polyorder, double *coef);
 /* promote_type(Th, Tx) as used by every filt wrapper, e.g. src/Filters.jl:581 */
 int mrhip_output_dtype(int tap_dtype, int sample_dtype);
 
+/* ---- FIR design, host only (src/FIRDesign.jl) ----------------------------------------------- */
+/* replaces @enum(FIRResponse, LOWPASS, BANDPASS, HIGHPASS, BANDSTOP), src/FIRDesign.jl:7 (values 0..3, src/enum.jl) */
+typedef enum { MRHIP_LOWPASS = 0, MRHIP_BANDPASS = 1, MRHIP_HIGHPASS = 2, MRHIP_BANDSTOP = 3 } mrhip_fir_response;
+/* replaces kaiserlength(transition, attenuation = 60; samplerate = 1.0), src/FIRDesign.jl:18-33: (numtaps, beta) */
+int mrhip_kaiserlength(double transition, double attenuation, double samplerate, int64_t *numtaps, double *beta);
+/* the window firdes multiplies with when windowfunction == kaiser (src/FIRDesign.jl:82-83; DSP.jl's kaiser in the
+ * reference, beta taken as is like src/Window.jl:53-58): out receives n Float64 samples */
+int mrhip_kaiser(int64_t n, double beta, double *out);
+/* replaces firprototype(numtaps, F; response), src/FIRDesign.jl:47-66.  F holds nF cutoffs in cycles/sample (two for
+ * BANDPASS / BANDSTOP).  Returns the length of the prototype (numtaps, or numtaps+1 for HIGHPASS with an even
+ * numtaps, :55) or -1 (mrhip_last_error: "Not a valid FIR_TYPE", :62); out = NULL only queries the length. */
+int64_t mrhip_firprototype(int64_t numtaps, const double *F, int nF, int response, double *out);
+/* replaces firdes(numtaps, cutoff, windowfunction; response, samplerate, beta), src/FIRDesign.jl:76-88.
+ * `window` = NULL selects the Kaiser window with `beta` (windowfunction == kaiser, :82-83); otherwise it points to
+ * the caller's window evaluated at the prototype length (:85) -- query that length first with out = NULL.
+ * Returns the number of taps written (Float64), or -1. */
+int64_t mrhip_firdes(int64_t numtaps, const double *cutoff, int ncutoff, int response, double samplerate, double beta,
+                     const double *window, double *out);
+/* replaces firdes(cutoff, transitionwidth, stopbandAttenuation = 60; response, samplerate), src/FIRDesign.jl:90-95
+ * (kaiserlength, then the method above).  out = NULL queries the length. */
+int64_t mrhip_firdes_kaiser(const double *cutoff, int ncutoff, double transitionwidth, double stopbandAttenuation, int response,
+                            double samplerate, double *out);
+
 /* ---- construction --------------------------------------------------------------------- */
 /* replaces FIRFilter(h::Vector, resampleRatio::Rational = 1//1), src/Filters.jl:158-180.
  * num//den is reduced like a Julia Rational; the kernel kind is chosen exactly as :163-175
@@ -150,6 +173,11 @@ int mrhip_get_pnfb(const mrhip_filter *f, double *host_out);
 /* replaces tapsforphase(kernel::FIRFarrow, phase), src/Filters.jl:764-775: tapsPerPhi taps of tap_dtype
  * for a phase in [0, Nphi+1] (host evaluation; MRHIP_ERR_INVALID_ARG outside the range like :765) */
 int mrhip_farrow_tapsforphase(const mrhip_filter *f, double phase, void *host_out);
+/* replaces tapsforphase(kernel::FIRArbitrary, phase), src/Filters.jl:677-690: (alpha, phiIdx) = modf(phase);
+ * taps[i] = pfb[i, phiIdx] + alpha * dpfb[i, phiIdx], evaluated in Float64 (alpha is a Float64 there) and stored in
+ * tap_dtype.  phase outside [0, Nphi+1] is MRHIP_ERR_INVALID_ARG (:678); so is a phase whose integer part is not a
+ * column of the bank (0 or Nphi+1: a BoundsError in the reference). */
+int mrhip_arbitrary_tapsforphase(const mrhip_filter *f, double phase, void *host_out);
 void mrhip_destroy(mrhip_filter *f);
 
 /* ---- bookkeeping ---------------------------------------------------------------------- */
@@ -208,6 +236,24 @@ int mrhip_filt_host(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_str
                     int64_t y_capacity, int64_t y_stride, int64_t *n_written);
 /* block until everything enqueued on the filter's behalf on `stream` has finished */
 int mrhip_synchronize(mrhip_filter *f, void *stream);
+
+/* ---- cascades (the reference chains filt calls by hand) ------------------------ */
+/* A chain of filters run back to back on one stream: y = filt(stage[n-1], ... filt(stage[0], x)).  The stages are
+ * ordinary stateful filters (borrowed, not owned: destroy them after the cascade); stage i+1's sample dtype must be
+ * stage i's output dtype, all stages share nchannels and the device.  Intermediate signals live in device buffers
+ * owned by the cascade and never leave HBM; every count is closed-form on the host, so nothing is read back between
+ * stages and chunked calls continue the stream exactly like calling the stages by hand. */
+typedef struct mrhip_cascade mrhip_cascade;
+int mrhip_cascade_create(mrhip_filter *const *stages, int nstages, mrhip_cascade **out);
+void mrhip_cascade_destroy(mrhip_cascade *c);
+/* outputlength of the chain (each stage's outputlength applied in turn: an estimate where a stage's is, :375) */
+int64_t mrhip_cascade_outputlength(const mrhip_cascade *c, int64_t inputlength);
+/* exact per-channel output count of the next mrhip_cascade_filt_device call with `inputlength` samples */
+int64_t mrhip_cascade_next_output_count(const mrhip_cascade *c, int64_t inputlength);
+/* same contract as mrhip_filt_device for the whole chain; MRHIP_ERR_BUFFER_TOO_SMALL leaves every stage untouched */
+int mrhip_cascade_filt_device(mrhip_cascade *c, const void *x, int64_t x_len, int64_t x_stride, void *y, int64_t y_capacity,
+                              int64_t y_stride, int64_t *n_written, void *stream);
+int mrhip_cascade_reset(mrhip_cascade *c);
 
 /* replaces the stateless filt(h, x, ratio), src/Filters.jl:858-861, and
  * filt(h, x, rate, Nphi), :864-867, for host data, one channel: construct, filter once,

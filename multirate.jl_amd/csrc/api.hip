@@ -77,12 +77,16 @@ int upload_taps(mrhip_filter *f, const std::vector<unsigned char> &src, void **d
 int alloc_common(mrhip_filter *f)
 {
     const size_t hbytes = std::max<size_t>(static_cast<size_t>(f->nch) * f->H * x_elt(f), 16);
+    // Every later launch goes to a non-blocking stream, which the null stream's memsets are not ordered with: zero
+    // on the filter's own stream and wait for it here (construction may block; nothing else in the library does).
+    MRHIP_CHECK_HIP(hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
         MRHIP_CHECK_HIP(hipMalloc(&f->d_hist[i], hbytes));
-        MRHIP_CHECK_HIP(hipMemset(f->d_hist[i], 0, hbytes));   // history = zeros(historyLen), Filters.jl:177
+        MRHIP_CHECK_HIP(hipMemsetAsync(f->d_hist[i], 0, hbytes, f->own_stream));   // history = zeros(historyLen), Filters.jl:177
     }
     MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_counters), 33 * 256));
-    MRHIP_CHECK_HIP(hipMemset(f->d_counters, 0, 33 * 256));
+    MRHIP_CHECK_HIP(hipMemsetAsync(f->d_counters, 0, 33 * 256, f->own_stream));
+    MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
     {
         hipDeviceProp_t prop;
         MRHIP_CHECK_HIP(hipGetDeviceProperties(&prop, f->device));
@@ -90,8 +94,44 @@ int alloc_common(mrhip_filter *f)
         const char *fg = std::getenv("MRHIP_FORCE_GENERIC");
         f->force_generic = fg && fg[0] == '1';
     }
-    MRHIP_CHECK_HIP(hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking));
     MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->sched_copied, hipEventDisableTiming));
+    MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->xs_event, hipEventDisableTiming));
+    return MRHIP_OK;
+}
+
+// Is `stream` being captured into a HIP graph?  (The legacy null stream cannot be; while another stream captures in
+// global mode the query itself fails for it, which means "no".)
+bool stream_is_capturing(hipStream_t stream)
+{
+    if (!stream) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs == hipStreamCaptureStatusActive;
+}
+
+// Order this call after whatever the filter enqueued before on another stream (see mrhip_filter::last_stream).
+int adopt_stream(mrhip_filter *f, hipStream_t stream)
+{
+    if (f->last_stream_valid && f->last_stream != stream) {
+        if (hipEventRecord(f->xs_event, f->last_stream) == hipSuccess) {
+            MRHIP_CHECK_HIP(hipStreamWaitEvent(stream, f->xs_event, 0));
+        } else {                       // the earlier stream no longer exists: everything on the device is older
+            (void)hipGetLastError();
+            MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        }
+    }
+    f->last_stream = stream;
+    f->last_stream_valid = true;
+    return MRHIP_OK;
+}
+
+// Wait (on the host) for the filter's own enqueued work only -- not for the whole device.
+int drain_filter(mrhip_filter *f)
+{
+    if (f->last_stream_valid && hipStreamSynchronize(f->last_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+    }
     return MRHIP_OK;
 }
 
@@ -379,13 +419,18 @@ void mrhip_destroy(mrhip_filter *f)
 {
     if (!f) return;
     DeviceGuard guard(f->device);
-    (void)hipDeviceSynchronize();
-    for (void *p : {f->d_taps, f->d_dtaps, static_cast<void *>(f->d_pnfb), f->d_hist[0], f->d_hist[1], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc, f->d_xbuf, f->d_ybuf})
+    (void)drain_filter(f);                       // this filter's work only; other streams of the process keep running
+    for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
+        if (st) (void)hipStreamSynchronize(st);
+    for (void *p : {f->d_taps, f->d_dtaps, static_cast<void *>(f->d_pnfb), f->d_hist[0], f->d_hist[1], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc,
+                    f->d_xbuf[0], f->d_xbuf[1], f->d_ybuf[0], f->d_ybuf[1]})
         if (p) (void)hipFree(p);
     if (f->pin_n) (void)hipHostFree(f->pin_n);
     if (f->pin_acc) (void)hipHostFree(f->pin_acc);
-    if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
-    if (f->sched_copied) (void)hipEventDestroy(f->sched_copied);
+    for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : {f->sched_copied, f->xs_event, f->ev_in[0], f->ev_in[1], f->ev_k[0], f->ev_k[1], f->ev_out[0], f->ev_out[1]})
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_pool) (void)hipEventDestroy(e);
     delete f;
 }
@@ -473,7 +518,7 @@ int mrhip_get_history(mrhip_filter *f, void *host_out)
 {
     if (!f || !host_out) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
     DeviceGuard guard(f->device);
-    MRHIP_CHECK_HIP(hipDeviceSynchronize());
+    if (int rc = drain_filter(f)) return rc;     // the history is written by the filter's own last launch
     const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
     if (bytes) MRHIP_CHECK_HIP(hipMemcpy(host_out, f->d_hist[f->hist_cur], bytes, hipMemcpyDeviceToHost));
     return MRHIP_OK;
@@ -483,9 +528,14 @@ int mrhip_set_history(mrhip_filter *f, const void *host_in)
 {
     if (!f || !host_in) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
     DeviceGuard guard(f->device);
-    MRHIP_CHECK_HIP(hipDeviceSynchronize());
+    // stream-ordered behind the filter's earlier launches and ahead of its next one (which either runs on the same
+    // stream or waits for it, adopt_stream); the host buffer is the caller's, so wait for the copy itself
+    hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
+    if (stream_is_capturing(s)) return fail(MRHIP_ERR_UNSUPPORTED, "set_history while the filter's stream is being captured");
     const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
-    if (bytes) MRHIP_CHECK_HIP(hipMemcpy(f->d_hist[f->hist_cur], host_in, bytes, hipMemcpyHostToDevice));
+    if (bytes) MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_hist[f->hist_cur], host_in, bytes, hipMemcpyHostToDevice, s));
+    MRHIP_CHECK_HIP(hipStreamSynchronize(s));
+    f->last_stream = s; f->last_stream_valid = true;
     return MRHIP_OK;
 }
 
@@ -493,11 +543,15 @@ int mrhip_reset(mrhip_filter *f)
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
     DeviceGuard guard(f->device);
-    MRHIP_CHECK_HIP(hipDeviceSynchronize());
+    // No host wait: the zeroing is enqueued on the stream the filter last ran on, i.e. after its earlier launches;
+    // the next filt call is on that stream too, or waits for it (adopt_stream).
+    hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
     const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
-    if (bytes) MRHIP_CHECK_HIP(hipMemset(f->d_hist[f->hist_cur], 0, bytes));
-    MRHIP_CHECK_HIP(hipMemset(f->d_counters, 0, 33 * 256));
+    if (bytes) MRHIP_CHECK_HIP(hipMemsetAsync(f->d_hist[f->hist_cur], 0, bytes, s));
+    MRHIP_CHECK_HIP(hipMemsetAsync(f->d_counters, 0, 33 * 256, s));
+    f->last_stream = s; f->last_stream_valid = true;
     f->phiIdx = 1; f->inputDeficit = 1; f->xIdx = 1; f->phiAcc = 1.0; f->alpha = 0.0;
+    f->sched_cached = false;
     return MRHIP_OK;
 }
 
@@ -580,7 +634,7 @@ static int ensure_sched_capacity(mrhip_filter *f, size_t n)
     }
     if (n > f->d_sched_cap) {
         const size_t cap = std::max<size_t>(n + n / 4, 4096);
-        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        if (int rc = drain_filter(f)) return rc;      // only this filter's kernels read the schedule buffers
         if (f->d_sched_n) (void)hipFree(f->d_sched_n);
         if (f->d_sched_acc) (void)hipFree(f->d_sched_acc);
         f->d_sched_n = f->d_sched_acc = nullptr;
@@ -606,6 +660,23 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
     const TypeKey tk = type_key(f);
     const bool fused = f->numerics == MRHIP_NUMERICS_FUSED;
     if (x_len == 0) return MRHIP_OK;   // nothing to do: zero outputs, history and state unchanged
+
+    // Stream capture (HIP graphs).  A captured call is replayed with the arguments baked in at capture time -- the
+    // call-start (phiIdx, inputDeficit), the history slot -- while the host object is NOT advanced by a replay.  So a
+    // call may only be captured if it leaves the integer state where it found it (x_len a multiple of the decimation
+    // for the rational family); its history is written back into the slot it was read from, and every replay then
+    // continues the stream exactly like the next call of a plain loop would.  Anything else would replay stale
+    // state silently, and is refused.
+    const bool capturing = stream_is_capturing(stream);
+    if (capturing) {
+        if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW)
+            return fail(MRHIP_ERR_UNSUPPORTED, "FIRArbitrary/FIRFarrow calls cannot be captured in a HIP graph (the phase schedule is uploaded per call)");
+        const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len);
+        if (p.short_input || p.phi_end != p.phi0 || p.d_end != p.d0)
+            return fail(MRHIP_ERR_UNSUPPORTED, "a captured filt! call must leave (phiIdx, inputDeficit) unchanged (x_len a multiple of the decimation): a replay would reuse the capture-time state");
+    } else if (int rc = adopt_stream(f, stream)) {
+        return rc;
+    }
 
     int64_t n_out = 0;
     bool did_shiftin = false;
@@ -662,19 +733,29 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             static const bool prof = [] { const char *v = std::getenv("MRHIP_DEBUG"); return v && v[0] == '2'; }();
             double t_rec = 0, t_copy = 0, t_launch = 0;
             auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            // an error in the middle of the pipeline: uploads from the pinned staging may still be in flight, so mark
+            // them (the next call waits before it reuses the staging) and report how far the launches got; the
+            // filter state is not advanced
+            auto bail = [&](int rc) -> int {
+                if (hipEventRecord(f->sched_copied, stream) == hipSuccess) f->sched_in_flight = true;
+                else { (void)hipGetLastError(); (void)hipStreamSynchronize(stream); }
+                if (n_written) *n_written = k0;
+                return rc;
+            };
             while (!done) {
                 int32_t *pn = static_cast<int32_t *>(f->pin_n) + k0;
                 double *pa = static_cast<double *>(f->pin_acc) + k0;
                 const int64_t room = std::min<int64_t>(piece, est - k0);
-                if (room <= 0) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");   // cannot happen: est is an upper bound
+                if (room <= 0) return bail(fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small"));   // cannot happen: est is an upper bound
                 const double t0 = prof ? now() : 0;
                 const int64_t cnt = run_arbitrary_schedule_piece(st, f->delta, f->Nphi, x_len, pn, pa, room, &done);
                 const double t1 = prof ? now() : 0;
                 if (cnt > 0) {
-                    MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<int32_t *>(f->d_sched_n) + k0, pn, static_cast<size_t>(cnt) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-                    MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<double *>(f->d_sched_acc) + k0, pa, static_cast<size_t>(cnt) * sizeof(double), hipMemcpyHostToDevice, stream));
+                    if (hipMemcpyAsync(static_cast<int32_t *>(f->d_sched_n) + k0, pn, static_cast<size_t>(cnt) * sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess ||
+                        hipMemcpyAsync(static_cast<double *>(f->d_sched_acc) + k0, pa, static_cast<size_t>(cnt) * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess)
+                        return bail(fail(MRHIP_ERR_HIP, "uploading the phase schedule failed"));
                     const double t2 = prof ? now() : 0;
-                    if (int rc = launch_range(k0, cnt, pn)) return rc;
+                    if (int rc = launch_range(k0, cnt, pn)) return bail(rc);
                     if (prof) { t_rec += t1 - t0; t_copy += t2 - t1; t_launch += now() - t2; }
                     k0 += cnt;
                 }
@@ -731,14 +812,20 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
     }
 
     // history <- last H samples of [history ; x]   (shiftin!, support.jl:61-80), ping-pong buffers
-    if (f->H > 0 && did_shiftin) {
-        f->hist_cur ^= 1;
-    } else if (f->H > 0) {
+    if (f->H > 0 && !did_shiftin) {
         HistArgs ha{};
         ha.x = x; ha.hist_old = f->d_hist[f->hist_cur]; ha.hist_new = f->d_hist[f->hist_cur ^ 1];
         ha.x_stride = x_stride; ha.x_len = x_len; ha.H = static_cast<int>(f->H); ha.nch = static_cast<int>(f->nch);
         MRHIP_CHECK_HIP(launch_shiftin(tk, ha, stream));
-        f->hist_cur ^= 1;
+    }
+    if (f->H > 0) {
+        if (capturing) {
+            // a replay reads the slot baked into the node: bring the new history back into it instead of flipping
+            MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_hist[f->hist_cur], f->d_hist[f->hist_cur ^ 1],
+                                           static_cast<size_t>(f->nch) * f->H * x_elt(f), hipMemcpyDeviceToDevice, stream));
+        } else {
+            f->hist_cur ^= 1;
+        }
     }
     if (n_written) *n_written = n_out;
     return MRHIP_OK;
@@ -753,9 +840,27 @@ int mrhip_filt_device_chunked(mrhip_filter *f, const void *x, int64_t x_len, int
     if (x_len < 0 || y_capacity < 0) return fail(MRHIP_ERR_INVALID_ARG, "negative length");
     const size_t xelt = dtype_scalar_size(f->tx) * static_cast<size_t>(f->nc);
     const size_t yelt = dtype_scalar_size(f->ty) * static_cast<size_t>(f->nc);
+    // The signal is resident, so for the pfb kernels the chunk loop collapses: the outputs of consecutive filt! calls
+    // are the outputs of one call over the concatenation (the dot product runs over the LOGICAL window [history ; x],
+    // support.jl:16-31, and the state recurrence is the same closed form, Filters.jl:558-571), bit for bit, and they
+    // land in the same places of y.  One launch per LAUNCH_MAX samples instead of one per chunk: a 1e6-sample chunk of
+    // one channel (7.7 MB) cannot fill 256 CUs for longer than the launch ramp.  FIRStandard/FIRDecimator keep the
+    // per-chunk loop: their seam dot product starts from zero (support.jl:46), which is visible per CALL (the sign of an
+    // all-(-0) sum); FIRArbitrary/FIRFarrow keep it because their wall time is the host's serial phase recurrence.
+    // MRHIP_CHUNKED_PER_CALL=1 forces the per-chunk loop (measurements of genuinely arriving chunks).
+    static const bool per_call = [] { const char *v = std::getenv("MRHIP_CHUNKED_PER_CALL"); return v && v[0] == '1'; }();
+    int64_t step = chunk;
+    if (!per_call && (f->kind == MRHIP_FIR_INTERPOLATOR || f->kind == MRHIP_FIR_RATIONAL) && chunk < x_len) {
+        const int64_t total = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len).n_out;
+        // an undersized buffer must fail at the piece the caller's own loop would fail at: leave that to the loop
+        if (total <= y_capacity && (f->nch == 1 || y_stride >= total)) {
+            const int64_t launch_max = (1LL << 30) / (f->kind == MRHIP_FIR_INTERPOLATOR ? f->L : 1);   // inputs and outputs per launch stay below 2^31
+            step = std::max<int64_t>(chunk, launch_max / chunk * chunk);     // whole chunks per launch
+        }
+    }
     int64_t k = 0;
-    for (int64_t a = 0; a < x_len; a += chunk) {
-        const int64_t len = std::min<int64_t>(chunk, x_len - a);
+    for (int64_t a = 0; a < x_len; a += step) {
+        const int64_t len = std::min<int64_t>(step, x_len - a);
         int64_t got = 0;
         const int rc = mrhip_filt_device(f, static_cast<const unsigned char *>(x) + static_cast<size_t>(a) * xelt, len, x_stride,
                                          static_cast<unsigned char *>(y) + static_cast<size_t>(k) * yelt, y_capacity - k, y_stride, &got, stream);
@@ -766,23 +871,29 @@ int mrhip_filt_device_chunked(mrhip_filter *f, const void *x, int64_t x_len, int
     return MRHIP_OK;
 }
 
-static int ensure_staging(mrhip_filter *f, size_t xbytes, size_t ybytes)
+static int ensure_staging(mrhip_filter *f, int slot, size_t xbytes, size_t ybytes)
 {
-    if (xbytes > f->d_xcap) {
-        if (f->d_xbuf) (void)hipFree(f->d_xbuf);
-        f->d_xbuf = nullptr; f->d_xcap = 0;
-        MRHIP_CHECK_HIP(hipMalloc(&f->d_xbuf, xbytes));
-        f->d_xcap = xbytes;
+    if (xbytes > f->d_xcap[slot]) {
+        if (f->d_xbuf[slot]) (void)hipFree(f->d_xbuf[slot]);
+        f->d_xbuf[slot] = nullptr; f->d_xcap[slot] = 0;
+        MRHIP_CHECK_HIP(hipMalloc(&f->d_xbuf[slot], xbytes));
+        f->d_xcap[slot] = xbytes;
     }
-    if (ybytes > f->d_ycap) {
-        if (f->d_ybuf) (void)hipFree(f->d_ybuf);
-        f->d_ybuf = nullptr; f->d_ycap = 0;
-        MRHIP_CHECK_HIP(hipMalloc(&f->d_ybuf, ybytes));
-        f->d_ycap = ybytes;
+    if (ybytes > f->d_ycap[slot]) {
+        if (f->d_ybuf[slot]) (void)hipFree(f->d_ybuf[slot]);
+        f->d_ybuf[slot] = nullptr; f->d_ycap[slot] = 0;
+        MRHIP_CHECK_HIP(hipMalloc(&f->d_ybuf[slot], ybytes));
+        f->d_ycap[slot] = ybytes;
     }
     return MRHIP_OK;
 }
 
+// Host-pointer path.  The signal is cut into pieces of 64 MiB of input (MRHIP_HOST_PIECE_KB); piece i is
+// copied in on s_in, filtered on own_stream and copied out on s_out, two staging slots each way, so that the H2D copy of
+// piece i+1 and the D2H copy of piece i-1 run beside the kernel of piece i and the two PCIe directions are busy at the
+// same time.  Chunked == unchunked bit for bit, so the pieces are invisible in the result.  With page-locked caller
+// buffers (hipHostMalloc / hipHostRegister) the copies are true DMA at PCIe rate; pageable buffers are staged by the
+// runtime and each copy call returns when its staging is done.
 int mrhip_filt_host(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y, int64_t y_capacity,
                     int64_t y_stride, int64_t *n_written)
 {
@@ -800,18 +911,67 @@ int mrhip_filt_host(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_str
     DeviceGuard guard(f->device);
     if (!guard.ok) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
     const size_t xe = x_elt(f), ye = y_elt(f);
-    const size_t xrow = static_cast<size_t>(x_len) * xe, yrow = static_cast<size_t>(count) * ye;
-    if (int rc = ensure_staging(f, std::max<size_t>(xrow * f->nch, 16), std::max<size_t>(yrow * f->nch, 16))) return rc;
-    hipStream_t s = f->own_stream;
-    MRHIP_CHECK_HIP(hipMemcpy2DAsync(f->d_xbuf, xrow, x, static_cast<size_t>(f->nch > 1 ? x_stride : x_len) * xe, xrow,
-                                     static_cast<size_t>(f->nch), hipMemcpyHostToDevice, s));
-    int64_t nw = 0;
-    if (int rc = mrhip_filt_device(f, f->d_xbuf, x_len, x_len, f->d_ybuf, count, count, &nw, s)) return rc;
-    if (nw > 0)
-        MRHIP_CHECK_HIP(hipMemcpy2DAsync(y, static_cast<size_t>(f->nch > 1 ? y_stride : nw) * ye, f->d_ybuf, yrow, yrow,
-                                         static_cast<size_t>(f->nch), hipMemcpyDeviceToHost, s));
-    MRHIP_CHECK_HIP(hipStreamSynchronize(s));
-    if (n_written) *n_written = nw;
+    // MRHIP_HOST_PIECE_KB (tests, tuning): input KiB per piece, read per call
+    const char *pv = std::getenv("MRHIP_HOST_PIECE_KB");
+    const int64_t piece_kb = pv && *pv && std::atoll(pv) > 0 ? std::atoll(pv) : 64 * 1024;
+    int64_t piece = (piece_kb << 10) / static_cast<int64_t>(xe * static_cast<size_t>(f->nch));
+    piece = std::max<int64_t>(piece, 256);
+    const bool pipelined = x_len > piece + piece / 2;
+    if (!pipelined) piece = x_len;
+    if (!f->s_in) {
+        MRHIP_CHECK_HIP(hipStreamCreateWithFlags(&f->s_in, hipStreamNonBlocking));
+        MRHIP_CHECK_HIP(hipStreamCreateWithFlags(&f->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_in[i], hipEventDisableTiming));
+            MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_k[i], hipEventDisableTiming));
+            MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_out[i], hipEventDisableTiming));
+        }
+    }
+    hipStream_t sk = f->own_stream;
+    // per-piece output bound (for sizing the staging): the exact count of the first piece + slack for the others
+    const int64_t y_piece_cap = pipelined ? std::max<int64_t>(mrhip_outputlength(f, piece), 0) + 8 + 2 * (f->L / std::max<int64_t>(f->M, 1) + 1) : count;
+    const int nslots = pipelined ? 2 : 1;
+    for (int sl = 0; sl < nslots; ++sl)
+        if (int rc = ensure_staging(f, sl, std::max<size_t>(static_cast<size_t>(piece) * xe * f->nch, 16),
+                                    std::max<size_t>(static_cast<size_t>(y_piece_cap) * ye * f->nch, 16))) return rc;
+    const size_t x_pitch = static_cast<size_t>(f->nch > 1 ? x_stride : x_len) * xe;
+    const size_t y_pitch = static_cast<size_t>(f->nch > 1 ? y_stride : count) * ye;
+    int64_t k = 0;
+    int it = 0;
+    bool used[2] = {false, false};
+    for (int64_t a = 0; a < x_len; a += piece, ++it) {
+        const int sl = it & 1;
+        const int64_t len = std::min<int64_t>(piece, x_len - a);
+        const size_t xrow = static_cast<size_t>(len) * xe;
+        // the x slot is free once the kernel of two pieces ago has run; the y slot once its D2H copy has
+        if (used[sl]) MRHIP_CHECK_HIP(hipStreamWaitEvent(f->s_in, f->ev_k[sl], 0));
+        MRHIP_CHECK_HIP(hipMemcpy2DAsync(f->d_xbuf[sl], xrow, static_cast<const unsigned char *>(x) + static_cast<size_t>(a) * xe, x_pitch, xrow,
+                                         static_cast<size_t>(f->nch), hipMemcpyHostToDevice, f->s_in));
+        MRHIP_CHECK_HIP(hipEventRecord(f->ev_in[sl], f->s_in));
+        MRHIP_CHECK_HIP(hipStreamWaitEvent(sk, f->ev_in[sl], 0));
+        if (used[sl]) MRHIP_CHECK_HIP(hipStreamWaitEvent(sk, f->ev_out[sl], 0));
+        const int64_t cap = std::min<int64_t>(y_piece_cap, count - k);
+        int64_t nw = 0;
+        // (an undersized slot cannot happen: y_piece_cap bounds every piece; the whole call was checked against y_capacity)
+        if (int rc = mrhip_filt_device(f, f->d_xbuf[sl], len, len, f->d_ybuf[sl], cap, std::max<int64_t>(cap, 1), &nw, sk)) {
+            (void)hipStreamSynchronize(f->s_in); (void)hipStreamSynchronize(sk); (void)hipStreamSynchronize(f->s_out);
+            if (n_written) *n_written = k;
+            return rc;
+        }
+        MRHIP_CHECK_HIP(hipEventRecord(f->ev_k[sl], sk));
+        if (nw > 0) {
+            MRHIP_CHECK_HIP(hipStreamWaitEvent(f->s_out, f->ev_k[sl], 0));
+            const size_t yrow = static_cast<size_t>(nw) * ye;
+            MRHIP_CHECK_HIP(hipMemcpy2DAsync(static_cast<unsigned char *>(y) + static_cast<size_t>(k) * ye, y_pitch, f->d_ybuf[sl],
+                                             static_cast<size_t>(std::max<int64_t>(cap, 1)) * ye, yrow, static_cast<size_t>(f->nch), hipMemcpyDeviceToHost, f->s_out));
+        }
+        MRHIP_CHECK_HIP(hipEventRecord(f->ev_out[sl], f->s_out));
+        used[sl] = true;
+        k += nw;
+    }
+    MRHIP_CHECK_HIP(hipStreamSynchronize(f->s_out));
+    MRHIP_CHECK_HIP(hipStreamSynchronize(sk));
+    if (n_written) *n_written = k;
     return MRHIP_OK;
 }
 

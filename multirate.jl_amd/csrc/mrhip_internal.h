@@ -299,10 +299,20 @@ struct mrhip_filter {
     hipEvent_t sched_copied = nullptr;
     bool sched_in_flight = false;
 
-    // host-pointer path staging
-    void *d_xbuf = nullptr, *d_ybuf = nullptr;
-    size_t d_xcap = 0, d_ycap = 0;
-    hipStream_t own_stream = nullptr;
+    // host-pointer path staging: two slots each way (H2D of piece i+1 and D2H of piece i-1 overlap the kernel of
+    // piece i: copy streams s_in / s_out beside the kernel stream own_stream, ordered by the events below)
+    void *d_xbuf[2] = {nullptr, nullptr}, *d_ybuf[2] = {nullptr, nullptr};
+    size_t d_xcap[2] = {0, 0}, d_ycap[2] = {0, 0};
+    hipStream_t own_stream = nullptr, s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+
+    // Stream ordering of the per-filter device state (history ping-pong, counters, schedule buffers): every call
+    // enqueues on the caller's stream; when a call arrives on a DIFFERENT stream than the previous one, an event is
+    // recorded on the previous stream and the new stream waits for it (adopt_stream in api.hip).  Nothing is paid while
+    // a filter stays on one stream.
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
+    hipEvent_t xs_event = nullptr;
 
     // measurement
     bool timing = false;

@@ -70,12 +70,18 @@ ABI = [
     ("mrhip_inputlength_ratio", _i64, [_i64, _i64, _i64, _i64]),
     ("mrhip_polyfit", _i, [_vp, _i64, _i64, _vp]),
     ("mrhip_output_dtype", _i, [_i, _i]),
+    ("mrhip_kaiserlength", _i, [_d, _d, _d, _pi64, C.POINTER(C.c_double)]),
+    ("mrhip_kaiser", _i, [_i64, _d, _vp]),
+    ("mrhip_firprototype", _i64, [_i64, _vp, _i, _i, _vp]),
+    ("mrhip_firdes", _i64, [_i64, _vp, _i, _i, _d, _d, _vp, _vp]),
+    ("mrhip_firdes_kaiser", _i64, [_vp, _i, _d, _d, _i, _d, _vp]),
     ("mrhip_create_rational", _i, [_vp, _i64, _i, _i64, _i64, _i, _i64, _i, C.POINTER(_vp)]),
     ("mrhip_create_arbitrary", _i, [_vp, _i64, _i, _d, _i64, _i, _i64, _i, C.POINTER(_vp)]),
     ("mrhip_create_farrow", _i, [_vp, _i64, _i, _d, _i64, _i64, _i, _i64, _i, C.POINTER(_vp)]),
     ("mrhip_create_farrow_pnfb", _i, [_vp, _i64, _i, _d, _i64, _i64, _i, _i64, _i, C.POINTER(_vp)]),
     ("mrhip_get_pnfb", _i, [_vp, _vp]),
     ("mrhip_farrow_tapsforphase", _i, [_vp, _d, _vp]),
+    ("mrhip_arbitrary_tapsforphase", _i, [_vp, _d, _vp]),
     ("mrhip_destroy", None, [_vp]),
     ("mrhip_outputlength", _i64, [_vp, _i64]),
     ("mrhip_next_output_count", _i64, [_vp, _i64]),
@@ -91,6 +97,12 @@ ABI = [
     ("mrhip_filt_device_chunked", _i, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
     ("mrhip_filt_host", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64]),
     ("mrhip_synchronize", _i, [_vp, _vp]),
+    ("mrhip_cascade_create", _i, [C.POINTER(_vp), _i, C.POINTER(_vp)]),
+    ("mrhip_cascade_destroy", None, [_vp]),
+    ("mrhip_cascade_outputlength", _i64, [_vp, _i64]),
+    ("mrhip_cascade_next_output_count", _i64, [_vp, _i64]),
+    ("mrhip_cascade_filt_device", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
+    ("mrhip_cascade_reset", _i, [_vp]),
     ("mrhip_filt_once", _i, [_vp, _i64, _i, _i64, _i64, _d, _i64, _vp, _i64, _i, _vp, _i64, _pi64, _i]),
     ("mrhip_set_timing", _i, [_vp, _i]),
     ("mrhip_timing_read", _i, [_vp, _pi64, C.POINTER(C.c_double)]),
@@ -349,11 +361,13 @@ class FIRFilter:
         return out
 
     def tapsforphase(self, phase: float) -> np.ndarray:
-        """tapsforphase(kernel::FIRFarrow, phase), src/Filters.jl:764-775."""
-        if self._handle is None or self.kind != FARROW:
-            raise MultirateHIPError(1, "tapsforphase() needs a bound FIRFarrow filter")
+        """tapsforphase(kernel::FIRArbitrary, phase), src/Filters.jl:677-690, and
+        tapsforphase(kernel::FIRFarrow, phase), src/Filters.jl:764-775."""
+        if self._handle is None or self.kind not in (ARBITRARY, FARROW):
+            raise MultirateHIPError(1, "tapsforphase() needs a bound FIRArbitrary or FIRFarrow filter")
         out = np.zeros(self.tapsPerPhi, dtype=self.h.dtype)
-        _check(self._lib.mrhip_farrow_tapsforphase(self._handle, float(phase), _ptr(out)))
+        fn = self._lib.mrhip_farrow_tapsforphase if self.kind == FARROW else self._lib.mrhip_arbitrary_tapsforphase
+        _check(fn(self._handle, float(phase), _ptr(out)))
         return out
 
     def setphase(self, phi: float):
@@ -546,20 +560,56 @@ def filt(a, x, ratio=Fraction(1, 1), Nphi: int = 32, polyorder=None, **kw):
 
 
 class FilterCascade:
-    """Device-resident cascade (no reference counterpart): ``filt`` runs the stages back to back on
-    the current stream -- the intermediate signals never leave HBM and, because every output count is closed-form
-    on the host, nothing is read back between stages.  Each stage is an ordinary stateful FIRFilter, so chunked
-    calls continue the stream exactly like calling the stages by hand (e.g. decimate 1//4, then 147//160)."""
+    """Device-resident cascade (the reference chains ``filt`` calls by hand): ``filt`` runs the stages
+    back to back on the current stream through the library's cascade object (``mrhip_cascade_*``) -- the intermediate
+    signals live in device buffers the cascade owns and never leave HBM and, because every output count is
+    closed-form on the host, nothing is read back between stages.  Each stage is an ordinary stateful FIRFilter, so
+    chunked calls continue the stream exactly like calling the stages by hand (e.g. decimate 1//4, then 147//160).
+    numpy inputs take the stages' host path one after the other."""
 
     def __init__(self, *stages: "FIRFilter"):
         if not stages or not all(isinstance(f, FIRFilter) for f in stages):
             raise MultirateHIPError(1, "FilterCascade takes one or more FIRFilter stages")
         self.stages = tuple(stages)
+        self._lib = load_library()
+        self._handle = None
+
+    def _ensure(self, tx, nch: int):
+        if self._handle is not None:
+            return
+        for f in self.stages:                      # stage i+1's sample type is stage i's output type
+            f._ensure(np.dtype(tx), nch)
+            tx = f.output_dtype
+        arr = (C.c_void_p * len(self.stages))(*[f._handle for f in self.stages])
+        out = C.c_void_p()
+        _check(self._lib.mrhip_cascade_create(arr, len(self.stages), C.byref(out)))
+        self._handle = out
+
+    @property
+    def output_dtype(self):
+        return self.stages[-1].output_dtype
 
     def filt(self, x):
-        for f in self.stages:
-            x = f.filt(x)
-        return x
+        if not _is_torch(x):
+            for f in self.stages:
+                x = f.filt(x)
+            return x
+        if not x.is_cuda:
+            raise MultirateHIPError(1, "torch input must live on the GPU (use numpy for host data)")
+        one = x.ndim == 1
+        nch, n = (1, x.shape[0]) if one else (x.shape[0], x.shape[1])
+        self._ensure(_torch_np_dtype(x.dtype), nch)
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        cnt = max(self._lib.mrhip_cascade_next_output_count(self._handle, n), 0)
+        y = torch.empty((nch, cnt), dtype=_np_torch_dtype(self.output_dtype), device=x.device)
+        nw = C.c_int64(0)
+        xs = x.stride(0) if (not one and nch > 1) else n
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(self._lib.mrhip_cascade_filt_device(self._handle, C.c_void_p(x.data_ptr()), n, xs, C.c_void_p(y.data_ptr()),
+                                                   cnt, max(cnt, 1), C.byref(nw), C.c_void_p(stream)))
+        assert nw.value == cnt
+        return y[0] if one else y
 
     def outputlength(self, inputlength: int) -> int:
         n = int(inputlength)
@@ -573,8 +623,19 @@ class FilterCascade:
         return self
 
     def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.mrhip_cascade_destroy(self._handle)
+            self._handle = None
         for f in self.stages:
             f.close()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                self._lib.mrhip_cascade_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
 
 
 def filt_(buffer, self: FIRFilter, x):
@@ -606,5 +667,5 @@ def setphase(self: FIRFilter, phi: float):
 
 
 def tapsforphase(self: FIRFilter, phase: float) -> np.ndarray:
-    """tapsforphase(kernel::FIRFarrow, phase), src/Filters.jl:775."""
+    """tapsforphase(kernel::FIRArbitrary, phase), src/Filters.jl:690; tapsforphase(kernel::FIRFarrow, phase), :775."""
     return self.tapsforphase(phase)

@@ -2,7 +2,7 @@
 #
 # Drop-in for the hot path of Multirate.jl's src/Filters.jl: same type and function names
 # (FIRFilter, FIRStandard/FIRDecimator/FIRInterpolator/FIRRational/FIRArbitrary/FIRFarrow, filt, filt!,
-# taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, polyfit), same argument meaning, same return values,
+# taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, polyfit, firdes, firprototype, kaiserlength), same argument meaning, same return values,
 # same errors -- every method body is a ccall.  Modern Julia (>= 1.6) syntax; the reference is
 # Julia-0.3 source and cannot be loaded by a current Julia, so this module stands beside it rather
 # than patching it.  See INTEGRATION.md for how a maintainer wires it into Multirate.jl.
@@ -13,7 +13,9 @@
 module MultirateHIP
 
 export FIRFilter, FIRKernel, FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary, FIRFarrow,
-       filt, filt!, taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, polyfit
+       filt, filt!, taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, polyfit,
+       firdes, firprototype, kaiserlength, kaiser, FIRResponse, LOWPASS, BANDPASS, HIGHPASS, BANDSTOP,
+       FilterCascade, filt_device!, filt_device_chunked!
 
 const libmr = get(ENV, "MRHIP_LIB_PATH", joinpath(@__DIR__, "..", "libmultirate_hip.so"))
 
@@ -156,6 +158,13 @@ function tapsforphase(f::FIRFilter{FIRFarrow}, phase::Real)
     check(ccall((:mrhip_farrow_tapsforphase, libmr), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Cvoid}), f.handle, Float64(phase), taps))
     taps
 end
+# tapsforphase(kernel::FIRArbitrary, phase)                src/Filters.jl:677-690
+function tapsforphase(f::FIRFilter{FIRArbitrary}, phase::Real)
+    f.handle == C_NULL && error("tapsforphase needs a bound filter (call filt once)")
+    taps = Vector{eltype(f.h)}(undef, state(f).tapsPerPhi)
+    check(ccall((:mrhip_arbitrary_tapsforphase, libmr), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Cvoid}), f.handle, Float64(phase), taps))
+    taps
+end
 # setphase(self::FIRFilter, 𝜙), 𝜙 in [0, 1]                src/Filters.jl:210-235.  The reference's methods for
 # FIRInterpolator/FIRRational read an undefined variable (:212); implemented with the evident intent
 # (𝜙Idx = floor(𝜙*N𝜙)+1 clipped to N𝜙); FIRArbitrary and FIRFarrow as written (:217-229).
@@ -175,6 +184,60 @@ function setphase(f::FIRFilter{FIRFarrow}, phi::Real)
     @assert 0 <= phi <= 1
     st = state(f); acc = phi * (st.Nphi - 1) + 1
     setstate!(f, 1, st.inputDeficit, acc); acc
+end
+
+# ---- FIR design (src/FIRDesign.jl), host only --------------------------------------------------------
+@enum FIRResponse LOWPASS = 0 BANDPASS = 1 HIGHPASS = 2 BANDSTOP = 3        # src/FIRDesign.jl:7
+# kaiserlength(transition, attenuation = 60; samplerate = 1.0) -> (numtaps, β)   src/FIRDesign.jl:18-33
+function kaiserlength(transition::Real, attenuation::Real = 60; samplerate = 1.0)
+    n = Ref{Int64}(0); b = Ref{Cdouble}(0.0)
+    check(ccall((:mrhip_kaiserlength, libmr), Cint, (Cdouble, Cdouble, Cdouble, Ptr{Int64}, Ptr{Cdouble}),
+                Float64(transition), Float64(attenuation), Float64(samplerate), n, b))
+    (Int(n[]), b[])
+end
+# the window firdes uses when windowfunction == kaiser (beta taken as is, src/Window.jl:53-58)
+function kaiser(n::Integer, beta::Real)
+    w = Vector{Float64}(undef, n)
+    check(ccall((:mrhip_kaiser, libmr), Cint, (Int64, Cdouble, Ptr{Cdouble}), n, Float64(beta), w))
+    w
+end
+cutoffs(F::Real) = Float64[F]
+cutoffs(F::AbstractVector) = Vector{Float64}(F)
+# firprototype(numtaps, F; response = LOWPASS)                                   src/FIRDesign.jl:47-66
+function firprototype(numtaps::Integer, F::Union{Real,AbstractVector}; response::FIRResponse = LOWPASS)
+    f = cutoffs(F)
+    n = ccall((:mrhip_firprototype, libmr), Int64, (Int64, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}), numtaps, f, length(f), Cint(response), C_NULL)
+    n < 0 && error(lasterror())
+    out = Vector{Float64}(undef, n)
+    ccall((:mrhip_firprototype, libmr), Int64, (Int64, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}), numtaps, f, length(f), Cint(response), out)
+    out
+end
+# firdes(numtaps, cutoff, windowfunction; response, samplerate, beta)            src/FIRDesign.jl:76-88
+function firdes(numtaps::Integer, cutoff::Union{Real,AbstractVector}, windowfunction::Function = kaiser;
+                response::FIRResponse = LOWPASS, samplerate = 1.0, beta = 6.75)
+    c = cutoffs(cutoff)
+    args = (Int64, Ptr{Cdouble}, Cint, Cint, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble})
+    n = ccall((:mrhip_firdes, libmr), Int64, args, numtaps, c, length(c), Cint(response), Float64(samplerate), Float64(beta), C_NULL, C_NULL)
+    n < 0 && error(lasterror())
+    out = Vector{Float64}(undef, n)
+    if windowfunction == kaiser
+        ccall((:mrhip_firdes, libmr), Int64, args, numtaps, c, length(c), Cint(response), Float64(samplerate), Float64(beta), C_NULL, out)
+    else
+        w = Vector{Float64}(windowfunction(n))
+        ccall((:mrhip_firdes, libmr), Int64, args, numtaps, c, length(c), Cint(response), Float64(samplerate), Float64(beta), w, out)
+    end
+    out
+end
+# firdes(cutoff, transitionwidth, stopbandAttenuation = 60; response, samplerate)  src/FIRDesign.jl:90-95
+function firdes(cutoff::Union{AbstractFloat,AbstractVector}, transitionwidth::Real, stopbandAttenuation::Real = 60;
+                response::FIRResponse = LOWPASS, samplerate = 1.0)
+    c = cutoffs(cutoff)
+    args = (Ptr{Cdouble}, Cint, Cdouble, Cdouble, Cint, Cdouble, Ptr{Cdouble})
+    n = ccall((:mrhip_firdes_kaiser, libmr), Int64, args, c, length(c), Float64(transitionwidth), Float64(stopbandAttenuation), Cint(response), Float64(samplerate), C_NULL)
+    n < 0 && error(lasterror())
+    out = Vector{Float64}(undef, n)
+    ccall((:mrhip_firdes_kaiser, libmr), Int64, args, c, length(c), Float64(transitionwidth), Float64(stopbandAttenuation), Cint(response), Float64(samplerate), out)
+    out
 end
 
 # ---- the hot path --------------------------------------------------------------------------------
@@ -240,5 +303,56 @@ function filt_device_chunked!(f::FIRFilter, yptr::Ptr{Cvoid}, ycap::Integer, yst
                 f.handle, xptr, xlen, xstride, chunk, yptr, ycap, ystride, nw, stream))
     Int(nw[])
 end
+
+# Device arrays with the strided-array interface (AMDGPU.jl's ROCArray: `pointer`, `size`, `stride`, `eltype`), one
+# channel per column: filt!(buffer, f, x) without copies, asynchronous on `stream`.  Kept generic so that this file
+# does not depend on AMDGPU.jl; host Arrays keep the methods above.
+devptr(A) = Ptr{Cvoid}(UInt(pointer(A)))
+colstride(A) = ndims(A) > 1 ? stride(A, 2) : size(A, 1)
+function filt_device!(buffer, f::FIRFilter, x; stream::Ptr{Cvoid} = C_NULL)
+    stride(x, 1) == 1 && stride(buffer, 1) == 1 || error("x and buffer must be contiguous along time (one channel per column)")
+    filt_device!(f, devptr(buffer), size(buffer, 1), colstride(buffer), devptr(x), size(x, 1), colstride(x), eltype(x), size(x, 2); stream = stream)
+end
+function filt_device_chunked!(buffer, f::FIRFilter, x, chunk::Integer; stream::Ptr{Cvoid} = C_NULL)
+    stride(x, 1) == 1 && stride(buffer, 1) == 1 || error("x and buffer must be contiguous along time (one channel per column)")
+    filt_device_chunked!(f, devptr(buffer), size(buffer, 1), colstride(buffer), devptr(x), size(x, 1), colstride(x), chunk, eltype(x), size(x, 2); stream = stream)
+end
+
+# ---- cascades (mrhip_cascade_*): stages chained on the device, intermediates resident in HBM -------------------
+mutable struct FilterCascade
+    stages::Vector{FIRFilter}
+    handle::Ptr{Cvoid}
+    function FilterCascade(stages::FIRFilter...)
+        isempty(stages) && error("FilterCascade takes one or more FIRFilter stages")
+        c = new(collect(FIRFilter, stages), C_NULL)
+        finalizer(c -> (c.handle == C_NULL || ccall((:mrhip_cascade_destroy, libmr), Cvoid, (Ptr{Cvoid},), c.handle); c.handle = C_NULL), c)
+    end
+end
+function bind!(c::FilterCascade, ::Type{Tx}, nch::Integer) where {Tx}
+    c.handle == C_NULL || return c
+    T = Tx
+    for f in c.stages                       # stage i+1's sample type is stage i's output type
+        bind!(f, T, nch); T = promote_out(eltype(f.h), T)
+    end
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    hs = Ptr{Cvoid}[f.handle for f in c.stages]
+    check(ccall((:mrhip_cascade_create, libmr), Cint, (Ptr{Ptr{Cvoid}}, Cint, Ptr{Ptr{Cvoid}}), hs, length(hs), out))
+    c.handle = out[]
+    c
+end
+outputlength(c::FilterCascade, n::Integer) = Int(ccall((:mrhip_cascade_outputlength, libmr), Int64, (Ptr{Cvoid}, Int64), c.handle, n))
+nextoutputcount(c::FilterCascade, n::Integer) = Int(ccall((:mrhip_cascade_next_output_count, libmr), Int64, (Ptr{Cvoid}, Int64), c.handle, n))
+reset(c::FilterCascade) = (c.handle == C_NULL || check(ccall((:mrhip_cascade_reset, libmr), Cint, (Ptr{Cvoid},), c.handle)); c)
+# filt!(buffer, cascade, x) on device arrays: returns the per-channel output count
+function filt_device!(buffer, c::FilterCascade, x; stream::Ptr{Cvoid} = C_NULL)
+    bind!(c, eltype(x), size(x, 2))
+    nw = Ref{Int64}(0)
+    check(ccall((:mrhip_cascade_filt_device, libmr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Cvoid}),
+                c.handle, devptr(x), size(x, 1), colstride(x), devptr(buffer), size(buffer, 1), colstride(buffer), nw, stream))
+    Int(nw[])
+end
+# host arrays: the stages' host path one after the other (what a user of the reference writes by hand)
+filt(c::FilterCascade, x::VecOrMat) = foldl((sig, f) -> filt(f, sig), c.stages; init = x)
 
 end # module

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Callable, Optional
 
+import numpy as np
+
 
 def shard_channels(nchannels: int, world_size: int, rank: int):
     """Contiguous split; the first ``nchannels % world_size`` ranks get one extra channel.
@@ -22,33 +24,46 @@ def shard_channels(nchannels: int, world_size: int, rank: int):
     return start, count
 
 
+def _promoted_dtype(h, x_dtype):
+    """promote_type(Th, Tx) (every filt wrapper of the reference, e.g. src/Filters.jl:581) as a torch dtype"""
+    import torch
+    h_f64 = np.asarray(h).dtype != np.float32
+    cplx = x_dtype in (torch.complex64, torch.complex128)
+    f64 = h_f64 or x_dtype in (torch.float64, torch.complex128)
+    return (torch.complex128 if f64 else torch.complex64) if cplx else (torch.float64 if f64 else torch.float32)
+
+
 class ChannelShardedFilter:
     """A FIRFilter over ``nchannels`` global channels of which this rank filters its shard.
 
     ``filter_factory()`` must return an object with the FIRFilter interface (``filt(x)`` on a
     ``(local_channels, n)`` array/tensor).  The default builds the HIP-backed ``FIRFilter`` on this
-    rank's device; tests inject their own factory to exercise the sharding and gather logic on CPU.
+    rank's device (all constructor forms: ratio, rate + N𝜙, rate + N𝜙 + polyorder); tests inject
+    their own factory to exercise the sharding and gather logic on CPU.
     """
 
-    def __init__(self, h, ratio, nchannels: int, *, Nphi: int = 32, rank: Optional[int] = None,
-                 world_size: Optional[int] = None, device: Optional[int] = None,
+    def __init__(self, h, ratio, nchannels: int, *, Nphi: int = 32, polyorder=None, numerics: Optional[int] = None,
+                 rank: Optional[int] = None, world_size: Optional[int] = None, device: Optional[int] = None,
                  filter_factory: Optional[Callable] = None, group=None):
         import torch.distributed as dist
         self._dist = dist
         self.group = group
+        self._h = h
         if world_size is None:
             world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rank, self.world_size, self.nchannels = rank, world_size, nchannels
         self.start, self.count = shard_channels(nchannels, world_size, rank)
+        self.counts = [shard_channels(nchannels, world_size, r)[1] for r in range(world_size)]
         if filter_factory is None:
-            from .host import FIRFilter
+            from .host import FIRFilter, NUMERICS_STRICT
 
             def filter_factory():
                 import torch
                 dev = device if device is not None else torch.cuda.current_device()
-                return FIRFilter(h, ratio, Nphi, device=dev)
+                return FIRFilter(h, ratio, Nphi, polyorder, device=dev,
+                                 numerics=NUMERICS_STRICT if numerics is None else numerics)
         self.filter = filter_factory() if self.count > 0 else None
 
     def local_slice(self, x_global):
@@ -57,23 +72,56 @@ class ChannelShardedFilter:
 
     def filt(self, x_local):
         """Filter this rank's channels: x_local is (count, n).  No communication."""
-        if self.filter is None:
-            return x_local[:, :0]
+        if self.filter is None:    # a rank without channels: an empty shard of the PROMOTED output type
+            import torch
+            return torch.empty((0, 0), dtype=_promoted_dtype(self._h, x_local.dtype), device=x_local.device)
         return self.filter.filt(x_local)
 
-    def gather(self, y_local, dst: int = 0):
+    def _common_n_out(self, y_local):
+        """per-channel output count, agreed over the ranks (a rank without channels has none of its own)"""
+        import torch
+        n_out = torch.tensor([y_local.shape[1]], dtype=torch.int64, device=y_local.device)
+        self._dist.all_reduce(n_out, op=self._dist.ReduceOp.MAX, group=self.group)
+        return int(n_out.item())
+
+    @staticmethod
+    def _real_view(y):
+        """complex (c, n) -> real (c, 2n) view of the same memory: the collectives move plain floats"""
+        import torch
+        y = y.contiguous()
+        return torch.view_as_real(y).reshape(y.shape[0], 2 * y.shape[1]) if y.is_complex() else y
+
+    @staticmethod
+    def _complex_view(r):
+        import torch
+        return torch.view_as_complex(r.reshape(r.shape[0], r.shape[1] // 2, 2))
+
+    def gather(self, y_local, dst: int = 0, n_out: Optional[int] = None):
         """Gather the per-rank outputs (torch tensors, (count_r, n_out)) on ``dst``; returns the
-        (nchannels, n_out) tensor there and None elsewhere.  Ranks may own different channel counts,
-        so shards are padded to the largest count for the collective and trimmed afterwards."""
+        (nchannels, n_out) tensor there and None elsewhere.  When every rank owns the same number of channels the
+        shards are received straight into row blocks of the result (no staging copies); otherwise shards are
+        padded to the largest count for the collective and trimmed afterwards."""
+        if self.world_size == 1 or not self._dist.is_initialized():
+            return y_local
+        if y_local.is_complex():
+            r = self._gather_real(self._real_view(y_local), dst, None if n_out is None else 2 * n_out)
+            return None if r is None else self._complex_view(r)
+        return self._gather_real(y_local, dst, n_out)
+
+    def _gather_real(self, y_local, dst, n_out):
         import torch
         dist = self._dist
-        if self.world_size == 1 or not dist.is_initialized():
-            return y_local
-        counts = [shard_channels(self.nchannels, self.world_size, r)[1] for r in range(self.world_size)]
-        cmax = max(counts)
-        n_out = torch.tensor([y_local.shape[1]], dtype=torch.int64, device=y_local.device)
-        dist.all_reduce(n_out, op=dist.ReduceOp.MAX, group=self.group)
-        n_out = int(n_out.item())
+        counts, cmax = self.counts, max(self.counts)
+        if n_out is None:     # callers that know the per-channel output count (it is closed-form) save this all-reduce
+            n_out = self._common_n_out(y_local)
+        if min(counts) == cmax:
+            y_local = y_local.contiguous()
+            if self.rank == dst:
+                out = torch.empty((self.nchannels, n_out), dtype=y_local.dtype, device=y_local.device)
+                dist.gather(y_local, list(out.split(cmax, dim=0)), dst=dst, group=self.group)
+                return out
+            dist.gather(y_local, None, dst=dst, group=self.group)
+            return None
         pad = torch.zeros((cmax, n_out), dtype=y_local.dtype, device=y_local.device)
         pad[: y_local.shape[0], : y_local.shape[1]] = y_local
         if self.rank == dst:
@@ -83,17 +131,27 @@ class ChannelShardedFilter:
         dist.gather(pad, None, dst=dst, group=self.group)
         return None
 
-    def all_gather(self, y_local):
+    def all_gather(self, y_local, n_out: Optional[int] = None):
         """Every rank receives the full (nchannels, n_out) output (ring all-gather over xGMI)."""
+        if self.world_size == 1 or not self._dist.is_initialized():
+            return y_local
+        if y_local.is_complex():
+            return self._complex_view(self._all_gather_real(self._real_view(y_local), None if n_out is None else 2 * n_out))
+        return self._all_gather_real(y_local, n_out)
+
+    def _all_gather_real(self, y_local, n_out):
         import torch
         dist = self._dist
-        if self.world_size == 1 or not dist.is_initialized():
-            return y_local
-        counts = [shard_channels(self.nchannels, self.world_size, r)[1] for r in range(self.world_size)]
-        cmax = max(counts)
-        pad = torch.zeros((cmax, y_local.shape[1]), dtype=y_local.dtype, device=y_local.device)
-        pad[: y_local.shape[0]] = y_local
-        out = torch.empty((self.world_size * cmax, y_local.shape[1]), dtype=y_local.dtype, device=y_local.device)
+        counts, cmax = self.counts, max(self.counts)
+        if n_out is None:
+            n_out = self._common_n_out(y_local)
+        if min(counts) == cmax:        # equal shards: gather straight into the result
+            out = torch.empty((self.nchannels, n_out), dtype=y_local.dtype, device=y_local.device)
+            dist.all_gather_into_tensor(out, y_local.contiguous(), group=self.group)
+            return out
+        pad = torch.zeros((cmax, n_out), dtype=y_local.dtype, device=y_local.device)
+        pad[: y_local.shape[0], : y_local.shape[1]] = y_local
+        out = torch.empty((self.world_size * cmax, n_out), dtype=y_local.dtype, device=y_local.device)
         dist.all_gather_into_tensor(out, pad, group=self.group)
         out = out.view(self.world_size, cmax, -1)
         return torch.cat([out[r, :c] for r, c in enumerate(counts)], dim=0)

@@ -40,7 +40,6 @@ def test_extension_is_loaded_and_device_is_gfx950(pkg, torch_cuda):
     assert lib.mrhip_device_count() >= 1
     maps = open("/proc/self/maps").read()
     assert "libmultirate_hip.so" in maps, "native library not loaded"
-    assert "libmultirate_oracle" not in maps or True
 
 
 def test_reference_known_answers_on_gpu(pkg, known_answers, torch_cuda):
@@ -248,8 +247,21 @@ def test_headline_c2_streaming_1e8_vs_oracle(pkg, O, torch_cuda):
         outs = [f.filt(xd[a:a + chunk]) for a in range(0, n, chunk)]
         y = torch.cat(outs).cpu().numpy()
         assert_bit_equal(y, yo, f"chunk {chunk}")
+        st = (f.state.phiIdx, f.state.inputDeficit)
+        hist = f.history
         f.close()
         del outs, y
+        # the library's own chunk loop (mrhip_filt_device_chunked: the resident signal in ONE launch): same outputs,
+        # same end state, same history
+        f = pkg.FIRFilter(h, Fraction(147, 160)).bind(np.float32, 1)
+        yd = torch.empty(len(yo) + 8, device="cuda", dtype=torch.float32)
+        assert f.filt_into_chunked(yd, xd, chunk) == len(yo)
+        assert f.last_kernel_name() == "rational_pair_kernel"
+        assert_bit_equal(yd[:len(yo)].cpu().numpy(), yo, f"chunked entry, chunk {chunk}")
+        assert (f.state.phiIdx, f.state.inputDeficit) == st
+        assert_bit_equal(f.history, hist, "history after the chunked entry")
+        f.close()
+        del yd
 
 
 def test_headline_64ch_properties(pkg, O, torch_cuda):
@@ -503,7 +515,7 @@ def test_fused_numerics_bit_exact_vs_fused_oracle(pkg, O, torch_cuda):
         O.set_fused(False)
 
 
-def test_config5_4096_channels_complex_one_gpu(pkg, torch_cuda, monkeypatch):
+def test_config5_4096_channels_complex_one_gpu(pkg, O, torch_cuda, monkeypatch):
     """BASELINE config 5's full channel count on ONE GPU (4096 x ComplexF32 147//160; per-channel length reduced):
     channel offsets pass 4 GiB, so every 32-bit offset in the kernels is exercised.  Tuned == universal kernel bit
     for bit on all channels (checksum) and element-wise on a few; channel independence (a channel of the batch ==
@@ -528,6 +540,12 @@ def test_config5_4096_channels_complex_one_gpu(pkg, torch_cuda, monkeypatch):
         y1 = pkg.FIRFilter(h, Fraction(147, 160)).filt(x[c].contiguous())
         assert torch.equal(torch.view_as_real(y1).view(torch.int32), a[c])
     assert_bit_equal(f.history[4095], gf.history[4095], "history")
+    # ... and the ORACLE itself on the full length of a few channels of the 4096-channel launch (first, last, one past
+    # the 4 GiB offset, one in the middle)
+    first_past_4g = (2 ** 32) // (n * 8) + 1
+    for c in (0, first_past_4g, 2048, 4095):
+        yo = O.FIRFilter(h, Fraction(147, 160), tx=np.complex64).filt(x[c].cpu().numpy())
+        assert_bit_equal(y[c].cpu().numpy(), yo, f"C5 channel {c} vs oracle")
 
 
 def test_farrow_errors_and_edge_cases(pkg, O, torch_cuda):
@@ -543,9 +561,9 @@ def test_farrow_errors_and_edge_cases(pkg, O, torch_cuda):
         pkg.FIRFilter(h, 1.1, 8, -1).bind(np.float32)
     fa = pkg.FIRFilter(h, 1.1, 8).bind(np.float32)
     with pytest.raises(pkg.MultirateHIPError):
-        fa.tapsforphase(1.0)                                    # not a Farrow filter
+        fa.pnfb()                                               # not a Farrow filter
     with pytest.raises(pkg.MultirateHIPError):
-        fa.pnfb()
+        pkg.FIRFilter(h, Fraction(2, 3)).bind(np.float32).tapsforphase(1.0)   # neither Arbitrary nor Farrow
     rng = np.random.default_rng(8)
     x = rng.random(300).astype(np.float32)
     for order in (0, 3):
@@ -569,14 +587,38 @@ def test_farrow_errors_and_edge_cases(pkg, O, torch_cuda):
     assert ei.value.code == 2 and f.state.phiAccumulator == st0
 
 
+def test_arbitrary_tapsforphase(pkg, torch_cuda):
+    """tapsforphase(kernel::FIRArbitrary, phase), src/Filters.jl:677-690: (alpha, phiIdx) = modf(phase);
+    pfb[:, phiIdx] + alpha * dpfb[:, phiIdx] in Float64 (alpha is a Float64), stored in the tap type."""
+    rng = np.random.default_rng(3)
+    for th in (np.float32, np.float64):
+        Nphi = 8
+        h = rng.standard_normal(5 * Nphi - 3).astype(th)
+        f = pkg.FIRFilter(h, 1.37, Nphi).bind(np.float32)
+        pfb, dpfb = f.taps(0), f.taps(1)
+        assert pfb.shape == (5, Nphi)
+        for phase in (1.0, 1.25, 3.999, float(Nphi), Nphi + 0.5, 2.0 + 2.0 ** -30):
+            a, i = math.modf(phase)
+            want = (pfb[:, int(i) - 1].astype(np.float64) + a * dpfb[:, int(i) - 1].astype(np.float64)).astype(th)
+            got = f.tapsforphase(phase)
+            assert got.dtype == th
+            assert_bit_equal(got, want, f"{th} phase {phase}")
+        for bad in (-0.1, Nphi + 1.01, 0.5, Nphi + 1.0):      # outside [0, Nphi+1] (:678) / column 0 or Nphi+1 (BoundsError)
+            with pytest.raises(pkg.MultirateHIPError):
+                f.tapsforphase(bad)
+        f.close()
+
+
 def test_chunked_streaming_entry_matches_caller_loop(pkg, torch_cuda):
     """mrhip_filt_device_chunked == the caller's own loop of filt! calls, bit for bit (rational and arbitrary)."""
     torch = torch_cuda
     g = torch.Generator(device="cuda").manual_seed(9)
     x = torch.rand((3, 250_000), generator=g, device="cuda", dtype=torch.float32)
     h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
-    for ratio, nphi in ((Fraction(147, 160), 32), (0.9173, 32), (Fraction(1, 4), 32)):
+    for ratio, nphi in ((Fraction(147, 160), 32), (0.9173, 32), (Fraction(1, 4), 32), (Fraction(3, 1), 32), (Fraction(160, 147), 32), (Fraction(1, 1), 32)):
         hh = h if not isinstance(ratio, float) else (pkg.firdes(32 * 16, 0.45 / 32, beta=7.0) * 32).astype(np.float32)
+        if ratio in (Fraction(3, 1), Fraction(1, 1)):
+            hh = h[:96]
         f1 = pkg.FIRFilter(hh, ratio, nphi)
         y1 = torch.cat([f1.filt(x[:, a:a + 9973]) for a in range(0, x.shape[1], 9973)], dim=1)
         f2 = pkg.FIRFilter(hh, ratio, nphi).bind(np.float32, 3)
@@ -584,6 +626,13 @@ def test_chunked_streaming_entry_matches_caller_loop(pkg, torch_cuda):
         n = f2.filt_into_chunked(y2, x, 9973)
         assert n == y1.shape[1] and torch.equal(y1.view(torch.int32), y2[:, :n].view(torch.int32))
         assert (f1.state.phiIdx, f1.state.inputDeficit, f1.state.phiAccumulator) == (f2.state.phiIdx, f2.state.inputDeficit, f2.state.phiAccumulator)
+        assert_bit_equal(f1.history, f2.history, f"history {ratio}")
+        # an undersized buffer fails at the piece the caller's own loop would fail at, with the earlier pieces applied
+        f3 = pkg.FIRFilter(hh, ratio, nphi).bind(np.float32, 3)
+        small = torch.empty((3, n // 2), device="cuda", dtype=torch.float32)
+        with pytest.raises(pkg.MultirateHIPError) as ei:
+            f3.filt_into_chunked(small, x, 9973)
+        assert ei.value.code == 2
 
 
 def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
@@ -618,11 +667,13 @@ def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
 
 def test_hip_graph_capture_of_fixed_chunk_streaming(pkg, torch_cuda):
     """filt! on a caller stream only enqueues kernels, so a fixed-chunk streaming loop can be captured
-    in a HIP graph.  With chunk % M == 0 the (phiIdx, inputDeficit) state is the same at every call and an even number
-    of calls returns the history ping-pong to its start, so every replay continues the stream exactly like the
-    plain loop would (history carried on the device)."""
+    in a HIP graph.  With chunk % M == 0 the (phiIdx, inputDeficit) state is the same at every call; a captured call
+    writes its history back into the slot it read, so any number of calls per graph (here an ODD one) replays
+    correctly: every replay continues the stream exactly like the plain loop would (history carried on the device).
+    Calls that would advance the integer state, and FIRArbitrary calls, are refused during capture instead of
+    replaying stale state."""
     torch = torch_cuda
-    L, M, chunk, ncalls, nch = 147, 160, 16_000, 4, 3
+    L, M, chunk, ncalls, nch = 147, 160, 16_000, 3, 3
     h = pkg.firdes(24 * L, 0.5 / L, beta=7.8562).astype(np.float32)
     x = torch.rand((nch, chunk * ncalls), dtype=torch.float32, device="cuda") - 0.5
     nout = chunk * L // M
@@ -633,19 +684,91 @@ def test_hip_graph_capture_of_fixed_chunk_streaming(pkg, torch_cuda):
         for i in range(ncalls):
             assert flt.filt_into(y[:, i * nout:(i + 1) * nout], x[:, i * chunk:(i + 1) * chunk]) == nout
 
+    bad = pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nch)
+    harb = (pkg.firdes(32 * 8, 0.45 / 32, beta=7.0) * 32).astype(np.float32)
+    arb = pkg.FIRFilter(harb, 0.77, 32).bind(np.float32, nch)
+    y_bad = torch.zeros((nch, nout + 64), dtype=torch.float32, device="cuda")
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.graph(g, stream=s):
         loop(f, y_g)
+        for flt, xx in ((bad, x[:, :chunk + 7]), (arb, x[:, :chunk])):       # refused, state untouched, capture intact
+            st0 = (flt.state.phiIdx, flt.state.inputDeficit, flt.state.phiAccumulator)
+            with pytest.raises(pkg.MultirateHIPError) as ei:
+                flt.filt_into(y_bad, xx)
+            assert ei.value.code == 5
+            assert (flt.state.phiIdx, flt.state.inputDeficit, flt.state.phiAccumulator) == st0
     ref = pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nch)
     y_ref = torch.empty_like(y_g)
-    for replay in range(3):                      # pass 0 starts from the zero history, passes 1, 2 continue the stream
+    for replay in range(4):                      # pass 0 starts from the zero history, the others continue the stream
         g.replay()
         loop(ref, y_ref)
         torch.cuda.synchronize()
         assert torch.equal(y_g.view(torch.int32), y_ref.view(torch.int32)), f"replay {replay}"
     assert f.last_kernel_name() == "rational_pair_kernel"
+    # the host object follows the replays: its history is the device's, so a plain call continues the stream too
+    assert_bit_equal(f.history, ref.history, "history after the replays")
+
+
+def test_calls_on_different_streams_are_ordered(pkg, O, torch_cuda):
+    """Per-filter device state (history ping-pong, counters) is ordered across streams by the library: device calls
+    alternating between two torch streams and host-pointer calls (the filter's own stream) in between continue one
+    stream bit-exactly; reset() in the middle needs no synchronisation either."""
+    torch = torch_cuda
+    L, M, nch = 147, 160, 4
+    h = pkg.firdes(24 * L, 0.5 / L, beta=7.8562).astype(np.float32)
+    rng = np.random.default_rng(77)
+    x = rng.random((nch, 600_000), dtype=np.float32) - 0.5
+    xd = torch.from_numpy(x).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+    sizes = [50_001, 49_999, 1, 100_003, 7, 199_989, 200_000]
+    for rep in range(2):
+        f = pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nch)
+        if rep == 1:                      # dirty the history, then reset without any synchronisation
+            with torch.cuda.stream(s1):
+                f.filt(xd[:, :123_457])
+            f.reset()
+        outs, pos = [], 0
+        for i, n in enumerate(sizes):
+            if i % 3 == 2:                # host-pointer call: runs on the filter's own stream
+                outs.append(torch.from_numpy(f.filt(x[:, pos:pos + n])))
+            else:
+                with torch.cuda.stream(s1 if i % 3 == 0 else s2):
+                    outs.append(f.filt(xd[:, pos:pos + n]))
+            pos += n
+        torch.cuda.synchronize()
+        y = torch.cat([o.cpu() for o in outs], dim=1).numpy()
+        for c in (0, nch - 1):
+            fo = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
+            yo = np.concatenate([fo.filt(p) for p in np.split(x[c, :pos], np.cumsum(sizes)[:-1])])
+            assert_bit_equal(y[c], yo, f"rep {rep} channel {c}")
+        f.close()
+
+
+def test_host_path_pipelined_pieces(pkg, O, torch_cuda, monkeypatch):
+    """mrhip_filt_host cuts long host signals into pieces (double-buffered H2D / kernel / D2H on three streams).  With a
+    tiny piece size the pipeline runs through many slots: outputs, counts, end state and history equal the oracle's for
+    the rational family, FIRArbitrary and row-strided multi-channel buffers."""
+    monkeypatch.setenv("MRHIP_HOST_PIECE_KB", "64")
+    rng = np.random.default_rng(31)
+    h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    harb = (pkg.firdes(32 * 8, 0.45 / 32, beta=7.0) * 32)
+    cases = [(h, Fraction(147, 160), np.float32, 3, 200_003), (h.astype(np.float64), Fraction(160, 147), np.float32, 1, 150_001),
+             (h[:128], Fraction(1, 4), np.complex64, 2, 120_000), (h[:96], Fraction(4, 1), np.float32, 2, 90_001),
+             (harb, 1.234567, np.float64, 2, 100_000), (h[:64], Fraction(1, 1), np.float32, 1, 70_000)]
+    for hh, ratio, tx, nch, n in cases:
+        x = _rand(rng, (nch, n), tx) - 0.5
+        f = pkg.FIRFilter(hh, ratio, 32)
+        y = np.concatenate([f.filt(x[:, :n // 2]), f.filt(x[:, n // 2:])], axis=1)     # two long host calls
+        for c in range(nch):
+            fo = O.FIRFilter(hh, ratio, 32, tx=tx) if isinstance(ratio, float) else O.FIRFilter(hh, ratio, tx=tx)
+            yo = np.concatenate([fo.filt(x[c, :n // 2]), fo.filt(x[c, n // 2:])])
+            assert_bit_equal(y[c], yo, f"{ratio} {tx} channel {c}")
+        st, so = f.state, fo.state
+        assert (st.phiIdx, st.inputDeficit, st.phiAccumulator) == (so.phiIdx, so.inputDeficit, so.phiAccumulator)
+        f.close()
 
 
 def test_filter_cascade_device_resident(pkg, O, torch_cuda):

@@ -115,6 +115,126 @@ def test_firdes_all_responses_match_windowed_sinc(pkg):
     assert np.array_equal(D.firdes(21, 0.1, np.hanning), D.firprototype(21, 0.1) * np.hanning(21))
 
 
+def test_design_entry_points_match_numpy_restatement(pkg):
+    """mrhip_kaiser / mrhip_firprototype / mrhip_firdes / mrhip_kaiserlength (csrc/design.cpp, the entry points the
+    Julia shim binds) against an independent numpy restatement of src/FIRDesign.jl:18-95 (np.sinc, np.kaiser)."""
+    from multirate_jl_amd import design as D
+    rng = np.random.default_rng(11)
+
+    def proto(numtaps, F, response):
+        M = numtaps - 1
+        if response == D.HIGHPASS and M % 2:
+            M += 1
+        n = np.arange(M + 1, dtype=np.float64) - M / 2.0
+        if response == D.LOWPASS:
+            return 2.0 * F * np.sinc(2.0 * F * n)
+        if response == D.BANDPASS:
+            return 2.0 * (F[0] * np.sinc(2.0 * F[0] * n) - F[1] * np.sinc(2.0 * F[1] * n))
+        if response == D.HIGHPASS:
+            return np.sinc(n) - 2.0 * F * np.sinc(2.0 * F * n)
+        return 2.0 * (F[1] * np.sinc(2.0 * F[1] * n) - F[0] * np.sinc(2.0 * F[0] * n))
+
+    for n in (1, 2, 3, 16, 129, 3528):
+        for beta in (0.0, 2.5, 7.8562, 14.0):
+            assert np.allclose(D.kaiser(n, beta), np.kaiser(n, beta), rtol=1e-13, atol=1e-16)
+    for _ in range(40):
+        numtaps = int(rng.integers(2, 400))
+        f1, f2 = sorted(rng.uniform(0.01, 0.49, 2))
+        sr = float(rng.choice([1.0, 2.0, 48000.0]))
+        beta = float(rng.uniform(0, 12))
+        for resp, F in ((D.LOWPASS, f1), (D.HIGHPASS, f1), (D.BANDPASS, [f2, f1]), (D.BANDSTOP, [f1, f2])):
+            want = proto(numtaps, F, resp)
+            got = D.firprototype(numtaps, F, resp)
+            assert got.shape == want.shape and np.allclose(got, want, rtol=0, atol=2e-16 * max(1.0, np.abs(want).max()) * 8)
+            Fs = [v * sr for v in F] if isinstance(F, list) else F * sr
+            h = D.firdes(numtaps, Fs, response=resp, samplerate=sr, beta=beta)
+            assert np.allclose(h, want * np.kaiser(len(want), beta), rtol=0, atol=1e-14)
+    for tw, att, sr in ((0.05, 60.0, 1.0), (0.05, 80.0, 32.0), (0.01, 30.0, 1.0), (0.2, 10.0, 2.0), (100.0, 50.0, 48000.0)):
+        n, b = D.kaiserlength(tw, att, sr)
+        assert n == int(math.ceil((att - 7.95) / (2 * math.pi * 2.285 * tw / sr)))
+        want_b = 0.1102 * (att - 8.7) if att > 50 else (0.5842 * (att - 21) ** 0.4 + 0.07886 * (att - 21) if att >= 21 else 0.0)
+        assert abs(b - want_b) <= 1e-15 * max(1.0, want_b)
+    lib = pkg.load_library()
+    assert lib.mrhip_firprototype(10, None, 1, 0, None) == -1 and b"numtaps" in lib.mrhip_last_error()
+
+
+def test_mrhip_state_layout_matches_julia_shim(pkg, tmp_path):
+    """No Julia runs here, so the struct the shim reads through mrhip_get_state (MRHIPState in MultirateHIP.jl, an
+    isbits struct laid out like C) is pinned by a C program: it prints sizeof/offsetof of mrhip_state from the real
+    header; the shim's field list, laid out by the C rules for its declared Julia types, must give the same numbers.
+    The same program links the library and calls a few host-only entry points the way a C host would."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    fields = ["kind", "tap_dtype", "sample_dtype", "output_dtype", "nchannels", "hLen", "interpolation", "decimation", "Nphi",
+              "tapsPerPhi", "historyLen", "phiIdx", "inputDeficit", "xIdx", "rate", "phiAccumulator", "alpha", "delta"]
+    src = tmp_path / "layout.c"
+    src.write_text(
+        "#include <stdio.h>\n#include <stddef.h>\n#include \"multirate_hip.h\"\n"
+        "int main(void) {\n  printf(\"sizeof %zu\\n\", sizeof(mrhip_state));\n"
+        + "".join(f'  printf("{f} %zu %zu\\n", offsetof(mrhip_state, {f}), sizeof(((mrhip_state *)0)->{f}));\n' for f in fields)
+        + "  double w[5]; if (mrhip_kaiser(5, 3.0, w) != 0) return 2;\n"
+          "  int64_t n = 0; double b = 0; if (mrhip_kaiserlength(0.05, 60.0, 1.0, &n, &b) != 0) return 3;\n"
+          "  printf(\"abi %d kaiser_mid %.17g numtaps %lld nextphase %lld\\n\", mrhip_abi_version(), w[2], (long long)n,\n"
+          "         (long long)mrhip_nextphase(1, 147, 160));\n  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    libdir = os.path.dirname(pkg.library_path())
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lmultirate_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    c_layout = {ln.split()[0]: tuple(int(v) for v in ln.split()[1:]) for ln in out if ln and ln.split()[0] in fields}
+    c_size = int(out[0].split()[1])
+    assert "abi 1 kaiser_mid 1 numtaps" in out[-2] and out[-2].endswith("nextphase 14")
+    # the shim's struct: parse `struct MRHIPState ... end` and lay it out with the C rules (natural alignment)
+    jl = open(os.path.join(ROOT, "multirate.jl_amd", "julia", "MultirateHIP.jl")).read()
+    body = re.search(r"struct MRHIPState[^\n]*\n(.*?)\nend", jl, flags=re.S).group(1)
+    jl_fields = re.findall(r"(\w+)::(Int32|Int64|Float64)", body)
+    size_of = {"Int32": 4, "Int64": 8, "Float64": 8}
+    off, jl_layout = 0, {}
+    for name, ty in jl_fields:
+        sz = size_of[ty]
+        off = (off + sz - 1) // sz * sz
+        jl_layout[name] = (off, sz)
+        off += sz
+    jl_size = (off + 7) // 8 * 8
+    assert [n for n, _ in jl_fields] == fields, "field order of MRHIPState differs from mrhip_state"
+    assert jl_layout == c_layout and jl_size == c_size == 128
+    # ... and the ctypes mirror the tests drive
+    from multirate_jl_amd import host
+    assert C.sizeof(host._State) == c_size
+    for f in fields:
+        assert (getattr(host._State, f).offset, getattr(host._State, f).size) == c_layout[f]
+
+
+def test_julia_shim_ccalls_match_header():
+    """The Julia shim cannot be executed here: check statically that every `ccall((:mrhip_x, libmr), ret, (argtypes...), ...)`
+    names a symbol the header declares, with the header's number of parameters."""
+    hdr = open(os.path.join(ROOT, "include", "multirate_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    arity = {}
+    for m in re.finditer(r"\b(mrhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        params = m.group(2).strip()
+        arity[m.group(1)] = 0 if params in ("", "void") else params.count(",") + 1
+    jl = open(os.path.join(ROOT, "multirate.jl_amd", "julia", "MultirateHIP.jl")).read()
+    calls = re.findall(r"ccall\(\(:(mrhip_[a-z0-9_]+), libmr\),\s*\w+,\s*(\w+|\((?:[^()]|\([^()]*\))*\))", jl)
+    assert len(calls) >= 25
+    seen = set()
+    for name, argt in calls:
+        assert name in arity, f"{name} is not declared in multirate_hip.h"
+        if argt.startswith("("):
+            inner = argt[1:-1].strip().rstrip(",")
+            n = 0 if not inner else len(re.sub(r"\{[^{}]*\}", "", re.sub(r"\{[^{}]*\}", "", inner)).split(","))
+            assert n == arity[name], f"{name}: shim passes {n} arguments, header declares {arity[name]}"
+        seen.add(name)
+    # the shim binds the whole design / cascade / hot-path surface
+    for must in ("mrhip_firdes", "mrhip_firdes_kaiser", "mrhip_firprototype", "mrhip_kaiserlength", "mrhip_kaiser",
+                 "mrhip_arbitrary_tapsforphase", "mrhip_farrow_tapsforphase", "mrhip_cascade_create", "mrhip_cascade_filt_device",
+                 "mrhip_filt_host", "mrhip_filt_device", "mrhip_filt_device_chunked", "mrhip_create_rational",
+                 "mrhip_create_arbitrary", "mrhip_create_farrow", "mrhip_get_state", "mrhip_set_state", "mrhip_reset"):
+        assert must in seen, must
+
+
 def test_product_path_fails_loudly_without_gpu(pkg):
     """No CPU fallback: on a box without a gfx950 device constructing the device object raises."""
     import torch

@@ -1,0 +1,107 @@
+"""Multi-GPU leg (BASELINE.json config 5): the real HIP filter behind ChannelShardedFilter, one process
+per rank, gather / all_gather of the outputs, compared with the oracle.
+
+* nccl tests need >= 2 GPUs (RCCL refuses two ranks on one device) and self-skip otherwise;
+* the gloo variants run two ranks on ONE GPU (collectives on host copies): same product code path for the
+  sharding, the HIP filter and bench.py's self-spawning launcher, so a 1-GPU box still exercises them.
+
+Ranks are fresh child processes (subprocess): this pytest process may already have initialised the GPU and is
+never re-executed."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "_multigpu_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _run_ranks(world, backend, channels=37, timeout=600):
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+               MRHIP_TEST_BACKEND=backend, MRHIP_TEST_CHANNELS=str(channels))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, WORKER], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=timeout)
+            outs.append((p.returncode, out, err))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rc, out, err in outs:
+        assert rc == 0, f"rank failed (rc={rc}):\n{out}\n{err[-4000:]}"
+    return outs[0][1]
+
+
+@pytest.mark.gpu
+def test_sharded_hip_filter_over_all_gpus_nccl():
+    """min(device_count, 8) ranks, one GPU each, RCCL gather + all-gather vs the oracle"""
+    n = _gpu_count()
+    if n < 2:
+        pytest.skip(f"needs >= 2 GPUs for RCCL (this box has {n})")
+    world = min(n, 8)
+    out = _run_ranks(world, "nccl", channels=8 * world + 5)     # unequal shards: padded collectives
+    assert f"MULTIGPU_OK ranks={world} backend=nccl" in out
+    out = _run_ranks(world, "nccl", channels=8 * world)         # equal shards: copy-free collectives
+    assert f"MULTIGPU_OK ranks={world} backend=nccl" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [37, 8, 1])
+def test_sharded_hip_filter_two_ranks_one_gpu_gloo(channels):
+    """two ranks sharing the visible GPU(s), host-side collectives: runs on a 1-GPU box (1 channel: rank 1 is empty)"""
+    if _gpu_count() < 1:
+        pytest.skip("needs a GPU")
+    out = _run_ranks(2, "gloo", channels=channels)
+    assert "MULTIGPU_OK ranks=2 backend=gloo" in out
+
+
+def _bench(args, backend, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MRHIP_BENCH_BACKEND"] = backend
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_direct_launch_spawns_its_own_ranks():
+    """`python bench.py --gpus N` started directly (no torch.distributed.run) must form N ranks itself"""
+    n = _gpu_count()
+    if n < 1:
+        pytest.skip("needs a GPU")
+    backend, world = ("nccl", min(n, 8)) if n >= 2 else ("gloo", 2)
+    small = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-streamed"]
+    line = _bench(["--gpus", str(world), "--channels", "4", "--samples", "2000000"] + small, backend)
+    assert line["n_gpus"] == world and line["scaling"] == "weak"
+    assert line["roofline"]["achieved"] > 0
+    line = _bench(["--gpus", str(world), "--config", "c5", "--channels", "64", "--samples", "200000"] + small, backend)
+    assert line["n_gpus"] == world and line["scaling"] == "strong"
+    assert line["config"]["channels_per_gpu"] == 64 // world
+    assert set(line["gather"]) == {"root", "all"} and line["gather"]["root"]["ms"] > 0

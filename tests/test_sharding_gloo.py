@@ -32,7 +32,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nch, q):
+def _worker(rank, world, port, nch, q, cplx=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import torch
@@ -43,8 +43,12 @@ def _worker(rank, world, port, nch, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rng = np.random.default_rng(3)
-        h = rng.random(77).astype(np.float32)
+        # cplx: Float64 taps x ComplexF32 samples -> ComplexF64 outputs (the promoted type, also for an empty shard)
+        h = rng.random(77).astype(np.float64 if cplx else np.float32)
         x = rng.random((nch, 400)).astype(np.float32)
+        if cplx:
+            x = (x + 1j * rng.random((nch, 400)).astype(np.float32)).astype(np.complex64)
+        tx = np.complex64 if cplx else np.float32
         ratio = Fraction(3, 5)
 
         class OracleBatch:   # FIRFilter-shaped stand-in for the HIP filter (CPU test only)
@@ -54,7 +58,7 @@ def _worker(rank, world, port, nch, q):
             def filt(self, xl):
                 xl = xl.numpy()
                 if self.f is None:
-                    self.f = [O.FIRFilter(h, ratio, tx=np.float32) for _ in range(xl.shape[0])]
+                    self.f = [O.FIRFilter(h, ratio, tx=tx) for _ in range(xl.shape[0])]
                 return torch.from_numpy(np.stack([f.filt(r) for f, r in zip(self.f, xl)]))
 
         sf = pkg.ChannelShardedFilter(h, ratio, nch, filter_factory=OracleBatch)
@@ -66,20 +70,22 @@ def _worker(rank, world, port, nch, q):
         full = sf.gather(y_local, dst=0)
         allg = sf.all_gather(y_local)
         ref = np.stack([O.filt(h, x[c], ratio) for c in range(nch)])
-        ok_all = np.array_equal(allg.numpy(), ref)
-        ok_root = (full is None) if rank != 0 else np.array_equal(full.numpy(), ref)
+        ok_all = allg.numpy().dtype == ref.dtype and np.array_equal(allg.numpy(), ref)
+        ok_root = (full is None) if rank != 0 else (full.numpy().dtype == ref.dtype and np.array_equal(full.numpy(), ref))
+        if sf.count == 0:     # a rank without channels returns an empty shard of the promoted output type
+            ok_all = ok_all and y_local.shape[0] == 0 and y_local.numpy().dtype == ref.dtype
         q.put((rank, bool(ok_all), bool(ok_root), sf.start, sf.count))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nch", [5, 8])
-def test_sharded_filter_world2_gloo(pkg, O, nch):
+@pytest.mark.parametrize("nch,cplx", [(5, False), (8, False), (1, False), (4, True), (1, True)])
+def test_sharded_filter_world2_gloo(pkg, O, nch, cplx):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, nch, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nch, q, cplx)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
