@@ -107,7 +107,7 @@ def cpu_baseline(h, seconds_budget=25.0):
 
     # all cores: one channel per usable core, one thread each (ctypes releases the GIL inside the C call)
     cores = max(1, host["usable_cores"])
-    n2 = 20_000_000
+    n2 = 4_000_000 if cores > 32 else 20_000_000      # keeps five oversubscription-free runs inside a few seconds
     xs = x[:n2]
     mtimes = []
     t_all = time.perf_counter()

@@ -179,6 +179,15 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
             PairArgs pa;
             dim3 block;
             size_t lds = 0;
+            if (plan_rational_opair(tk, a, f->num_cus, &pa, &block, &lds)) {
+                *did_shiftin = a.H > 0;
+                return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
+            }
+        }
+        {
+            PairArgs pa;
+            dim3 block;
+            size_t lds = 0;
             if (plan_interp_pair(tk, a, f->num_cus, &pa, &block, &lds)) {
                 *did_shiftin = a.H > 0;
                 return launch_interp_pair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
@@ -848,7 +857,8 @@ int mrhip_filt_device_chunked(mrhip_filter *f, const void *x, int64_t x_len, int
     // per-chunk loop: their seam dot product starts from zero (support.jl:46), which is visible per CALL (the sign of an
     // all-(-0) sum); FIRArbitrary/FIRFarrow keep it because their wall time is the host's serial phase recurrence.
     // MRHIP_CHUNKED_PER_CALL=1 forces the per-chunk loop (measurements of genuinely arriving chunks).
-    static const bool per_call = [] { const char *v = std::getenv("MRHIP_CHUNKED_PER_CALL"); return v && v[0] == '1'; }();
+    const char *pcv = std::getenv("MRHIP_CHUNKED_PER_CALL");
+    const bool per_call = pcv && pcv[0] == '1';
     int64_t step = chunk;
     if (!per_call && (f->kind == MRHIP_FIR_INTERPOLATOR || f->kind == MRHIP_FIR_RATIONAL) && chunk < x_len) {
         const int64_t total = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len).n_out;

@@ -153,6 +153,7 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     int cM;                  // c*M
     int J;                   // steps per tile
     int tile_len;            // samples staged per tile (multiple of 4)
+    int tail;                // samples a tile of j steps needs beyond j*cM (window overhang; pair_loader.h)
     int dma_rounds;          // LDS-DMA instructions per wave per tile
     int stage_bytes;         // LDS bytes per pipeline stage
     int ns;                  // pipeline stages (the DMA runs ns-1 tiles ahead of the compute waves)
@@ -234,6 +235,9 @@ bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef);
 bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                                 const char **kname, int num_cus, unsigned *counters);   // also performs shiftin! into a.hist_new
+bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
+hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
+                                 const char **kname, int num_cus, unsigned *counters);   // two outputs per lane (L > M, and M > L below 0.7); also performs shiftin!
 bool plan_interp_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_interp_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                               const char **kname, int num_cus, unsigned *counters);   // FIRInterpolator, two phases per lane; also performs shiftin!

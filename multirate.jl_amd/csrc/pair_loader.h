@@ -1,0 +1,171 @@
+// pair_loader.h -- the loader wave shared by the ring-pipelined FIRRational kernels (kernels_rational_pair.hip:
+// two input positions per lane, M > L; kernels_rational_opair.hip: two outputs per lane, either direction):
+// grouped dynamic scheduling of the steps, tiles staged HBM -> LDS by LDS-DMA ns-1 tiles ahead of the compute waves,
+// tile descriptors published through LDS, counters re-armed by the last workgroup, shiftin! fused at the end.
+// gfx950 only.
+#ifndef MRHIP_PAIR_LOADER_H
+#define MRHIP_PAIR_LOADER_H
+
+#include "mrhip_internal.h"
+#include "pair_device.h"
+
+namespace mrhip {
+namespace dev {
+
+struct TileAt { int ch, st, jt; };                      // channel, first step within the channel, steps
+
+// step number (channel-major) -> tile: multiply-high by floor(2^32/spc) + fix-ups
+__device__ __forceinline__ TileAt pair_tile_at(const PairArgs &pa, unsigned g, unsigned jt)
+{
+    const unsigned spc = pa.steps_per_channel;
+    unsigned q = __umulhi(g, pa.spc_magic);
+    unsigned r = g - q * spc;
+    if (r >= spc) { ++q; r -= spc; }
+    if (r >= spc) { ++q; r -= spc; }
+    return TileAt{static_cast<int>(q), static_cast<int>(r), static_cast<int>(umin(jt, spc - r))};
+}
+
+// The whole life of the loader wave (the last wave of the workgroup).  A tile of jt steps needs
+// jt * pa.cM + pa.tail samples of one channel; NC = components per sample (1: Float32, 2: ComplexF32 / one Float64).
+template <int NC>
+__device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairArgs &pa, unsigned char *smem, int lane)
+{
+    volatile unsigned *const tile_flag = reinterpret_cast<volatile unsigned *>(smem + pa.flags_off);   // [ns][2]: first step, steps (0 = end)
+    auto tile_at = [&](unsigned g, unsigned jt) -> TileAt { return pair_tile_at(pa, g, jt); };
+    // ================= loader wave: HBM -> LDS, one tile ahead of the compute waves =================
+    // It is the only wave that waits on vmcnt, so the compute waves' output stores stay in flight
+    // across tiles (their barrier carries no memory wait).
+    // Stages one tile; returns the number of LDS-DMA operations it left in flight (0 for the
+    // checked register path, which drains everything before returning).
+    auto stage_tile = [&](const TileAt &ta, int stage) -> int {
+        const int sch = ta.ch;
+        constexpr int EPC = 4 / NC;                                 // samples per 16-byte DMA chunk
+        const int tlen = (ta.jt * pa.cM + pa.tail + EPC - 1) / EPC * EPC;   // samples this tile needs, whole chunks
+        const int nchunks = tlen / EPC;
+        const int nslots = (nchunks + 63) >> 6;                     // 1 KiB LDS slots
+        const float *__restrict__ xc = static_cast<const float *>(a.x) + static_cast<long long>(sch) * a.x_stride * NC;
+        const long long o = pa.o0 + static_cast<long long>(ta.st) * pa.cM;   // x index of LDS sample 0 (may be < 0)
+        unsigned char *st = smem + static_cast<size_t>(stage) * pa.stage_bytes;
+        const bool interior = o >= 0 && o + tlen <= a.x_len;             // wave-uniform
+        if (interior) {
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
+            for (int slot = 0; slot < nslots; ++slot) {
+                const int ci = slot * 64 + lane;
+                const int cis = ci < nchunks ? ci : 0;                   // padding lanes re-read chunk 0 into LDS padding
+                dma16(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
+            }
+            return nslots;
+        }
+        // first / last tile of a channel: history seam and end of input, element-wise checked
+        const float *__restrict__ hc = static_cast<const float *>(a.hist) + static_cast<long long>(sch) * a.H * NC;
+        float *l = reinterpret_cast<float *>(st);
+        for (int ci = lane; ci < nchunks; ci += 64) {
+            float4 v;
+            float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const long long gi = o + static_cast<long long>(EPC) * ci + e;
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                    float val = 0.f;
+                    if (gi >= 0) { if (gi < a.x_len) val = xc[gi * NC + cc]; }
+                    else if (gi >= -static_cast<long long>(a.H)) val = hc[(a.H + gi) * NC + cc];
+                    pv[e * NC + cc] = val;
+                }
+            }
+            *reinterpret_cast<float4 *>(l + ci * 4) = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        return 0;
+    };
+    // pa.ns LDS stages, the DMA runs ns-1 tiles ahead: while the compute waves work on tile i the loader
+    // has tiles i+1 .. i+ns-2 landing and tile i+ns-1 being issued, so the HBM stream never pauses.
+    // `hist` is a shift register of the LDS-DMA operation counts of the tiles issued so far (6 bits each,
+    // newest in the low bits): tile i+1 has landed once no more operations are outstanding than the ns-2
+    // newest tiles own.
+    const unsigned grp = blockIdx.x % static_cast<unsigned>(pa.ngroups);
+    const unsigned grp_lo = umin(grp * pa.steps_per_group, pa.total_steps);
+    const unsigned grp_hi = umin(grp_lo + pa.steps_per_group, pa.total_steps);
+    unsigned *const ctr = pa.counters + grp * 64u;            // one counter per 256 bytes
+    unsigned pend = 0;                                        // lane 0: the grab number drawn ahead of need
+    // small launches (at most a couple of grabs per workgroup) skip the atomics: grab numbers are dealt
+    // round-robin from the workgroup number, which costs nothing and balances just as well
+    unsigned static_next = blockIdx.x / static_cast<unsigned>(pa.ngroups);
+    const unsigned static_stride = (gridDim.x + static_cast<unsigned>(pa.ngroups) - 1u - grp) / static_cast<unsigned>(pa.ngroups);
+    auto grab_issue = [&]() {
+        if (pa.static_grabs) { pend = static_next; static_next += static_stride; }
+        else if (lane == 0) pend = atomicAdd(ctr, 1u);
+    };
+    unsigned ra = 0, rb = 0;                                  // the current grab's steps [ra, rb)
+    bool more = true;                                         // false after the first empty grab
+    auto grab_take = [&]() {                                  // the compiler waits for `pend` here (vmcnt(0))
+        const unsigned t = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(pend)));
+        const unsigned long long lo = static_cast<unsigned long long>(grp_lo) + static_cast<unsigned long long>(t) * pa.J;
+        if (lo < grp_hi) { ra = static_cast<unsigned>(lo); rb = umin(ra + pa.J, grp_hi); grab_issue(); }
+        else { more = false; ra = rb = 0; }
+    };
+    unsigned long long hist = 0;
+    auto newest_ops = [&](int ntiles) -> int {
+        int n = 0;
+        for (int k = 0; k < ntiles; ++k) n += static_cast<int>((hist >> (6 * k)) & 63u);
+        return n < 60 ? n : 60;               // the counter itself holds at most 63
+    };
+    // next tile of the stream -> stage `stage`; returns false at the end of the stream (end marker published)
+    auto produce = [&](int stage) -> bool {
+        if (ra >= rb && more) grab_take();
+        if (ra >= rb) {
+            if (lane == 0) { tile_flag[2 * stage] = 0u; tile_flag[2 * stage + 1] = 0u; }
+            hist <<= 6;
+            return false;
+        }
+        const TileAt ta = tile_at(ra, rb - ra);
+        if (lane == 0) { tile_flag[2 * stage] = ra; tile_flag[2 * stage + 1] = static_cast<unsigned>(ta.jt); }
+        hist = (hist << 6) | static_cast<unsigned>((pa.ablate & 1) ? 0 : stage_tile(ta, stage));
+        ra += static_cast<unsigned>(ta.jt);
+        return true;
+    };
+    grab_issue();
+    unsigned pipeline = 0;                    // bit k: the tile opened k barriers from now exists
+    for (int k = 0; k < pa.ns - 1; ++k)
+        if (produce(k)) pipeline |= 1u << k;  // after the end of the stream produce() keeps publishing end markers
+    wait_vmcnt_le(newest_ops(pa.ns - 2));     // tile 0 has landed (only the later tiles' operations may remain)
+    int pstage = pa.ns - 1;
+    for (;;) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the tile descriptors published so far are in LDS
+        __builtin_amdgcn_s_barrier();         // the next tile is published; the stage of the tile before it is free again
+        if (!(pipeline & 1u)) break;          // that was the end marker: every wave of the workgroup leaves
+        pipeline >>= 1;
+        if (produce(pstage)) pipeline |= 1u << (pa.ns - 2);
+        pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
+        wait_vmcnt_le(newest_ops(pa.ns - 2)); // everything older than the ns-2 newest tiles has landed
+    }
+    // the last workgroup to finish re-arms the counters for the next launch (stream order makes it visible)
+    if (lane == 0 && !pa.static_grabs) {
+        unsigned *const done = pa.counters + static_cast<unsigned>(pa.ngroups) * 64u;
+        if (atomicAdd(done, 1u) == gridDim.x - 1) {
+            for (int k = 0; k < pa.ngroups; ++k) pa.counters[k * 64] = 0u;
+            *done = 0u;
+        }
+    }
+    // shiftin! (support.jl:61-80), fused: hist_new <- last H samples of [hist ; x] for the channels this
+    // workgroup is responsible for (round-robin); hist_new is the other ping-pong buffer, nobody reads it
+    // during this launch.  Saves one kernel launch per filt! call.
+    if (a.H > 0) {
+        const float *__restrict__ xin = static_cast<const float *>(a.x);
+        const float *__restrict__ hold = static_cast<const float *>(a.hist);
+        float *__restrict__ hnew = static_cast<float *>(a.hist_new);
+        for (int c2 = blockIdx.x; c2 < a.nch; c2 += gridDim.x)
+            for (int i = lane; i < a.H; i += 64) {
+                const long long e = static_cast<long long>(i) + a.x_len;          // index into [hist ; x]
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc)
+                    hnew[(static_cast<long long>(c2) * a.H + i) * NC + cc] =
+                        e < a.H ? hold[(static_cast<long long>(c2) * a.H + e) * NC + cc]
+                                : xin[(static_cast<long long>(c2) * a.x_stride + (e - a.H)) * NC + cc];
+            }
+    }
+}
+
+}  // namespace dev
+}  // namespace mrhip
+#endif

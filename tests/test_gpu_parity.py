@@ -323,7 +323,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, Fraction(L, M))
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_pair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"), (L, M, hl)
+        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_pair_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"), (L, M, hl)
         tuned_seen.add(f.last_kernel_name())
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, Fraction(L, M))
@@ -332,7 +332,59 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         assert_bit_equal(y_t, y_g, f"tuned vs generic L={L} M={M} hLen={hl} {th} {tx}")
         assert_bit_equal(f.history, g.history, "history")
-    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_pair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"}, tuned_seen
+    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_pair_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"}, tuned_seen
+
+
+def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
+    """rational_opair_kernel (two adjacent OUTPUTS per lane, window offsets resolved by exact no-op slots): L > M
+    ratios (160//147, 3//2, ...), the M > L ratios the position-pair kernel leaves (5//9), and -- with the position-pair
+    kernel switched off -- its own ratios (147//160), for every tapsPerPhi class (odd, even, 1, 32), Float32 and
+    ComplexF32, STRICT and FUSED, multi-channel, chunked with 1-sample and prime pieces; inputs contain -0.0, +-Inf
+    and NaN runs (a skipped slot must not turn into 0*Inf or flip the sign of an all-zero sum).  Bit-exact against
+    the universal kernel on all channels and against the oracle on one."""
+    torch = torch_cuda
+    rng = np.random.default_rng(2025)
+    cases = [(160, 147, 24 * 160, False), (160, 147, 24 * 160 - 77, False), (3, 2, 72, False), (3, 2, 3 * 32, False), (3, 2, 3, False),
+             (7, 5, 100, False), (5, 3, 23, False), (9, 5, 9 * 17, False), (16, 9, 16 * 31 - 5, False), (32, 31, 32 * 8, False),
+             (5, 9, 5 * 13, False), (4, 7, 4 * 32, False), (147, 160, 3528, True), (9, 10, 9 * 7, True), (31, 32, 31 * 2 - 1, True)]
+    for (L, M, hl, disable_pair) in cases:
+        for tx in (np.float32, np.complex64):
+            for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
+                if numerics == pkg.NUMERICS_FUSED and hl % 2:
+                    continue
+                nch = int(rng.integers(1, 5))
+                h = rng.standard_normal(hl).astype(np.float32)
+                h[rng.integers(0, hl, 3)] = 0.0
+                x = _rand(rng, (nch, 30_011), tx) - 0.5
+                xr = x.view(np.float32)
+                xr[:, 500:560] = -0.0                                   # an all-(-0) window
+                xr[0, 2000] = np.inf; xr[0, 2100] = -np.inf; xr[nch - 1, 4000:4003] = np.nan
+                xd = torch.from_numpy(x).cuda()
+                sizes = [10_007, 1, 13, 19_990]
+                if disable_pair:
+                    monkeypatch.setenv("MRHIP_PAIR", "0")
+                f = pkg.FIRFilter(h, Fraction(L, M), numerics=numerics)
+                y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+                kn = f.last_kernel_name()
+                monkeypatch.delenv("MRHIP_PAIR", raising=False)
+                monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+                g = pkg.FIRFilter(h, Fraction(L, M), numerics=numerics)
+                y_g = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
+                monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+                if not disable_pair:
+                    assert kn == "rational_opair_kernel", (L, M, hl, kn)
+                assert_bit_equal(y_t, y_g, f"opair vs generic L={L} M={M} hLen={hl} {tx} numerics={numerics} kernel={kn}")
+                assert_bit_equal(f.history, g.history, "history")
+                assert (f.state.phiIdx, f.state.inputDeficit) == (g.state.phiIdx, g.state.inputDeficit)
+                if numerics == pkg.NUMERICS_STRICT:
+                    fo = O.FIRFilter(h, Fraction(L, M), tx=tx)
+                    yo = np.concatenate([fo.filt(p) for p in np.split(x[nch - 1], np.cumsum(sizes)[:-1])])
+                    # NaN payloads/signs are the host FPU's on the oracle side (x86's default NaN has the sign bit set,
+                    # the GPU's does not): NaNs must sit in the same places, everything else is compared bit for bit
+                    got, want = y_t[nch - 1].view(np.float32), yo.view(np.float32)
+                    assert np.array_equal(np.isnan(got), np.isnan(want)), f"NaN positions L={L} M={M} hLen={hl} {tx}"
+                    ok = ~np.isnan(want)
+                    assert_bit_equal(got[ok], want[ok], f"opair vs oracle L={L} M={M} hLen={hl} {tx}")
 
 
 def test_arbitrary_tuned_and_generic_agree(pkg, torch_cuda, monkeypatch):
