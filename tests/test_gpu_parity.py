@@ -313,7 +313,8 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
              (1, 4, 128, np.float32, np.float32), (1, 1, 64, np.float32, np.complex64), (1, 2, 200, np.float32, np.float32),
              (1, 8, 131, np.float32, np.complex64), (1, 1, 300, np.float32, np.float32), (1, 4, 509, np.float32, np.complex64),
              (5, 1, 160, np.float32, np.float32), (3, 1, 17, np.float32, np.complex64), (7, 1, 50, np.float32, np.float32),
-             (2, 1, 64, np.float32, np.complex64), (33, 1, 33 * 32, np.float32, np.float32), (6, 1, 100, np.float64, np.float64)]
+             (2, 1, 64, np.float32, np.complex64), (33, 1, 33 * 32, np.float32, np.float32), (6, 1, 100, np.float64, np.float64),
+             (160, 147, 24 * 160, np.float32, np.float32), (3, 2, 72, np.float32, np.complex64), (5, 9, 65, np.float32, np.float32)]
     tuned_seen = set()
     for (L, M, hl, th, tx) in cases:
         h = rng.standard_normal(hl).astype(th)
