@@ -157,13 +157,16 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     int dma_rounds;          // LDS-DMA instructions per wave per tile
     int stage_bytes;         // LDS bytes per pipeline stage
     int ns;                  // pipeline stages (the DMA runs ns-1 tiles ahead of the compute waves)
-    int nc;                  // components per sample: 1 = Float32, 2 = ComplexF32
+    int nc;                  // components per sample: 1 = real, 2 = complex
+    int x_f64, r_f64;        // Float64 samples / Float64 arithmetic (opair kernel)
     int ablate;              // timing experiments only (MRHIP_PS_ABLATE)
     unsigned steps_per_channel;   // ceil(n_out / P)
     unsigned total_steps;         // steps_per_channel * channels
     unsigned steps_per_group;     // ceil(total_steps / ngroups): group g owns steps [g*S, (g+1)*S)
     int ngroups;                  // scheduling groups; workgroup b draws grabs of J steps from group b % ngroups
     int flags_off;                // LDS byte offset of the per-stage tile descriptors
+    int bank_off;                 // LDS byte offset of the tap bank staged by the compute waves before the first tile (-1: none;
+                                  // the loader wave then joins one extra barrier before its first tile barrier)
     int static_grabs;             // 1: grabs are dealt round-robin without atomics (small launches)
     unsigned *counters;           // device: [g*64] next grab of group g, [ngroups*64] workgroups finished (re-arms all)
     unsigned spc_magic;           // floor(2^32 / steps_per_channel) (0xffffffff for 1): step number -> channel by multiply-high
@@ -232,9 +235,6 @@ hipError_t launch_farrow_tiled(const TypeKey &tk, bool fused, const FarrowArgs &
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
 // least-squares polynomial fit of y[0..n) at x = 1..n (support.jl:85-88); coef receives polyorder+1 ascending powers
 bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef);
-bool plan_rational_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
-hipError_t launch_rational_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
-                                const char **kname, int num_cus, unsigned *counters);   // also performs shiftin! into a.hist_new
 bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                                  const char **kname, int num_cus, unsigned *counters);   // two outputs per lane (L > M, and M > L below 0.7); also performs shiftin!

@@ -1,5 +1,4 @@
-// pair_loader.h -- the loader wave shared by the ring-pipelined FIRRational kernels (kernels_rational_pair.hip:
-// two input positions per lane, M > L; kernels_rational_opair.hip: two outputs per lane, either direction):
+// pair_loader.h -- the loader wave shared by the ring-pipelined FIRRational kernels (kernels_rational_opair.hip: two outputs per lane):
 // grouped dynamic scheduling of the steps, tiles staged HBM -> LDS by LDS-DMA ns-1 tiles ahead of the compute waves,
 // tile descriptors published through LDS, counters re-armed by the last workgroup, shiftin! fused at the end.
 // gfx950 only.
@@ -128,6 +127,7 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
     unsigned pipeline = 0;                    // bit k: the tile opened k barriers from now exists
     for (int k = 0; k < pa.ns - 1; ++k)
         if (produce(k)) pipeline |= 1u << k;  // after the end of the stream produce() keeps publishing end markers
+    if (pa.bank_off >= 0) __builtin_amdgcn_s_barrier();   // the compute waves' tap-bank barrier (the bank lives in stage ns-1, first written below after the next barrier)
     wait_vmcnt_le(newest_ops(pa.ns - 2));     // tile 0 has landed (only the later tiles' operations may remain)
     int pstage = pa.ns - 1;
     for (;;) {

@@ -21,11 +21,13 @@ for d in sys.argv[1:]:
         meta = {}
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if not k.startswith(("poly", "arb", "shiftin", "deci", "rational", "fir")):
+            if not k.startswith(("poly", "arb", "shiftin", "deci", "rational", "fir", "interp", "farrow")):
                 continue
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            meta[k] = {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"]),
-                       "wg": int(r["Workgroup_Size"]), "grid": int(r["Grid_Size"])}
+            # (rocprofv3's VGPR_Count / LDS_Block_Size columns are NOT reported here: for these kernels they read 40 VGPRs
+            #  and 0 LDS while the code object says 76-131 VGPRs and the launch uses tens of KB of dynamic LDS --
+            #  occupancy must be taken from the code-object metadata and the launch's own debug line, MRHIP_DEBUG=1)
+            meta[k] = {"wg": int(r["Workgroup_Size"]), "grid": int(r["Grid_Size"])}
         out.setdefault(d, {})["counters_avg_per_dispatch"] = {
             k: dict(meta[k], dispatches=len(next(iter(v.values()))), **{c: round(sum(x) / len(x), 1) for c, x in v.items()})
             for k, v in agg.items()}

@@ -256,7 +256,7 @@ def test_headline_c2_streaming_1e8_vs_oracle(pkg, O, torch_cuda):
         f = pkg.FIRFilter(h, Fraction(147, 160)).bind(np.float32, 1)
         yd = torch.empty(len(yo) + 8, device="cuda", dtype=torch.float32)
         assert f.filt_into_chunked(yd, xd, chunk) == len(yo)
-        assert f.last_kernel_name() == "rational_pair_kernel"
+        assert f.last_kernel_name() == "rational_opair_kernel"
         assert_bit_equal(yd[:len(yo)].cpu().numpy(), yo, f"chunked entry, chunk {chunk}")
         assert (f.state.phiIdx, f.state.inputDeficit) == st
         assert_bit_equal(f.history, hist, "history after the chunked entry")
@@ -324,7 +324,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, Fraction(L, M))
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_pair_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"), (L, M, hl)
+        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"), (L, M, hl)
         tuned_seen.add(f.last_kernel_name())
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, Fraction(L, M))
@@ -333,48 +333,45 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         assert_bit_equal(y_t, y_g, f"tuned vs generic L={L} M={M} hLen={hl} {th} {tx}")
         assert_bit_equal(f.history, g.history, "history")
-    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_pair_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"}, tuned_seen
+    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"}, tuned_seen
 
 
 def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
     """rational_opair_kernel (two adjacent OUTPUTS per lane, window offsets resolved by exact no-op slots): L > M
-    ratios (160//147, 3//2, ...), the M > L ratios the position-pair kernel leaves (5//9), and -- with the position-pair
-    kernel switched off -- its own ratios (147//160), for every tapsPerPhi class (odd, even, 1, 32), Float32 and
-    ComplexF32, STRICT and FUSED, multi-channel, chunked with 1-sample and prime pieces; inputs contain -0.0, +-Inf
-    and NaN runs (a skipped slot must not turn into 0*Inf or flip the sign of an all-zero sum).  Bit-exact against
-    the universal kernel on all channels and against the oracle on one."""
+    ratios (160//147, 3//2, ...) and M > L ratios (147//160, 5//9, ...), every tapsPerPhi class (odd, even, 1, 32),
+    Float32 / ComplexF32 / Float64 samples, Float32 and Float64 taps (incl. the README's Float64 taps x Float32
+    samples), STRICT and FUSED, multi-channel, chunked with 1-sample and prime pieces; inputs contain -0.0, +-Inf and
+    NaN runs (a skipped slot must not turn into 0*Inf or flip the sign of an all-zero sum).  Bit-exact against the
+    universal kernel on all channels and against the oracle on one."""
     torch = torch_cuda
     rng = np.random.default_rng(2025)
-    cases = [(160, 147, 24 * 160, False), (160, 147, 24 * 160 - 77, False), (3, 2, 72, False), (3, 2, 3 * 32, False), (3, 2, 3, False),
-             (7, 5, 100, False), (5, 3, 23, False), (9, 5, 9 * 17, False), (16, 9, 16 * 31 - 5, False), (32, 31, 32 * 8, False),
-             (5, 9, 5 * 13, False), (4, 7, 4 * 32, False), (147, 160, 3528, True), (9, 10, 9 * 7, True), (31, 32, 31 * 2 - 1, True)]
-    for (L, M, hl, disable_pair) in cases:
-        for tx in (np.float32, np.complex64):
+    cases = [(160, 147, 24 * 160), (160, 147, 24 * 160 - 77), (3, 2, 72), (3, 2, 3 * 32), (3, 2, 3),
+             (7, 5, 100), (5, 3, 23), (9, 5, 9 * 17), (16, 9, 16 * 31 - 5), (32, 31, 32 * 8),
+             (5, 9, 5 * 13), (4, 7, 4 * 32), (147, 160, 3528), (9, 10, 9 * 7), (31, 32, 31 * 2 - 1)]
+    combos = [(np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32)]
+    for (L, M, hl) in cases:
+        for th, tx in combos:
             for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
-                if numerics == pkg.NUMERICS_FUSED and hl % 2:
-                    continue
+                if numerics == pkg.NUMERICS_FUSED and (hl % 2 or th == np.float64 and L % 2):
+                    continue                                            # (thin the matrix)
                 nch = int(rng.integers(1, 5))
-                h = rng.standard_normal(hl).astype(np.float32)
+                h = rng.standard_normal(hl).astype(th)
                 h[rng.integers(0, hl, 3)] = 0.0
                 x = _rand(rng, (nch, 30_011), tx) - 0.5
-                xr = x.view(np.float32)
+                xr = x.view(np.float64 if tx == np.float64 else np.float32)
                 xr[:, 500:560] = -0.0                                   # an all-(-0) window
                 xr[0, 2000] = np.inf; xr[0, 2100] = -np.inf; xr[nch - 1, 4000:4003] = np.nan
                 xd = torch.from_numpy(x).cuda()
                 sizes = [10_007, 1, 13, 19_990]
-                if disable_pair:
-                    monkeypatch.setenv("MRHIP_PAIR", "0")
                 f = pkg.FIRFilter(h, Fraction(L, M), numerics=numerics)
                 y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
                 kn = f.last_kernel_name()
-                monkeypatch.delenv("MRHIP_PAIR", raising=False)
                 monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
                 g = pkg.FIRFilter(h, Fraction(L, M), numerics=numerics)
                 y_g = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
                 monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
-                if not disable_pair:
-                    assert kn == "rational_opair_kernel", (L, M, hl, kn)
-                assert_bit_equal(y_t, y_g, f"opair vs generic L={L} M={M} hLen={hl} {tx} numerics={numerics} kernel={kn}")
+                assert kn == "rational_opair_kernel", (L, M, hl, th, tx, kn)
+                assert_bit_equal(y_t, y_g, f"opair vs generic L={L} M={M} hLen={hl} {th} {tx} numerics={numerics}")
                 assert_bit_equal(f.history, g.history, "history")
                 assert (f.state.phiIdx, f.state.inputDeficit) == (g.state.phiIdx, g.state.inputDeficit)
                 if numerics == pkg.NUMERICS_STRICT:
@@ -382,10 +379,11 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
                     yo = np.concatenate([fo.filt(p) for p in np.split(x[nch - 1], np.cumsum(sizes)[:-1])])
                     # NaN payloads/signs are the host FPU's on the oracle side (x86's default NaN has the sign bit set,
                     # the GPU's does not): NaNs must sit in the same places, everything else is compared bit for bit
-                    got, want = y_t[nch - 1].view(np.float32), yo.view(np.float32)
-                    assert np.array_equal(np.isnan(got), np.isnan(want)), f"NaN positions L={L} M={M} hLen={hl} {tx}"
+                    ft = np.float64 if yo.dtype in (np.float64, np.complex128) else np.float32
+                    got, want = y_t[nch - 1].view(ft), yo.view(ft)
+                    assert np.array_equal(np.isnan(got), np.isnan(want)), f"NaN positions L={L} M={M} hLen={hl} {th} {tx}"
                     ok = ~np.isnan(want)
-                    assert_bit_equal(got[ok], want[ok], f"opair vs oracle L={L} M={M} hLen={hl} {tx}")
+                    assert_bit_equal(got[ok], want[ok], f"opair vs oracle L={L} M={M} hLen={hl} {th} {tx}")
 
 
 def test_arbitrary_tuned_and_generic_agree(pkg, torch_cuda, monkeypatch):
@@ -526,8 +524,8 @@ def test_dynamic_scheduling_paths_match_generic_at_scale(pkg, torch_cuda, monkey
     xr = torch.rand((nch, n, 2), generator=g, device="cuda", dtype=torch.float32) - 0.5
     xc = torch.view_as_complex(xr)
     rng = np.random.default_rng(3)
-    for (L, M, hl, kname) in [(147, 160, 147 * 24, "rational_pair_kernel"), (4, 1, 128, "interp_pair_kernel"),
-                              (13, 16, 13 * 9, "rational_pair_kernel"), (3, 1, 3 * 20, "interp_pair_kernel")]:
+    for (L, M, hl, kname) in [(147, 160, 147 * 24, "rational_opair_kernel"), (4, 1, 128, "interp_pair_kernel"),
+                              (13, 16, 13 * 9, "rational_opair_kernel"), (3, 1, 3 * 20, "interp_pair_kernel")]:
         h = rng.standard_normal(hl).astype(np.float32)
         sizes = [120_001, 7, 179_992]
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
@@ -581,7 +579,7 @@ def test_config5_4096_channels_complex_one_gpu(pkg, O, torch_cuda, monkeypatch):
     assert x.numel() * 8 > 2 ** 32
     f = pkg.FIRFilter(h, Fraction(147, 160))
     y = f.filt(x)
-    assert f.last_kernel_name() == "rational_pair_kernel" and y.shape == (nch, n * 147 // 160)
+    assert f.last_kernel_name() == "rational_opair_kernel" and y.shape == (nch, n * 147 // 160)
     monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
     gf = pkg.FIRFilter(h, Fraction(147, 160))
     yg = gf.filt(x)
@@ -759,7 +757,7 @@ def test_hip_graph_capture_of_fixed_chunk_streaming(pkg, torch_cuda):
         loop(ref, y_ref)
         torch.cuda.synchronize()
         assert torch.equal(y_g.view(torch.int32), y_ref.view(torch.int32)), f"replay {replay}"
-    assert f.last_kernel_name() == "rational_pair_kernel"
+    assert f.last_kernel_name() == "rational_opair_kernel"
     # the host object follows the replays: its history is the device's, so a plain call continues the stream too
     assert_bit_equal(f.history, ref.history, "history after the replays")
 
@@ -873,8 +871,8 @@ def test_arbitrary_phase_recurrence_many_rates(pkg, O, torch_cuda):
 
 
 def test_long_launch_two_stage_tiles_match_generic(pkg, O, torch_cuda, monkeypatch):
-    """Long launches (>= 48 tiles per resident workgroup) switch the pair kernel to two LDS stages of larger tiles
-    (plan_rational_pair): Float32 64 ch x 3.3e6 and ComplexF32 96 ch x 1.5e6 in ragged pieces, against the universal
+    """Long launches (tens of tiles per resident workgroup: dynamic grabs, full-size two-stage tiles,
+    plan_rational_opair): Float32 64 ch x 3.3e6 and ComplexF32 96 ch x 1.5e6 in ragged pieces, against the universal
     kernel bit for bit, plus oracle spot checks at the seams."""
     torch = torch_cuda
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -891,7 +889,7 @@ def test_long_launch_two_stage_tiles_match_generic(pkg, O, torch_cuda, monkeypat
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, Fraction(L, M))
         y_t = torch.cat(_run_chunks(f, x, sizes), dim=-1)
-        assert f.last_kernel_name() == "rational_pair_kernel"
+        assert f.last_kernel_name() == "rational_opair_kernel"
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         gf = pkg.FIRFilter(h, Fraction(L, M))
         y_g = torch.cat(_run_chunks(gf, x, sizes), dim=-1)
