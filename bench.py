@@ -31,9 +31,9 @@ One JSON line is printed by rank 0.  `roofline.achieved` = algorithmic bytes per
 (7.675 B per input sample per channel = 4 B read + 0.91875 * 4 B written; 15.35 B for ComplexF32) x
 samples per launch / average launch duration of the dominant kernel, measured with HIP events recorded on the
 launch stream around the compute-kernel launches of the timed region (mrhip_set_timing / mrhip_timing_read; every
-launch when a pass is one call, every 4th in the chunked stream: the event records themselves cost a few
-microseconds of stream time per launch, so bracketing every 120 us launch would slow the very throughput being
-measured).  `cpu_baseline` = the CPU oracle (a C port of the reference algorithm; the reference itself is
+launch when a pass is one call; in the chunked stream one bracket around every 10 consecutive launches, the gaps
+between them included: an event pair around a single 110 us launch reads ~5 us more than the kernel's own
+timestamps in a rocprofv3 trace and costs stream time itself).  `cpu_baseline` = the CPU oracle (a C port of the reference algorithm; the reference itself is
 Julia-0.3 source and cannot run) on ONE core (the reference is single-threaded), median of 5 runs over a bounded
 sample; `cpu_baseline_all_cores` = the same port with one channel per logical core.
 """
@@ -256,7 +256,7 @@ def run_headline(args, R):
     h = pkg.firdes(TAPS_PER_PHI * L, 0.5 / L, beta=7.8562).astype(np.float32)
     nch, n = args.channels or 64, args.samples or 100_000_000
     chunk = args.chunk if 0 < args.chunk < n else n
-    time_every = args.time_every if args.time_every > 0 else (1 if chunk == n else 4)
+    time_every = args.time_every if args.time_every != 0 else (1 if chunk == n else -10)
     n_out_total = (n * L + M - 1) // M
 
     gen = torch.Generator(device=dev).manual_seed(0x4D520000 + rank)
@@ -299,7 +299,7 @@ def run_headline(args, R):
     if world == 1 and chunk == n and n > 1_000_000 and not args.no_streamed:
         sc = 1_000_000
         one_step(sc); torch.cuda.synchronize(dev)
-        filt.set_timing(4)
+        filt.set_timing(-10)         # one HIP-event bracket around every 10 consecutive launches (gaps included)
         ts = time.perf_counter()
         for _ in range(args.steps):
             one_step(sc)
@@ -467,8 +467,8 @@ def main():
     ap.add_argument("--samples", type=int, default=0, help="input samples per channel per step (default 1e8 headline, 1e6 c5)")
     ap.add_argument("--chunk", type=int, default=0, help="samples per channel per filt! call (0 = the whole batch in one call)")
     ap.add_argument("--numerics", choices=["strict", "fused"], default="strict")
-    ap.add_argument("--time-every", type=int, default=0, help="bracket every n-th kernel launch of the timed region with HIP events "
-                    "(0 = every launch when a pass is one call, every 4th when it is chunked: the brackets cost stream time)")
+    ap.add_argument("--time-every", type=int, default=0, help="n > 0: bracket every n-th kernel launch of the timed region with HIP events; "
+                    "-n: one bracket around every n consecutive launches (0 = every launch when a pass is one call, groups of 10 when it is chunked)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true", help="skip the extra chunked passes reported as `streamed_1e6_chunks`")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check (timing experiments)")

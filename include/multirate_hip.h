@@ -269,7 +269,9 @@ int mrhip_filt_once(const void *h, int64_t hLen, int tap_dtype, int64_t num, int
  * for the recorded events, returns how many launches were bracketed since the last read and the sum
  * of their durations in milliseconds, and clears the log.  bench.py uses it for roofline.achieved.
  * enabled = n > 1 brackets every n-th compute launch only (the two event records cost a few microseconds of
- * stream time per launch, which a throughput measurement of back-to-back launches would otherwise include). */
+ * stream time per launch, which a throughput measurement of back-to-back launches would otherwise include).
+ * enabled = -n < -1 puts ONE bracket around every n consecutive compute launches: mrhip_timing_read then returns the
+ * launches covered by complete groups and the groups' total duration, gaps between the launches included. */
 int mrhip_set_timing(mrhip_filter *f, int enabled);
 int mrhip_timing_read(mrhip_filter *f, int64_t *n_launches, double *total_ms);
 /* name of the device kernel the last filt call dispatched (for profiles / logs) */

@@ -588,6 +588,30 @@ static int timing_mark(mrhip_filter *f, hipStream_t stream)
 {
     if (!f->timing) return MRHIP_OK;
     static const bool attach = [] { const char *v = std::getenv("MRHIP_TIMING_ATTACH"); return v && v[0] == '1'; }();
+    if (f->timing_group > 1) {
+        // group mode: ONE event pair around every `timing_group` consecutive compute launches (the gaps between the
+        // launches of a group are inside the bracket -- a streaming cost -- and the marker packets' own stream time is
+        // shared by the whole group); an incomplete last group is dropped by mrhip_timing_read
+        if (!f->timing_open) {
+            f->timing_open = true;
+            if (f->timing_launch % f->timing_group == 0) {
+                while (f->ev_pool.size() < f->ev_used + 2) {
+                    hipEvent_t e = nullptr;
+                    MRHIP_CHECK_HIP(hipEventCreate(&e));
+                    f->ev_pool.push_back(e);
+                }
+                MRHIP_CHECK_HIP(hipEventRecord(f->ev_pool[f->ev_used], stream));
+                f->ev_used += 1;                               // the stop event follows when the group is complete
+            }
+        } else {
+            f->timing_open = false;
+            if (++f->timing_launch % f->timing_group == 0) {
+                MRHIP_CHECK_HIP(hipEventRecord(f->ev_pool[f->ev_used], stream));
+                f->ev_used += 1;
+            }
+        }
+        return MRHIP_OK;
+    }
     if (!f->timing_open) {
         f->timing_open = true;
         const bool take = (f->timing_launch++ % f->timing_stride) == 0;
@@ -1001,6 +1025,7 @@ int mrhip_set_timing(mrhip_filter *f, int enabled)
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
     f->timing = enabled != 0;
     f->timing_stride = enabled > 1 ? enabled : 1;     // enabled = n > 1: bracket every n-th compute launch
+    f->timing_group = enabled < -1 ? -enabled : 1;    // enabled = -n < -1: one bracket around every n consecutive launches
     f->timing_launch = 0; f->timing_open = false; f->ev_skip = false;
     f->ev_used = 0;
     return MRHIP_OK;
@@ -1012,15 +1037,16 @@ int mrhip_timing_read(mrhip_filter *f, int64_t *n_launches, double *total_ms)
     DeviceGuard guard(f->device);
     *n_launches = 0;
     *total_ms = 0.0;
-    const size_t pairs = f->ev_used / 2;
+    const size_t pairs = f->ev_used / 2;              // (group mode: a start event without its stop is dropped)
     for (size_t i = 0; i < pairs; ++i) {
         float ms = 0.f;
         MRHIP_CHECK_HIP(hipEventSynchronize(f->ev_pool[2 * i + 1]));
         MRHIP_CHECK_HIP(hipEventElapsedTime(&ms, f->ev_pool[2 * i], f->ev_pool[2 * i + 1]));
         *total_ms += ms;
     }
-    *n_launches = static_cast<int64_t>(pairs);
+    *n_launches = static_cast<int64_t>(pairs) * f->timing_group;
     f->ev_used = 0;
+    f->timing_launch = 0; f->timing_open = false;
     return MRHIP_OK;
 }
 

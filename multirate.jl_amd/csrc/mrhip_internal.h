@@ -321,6 +321,7 @@ struct mrhip_filter {
     // measurement
     bool timing = false;
     int timing_stride = 1;            // bracket every timing_stride-th compute launch (1 = all)
+    int timing_group = 1;             // > 1: one bracket around every timing_group consecutive compute launches
     int64_t timing_launch = 0;        // compute launches seen since timing was enabled
     bool timing_open = false;         // between the two marks of a launch
     bool ev_skip = false;             // ... of a launch that is not bracketed
