@@ -1,5 +1,5 @@
 // kernels_rational_opair.hip -- FIRRational with 1/2 < M/L < 2 in either direction (147//160: the headline; 160//147,
-// 3//2, ...), tapsPerPhi <= 32: Float32, ComplexF32 and Float64 samples, Float32 or Float64 arithmetic.  This file holds
+// 3//2, ...), tapsPerPhi <= 48 (Float64 arithmetic: 32): Float32, ComplexF32 and Float64 samples, Float32 or Float64 arithmetic.  This file holds
 // the planning and the dispatch; the kernel itself is opair_kernel.inc, instantiated by kernels_rational_opair_*.hip.
 //
 // Mapping.  (Round 1's kernel gave a lane two adjacent INPUT positions: with M > L a position produces at most one
@@ -52,7 +52,7 @@ inline int opair_env_int(const char *name, int dflt)
 }
 }  // namespace
 
-// Covers FIRRational with tapsPerPhi <= 32 and 1/2 < M/L < 2 (M != L; SMIN = floor(M/L)) for Float32 arithmetic (Float32 or
+// Covers FIRRational with tapsPerPhi <= 48 (Float64 arithmetic: 32) and 1/2 < M/L < 2 (M != L; SMIN = floor(M/L)) for Float32 arithmetic (Float32 or
 // ComplexF32 samples, Float32 taps) and Float64 arithmetic on real samples (Float64 x Float64; Float64 taps x Float32
 // samples).  Returns false otherwise (the caller tries the next kernel).
 bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
@@ -63,9 +63,9 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
     const int nc = tk.complex_x ? 2 : 1;
     const long long es = (tk.x_f64 ? 8 : 4) * nc;        // bytes per input sample
 #ifdef MRHIP_PS_FAST_BUILD
-    if (a.T != 24) return false;
+    if (a.T != 24 && !(!tk.r_f64 && (a.T == 36 || a.T == 48))) return false;
 #endif
-    if (a.T < 1 || a.T > 32) return false;
+    if (a.T < 1 || a.T > (tk.r_f64 ? 32 : 48)) return false;
     if (a.L < 2 || a.M < 2 || a.zero_start_below > 0) return false;
     if (!(2LL * a.M > a.L && a.M < 2LL * a.L)) return false;
     const int smin = a.M > a.L ? 1 : 0;
@@ -94,8 +94,11 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
     const int tail = a.T + smin + 4;                    // run overhang beyond the period: offsets <= smin + 2, + even rounding
     // resident workgroups per CU: 76-81 VGPRs allow 6 waves per SIMD = 24 per CU; a six-wave workgroup gets three, not
     // four (its waves land 2,2,1,1 on the SIMDs and the fourth rarely fits: kernels measured with MRHIP_PAIR_PROBE in round 1)
-    // (ComplexF32: 83 VGPRs, 5 waves per SIMD = 20 per CU; Float64 arithmetic: ~135 VGPRs, 3 per SIMD = 12 per CU)
-    int wg_per_cu = std::max(1, std::min(4, (tk.r_f64 ? 12 : nc == 2 ? 20 : 24) / (nwaves + 1)));
+    // waves per CU the registers allow: two tap columns + ring + accumulators = 2T + 30 VGPRs (ComplexF32: + 36), in
+    // granules of 8: T = 24 -> 80 -> 6 per SIMD = 24 per CU (ComplexF32: 88 -> 20); Float64 arithmetic: ~135 -> 3 per SIMD
+    const int vgpr_est = (2 * a.T + (nc == 2 ? 36 : 30) + 7) / 8 * 8;
+    const int waves_per_cu = tk.r_f64 ? 12 : 4 * std::min(8, 512 / vgpr_est);
+    int wg_per_cu = std::max(1, std::min(4, waves_per_cu / (nwaves + 1)));
     if (nwaves + 1 == 6 && !tk.r_f64) wg_per_cu = 3;
     // TWO pipeline stages of tiles as large as the LDS allows (the DMA runs one tile ahead, far more than the HBM
     // latency; every tile costs ~1000 cycles of barrier skew, ring priming and drain).  Measured on 147//160 Float32,
