@@ -161,6 +161,13 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
     *did_shiftin = false;
     if (!f->force_generic) {
         if (a.L == 1) {
+            PairArgs spa;
+            dim3 sblock;
+            size_t slds = 0;
+            if (plan_fir_stream(tk, a, f->num_cus, &spa, &sblock, &slds)) {
+                *did_shiftin = a.H > 0;          // its loader waves write the call-end history themselves
+                return launch_fir_stream(fused, a, spa, sblock, slds, s, kname, f->num_cus, f->d_counters);
+            }
             DirectArgs da;
             size_t lds = 0;
             if (plan_fir_direct(tk, a, f->num_cus, &da, &lds))

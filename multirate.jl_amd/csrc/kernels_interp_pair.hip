@@ -13,7 +13,7 @@
 // Consecutive lanes own consecutive output pairs, so results go straight from the accumulators to one
 // dense 2-sample store per lane (no staging through LDS).
 //
-// Everything around the dot products is the machinery of kernels_rational_pair.hip: a loader wave streams
+// Everything around the dot products is the machinery of the rational kernel (pair_loader.h): a loader wave streams
 // tiles HBM -> LDS with LDS-DMA three stages deep, hands out the work in dynamically drawn grabs of J steps
 // (32 XCD-local counters), publishes tiles through LDS, and performs shiftin! at the end of the launch; the
 // compute waves fetch the window through a small register ring with compile-time wait counts.
@@ -27,6 +27,7 @@
 
 #include "mrhip_internal.h"
 #include "pair_device.h"
+#include "pair_loader.h"
 
 #pragma clang fp contract(off)
 
@@ -67,137 +68,14 @@ void interp_pair_kernel(PolyArgs a, PairArgs pa)
     const int ncw = (blockDim.x >> 6) - 1;      // compute waves; the last wave of the workgroup is the loader
     const int CP = pa.cM, LP = pa.c, L = a.L;
 
-    // ---- tile walk shared by both roles (see kernels_rational_pair.hip): steps of CP positions, numbered
+    // ---- tile walk shared by both roles (see opair_kernel.inc): steps of CP positions, numbered
     // channel-major, drawn in grabs of J from 32 group counters by the loader wave, published through LDS
-    const unsigned spc = static_cast<unsigned>(pa.steps_per_channel);
-    struct TileAt { int ch, st, jt; };
-    auto tile_at = [&](unsigned g, unsigned jt) -> TileAt {
-        unsigned q = __umulhi(g, pa.spc_magic);
-        unsigned r = g - q * spc;
-        if (r >= spc) { ++q; r -= spc; }
-        if (r >= spc) { ++q; r -= spc; }
-        return TileAt{static_cast<int>(q), static_cast<int>(r), static_cast<int>(umin(jt, spc - r))};
-    };
+    auto tile_at = [&](unsigned g, unsigned jt) -> TileAt { return pair_tile_at(pa, g, jt); };
     volatile unsigned *const tile_flag = reinterpret_cast<volatile unsigned *>(smem + pa.flags_off);   // [ns][2]
 
     if (wave == ncw) {
-        // ================= loader wave =================
-        auto stage_tile = [&](const TileAt &ta, int stage) -> int {
-            constexpr int EPC = 4 / NC;                                 // samples per 16-byte DMA chunk
-            const int tlen = (ta.jt * CP + T - 1 + EPC - 1) / EPC * EPC;  // samples this tile needs, whole chunks
-            const int nchunks = tlen / EPC;
-            const int nslots = (nchunks + 63) >> 6;                     // 1 KiB LDS slots
-            const float *__restrict__ xc = static_cast<const float *>(a.x) + static_cast<long long>(ta.ch) * a.x_stride * NC;
-            // x index (0-based) of LDS sample 0: the oldest sample of the tile's first position
-            const long long o = static_cast<long long>(ta.st) * CP - (T - 1);
-            unsigned char *st = smem + static_cast<size_t>(stage) * pa.stage_bytes;
-            const bool interior = o >= 0 && o + tlen <= a.x_len;        // wave-uniform
-            if (interior) {
-                const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
-                for (int slot = 0; slot < nslots; ++slot) {
-                    const int ci = slot * 64 + lane;
-                    const int cis = ci < nchunks ? ci : 0;              // padding lanes re-read chunk 0 into LDS padding
-                    dma16(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
-                }
-                return nslots;
-            }
-            // first / last tile of a channel: history seam and end of input, element-wise checked
-            const float *__restrict__ hc = static_cast<const float *>(a.hist) + static_cast<long long>(ta.ch) * a.H * NC;
-            float *l = reinterpret_cast<float *>(st);
-            for (int ci = lane; ci < nchunks; ci += 64) {
-                float4 v;
-                float *pv = reinterpret_cast<float *>(&v);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const long long gi = o + static_cast<long long>(EPC) * ci + e;
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) {
-                        float val = 0.f;
-                        if (gi >= 0) { if (gi < a.x_len) val = xc[gi * NC + cc]; }
-                        else if (gi >= -static_cast<long long>(a.H)) val = hc[(a.H + gi) * NC + cc];
-                        pv[e * NC + cc] = val;
-                    }
-                }
-                *reinterpret_cast<float4 *>(l + ci * 4) = v;
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            return 0;
-        };
-        const unsigned grp = blockIdx.x % static_cast<unsigned>(pa.ngroups);
-        const unsigned grp_lo = umin(grp * pa.steps_per_group, pa.total_steps);
-        const unsigned grp_hi = umin(grp_lo + pa.steps_per_group, pa.total_steps);
-        unsigned *const ctr = pa.counters + grp * 64u;
-        unsigned pend = 0;
-        unsigned static_next = blockIdx.x / static_cast<unsigned>(pa.ngroups);
-        const unsigned static_stride = (gridDim.x + static_cast<unsigned>(pa.ngroups) - 1u - grp) / static_cast<unsigned>(pa.ngroups);
-        auto grab_issue = [&]() {
-            if (pa.static_grabs) { pend = static_next; static_next += static_stride; }
-            else if (lane == 0) pend = atomicAdd(ctr, 1u);
-        };
-        unsigned ra = 0, rb = 0;
-        bool more = true;
-        auto grab_take = [&]() {
-            const unsigned t = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(pend)));
-            const unsigned long long lo = static_cast<unsigned long long>(grp_lo) + static_cast<unsigned long long>(t) * pa.J;
-            if (lo < grp_hi) { ra = static_cast<unsigned>(lo); rb = umin(ra + pa.J, grp_hi); grab_issue(); }
-            else { more = false; ra = rb = 0; }
-        };
-        unsigned long long hist = 0;
-        auto newest_ops = [&](int ntiles) -> int {
-            int n = 0;
-            for (int k = 0; k < ntiles; ++k) n += static_cast<int>((hist >> (6 * k)) & 63u);
-            return n < 60 ? n : 60;
-        };
-        auto produce = [&](int stage) -> bool {
-            if (ra >= rb && more) grab_take();
-            if (ra >= rb) {
-                if (lane == 0) { tile_flag[2 * stage] = 0u; tile_flag[2 * stage + 1] = 0u; }
-                hist <<= 6;
-                return false;
-            }
-            const TileAt ta = tile_at(ra, rb - ra);
-            if (lane == 0) { tile_flag[2 * stage] = ra; tile_flag[2 * stage + 1] = static_cast<unsigned>(ta.jt); }
-            hist = (hist << 6) | static_cast<unsigned>(stage_tile(ta, stage));
-            ra += static_cast<unsigned>(ta.jt);
-            return true;
-        };
-        grab_issue();
-        unsigned pipeline = 0;
-        for (int k = 0; k < pa.ns - 1; ++k)
-            if (produce(k)) pipeline |= 1u << k;
-        wait_vmcnt_le(newest_ops(pa.ns - 2));
-        int pstage = pa.ns - 1;
-        for (;;) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (!(pipeline & 1u)) break;
-            pipeline >>= 1;
-            if (produce(pstage)) pipeline |= 1u << (pa.ns - 2);
-            pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
-            wait_vmcnt_le(newest_ops(pa.ns - 2));
-        }
-        if (lane == 0 && !pa.static_grabs) {
-            unsigned *const done = pa.counters + static_cast<unsigned>(pa.ngroups) * 64u;
-            if (atomicAdd(done, 1u) == gridDim.x - 1) {
-                for (int k = 0; k < pa.ngroups; ++k) pa.counters[k * 64] = 0u;
-                *done = 0u;
-            }
-        }
-        // shiftin! (support.jl:61-80), fused
-        if (a.H > 0) {
-            const float *__restrict__ xin = static_cast<const float *>(a.x);
-            const float *__restrict__ hold = static_cast<const float *>(a.hist);
-            float *__restrict__ hnew = static_cast<float *>(a.hist_new);
-            for (int c2 = blockIdx.x; c2 < a.nch; c2 += gridDim.x)
-                for (int i = lane; i < a.H; i += 64) {
-                    const long long e = static_cast<long long>(i) + a.x_len;
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc)
-                        hnew[(static_cast<long long>(c2) * a.H + i) * NC + cc] =
-                            e < a.H ? hold[(static_cast<long long>(c2) * a.H + e) * NC + cc]
-                                    : xin[(static_cast<long long>(c2) * a.x_stride + (e - a.H)) * NC + cc];
-                }
-        }
+        // ================= loader wave (pair_loader.h): cM = positions per step, tail = T - 1, o0 = -(T - 1) =================
+        pair_loader_wave<NC>(a, pa, smem, lane);
         return;
     }
 
@@ -384,7 +262,9 @@ bool plan_interp_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArg
     pa.dma_rounds = static_cast<int>(nslots);
     pa.stage_bytes = static_cast<int>(stage_bytes);
     pa.ns = ns; pa.nc = nc;
-    pa.o0 = -(a.T - 1);
+    pa.o0 = -(a.T - 1);           // x index of LDS sample 0 of a channel's first tile: the oldest sample of its first position
+    pa.tail = a.T - 1;            // a tile of j steps needs j*CP + T - 1 samples (pair_loader.h)
+    pa.bank_off = -1; pa.pad_every = 0;
     static const int env_ablate = int_env_int("MRHIP_PS_ABLATE", 0);
     pa.ablate = env_ablate;
     pa.steps_per_channel = static_cast<unsigned>(spc);

@@ -165,6 +165,7 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     unsigned steps_per_group;     // ceil(total_steps / ngroups): group g owns steps [g*S, (g+1)*S)
     int ngroups;                  // scheduling groups; workgroup b draws grabs of J steps from group b % ngroups
     int flags_off;                // LDS byte offset of the per-stage tile descriptors
+    int pad_every;                // > 0: one 16-byte pad chunk after every pad_every data chunks of a staged tile (pair_loader.h)
     int bank_off;                 // LDS byte offset of the tap bank staged by the compute waves before the first tile (-1: none;
                                   // the loader wave then joins one extra barrier before its first tile barrier)
     int static_grabs;             // 1: grabs are dealt round-robin without atomics (small launches)
@@ -241,6 +242,9 @@ hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &
 bool plan_interp_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_interp_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                               const char **kname, int num_cus, unsigned *counters);   // FIRInterpolator, two phases per lane; also performs shiftin!
+bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
+hipError_t launch_fir_stream(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
+                             const char **kname, int num_cus, unsigned *counters);   // FIRStandard / FIRDecimator, streaming form; also performs shiftin!
 bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectArgs *out, size_t *lds);
 hipError_t launch_fir_direct(const TypeKey &tk, bool fused, const PolyArgs &a, const DirectArgs &da, size_t lds, hipStream_t s,
                              const char **kname, int num_cus);

@@ -41,7 +41,11 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
         constexpr int EPC = 4 / NC;                                 // samples per 16-byte DMA chunk
         const int tlen = (ta.jt * pa.cM + pa.tail + EPC - 1) / EPC * EPC;   // samples this tile needs, whole chunks
         const int nchunks = tlen / EPC;
-        const int nslots = (nchunks + 63) >> 6;                     // 1 KiB LDS slots
+        // pa.pad_every = cd > 0: one 16-byte pad chunk after every cd data chunks (data chunk d lives at LDS chunk
+        // d + d / cd), so that lanes whose runs start cd chunks apart hit different banks (kernels_fir_stream.hip)
+        const int cd = pa.pad_every;
+        const int nlds = cd > 0 ? (nchunks + cd - 1) / cd * (cd + 1) : nchunks;
+        const int nslots = (nlds + 63) >> 6;                        // 1 KiB LDS slots
         const float *__restrict__ xc = static_cast<const float *>(a.x) + static_cast<long long>(sch) * a.x_stride * NC;
         const long long o = pa.o0 + static_cast<long long>(ta.st) * pa.cM;   // x index of LDS sample 0 (may be < 0)
         unsigned char *st = smem + static_cast<size_t>(stage) * pa.stage_bytes;
@@ -50,7 +54,9 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
             const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
             for (int slot = 0; slot < nslots; ++slot) {
                 const int ci = slot * 64 + lane;
-                const int cis = ci < nchunks ? ci : 0;                   // padding lanes re-read chunk 0 into LDS padding
+                int d = ci;
+                if (cd > 0) { const int g = ci / (cd + 1), r = ci - g * (cd + 1); d = r == cd ? 0 : g * cd + r; }
+                const int cis = d < nchunks ? d : 0;                     // pad chunks and padding lanes re-read chunk 0
                 dma16(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
             }
             return nslots;
@@ -72,7 +78,7 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
                     pv[e * NC + cc] = val;
                 }
             }
-            *reinterpret_cast<float4 *>(l + ci * 4) = v;
+            *reinterpret_cast<float4 *>(l + (cd > 0 ? ci + ci / cd : ci) * 4) = v;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         return 0;

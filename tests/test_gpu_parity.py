@@ -324,7 +324,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, Fraction(L, M))
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"), (L, M, hl)
+        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel", "fir_stream_kernel"), (L, M, hl)
         tuned_seen.add(f.last_kernel_name())
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, Fraction(L, M))
@@ -333,7 +333,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         assert_bit_equal(y_t, y_g, f"tuned vs generic L={L} M={M} hLen={hl} {th} {tx}")
         assert_bit_equal(f.history, g.history, "history")
-    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel"}, tuned_seen
+    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel", "fir_stream_kernel"}, tuned_seen
 
 
 def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
@@ -387,6 +387,54 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
                     assert np.array_equal(np.isnan(got), np.isnan(want)), f"NaN positions L={L} M={M} hLen={hl} {th} {tx}"
                     ok = ~np.isnan(want)
                     assert_bit_equal(got[ok], want[ok], f"opair vs oracle L={L} M={M} hLen={hl} {th} {tx}")
+
+
+def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
+    """fir_stream_kernel (FIRStandard / FIRDecimator, Float32 arithmetic, loader-wave staging, padded LDS tile, scalar
+    taps): M in {1, 2, 4, 8}, tap counts 32..512 (multiples of 16), Float32 and ComplexF32, STRICT and FUSED,
+    multi-channel, chunked with 1-sample pieces and pieces shorter than the history (the start-from-zero quirk of the
+    Vector seam variant, support.jl:46, applies to the first hLen outputs of EVERY call); inputs contain -0.0, +-Inf,
+    NaN.  Bit-exact against the universal kernel, the direct kernel it replaces, and the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    for M in (1, 2, 4, 8):
+        for T in (32, 48, 128, 512):
+            for tx in (np.float32, np.complex64):
+                for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
+                    if numerics == pkg.NUMERICS_FUSED and T not in (48, 128):
+                        continue
+                    nch = int(rng.integers(1, 6))
+                    h = rng.standard_normal(T).astype(np.float32)
+                    h[rng.integers(0, T, 2)] = 0.0
+                    x = _rand(rng, (nch, 40_009), tx) - 0.5
+                    xr = x.view(np.float32)
+                    xr[:, 300:300 + 2 * T] = -0.0                      # all-(-0) windows: the zero-start quirk shows as a sign
+                    xr[0, 5000] = np.inf; xr[0, 5100] = -np.inf; xr[nch - 1, 9000:9003] = np.nan
+                    xd = torch.from_numpy(x).cuda()
+                    sizes = [10_007, 1, 13, T // 2, 19_990, 40_009 - 10_007 - 1 - 13 - T // 2 - 19_990]
+                    ys = {}
+                    for mode in ("stream", "direct", "generic"):
+                        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False); monkeypatch.delenv("MRHIP_STREAM", raising=False)
+                        if mode == "direct":
+                            monkeypatch.setenv("MRHIP_STREAM", "0")
+                        if mode == "generic":
+                            monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+                        f = pkg.FIRFilter(h, Fraction(1, M), numerics=numerics)
+                        y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+                        ys[mode] = (y, f.history.copy(), f.last_kernel_name(), (f.state.phiIdx, f.state.inputDeficit))
+                    monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False); monkeypatch.delenv("MRHIP_STREAM", raising=False)
+                    assert ys["stream"][2] == "fir_stream_kernel" and ys["direct"][2].startswith("fir_direct") and ys["generic"][2] == "poly_generic_kernel"
+                    for other in ("direct", "generic"):
+                        assert_bit_equal(ys["stream"][0], ys[other][0], f"stream vs {other} M={M} T={T} {tx} numerics={numerics}")
+                        assert_bit_equal(ys["stream"][1], ys[other][1], "history")
+                        assert ys["stream"][3] == ys[other][3]
+                    if numerics == pkg.NUMERICS_STRICT:
+                        fo = O.FIRFilter(h, Fraction(1, M), tx=tx)
+                        yo = np.concatenate([fo.filt(p) for p in np.split(x[nch - 1], np.cumsum(sizes)[:-1])])
+                        got, want = ys["stream"][0][nch - 1].view(np.float32), yo.view(np.float32)
+                        assert np.array_equal(np.isnan(got), np.isnan(want))
+                        ok = ~np.isnan(want)
+                        assert_bit_equal(got[ok], want[ok], f"stream vs oracle M={M} T={T} {tx}")
 
 
 def test_arbitrary_tuned_and_generic_agree(pkg, torch_cuda, monkeypatch):
