@@ -137,11 +137,19 @@ void fir_stream_kernel(PolyArgs a, PairArgs pa)
                             for (int cc = 0; cc < NC; ++cc) w[ii * SPR + e][cc] = __uint_as_float(u[e * NC + cc]);
                     }
                 };
+                // ComplexF32: (re, im) of a sample share the tap -> one packed multiply and one packed add per sample and
+                // output, written out by hand (this file is compiled with -fno-slp-vectorize: left to itself the
+                // vectoriser packs the second output ACROSS samples and pays two v_mov shuffles per packed operation)
                 auto mac = [&](float (&acc)[NC], float t, const float (&w)[NC]) {
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) {
-                        if constexpr (FUSED) acc[cc] = __builtin_fmaf(t, w[cc], acc[cc]);
-                        else { const float p = t * w[cc]; acc[cc] = acc[cc] + p; }
+                    if constexpr (NC == 2) {
+                        v2f_t av = {acc[0], acc[1]};
+                        const v2f_t wv = {w[0], w[1]}, tv = {t, t};
+                        if constexpr (FUSED) av = __builtin_elementwise_fma(tv, wv, av);
+                        else { const v2f_t p = tv * wv; av = av + p; }
+                        acc[0] = av.x; acc[1] = av.y;
+                    } else {
+                        if constexpr (FUSED) acc[0] = __builtin_fmaf(t, w[0], acc[0]);
+                        else { const float p = t * w[0]; acc[0] = acc[0] + p; }
                     }
                 };
                 auto init = [&](float (&acc)[NC], float t, const float (&w)[NC], bool zs) {   // first product initialises (support.jl:35,46)
