@@ -1,5 +1,7 @@
-// kernels_fir_direct.hip -- tuned gfx950 kernel for the single-column kernels: FIRStandard (M = 1)
-// and FIRDecimator (L = 1), any tap count, every dtype.
+// kernels_fir_direct.hip -- gfx950 kernel for the single-column kernels FIRStandard (M = 1) and FIRDecimator (L = 1),
+// tap counts up to 512, every dtype and every M: what kernels_fir_stream.hip (Float32 arithmetic, M in {1,2,4,8},
+// 32..512 taps) does not take.  (Round 1's two-outputs-per-lane variant of this kernel is superseded by the streaming
+// kernel and gone.)
 //
 // reference: src/Filters.jl:450-473 (Standard), :598-631 (Decimator); dot: src/support.jl:33-55.
 //
@@ -162,189 +164,6 @@ __global__ __launch_bounds__(kDirectThreads) void fir_direct_kernel(PolyArgs a, 
 }
 
 
-// ---- two adjacent outputs per lane -------------------------------------------------------------------------
-// Outputs 2k and 2k+1 of a lane use windows that start M samples apart: one run of T+M samples feeds both, sample s
-// meeting tap s of the first output and tap s-M of the second -- half the LDS reads per output of the kernel above,
-// and no per-tap address arithmetic: the tile is transposed by residue mod R = 2M (a lane's run starts in row 0),
-// so sample s = c*R + r sits at row-base[r] + c, fetched with an immediate offset from one of R row-base
-// registers that advance once per 64 samples.  In the unguarded 64-sample blocks the taps come from scalar loads
-// (wave-uniform index, constant address space) and feed the VALU as SGPR operands; the guarded head/tail paths use the
-// packed copies (tvA lane l of register o: tap 64o+l; tvB: tap 64o+l-M) broadcast with v_readlane.  Blocks of 64 samples that lie wholly inside
-// [M, T) run without any guard; the first M samples (first output only), a partial last block and the last M
-// samples (second output only) take guarded paths.  Requires M in {1,2,4,8} (R divides 64) and T >= 64.
-template <typename TX, typename R, int NC, bool FUSED, int NCH, int M>
-__global__ __launch_bounds__(kDirectThreads) void fir_direct_pair_kernel(PolyArgs a, DirectArgs da)
-{
-    constexpr int RR = 2 * M;                                   // residue rows
-    struct alignas(sizeof(TX) * NC) Sample { TX c[NC]; };
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Sample *const lds = reinterpret_cast<Sample *>(smem);
-
-    const int tid = threadIdx.x;
-    const int T = a.T, QP = da.row_pitch;
-    const R *__restrict__ taps_g = static_cast<const R *>(a.taps);
-    // the tap vector is never written while a filter exists: reading it through the constant address space lets the
-    // compiler use scalar loads for wave-uniform indices (it cannot prove that for a plain global pointer next to the y stores)
-    typedef const __attribute__((address_space(4))) R *const_taps_t;
-    const const_taps_t taps_c = (const_taps_t)(taps_g);
-    R tvA[NCH], tvB[NCH];
-    {
-        const int l = tid & 63;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int i = 64 * c + l;
-            tvA[c] = i < T ? taps_g[i] : static_cast<R>(0);
-            tvB[c] = (i >= M && i - M < T) ? taps_g[i - M] : static_cast<R>(0);
-        }
-    }
-    const long long tile_out = static_cast<long long>(da.J) * kDirectThreads * 2;
-    const long long tile_in = tile_out * M;
-    const int nfull = T / 64;                                   // 64-sample blocks wholly below T
-
-    for (long long tile = blockIdx.x; tile < da.total_tiles; tile += gridDim.x) {
-        const int ch = static_cast<int>(tile / da.tiles_per_channel);
-        const long long tau = tile - static_cast<long long>(ch) * da.tiles_per_channel;
-        const Sample *__restrict__ xc = static_cast<const Sample *>(a.x) + static_cast<long long>(ch) * a.x_stride;
-        const Sample *__restrict__ hc = static_cast<const Sample *>(a.hist) + static_cast<long long>(ch) * a.H;
-        R *__restrict__ yc = static_cast<R *>(a.y) + (static_cast<long long>(ch) * a.y_stride + tau * tile_out) * NC;
-        const long long o = a.d0 - T + tau * tile_in;           // x index (0-based) of tile sample 0
-
-        __syncthreads();   // previous tile's reads are done
-        for (int s = tid; s < da.tile_len; s += kDirectThreads) {
-            const long long gi = o + s;
-            Sample v;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) v.c[c] = static_cast<TX>(0);
-            if (gi >= 0) { if (gi < a.x_len) v = xc[gi]; }
-            else if (gi >= -static_cast<long long>(a.H)) v = hc[a.H + gi];
-            lds[(s % RR) * QP + s / RR] = v;
-        }
-        __syncthreads();
-
-        const long long remaining = a.n_out - tau * tile_out;
-#pragma unroll 1
-        for (int j = 0; j < da.J; ++j) {
-            const int kp = j * kDirectThreads + tid;              // output PAIR index inside the tile
-            const long long k0 = 2LL * kp;
-            if (k0 >= remaining) break;
-            const Sample *wpr[RR];                                // row bases: sample c*RR + r lives at wpr[r][c]
-#pragma unroll
-            for (int r = 0; r < RR; ++r) wpr[r] = lds + r * QP + kp;
-            R acc0[NC], acc1[NC];
-            const long long n0 = a.d0 + (tau * tile_out + k0) * M;    // 1-based newest-sample index of output 0
-            const bool zs0 = n0 < a.zero_start_below, zs1 = n0 + M < a.zero_start_below;   // support.jl:46
-            auto init = [&](R (&acc)[NC], R t, const Sample &v, bool zs) {   // first product initialises (support.jl:35,46)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] = t * static_cast<R>(v.c[c]);
-                if (zs) {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) acc[c] = static_cast<R>(0) + acc[c];
-                }
-            };
-            auto macs = [&](R (&acc)[NC], R t, const Sample &v) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] = mac<R, FUSED>(t, static_cast<R>(v.c[c]), acc[c]);
-            };
-            // ---- 64-sample blocks wholly inside [0, T): no guards (o64, g8, u are compile-time after unrolling)
-#pragma unroll
-            for (int o64 = 0; o64 < NCH; ++o64) {
-                if (o64 < nfull) {                                // wave-uniform
-#pragma unroll
-                    for (int g8 = 0; g8 < 8; ++g8) {
-                        // 8 samples per trip: the LDS reads are independent of the arithmetic, so the compiler issues
-                        // them ahead of the previous trip's multiply-adds
-                        Sample v8[8];
-                        R tA8[8], tB8[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int e = g8 * 8 + u;
-                            v8[u] = wpr[e % RR][o64 * (64 / RR) + e / RR];
-                            // wave-uniform index in the CONSTANT address space: s_load, the tap is an SGPR operand of the
-                            // VALU (no v_readlane broadcast: 9 instead of 11 instructions per 8 multiply/adds)
-                            tA8[u] = taps_c[64 * o64 + e];
-                            tB8[u] = (64 * o64 + e >= M) ? taps_c[64 * o64 + e - M] : static_cast<R>(0);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int e = g8 * 8 + u;
-                            if (o64 == 0 && e == 0) init(acc0, tA8[u], v8[u], zs0); else macs(acc0, tA8[u], v8[u]);
-                            if (o64 == 0 && e < M) {}                                  // output 1 starts at sample M
-                            else if (o64 == 0 && e == M) init(acc1, tB8[u], v8[u], zs1);
-                            else macs(acc1, tB8[u], v8[u]);
-                        }
-                    }
-                }
-            }
-            // ---- tail: samples [64*nfull, T+M), guarded per sample (wave-uniform conditions; 64*nfull >= 64 > M)
-            for (int sidx = 64 * nfull; sidx < T + M; ++sidx) {
-                const int o64 = sidx >> 6, e = sidx & 63;
-                R tA = static_cast<R>(0), tB = static_cast<R>(0);
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-                    if (c == o64) { tA = bcast_lane<R>(tvA[c], e); tB = bcast_lane<R>(tvB[c], e); }
-                const Sample v = lds[(sidx % RR) * QP + kp + sidx / RR];
-                if (sidx < T) macs(acc0, tA, v);
-                macs(acc1, tB, v);
-            }
-            if (k0 + 1 < remaining) {
-                R o2[2 * NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { o2[c] = acc0[c]; o2[NC + c] = acc1[c]; }
-                __builtin_memcpy(yc + k0 * NC, o2, sizeof(o2));
-            } else {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) yc[k0 * NC + c] = acc0[c];
-            }
-        }
-    }
-}
-
-template <int NC>
-hipError_t launch_direct_pair(bool fused, const PolyArgs &a, DirectArgs da, size_t lds, hipStream_t s, int num_cus)
-{
-    auto go = [&](auto kfn) -> hipError_t {
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               static_cast<int>(lds));
-            if (e != hipSuccess) return e;
-        }
-        int per_cu = 0;
-        hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kDirectThreads, lds);
-        if (eo != hipSuccess) return eo;
-        if (per_cu < 1) per_cu = 1;
-        long long g = static_cast<long long>(num_cus) * per_cu;
-        if (g > da.total_tiles) g = da.total_tiles;
-        if (g < 1) g = 1;
-        static int dbg = -1;
-        if (dbg < 0) { const char *v = std::getenv("MRHIP_DEBUG"); dbg = (v && v[0] == '1') ? 1 : 0; }
-        if (dbg == 1) {
-            dbg = 0;
-            hipFuncAttributes fa;
-            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kfn));
-            std::fprintf(stderr, "[mrhip] fir_direct_pair T=%d M=%d grid=%lld lds=%zu occ/CU=%d regs=%d J=%d tile_len=%d pitch=%d tiles=%lld\n",
-                         a.T, a.M, g, lds, per_cu, fa.numRegs, da.J, da.tile_len, da.row_pitch, da.total_tiles);
-        }
-        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kDirectThreads), lds, s, a, da);
-        return hipGetLastError();
-    };
-    const int nch = (a.T + a.M + 63) / 64;
-#define MRHIP_GOP(N, MM) (fused ? go(fir_direct_pair_kernel<float, float, NC, true, N, MM>) : go(fir_direct_pair_kernel<float, float, NC, false, N, MM>))
-#define MRHIP_GOM(N)                                  \
-    switch (a.M) {                                    \
-    case 1: return MRHIP_GOP(N, 1);                   \
-    case 2: return MRHIP_GOP(N, 2);                   \
-    case 4: return MRHIP_GOP(N, 4);                   \
-    case 8: return MRHIP_GOP(N, 8);                   \
-    default: return hipErrorInvalidValue;             \
-    }
-    if (nch <= 3) { MRHIP_GOM(3) }
-    if (nch <= 5) { MRHIP_GOM(5) }
-    if (nch <= 9) { MRHIP_GOM(9) }
-#undef MRHIP_GOM
-#undef MRHIP_GOP
-    return hipErrorInvalidValue;
-}
-
 template <typename TX, typename R, int NC>
 hipError_t launch_direct(bool fused, const PolyArgs &a, DirectArgs da, size_t lds, hipStream_t s, int num_cus)
 {
@@ -391,12 +210,8 @@ bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectAr
     static const int enabled = [] { const char *v = std::getenv("MRHIP_DIRECT"); return !(v && v[0] == '0'); }();
     if (!enabled || a.L != 1 || a.T > 512) return false;   // packed taps: up to 8 registers
     const int sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
-    static const int pair_enabled = [] { const char *v = std::getenv("MRHIP_DIRECT_PAIR"); return !(v && v[0] == '0'); }();
-    // two adjacent outputs per lane (fir_direct_pair_kernel): Float32 arithmetic, M in {1,2,4,8}, 64 <= T, T+M <= 576
-    const bool pair = pair_enabled && !tk.x_f64 && !tk.r_f64 && (a.M == 1 || a.M == 2 || a.M == 4 || a.M == 8) && a.T >= 64 &&
-                      a.T + a.M <= 576;
-    const long long opt = pair ? 2 : 1;                  // outputs per thread per step
-    const long long rows = pair ? 2 * a.M : a.M;         // residue rows of the transposed tile
+    const long long opt = 1;                             // outputs per thread per step
+    const long long rows = a.M;                          // residue rows of the transposed tile
     // J steps of 256 threads; keep the tile near 24 KiB
     static const int tile_kib = [] { const char *v = std::getenv("MRHIP_DIRECT_TILE_KIB"); return v && *v ? std::atoi(v) : 24; }();
     long long J = (static_cast<long long>(tile_kib) * 1024 / sb - a.T) / (static_cast<long long>(kDirectThreads) * opt * a.M);
@@ -415,7 +230,6 @@ bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectAr
     da.J = static_cast<int>(J);
     da.tile_len = static_cast<int>(tile_len);
     da.row_pitch = static_cast<int>(pitch);
-    da.pair = pair ? 1 : 0;
     da.tiles_per_channel = (a.n_out + J * kDirectThreads * opt - 1) / (J * kDirectThreads * opt);
     da.total_tiles = da.tiles_per_channel * a.nch;
     *out = da;
@@ -426,10 +240,6 @@ bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectAr
 hipError_t launch_fir_direct(const TypeKey &tk, bool fused, const PolyArgs &a, const DirectArgs &da, size_t lds, hipStream_t s,
                              const char **kname, int num_cus)
 {
-    if (da.pair) {
-        *kname = "fir_direct_pair_kernel";
-        return tk.complex_x ? launch_direct_pair<2>(fused, a, da, lds, s, num_cus) : launch_direct_pair<1>(fused, a, da, lds, s, num_cus);
-    }
     *kname = "fir_direct_kernel";
     if (!tk.x_f64 && !tk.r_f64) return tk.complex_x ? launch_direct<float, float, 2>(fused, a, da, lds, s, num_cus) : launch_direct<float, float, 1>(fused, a, da, lds, s, num_cus);
     if (!tk.x_f64 && tk.r_f64) return tk.complex_x ? launch_direct<float, double, 2>(fused, a, da, lds, s, num_cus) : launch_direct<float, double, 1>(fused, a, da, lds, s, num_cus);

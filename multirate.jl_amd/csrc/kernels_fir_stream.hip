@@ -1,5 +1,5 @@
 // kernels_fir_stream.hip -- FIRStandard (M = 1) and FIRDecimator (L = 1, M in {2, 4, 8}) with Float32 arithmetic
-// (Float32 or ComplexF32 samples, Float32 taps), tap counts that are multiples of 16 up to 512: the streaming form of
+// (Float32 or ComplexF32 samples, Float32 taps), 32 to 512 taps: the streaming form of
 // kernels_fir_direct.hip (BASELINE config 3b).
 //
 // reference: src/Filters.jl:450-473 (Standard), :598-631 (Decimator); dot: src/support.jl:33-55.
@@ -61,7 +61,6 @@ struct StreamGeo {
     static constexpr bool PAD = CD >= 2;
     static constexpr int CPB = CD >= 8 ? 8 : 4;             // reads per block (a multiple of CD when padded)
     static constexpr int BS = CPB * SPR;                    // samples per block
-    static constexpr int TAILR = (M + SPR - 1) / SPR;       // reads of the M extra samples of the second output
     static_assert(BS > M && BS % SPR == 0 && (!PAD || CPB % CD == 0), "block geometry");
     // byte offset of read i of a lane's run (i = block * CPB + ii): pads after every CD chunks
     static constexpr int read_off(int i) { return PAD ? 16 * (i + i / CD) : RD * i; }
@@ -94,7 +93,7 @@ void fir_stream_kernel(PolyArgs a, PairArgs pa)
     //  s_load_dwordx4/x8/x16)
     const const_taps_t tc = (const_taps_t)(static_cast<const float *>(__builtin_assume_aligned(a.taps, 64)));
     const int T = a.T;
-    const int NB = T / BS;                      // whole blocks of the first output's window (T % BS == 0)
+    const int NB = T / BS;                      // whole blocks of the first output's window (>= 2: T >= 32, BS <= 16)
     const int n_out = static_cast<int>(a.n_out);
     const int lanes = pa.P >> 1;                // lanes that own an output pair
 
@@ -188,10 +187,26 @@ void fir_stream_kernel(PolyArgs a, PairArgs pa)
                         mac(acc1, tc[jb + e - M], w[e]);
                     }
                 }
-                // tail: the M samples past the first output's window belong to the second output alone
-                load_block(NB, w, std::integral_constant<int, G::TAILR>{});
+                // tail: what is left of the first output's window when T is not a whole number of blocks (both outputs),
+                // then the M samples past it, which belong to the second output alone; one read at a time, the
+                // conditions are wave-uniform (j and T are)
+                for (int j0 = NB * BS; j0 < T + M; j0 += SPR) {
+                    const int ri = j0 / SPR;                               // read index inside the lane's run
+                    const unsigned char *const p = run + (G::PAD ? 16 * (ri + ri / (G::CD > 0 ? G::CD : 1)) : G::RD * ri);
+                    const read_t v = *reinterpret_cast<const read_t *>(p);
+                    unsigned u[4];
+                    if constexpr (G::RD == 8) { u[0] = v.x; u[1] = v.y; u[2] = u[3] = 0u; }
+                    else { u[0] = v.x; u[1] = v.y; u[2] = v.z; u[3] = v.w; }
 #pragma unroll
-                for (int e = 0; e < M; ++e) mac(acc1, tc[T - M + e], w[e]);
+                    for (int e = 0; e < SPR; ++e) {
+                        float we[NC];
+#pragma unroll
+                        for (int cc = 0; cc < NC; ++cc) we[cc] = __uint_as_float(u[e * NC + cc]);
+                        const int jj = j0 + e;
+                        if (jj < T) mac(acc0, tc[jj], we);
+                        if (jj < T + M) mac(acc1, tc[jj - M], we);
+                    }
+                }
 
                 float *const dst = yc + static_cast<long long>(k0) * NC;
                 if (k0 + 1 < remaining) {
@@ -251,14 +266,14 @@ constexpr int stream_pad_every(int M)
 
 }  // namespace
 
-// Covers L == 1 with Float32 arithmetic, M in {1, 2, 4, 8}, T a multiple of 16 in [32, 512].  Returns false otherwise
+// Covers L == 1 with Float32 arithmetic, M in {1, 2, 4, 8}, 32 <= T <= 512.  Returns false otherwise
 // (the caller falls back to kernels_fir_direct.hip).
 bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {
     if (!stream_env_int("MRHIP_STREAM", 1)) return false;   // read per call: tests switch kernels at run time
     if (tk.x_f64 || tk.r_f64 || a.L != 1) return false;
     if (!(a.M == 1 || a.M == 2 || a.M == 4 || a.M == 8)) return false;
-    if (a.T < 32 || a.T > 512 || a.T % 16 != 0) return false;
+    if (a.T < 32 || a.T > 512) return false;
     const int nc = tk.complex_x ? 2 : 1;
     const long long es = 4 * nc;
     const int pad_every = nc == 2 ? stream_pad_every<2>(a.M) : stream_pad_every<1>(a.M);

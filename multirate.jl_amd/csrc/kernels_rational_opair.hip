@@ -84,6 +84,11 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
             const double score = static_cast<double>(lanes) / padded * (padded < 192 ? 0.5 + 0.5 * padded / 192.0 : 1.0);
             if (score > best + 1e-9) { best = score; best_c = c; }
         }
+    // Small launches (a 1e6-sample chunk of one channel: ~1000 steps) are all ramp: the smallest workgroup with at least
+    // two compute waves starts sooner and gives every CU something to do (C1: 11.9 vs 13.9 us, per-chunk streaming 7.4 vs 6.0 %)
+    if (a.n_out * a.nch < (1LL << 22))
+        for (int c = 2; static_cast<long long>(c) * a.L / 2 <= kOMaxThreads && static_cast<long long>(c) * a.L <= 1024; c += 2)
+            if (static_cast<long long>(c) * a.L / 2 >= 128) { best_c = c; break; }
     if (env_c > 0 && env_c % 2 == 0 && static_cast<long long>(env_c) * a.L / 2 <= kOMaxThreads && static_cast<long long>(env_c) * a.L <= 1024) best_c = env_c;
     if (!best_c) return false;
     const int c = best_c;

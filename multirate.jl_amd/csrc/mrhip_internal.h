@@ -183,7 +183,6 @@ struct DirectArgs {          // tiling of the single-column kernel (kernels_fir_
     int J;                   // steps of 256 outputs per tile
     int tile_len;            // samples staged per tile
     int row_pitch;           // samples per residue row of the transposed LDS tile
-    int pair;                // 1: two adjacent outputs per lane (fir_direct_pair_kernel), rows = 2*M
     long long tiles_per_channel;
     long long total_tiles;
 };

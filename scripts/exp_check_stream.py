@@ -11,7 +11,7 @@ pkg = ge.load_package()
 ok = True
 rng = np.random.default_rng(5)
 for M in (1, 2, 4, 8):
-    for T in (32, 128, 208, 512):
+    for T in (32, 33, 47, 127, 128, 129, 208, 500, 512):
         for dt, nch, n in ((torch.float32, 5, 300_000), (torch.complex64, 3, 200_000), (torch.float32, 64, 1_000_000 if T == 128 else 50_000)):
             h = rng.standard_normal(T).astype(np.float32)
             if dt == torch.complex64:

@@ -324,7 +324,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, Fraction(L, M))
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel", "fir_stream_kernel"), (L, M, hl)
+        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_stream_kernel"), (L, M, hl)
         tuned_seen.add(f.last_kernel_name())
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, Fraction(L, M))
@@ -333,7 +333,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         assert_bit_equal(y_t, y_g, f"tuned vs generic L={L} M={M} hLen={hl} {th} {tx}")
         assert_bit_equal(f.history, g.history, "history")
-    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_direct_pair_kernel", "fir_stream_kernel"}, tuned_seen
+    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_stream_kernel"}, tuned_seen
 
 
 def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
@@ -391,14 +391,14 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
 
 def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
     """fir_stream_kernel (FIRStandard / FIRDecimator, Float32 arithmetic, loader-wave staging, padded LDS tile, scalar
-    taps): M in {1, 2, 4, 8}, tap counts 32..512 (multiples of 16), Float32 and ComplexF32, STRICT and FUSED,
+    taps): M in {1, 2, 4, 8}, tap counts 32..512 (whole blocks and ragged), Float32 and ComplexF32, STRICT and FUSED,
     multi-channel, chunked with 1-sample pieces and pieces shorter than the history (the start-from-zero quirk of the
     Vector seam variant, support.jl:46, applies to the first hLen outputs of EVERY call); inputs contain -0.0, +-Inf,
     NaN.  Bit-exact against the universal kernel, the direct kernel it replaces, and the oracle."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     for M in (1, 2, 4, 8):
-        for T in (32, 48, 128, 512):
+        for T in (32, 33, 48, 127, 128, 500, 512):
             for tx in (np.float32, np.complex64):
                 for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
                     if numerics == pkg.NUMERICS_FUSED and T not in (48, 128):
