@@ -84,8 +84,8 @@ int alloc_common(mrhip_filter *f)
         MRHIP_CHECK_HIP(hipMalloc(&f->d_hist[i], hbytes));
         MRHIP_CHECK_HIP(hipMemsetAsync(f->d_hist[i], 0, hbytes, f->own_stream));   // history = zeros(historyLen), Filters.jl:177
     }
-    MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_counters), 33 * 256));
-    MRHIP_CHECK_HIP(hipMemsetAsync(f->d_counters, 0, 33 * 256, f->own_stream));
+    MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_counters), mrhip::kCounterBytes));
+    MRHIP_CHECK_HIP(hipMemsetAsync(f->d_counters, 0, mrhip::kCounterBytes, f->own_stream));
     MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
     {
         hipDeviceProp_t prop;
@@ -177,6 +177,10 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
             PairArgs pa;
             dim3 block;
             size_t lds = 0;
+            if (plan_rational_owave(tk, a, f->num_cus, &pa)) {
+                *did_shiftin = a.H > 0;
+                return launch_rational_owave(fused, a, pa, s, kname, f->num_cus, f->d_counters);
+            }
             if (plan_rational_opair(tk, a, f->num_cus, &pa, &block, &lds)) {
                 *did_shiftin = a.H > 0;
                 return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
@@ -555,7 +559,7 @@ int mrhip_reset(mrhip_filter *f)
     hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
     const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
     if (bytes) MRHIP_CHECK_HIP(hipMemsetAsync(f->d_hist[f->hist_cur], 0, bytes, s));
-    MRHIP_CHECK_HIP(hipMemsetAsync(f->d_counters, 0, 33 * 256, s));
+    MRHIP_CHECK_HIP(hipMemsetAsync(f->d_counters, 0, mrhip::kCounterBytes, s));
     f->last_stream = s; f->last_stream_valid = true;
     f->phiIdx = 1; f->inputDeficit = 1; f->xIdx = 1; f->phiAcc = 1.0; f->alpha = 0.0;
     f->sched_cached = false;

@@ -105,6 +105,7 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
     const int waves_per_cu = tk.r_f64 ? 12 : 4 * std::min(8, 512 / vgpr_est);
     int wg_per_cu = std::max(1, std::min(4, waves_per_cu / (nwaves + 1)));
     if (nwaves + 1 == 6 && !tk.r_f64) wg_per_cu = 3;
+    if (const int env_w = opair_env_int("MRHIP_OPAIR_WGPC", 0); env_w > 0) wg_per_cu = env_w;   // experiments
     // TWO pipeline stages of tiles as large as the LDS allows (the DMA runs one tile ahead, far more than the HBM
     // latency; every tile costs ~1000 cycles of barrier skew, ring priming and drain).  Measured on 147//160 Float32,
     // c = 6: two stages of J = 6 steps 65.7 % / 56.1 % (one call / 1e6-sample launches) vs three stages of J = 4 63.5 / 52.3.

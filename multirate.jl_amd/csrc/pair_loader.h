@@ -136,15 +136,39 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
     if (pa.bank_off >= 0) __builtin_amdgcn_s_barrier();   // the compute waves' tap-bank barrier (the bank lives in stage ns-1, first written below after the next barrier)
     wait_vmcnt_le(newest_ops(pa.ns - 2));     // tile 0 has landed (only the later tiles' operations may remain)
     int pstage = pa.ns - 1;
+#ifdef MRHIP_OPAIR_PROBE
+    unsigned long long pr_bar = 0, pr_vm = 0;
+    const unsigned long long pr_t0 = clock64();
+#endif
     for (;;) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the tile descriptors published so far are in LDS
+#ifdef MRHIP_OPAIR_PROBE
+        const unsigned long long pr_a = clock64();
+#endif
         __builtin_amdgcn_s_barrier();         // the next tile is published; the stage of the tile before it is free again
+#ifdef MRHIP_OPAIR_PROBE
+        pr_bar += clock64() - pr_a;
+#endif
         if (!(pipeline & 1u)) break;          // that was the end marker: every wave of the workgroup leaves
         pipeline >>= 1;
         if (produce(pstage)) pipeline |= 1u << (pa.ns - 2);
         pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
+#ifdef MRHIP_OPAIR_PROBE
+        const unsigned long long pr_b = clock64();
+#endif
         wait_vmcnt_le(newest_ops(pa.ns - 2)); // everything older than the ns-2 newest tiles has landed
+#ifdef MRHIP_OPAIR_PROBE
+        pr_vm += clock64() - pr_b;
+#endif
     }
+#ifdef MRHIP_OPAIR_PROBE
+    if (pa.probe && lane == 0) {   // loader record (slot 7 of the workgroup): hardware id, total, barrier wait, vmcnt wait
+        unsigned long long *r = pa.probe + (static_cast<unsigned long long>(blockIdx.x) * 8u + 7u) * 4u;
+        const unsigned hw = __builtin_amdgcn_s_getreg(0xF804), xcc = __builtin_amdgcn_s_getreg(0xF814);
+        r[0] = hw | (static_cast<unsigned long long>(xcc) << 32) | (1ULL << 63);
+        r[1] = clock64() - pr_t0; r[2] = pr_bar; r[3] = pr_vm;
+    }
+#endif
     // the last workgroup to finish re-arms the counters for the next launch (stream order makes it visible)
     if (lane == 0 && !pa.static_grabs) {
         unsigned *const done = pa.counters + static_cast<unsigned>(pa.ngroups) * 64u;
