@@ -177,10 +177,6 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
             PairArgs pa;
             dim3 block;
             size_t lds = 0;
-            if (plan_rational_owave(tk, a, f->num_cus, &pa)) {
-                *did_shiftin = a.H > 0;
-                return launch_rational_owave(fused, a, pa, s, kname, f->num_cus, f->d_counters);
-            }
             if (plan_rational_opair(tk, a, f->num_cus, &pa, &block, &lds)) {
                 *did_shiftin = a.H > 0;
                 return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);

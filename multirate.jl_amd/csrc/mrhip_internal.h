@@ -176,19 +176,11 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     long long tile_out;      // J*c*L
     long long tiles_per_channel;
     long long total_tiles;
-    int nt;                  // owave kernel: slice types = ceil(P / 128) (a wave owns outputs [128k, 128k+128) of every step)
-    int cps;                 // owave kernel: 16-byte chunks of one step's slice (the samples the 64 lanes of a type touch)
-    unsigned cps_magic;      // ceil(2^32 / cps)
-    unsigned main_steps;     // owave kernel: steps [0, main_steps) belong to the group pools, the rest to the chip-wide pool
     unsigned long long *probe;   // diagnostics (MRHIP_PAIR_PROBE=1): per-workgroup (shader cycles, 100 MHz ticks) of the tile loop
 };
 
-// the wave-autonomous output-pair kernel (kernels_rational_owave.hip)
-constexpr int kOwThreads = 256;      // four waves per workgroup: one per SIMD
-constexpr int kOwMaxTypes = 8;       // slice types (P <= 1024)
-constexpr int kOwGroups = 32;        // scheduling groups (XCD-local: group = workgroup number mod 32)
-// scheduling counters of all pair kernels: [g*64] (256 bytes apart); the owave kernel uses (32 groups + the chip-wide pool) x 8 types + 1
-constexpr size_t kCounterBytes = (static_cast<size_t>(kOwGroups + 1) * kOwMaxTypes + 1) * 256;
+// scheduling counters of the pair kernels: [g*64] for group g < 32 (256 bytes apart), [32*64] workgroups finished
+constexpr size_t kCounterBytes = 33 * 256;
 
 struct DirectArgs {          // tiling of the single-column kernel (kernels_fir_direct.hip)
     int J;                   // steps of 256 outputs per tile
@@ -249,10 +241,6 @@ bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef);
 bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                                  const char **kname, int num_cus, unsigned *counters);   // two outputs per lane (L > M, and M > L below 0.7); also performs shiftin!
-bool plan_rational_owave(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out);
-bool owave_finish_plan(PairArgs *pa, int regs, int es, int rs, const PolyArgs &a, size_t *lds, int *wg_per_cu);
-hipError_t launch_rational_owave(bool fused, const PolyArgs &a, const PairArgs &pa, hipStream_t s, const char **kname, int num_cus,
-                                 unsigned *counters);   // wave-autonomous form of the output-pair kernel; also performs shiftin!
 bool plan_interp_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_interp_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                               const char **kname, int num_cus, unsigned *counters);   // FIRInterpolator, two phases per lane; also performs shiftin!

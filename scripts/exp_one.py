@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One configuration, a few launches: the program to put behind `rocprofv3 --pmc ... --` for A/B counter passes
-(the library and the kernel switches come from the environment: MRHIP_LIB_PATH, MRHIP_OWAVE, ...).
+(the library and the kernel switches come from the environment: MRHIP_LIB_PATH, MRHIP_OPAIR_C, ...).
     python3 scripts/exp_one.py [--long N] [--ratio 147/160] [--dtype float32] [--taps64 0] [--reps 3]
 """
 import os, sys, time
