@@ -1,5 +1,5 @@
-// kernels_fir_stream.hip -- FIRStandard (M = 1) and FIRDecimator (L = 1, M in {2, 4, 8}) with Float32 arithmetic
-// (Float32 or ComplexF32 samples, Float32 taps), 32 to 512 taps: the streaming form of
+// kernels_fir_stream.hip -- FIRStandard (M = 1) and FIRDecimator (L = 1, M = 2..16) with Float32 arithmetic
+// (Float32 or ComplexF32 samples, Float32 taps), 16 (or one block of reads) to 512 taps: the streaming form of
 // kernels_fir_direct.hip (BASELINE config 3b).
 //
 // reference: src/Filters.jl:450-473 (Standard), :598-631 (Decimator); dot: src/support.jl:33-55.
@@ -16,11 +16,13 @@
 // operands (no tap registers, no broadcasts).  The run is fetched 16 bytes at a time (ds_read_b128: four Float32 or
 // two ComplexF32 samples; 8 bytes for Float32 single-rate, whose lanes are 8 bytes apart).
 //
-// Bank conflicts.  Lanes start S = 2*M*sizeof(sample) bytes apart.  S = 8 or 16 is conflict-free as it is.  For
-// S = 32, 64, 128 a linear tile would put the 16 lanes of a ds_read_b128 group on 8, 4, 2 distinct bank groups; the
-// loader therefore writes one 16-byte PAD chunk after every S/16 data chunks (LDS-DMA takes a per-lane source address,
-// so the pad costs nothing but 1/(S/16 + 1) of the LDS and of the DMA instructions): lanes then start an ODD number
-// of chunks apart and the 16 lanes of a group cover all 64 banks exactly once.
+// Bank conflicts.  Lanes start S = 2*M*sizeof(sample) bytes apart.  When S is not a multiple of 16 (Float32 samples, odd M)
+// the run is read 8 bytes at a time: the 32 lanes of a ds_read_b64 group are 2M dwords apart, gcd(2M, 64) = 2, so they
+// cover all 64 banks exactly once.  Otherwise the run is read 16 bytes at a time and lanes start CD = S/16 chunks apart:
+// an odd CD is conflict-free as it is (the 16 lanes of a ds_read_b128 group land on 16 different chunk positions mod 16);
+// for an even CD (S = 32, 64, 96, 128, ...) a linear tile would put them on 8, 4, ... distinct positions, and the loader
+// therefore writes one 16-byte PAD chunk after every CD data chunks (LDS-DMA takes a per-lane source address, so the
+// pad costs nothing but 1/(CD + 1) of the LDS and of the DMA instructions): lanes then start an odd number of chunks apart.
 //
 // Arithmetic: exactly the generic kernel's (STRICT: separately rounded multiply and add, oldest sample first, first
 // product initialises the accumulator, the start-from-zero quirk of the Vector seam variant, support.jl:46; FUSED:
@@ -55,11 +57,13 @@ template <int NC, int M>
 struct StreamGeo {
     static constexpr int ES = 4 * NC;                       // bytes per sample
     static constexpr int S = 2 * M * ES;                    // bytes between the runs of adjacent lanes
-    static constexpr int RD = S == 8 ? 8 : 16;              // bytes per LDS read
+    static constexpr int RD = S % 16 ? 8 : 16;              // bytes per LDS read
     static constexpr int SPR = RD / ES;                     // samples per read
-    static constexpr int CD = S / 16;                       // data chunks per lane stride (0 for S = 8)
-    static constexpr bool PAD = CD >= 2;
-    static constexpr int CPB = CD >= 8 ? 8 : 4;             // reads per block (a multiple of CD when padded)
+    static constexpr int CD = RD == 16 ? S / 16 : 0;        // data chunks per lane stride (16-byte reads only)
+    static constexpr bool PAD = CD >= 2 && CD % 2 == 0;
+    // reads per block: a multiple of CD when padded (a block must advance a whole number of pad periods), and enough
+    // samples to reach past the second output's start
+    static constexpr int CPB = PAD ? (CD > 4 ? CD : 4) : (4 * SPR > M ? 4 : 8);
     static constexpr int BS = CPB * SPR;                    // samples per block
     static_assert(BS > M && BS % SPR == 0 && (!PAD || CPB % CD == 0), "block geometry");
     // byte offset of read i of a lane's run (i = block * CPB + ii): pads after every CD chunks
@@ -93,7 +97,7 @@ void fir_stream_kernel(PolyArgs a, PairArgs pa)
     //  s_load_dwordx4/x8/x16)
     const const_taps_t tc = (const_taps_t)(static_cast<const float *>(__builtin_assume_aligned(a.taps, 64)));
     const int T = a.T;
-    const int NB = T / BS;                      // whole blocks of the first output's window (>= 2: T >= 32, BS <= 16)
+    const int NB = T / BS;                      // whole blocks of the first output's window (>= 1: the plan requires T >= BS)
     const int n_out = static_cast<int>(a.n_out);
     const int lanes = pa.P >> 1;                // lanes that own an output pair
 
@@ -257,32 +261,40 @@ hipError_t launch_stream_nm(bool fused, dim3 block, size_t lds, hipStream_t s, c
     return fused ? go(fir_stream_kernel<NC, M, true>) : go(fir_stream_kernel<NC, M, false>);
 }
 
+// the decimations the kernel is instantiated for
+#define MRHIP_STREAM_MS(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+
 template <int NC>
-constexpr int stream_pad_every(int M)
+bool stream_geometry(int M, int *pad_every, int *min_taps)      // false: M is not instantiated
 {
-    return M == 1 ? StreamGeo<NC, 1>::PAD * StreamGeo<NC, 1>::CD : M == 2 ? StreamGeo<NC, 2>::PAD * StreamGeo<NC, 2>::CD
-         : M == 4 ? StreamGeo<NC, 4>::PAD * StreamGeo<NC, 4>::CD : StreamGeo<NC, 8>::PAD * StreamGeo<NC, 8>::CD;
+    switch (M) {
+#define MRHIP_X(MV) case MV: *pad_every = StreamGeo<NC, MV>::PAD ? StreamGeo<NC, MV>::CD : 0; *min_taps = StreamGeo<NC, MV>::BS; return true;
+        MRHIP_STREAM_MS(MRHIP_X)
+#undef MRHIP_X
+    default: return false;
+    }
 }
 
 }  // namespace
 
-// Covers L == 1 with Float32 arithmetic, M in {1, 2, 4, 8}, 32 <= T <= 512.  Returns false otherwise
-// (the caller falls back to kernels_fir_direct.hip).
+// Covers L == 1 with Float32 arithmetic, M <= 16, max(16, one block) <= T <= 512.  Returns false
+// otherwise (the caller falls back to kernels_fir_direct.hip).
 bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {
     if (!stream_env_int("MRHIP_STREAM", 1)) return false;   // read per call: tests switch kernels at run time
     if (tk.x_f64 || tk.r_f64 || a.L != 1) return false;
-    if (!(a.M == 1 || a.M == 2 || a.M == 4 || a.M == 8)) return false;
-    if (a.T < 32 || a.T > 512) return false;
     const int nc = tk.complex_x ? 2 : 1;
     const long long es = 4 * nc;
-    const int pad_every = nc == 2 ? stream_pad_every<2>(a.M) : stream_pad_every<1>(a.M);
+    int pad_every = 0, min_taps = 0;
+    if (a.M > 16 || !(nc == 2 ? stream_geometry<2>(static_cast<int>(a.M), &pad_every, &min_taps) : stream_geometry<1>(static_cast<int>(a.M), &pad_every, &min_taps))) return false;
+    if (a.T < std::max(16, min_taps) || a.T > 512) return false;   // the head block is a whole block of taps
     // compute waves: 3 (+ loader = a 256-thread workgroup) unless overridden; a step is 2 outputs per lane
     int ncw = stream_env_int("MRHIP_STREAM_WAVES", 3);
     if (ncw < 1) ncw = 1;
     if (ncw > 7) ncw = 7;
     const long long P = 128LL * ncw, cM = P * a.M;
     const long long tail = a.T + 16;                            // run overhang T - M beyond the step, + the rounding of the last read
+    // (the head block reads a whole block: BS <= T samples, inside the run)
     const int wg_per_cu = std::max(1, std::min(6, 32 / (ncw + 1)));
     const int ns = 2;
     // stage size: as many steps as the LDS share allows, at most 60 DMA slots
@@ -338,17 +350,14 @@ hipError_t launch_fir_stream(bool fused, const PolyArgs &a, const PairArgs &pa_i
     PairArgs pa = pa_in;
     pa.counters = counters;
     *kname = "fir_stream_kernel";
-#define MRHIP_SM(NCV)                                                                          \
-    switch (a.M) {                                                                             \
-    case 1: return launch_stream_nm<NCV, 1>(fused, block, lds, s, a, pa, num_cus);             \
-    case 2: return launch_stream_nm<NCV, 2>(fused, block, lds, s, a, pa, num_cus);             \
-    case 4: return launch_stream_nm<NCV, 4>(fused, block, lds, s, a, pa, num_cus);             \
-    case 8: return launch_stream_nm<NCV, 8>(fused, block, lds, s, a, pa, num_cus);             \
-    default: return hipErrorInvalidValue;                                                      \
+#define MRHIP_X2(MV) case MV: return launch_stream_nm<2, MV>(fused, block, lds, s, a, pa, num_cus);
+#define MRHIP_X1(MV) case MV: return launch_stream_nm<1, MV>(fused, block, lds, s, a, pa, num_cus);
+    if (pa.nc == 2) {
+        switch (a.M) { MRHIP_STREAM_MS(MRHIP_X2) default: return hipErrorInvalidValue; }
     }
-    if (pa.nc == 2) { MRHIP_SM(2) }
-    MRHIP_SM(1)
-#undef MRHIP_SM
+    switch (a.M) { MRHIP_STREAM_MS(MRHIP_X1) default: return hipErrorInvalidValue; }
+#undef MRHIP_X1
+#undef MRHIP_X2
 }
 
 }  // namespace mrhip

@@ -40,6 +40,11 @@ namespace mrhip {
 // (Float64 samples, or Float32 samples widened: the README's mixed case), one unit per SMIN = floor(M/L)
 hipError_t launch_opair_f32_s0(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_f32_s1(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+// SMIN = 2..5 (decimating ratios up to M/L < 6): Float32 arithmetic, tapsPerPhi <= 32
+hipError_t launch_opair_f32_s2(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_opair_f32_s3(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_opair_f32_s4(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_opair_f32_s5(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_wide_s0(bool x_f64, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_wide_s1(bool x_f64, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 
@@ -67,8 +72,9 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
 #endif
     if (a.T < 1 || a.T > (tk.r_f64 ? 32 : 48)) return false;
     if (a.L < 2 || a.M < 2 || a.zero_start_below > 0) return false;
-    if (!(2LL * a.M > a.L && a.M < 2LL * a.L)) return false;
-    const int smin = a.M > a.L ? 1 : 0;
+    const int smin = static_cast<int>(a.M / a.L);        // the two windows of a lane start SMIN or SMIN + 1 samples apart
+    if (smin > 5) return false;
+    if (smin >= 2 && (tk.r_f64 || a.T > 32)) return false;   // instantiated for Float32 arithmetic, tapsPerPhi <= 32
     const int env_c = opair_env_int("MRHIP_OPAIR_C", 0), env_j = opair_env_int("MRHIP_OPAIR_J", 0), env_ns = opair_env_int("MRHIP_OPAIR_NS", 0);
     // c: lanes = c*L/2 <= 512; c*L and c*M even (a lane owns two outputs; the run base keeps its parity from step to
     // step) => c even, L and M being coprime.  Among the sizes with 3..7 full-ish compute waves take the fullest.
@@ -174,12 +180,19 @@ hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &
     PairArgs pa = pa_in;
     pa.counters = counters;
     *kname = "rational_opair_kernel";
-    const bool up = a.L > a.M;                 // SMIN = 0
+    const int smin = static_cast<int>(a.M / a.L);
     if (pa.r_f64)
-        return up ? launch_opair_wide_s0(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus)
-                  : launch_opair_wide_s1(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus);
-    return up ? launch_opair_f32_s0(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus)
-              : launch_opair_f32_s1(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
+        return smin == 0 ? launch_opair_wide_s0(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus)
+                         : launch_opair_wide_s1(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus);
+    switch (smin) {
+    case 0: return launch_opair_f32_s0(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
+    case 1: return launch_opair_f32_s1(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
+    case 2: return launch_opair_f32_s2(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
+    case 3: return launch_opair_f32_s3(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
+    case 4: return launch_opair_f32_s4(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
+    case 5: return launch_opair_f32_s5(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace mrhip

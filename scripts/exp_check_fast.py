@@ -11,7 +11,8 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 ok = True
 TAPS = [int(a) for a in sys.argv[1:]] or [24]         # tapsPerPhi values to check (FAST build: 24, 36, 48)
-for (L, M, T) in [(l, m, t) for t in TAPS for (l, m) in ((147, 160), (160, 147), (2, 3), (3, 2))]:
+RATIOS = [tuple(int(v) for v in r.split("/")) for r in os.environ.get("RATIOS", "147/160,160/147,2/3,3/2").split(",")]   # L/M list
+for (L, M, T) in [(l, m, t) for t in TAPS for (l, m) in RATIOS]:
     if T > 32 and False:
         continue
     h32 = pkg.firdes(T * L, 0.5 / max(L, M), beta=7.8562).astype(np.float32)

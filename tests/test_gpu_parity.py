@@ -338,7 +338,8 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
 
 def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
     """rational_opair_kernel (two adjacent OUTPUTS per lane, window offsets resolved by exact no-op slots): L > M
-    ratios (160//147, 3//2, ...) and M > L ratios (147//160, 5//9, ...), every tapsPerPhi class (odd, even, 1, 32),
+    ratios (160//147, 3//2, ... and beyond two: 441//160, 7//3, 511//2), M > L ratios (147//160, 5//9, ...) up to
+    M/L < 6 (160//441, 3//17, 2//11: window distance SMIN = 2..5), every tapsPerPhi class (odd, even, 1, 32),
     Float32 / ComplexF32 / Float64 samples, Float32 and Float64 taps (incl. the README's Float64 taps x Float32
     samples), STRICT and FUSED, multi-channel, chunked with 1-sample and prime pieces; inputs contain -0.0, +-Inf and
     NaN runs (a skipped slot must not turn into 0*Inf or flip the sign of an all-zero sum).  Bit-exact against the
@@ -348,12 +349,16 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
     cases = [(160, 147, 24 * 160), (160, 147, 24 * 160 - 77), (3, 2, 72), (3, 2, 3 * 32), (3, 2, 3),
              (7, 5, 100), (5, 3, 23), (9, 5, 9 * 17), (16, 9, 16 * 31 - 5), (32, 31, 32 * 8),
              (5, 9, 5 * 13), (4, 7, 4 * 32), (147, 160, 3528), (9, 10, 9 * 7), (31, 32, 31 * 2 - 1),
-             (2, 3, 72), (3, 2, 3 * 33), (160, 147, 160 * 48 - 5), (5, 9, 5 * 47), (147, 160, 147 * 40), (7, 5, 7 * 41 - 3)]   # 33..48 taps per phase: Float32 arithmetic only
+             (2, 3, 72), (3, 2, 3 * 33), (160, 147, 160 * 48 - 5), (5, 9, 5 * 47), (147, 160, 147 * 40), (7, 5, 7 * 41 - 3),   # 33..48 taps per phase: Float32 arithmetic only
+             (441, 160, 441 * 24 - 3), (7, 3, 7 * 24), (5, 2, 5 * 9), (511, 2, 511 * 3), (9, 4, 9 * 32),                      # L >= 2M
+             (160, 441, 160 * 24), (3, 17, 72), (2, 5, 2 * 31), (3, 10, 3 * 8), (2, 9, 64), (2, 11, 2 * 17 - 1), (3, 8, 3 * 32)]   # M >= 2L: Float32 arithmetic, <= 32 taps per phase
     combos = [(np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32)]
     for (L, M, hl) in cases:
         for th, tx in combos:
             if -(-hl // L) > 32 and th == np.float64:
                 continue                                                # Float64 arithmetic keeps two columns of <= 32 taps
+            if M >= 2 * L and th == np.float64:
+                continue                                                # window distances of 2..5 samples: Float32 arithmetic only
             for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
                 if numerics == pkg.NUMERICS_FUSED and (hl % 2 or th == np.float64 and L % 2):
                     continue                                            # (thin the matrix)
@@ -391,14 +396,18 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
 
 def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
     """fir_stream_kernel (FIRStandard / FIRDecimator, Float32 arithmetic, loader-wave staging, padded LDS tile, scalar
-    taps): M in {1, 2, 4, 8}, tap counts 32..512 (whole blocks and ragged), Float32 and ComplexF32, STRICT and FUSED,
+    taps): M = 1..16, tap counts 32..512 (whole blocks and ragged), Float32 and ComplexF32, STRICT and FUSED,
     multi-channel, chunked with 1-sample pieces and pieces shorter than the history (the start-from-zero quirk of the
     Vector seam variant, support.jl:46, applies to the first hLen outputs of EVERY call); inputs contain -0.0, +-Inf,
     NaN.  Bit-exact against the universal kernel, the direct kernel it replaces, and the oracle."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
-    for M in (1, 2, 4, 8):
-        for T in (32, 33, 48, 127, 128, 500, 512):
+    for M in range(1, 17):
+        for T in (16, 24, 32, 33, 48, 127, 128, 500, 512):
+            if T < 32 and (M > 8 or M == 6):
+                continue                                                # below one block of reads for some of these: the direct kernel's
+            if M not in (1, 2, 4, 8) and T in (33, 127, 500):
+                continue                                                # (thin the matrix for the later instantiations)
             for tx in (np.float32, np.complex64):
                 for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
                     if numerics == pkg.NUMERICS_FUSED and T not in (48, 128):
