@@ -182,15 +182,6 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
                 return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
             }
         }
-        {
-            PairArgs pa;
-            dim3 block;
-            size_t lds = 0;
-            if (plan_interp_pair(tk, a, f->num_cus, &pa, &block, &lds)) {
-                *did_shiftin = a.H > 0;
-                return launch_interp_pair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
-            }
-        }
         TileArgs ta;
         dim3 grid, block;
         size_t lds = 0;

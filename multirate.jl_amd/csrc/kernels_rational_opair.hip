@@ -1,6 +1,8 @@
-// kernels_rational_opair.hip -- FIRRational with 1/2 < M/L < 2 in either direction (147//160: the headline; 160//147,
-// 3//2, ...), tapsPerPhi <= 48 (Float64 arithmetic: 32): Float32, ComplexF32 and Float64 samples, Float32 or Float64 arithmetic.  This file holds
-// the planning and the dispatch; the kernel itself is opair_kernel.inc, instantiated by kernels_rational_opair_*.hip.
+// kernels_rational_opair.hip -- the polyphase kernel: FIRRational with L > M (any ratio: 160//147, 441//160, 7//2, ...) and
+// with M > L up to M/L < 6 (147//160: the headline; 160//441, 3//17, ...), and FIRInterpolator (M = 1); tapsPerPhi <= 48
+// (Float64 arithmetic: 32; M >= 2L: 32, Float32 arithmetic): Float32, ComplexF32 and Float64 samples, Float32 or Float64
+// arithmetic.  This file holds the planning and the dispatch; the kernel itself is opair_kernel.inc, instantiated by
+// kernels_rational_opair_*.hip (one unit per arithmetic width and per window distance SMIN = floor(M/L) = 0..5).
 //
 // Mapping.  (Round 1's kernel gave a lane two adjacent INPUT positions: with M > L a position produces at most one
 // output, 8 % of the positions of 147//160 none, and with L > M a position produces one or two, which would need a
@@ -57,9 +59,10 @@ inline int opair_env_int(const char *name, int dflt)
 }
 }  // namespace
 
-// Covers FIRRational with tapsPerPhi <= 48 (Float64 arithmetic: 32) and 1/2 < M/L < 2 (M != L; SMIN = floor(M/L)) for Float32 arithmetic (Float32 or
-// ComplexF32 samples, Float32 taps) and Float64 arithmetic on real samples (Float64 x Float64; Float64 taps x Float32
-// samples).  Returns false otherwise (the caller tries the next kernel).
+// Covers FIRRational and FIRInterpolator with tapsPerPhi <= 48 (Float64 arithmetic: 32) and M/L < 6 (L >= 2, SMIN = floor(M/L);
+// SMIN >= 2: Float32 arithmetic and tapsPerPhi <= 32) for Float32 arithmetic (Float32 or ComplexF32 samples, Float32 taps)
+// and Float64 arithmetic on real samples (Float64 x Float64; Float64 taps x Float32 samples).  Returns false otherwise
+// (the caller tries the next kernel).
 bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {
     if (!opair_env_int("MRHIP_OPAIR", 1)) return false;   // read per call: tests switch kernels at run time
@@ -71,7 +74,7 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
     if (a.T != 24 && !(!tk.r_f64 && (a.T == 36 || a.T == 48))) return false;
 #endif
     if (a.T < 1 || a.T > (tk.r_f64 ? 32 : 48)) return false;
-    if (a.L < 2 || a.M < 2 || a.zero_start_below > 0) return false;
+    if (a.L < 2 || a.M < 1 || a.zero_start_below > 0) return false;   // (L == 1: the single-column kernels; M == 1: FIRInterpolator)
     const int smin = static_cast<int>(a.M / a.L);        // the two windows of a lane start SMIN or SMIN + 1 samples apart
     if (smin > 5) return false;
     if (smin >= 2 && (tk.r_f64 || a.T > 32)) return false;   // instantiated for Float32 arithmetic, tapsPerPhi <= 32

@@ -240,10 +240,7 @@ hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
 bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef);
 bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
-                                 const char **kname, int num_cus, unsigned *counters);   // two outputs per lane (L > M, and M > L below 0.7); also performs shiftin!
-bool plan_interp_pair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
-hipError_t launch_interp_pair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
-                              const char **kname, int num_cus, unsigned *counters);   // FIRInterpolator, two phases per lane; also performs shiftin!
+                                 const char **kname, int num_cus, unsigned *counters);   // FIRRational and FIRInterpolator, two outputs per lane; also performs shiftin!
 bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_fir_stream(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                              const char **kname, int num_cus, unsigned *counters);   // FIRStandard / FIRDecimator, streaming form; also performs shiftin!

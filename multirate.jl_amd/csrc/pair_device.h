@@ -1,5 +1,4 @@
-// pair_device.h -- device-side helpers shared by the ring-pipelined kernels (kernels_rational_pair.hip,
-// kernels_interp_pair.hip): hand-issued LDS reads/writes with counted waits, LDS-DMA, compile-time bookkeeping
+// pair_device.h -- device-side helpers shared by the loader-wave kernels (opair_kernel.inc, kernels_fir_stream.hip): hand-issued LDS reads/writes with counted waits, LDS-DMA, compile-time bookkeeping
 // of the register-ring pipeline.  gfx950 only.
 #ifndef MRHIP_PAIR_DEVICE_H
 #define MRHIP_PAIR_DEVICE_H

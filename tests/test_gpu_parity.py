@@ -324,7 +324,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, Fraction(L, M))
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_stream_kernel"), (L, M, hl)
+        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_opair_kernel", "fir_direct_kernel", "fir_stream_kernel"), (L, M, hl)
         tuned_seen.add(f.last_kernel_name())
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, Fraction(L, M))
@@ -333,7 +333,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         assert_bit_equal(y_t, y_g, f"tuned vs generic L={L} M={M} hLen={hl} {th} {tx}")
         assert_bit_equal(f.history, g.history, "history")
-    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_opair_kernel", "interp_pair_kernel", "fir_direct_kernel", "fir_stream_kernel"}, tuned_seen
+    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_opair_kernel", "fir_direct_kernel", "fir_stream_kernel"}, tuned_seen
 
 
 def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
@@ -584,8 +584,8 @@ def test_dynamic_scheduling_paths_match_generic_at_scale(pkg, torch_cuda, monkey
     xr = torch.rand((nch, n, 2), generator=g, device="cuda", dtype=torch.float32) - 0.5
     xc = torch.view_as_complex(xr)
     rng = np.random.default_rng(3)
-    for (L, M, hl, kname) in [(147, 160, 147 * 24, "rational_opair_kernel"), (4, 1, 128, "interp_pair_kernel"),
-                              (13, 16, 13 * 9, "rational_opair_kernel"), (3, 1, 3 * 20, "interp_pair_kernel")]:
+    for (L, M, hl, kname) in [(147, 160, 147 * 24, "rational_opair_kernel"), (4, 1, 128, "rational_opair_kernel"),
+                              (13, 16, 13 * 9, "rational_opair_kernel"), (3, 1, 3 * 20, "rational_opair_kernel")]:
         h = rng.standard_normal(hl).astype(np.float32)
         sizes = [120_001, 7, 179_992]
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
