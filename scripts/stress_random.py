@@ -70,7 +70,7 @@ def main():
         else:
             kind = rng.choice(["rational", "rational", "near1", "interp", "decim", "standard", "h147"])
             if args.big:
-                kind = rng.choice(["near1", "near1", "h147", "interp"])
+                kind = rng.choice(["near1", "near1", "h147", "interp", "wide", "wide", "decim16"])
             if kind == "h147":
                 L, M = 147, 160
             elif kind == "near1":
@@ -79,6 +79,13 @@ def main():
                 L, M = int(rng.integers(2, 40)), 1
             elif kind == "decim":
                 L, M = 1, int(rng.integers(2, 70))
+            elif kind == "decim16":
+                L, M = 1, int(rng.integers(1, 17))
+            elif kind == "wide":                 # ratios beyond (1/2, 2): L >= 2M and 2 <= M/L < 6
+                while True:
+                    L, M = int(rng.integers(2, 30)), int(rng.integers(1, 60))
+                    if math.gcd(L, M) == 1 and (L >= 2 * M or (M >= 2 * L and M < 6 * L)):
+                        break
             elif kind == "standard":
                 L, M = 1, 1
             else:
@@ -88,7 +95,7 @@ def main():
             tmax = (33 if args.big else 44) if L > 1 else 700
             hl = max(2, int(rng.integers(1, tmax)) * L - int(rng.integers(0, L)))
             if L == 1:
-                hl = int(rng.integers(2, 700))
+                hl = int(rng.integers(2, 700)) if kind != "decim16" else int(rng.integers(16, 400))
             h = rng.standard_normal(hl).astype(th)
             mk = lambda: pkg.FIRFilter(h, Fraction(L, M))
             mko = lambda: O.FIRFilter(h, Fraction(L, M), tx=tx)
