@@ -1,0 +1,12 @@
+// kernels_fir_stream_mix.hip -- instantiations of fir_stream_kernel.inc: Float32 / ComplexF32 samples with Float64 taps (samples widened exactly on load), M = 1..16, STRICT and FUSED.
+#include "fir_stream_kernel.inc"
+
+namespace mrhip {
+
+hipError_t launch_fir_stream_mix(int nc, bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus)
+{
+    return nc == 2 ? launch_stream_m<float, double, 2>(fused, block, lds, s, a, pa, num_cus)
+                   : launch_stream_m<float, double, 1>(fused, block, lds, s, a, pa, num_cus);
+}
+
+}  // namespace mrhip

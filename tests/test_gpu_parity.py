@@ -395,8 +395,8 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
 
 
 def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
-    """fir_stream_kernel (FIRStandard / FIRDecimator, Float32 arithmetic, loader-wave staging, padded LDS tile, scalar
-    taps): M = 1..16, tap counts 32..512 (whole blocks and ragged), Float32 and ComplexF32, STRICT and FUSED,
+    """fir_stream_kernel (FIRStandard / FIRDecimator, Float32 and Float64 arithmetic, loader-wave staging, padded LDS tile,
+    scalar taps): M = 1..16, tap counts 32..512 (whole blocks and ragged), Float32 and ComplexF32, STRICT and FUSED,
     multi-channel, chunked with 1-sample pieces and pieces shorter than the history (the start-from-zero quirk of the
     Vector seam variant, support.jl:46, applies to the first hLen outputs of EVERY call); inputs contain -0.0, +-Inf,
     NaN.  Bit-exact against the universal kernel, the direct kernel it replaces, and the oracle."""
@@ -408,15 +408,19 @@ def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
                 continue                                                # below one block of reads for some of these: the direct kernel's
             if M not in (1, 2, 4, 8) and T in (33, 127, 500):
                 continue                                                # (thin the matrix for the later instantiations)
-            for tx in (np.float32, np.complex64):
+            for th, tx in ((np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32), (np.float64, np.complex64)):
+                if th == np.float64 and (T in (33, 127, 500) or (M not in (1, 2, 3, 4, 8, 16) and T != 48)):
+                    continue                                            # (thin the matrix for Float64 arithmetic)
+                if th == np.float64 and T < 32 and M > 4:
+                    continue                                            # below one block of reads for some: the direct kernel's
                 for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
                     if numerics == pkg.NUMERICS_FUSED and T not in (48, 128):
                         continue
                     nch = int(rng.integers(1, 6))
-                    h = rng.standard_normal(T).astype(np.float32)
+                    h = rng.standard_normal(T).astype(th)
                     h[rng.integers(0, T, 2)] = 0.0
                     x = _rand(rng, (nch, 40_009), tx) - 0.5
-                    xr = x.view(np.float32)
+                    xr = x.view(np.float64 if tx == np.float64 else np.float32)
                     xr[:, 300:300 + 2 * T] = -0.0                      # all-(-0) windows: the zero-start quirk shows as a sign
                     xr[0, 5000] = np.inf; xr[0, 5100] = -np.inf; xr[nch - 1, 9000:9003] = np.nan
                     xd = torch.from_numpy(x).cuda()
@@ -434,13 +438,14 @@ def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
                     monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False); monkeypatch.delenv("MRHIP_STREAM", raising=False)
                     assert ys["stream"][2] == "fir_stream_kernel" and ys["direct"][2].startswith("fir_direct") and ys["generic"][2] == "poly_generic_kernel"
                     for other in ("direct", "generic"):
-                        assert_bit_equal(ys["stream"][0], ys[other][0], f"stream vs {other} M={M} T={T} {tx} numerics={numerics}")
+                        assert_bit_equal(ys["stream"][0], ys[other][0], f"stream vs {other} M={M} T={T} {th} {tx} numerics={numerics}")
                         assert_bit_equal(ys["stream"][1], ys[other][1], "history")
                         assert ys["stream"][3] == ys[other][3]
                     if numerics == pkg.NUMERICS_STRICT:
                         fo = O.FIRFilter(h, Fraction(1, M), tx=tx)
                         yo = np.concatenate([fo.filt(p) for p in np.split(x[nch - 1], np.cumsum(sizes)[:-1])])
-                        got, want = ys["stream"][0][nch - 1].view(np.float32), yo.view(np.float32)
+                        ft = np.float64 if yo.dtype in (np.float64, np.complex128) else np.float32
+                        got, want = ys["stream"][0][nch - 1].view(ft), yo.view(ft)
                         assert np.array_equal(np.isnan(got), np.isnan(want))
                         ok = ~np.isnan(want)
                         assert_bit_equal(got[ok], want[ok], f"stream vs oracle M={M} T={T} {tx}")
