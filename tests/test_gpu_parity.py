@@ -451,6 +451,33 @@ def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
                         assert_bit_equal(got[ok], want[ok], f"stream vs oracle M={M} T={T} {tx}")
 
 
+def test_stream_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
+    """fir_stream_kernel beyond the direct kernel's 512 taps (scalar tap loads have no register budget): 1024 to 3001 taps,
+    single-rate and decimating, Float32 / ComplexF32 / Float64; bit-exact against the universal kernel and the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    for (M, T, th, tx) in [(1, 1024, np.float32, np.float32), (4, 2049, np.float32, np.complex64), (3, 3001, np.float32, np.float32),
+                           (1, 1500, np.float64, np.float64), (8, 1024, np.float64, np.float32), (5, 777, np.float32, np.complex64)]:
+        nch = int(rng.integers(1, 4))
+        h = rng.standard_normal(T).astype(th)
+        x = _rand(rng, (nch, 30_011), tx) - 0.5
+        xd = torch.from_numpy(x).cuda()
+        sizes = [9_001, 1, T // 3, 30_011 - 9_001 - 1 - T // 3]
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        f = pkg.FIRFilter(h, Fraction(1, M))
+        y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+        assert f.last_kernel_name() == "fir_stream_kernel", (M, T, f.last_kernel_name())
+        monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+        g = pkg.FIRFilter(h, Fraction(1, M))
+        yg = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        assert_bit_equal(y, yg, f"stream vs generic M={M} T={T} {th} {tx}")
+        assert_bit_equal(f.history, g.history, "history")
+        fo = O.FIRFilter(h, Fraction(1, M), tx=tx)
+        yo = np.concatenate([fo.filt(p) for p in np.split(x[nch - 1], np.cumsum(sizes)[:-1])])
+        assert_bit_equal(y[nch - 1], yo, f"stream vs oracle M={M} T={T} {th} {tx}")
+
+
 def test_arbitrary_tuned_and_generic_agree(pkg, torch_cuda, monkeypatch):
     torch = torch_cuda
     rng = np.random.default_rng(31)
@@ -752,14 +779,14 @@ def test_chunked_streaming_entry_matches_caller_loop(pkg, torch_cuda):
 
 
 def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
-    """Filters the register-resident kernels do not take (tapsPerPhi > 48, or > 32 with Float64 arithmetic, L > 512 phases, hLen > 512 single-rate /
-    decimating) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
+    """Filters the register-resident kernels do not take (tapsPerPhi > 48, or > 32 with Float64 arithmetic, L > 512 phases, hLen > 512 with a decimation above 16 or
+    ComplexF64 samples) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
     across chunk seams, for every dtype combination, 1..35 channels (all channels-per-lane variants + ragged group)."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     cases = [(2, 3, 100, np.float32, np.float32, 35), (3, 2, 200, np.float32, np.complex64, 9), (147, 160, 147 * 50, np.float32, np.float32, 33),
              (2, 3, 72, np.float64, np.float64, 4),
-             (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 3, 700, np.float32, np.float32, 5),
+             (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 19, 700, np.float32, np.float32, 5),
              (1, 1, 600, np.float64, np.complex128, 2), (5, 64, 5 * 40, np.float64, np.float32, 32), (4, 7, 4 * 33, np.float32, np.float64, 1)]
     for (L, M, hl, th, tx, nch) in cases:
         h = rng.standard_normal(hl).astype(th)
