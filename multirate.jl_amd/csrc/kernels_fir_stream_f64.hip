@@ -1,11 +1,12 @@
-// kernels_fir_stream_f64.hip -- instantiations of fir_stream_kernel.inc: Float64 samples, Float64 arithmetic, M = 1..16, STRICT and FUSED.
+// kernels_fir_stream_f64.hip -- instantiations of fir_stream_kernel.inc: Float64 and ComplexF64 samples, Float64 arithmetic, M = 1..16, STRICT and FUSED.
 #include "fir_stream_kernel.inc"
 
 namespace mrhip {
 
-hipError_t launch_fir_stream_f64(bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus)
+hipError_t launch_fir_stream_f64(int nc, bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus)
 {
-    return launch_stream_m<double, double, 1>(fused, block, lds, s, a, pa, num_cus);
+    return nc == 2 ? launch_stream_m<double, double, 2>(fused, block, lds, s, a, pa, num_cus)
+                   : launch_stream_m<double, double, 1>(fused, block, lds, s, a, pa, num_cus);
 }
 
 }  // namespace mrhip

@@ -408,9 +408,12 @@ def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
                 continue                                                # below one block of reads for some of these: the direct kernel's
             if M not in (1, 2, 4, 8) and T in (33, 127, 500):
                 continue                                                # (thin the matrix for the later instantiations)
-            for th, tx in ((np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32), (np.float64, np.complex64)):
+            for th, tx in ((np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32), (np.float64, np.complex64),
+                           (np.float64, np.complex128), (np.float32, np.complex128)):
                 if th == np.float64 and (T in (33, 127, 500) or (M not in (1, 2, 3, 4, 8, 16) and T != 48)):
                     continue                                            # (thin the matrix for Float64 arithmetic)
+                if tx == np.complex128 and (T not in (48, 128) or (th == np.float32 and M not in (1, 5))):
+                    continue
                 if th == np.float64 and T < 32 and M > 4:
                     continue                                            # below one block of reads for some: the direct kernel's
                 for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
@@ -420,7 +423,7 @@ def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
                     h = rng.standard_normal(T).astype(th)
                     h[rng.integers(0, T, 2)] = 0.0
                     x = _rand(rng, (nch, 40_009), tx) - 0.5
-                    xr = x.view(np.float64 if tx == np.float64 else np.float32)
+                    xr = x.view(np.float64 if tx in (np.float64, np.complex128) else np.float32)
                     xr[:, 300:300 + 2 * T] = -0.0                      # all-(-0) windows: the zero-start quirk shows as a sign
                     xr[0, 5000] = np.inf; xr[0, 5100] = -np.inf; xr[nch - 1, 9000:9003] = np.nan
                     xd = torch.from_numpy(x).cuda()
@@ -436,7 +439,7 @@ def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
                         y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
                         ys[mode] = (y, f.history.copy(), f.last_kernel_name(), (f.state.phiIdx, f.state.inputDeficit))
                     monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False); monkeypatch.delenv("MRHIP_STREAM", raising=False)
-                    assert ys["stream"][2] == "fir_stream_kernel" and ys["direct"][2].startswith("fir_direct") and ys["generic"][2] == "poly_generic_kernel"
+                    assert ys["stream"][2] == "fir_stream_kernel" and ys["direct"][2].startswith(("fir_direct", "poly_tiled")) and ys["generic"][2] == "poly_generic_kernel", (M, T, th, tx, ys["stream"][2], ys["direct"][2])
                     for other in ("direct", "generic"):
                         assert_bit_equal(ys["stream"][0], ys[other][0], f"stream vs {other} M={M} T={T} {th} {tx} numerics={numerics}")
                         assert_bit_equal(ys["stream"][1], ys[other][1], "history")
