@@ -1,6 +1,6 @@
 // kernels_rational_opair.hip -- the polyphase kernel: FIRRational with L > M (any ratio: 160//147, 441//160, 7//2, ...) and
 // with M > L up to M/L < 6 (147//160: the headline; 160//441, 3//17, ...), and FIRInterpolator (M = 1); tapsPerPhi <= 48
-// (Float64 arithmetic: 32; M >= 2L: 32, Float32 arithmetic): Float32, ComplexF32 and Float64 samples, Float32 or Float64
+// (Float32 samples: 64; Float64 arithmetic: 32; M >= 2L: 32, Float32 arithmetic): Float32, ComplexF32 and Float64 samples, Float32 or Float64
 // arithmetic.  This file holds the planning and the dispatch; the kernel itself is opair_kernel.inc, instantiated by
 // kernels_rational_opair_*.hip (one unit per arithmetic width and per window distance SMIN = floor(M/L) = 0..5).
 //
@@ -42,6 +42,9 @@ namespace mrhip {
 // (Float64 samples, or Float32 samples widened: the README's mixed case), one unit per SMIN = floor(M/L)
 hipError_t launch_opair_f32_s0(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_f32_s1(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+// 49..64 taps per phase (Float32 samples, SMIN <= 1: 140-160 VGPRs, one 8-wave workgroup per CU)
+hipError_t launch_opair_f32_s0_long(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_opair_f32_s1_long(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 // SMIN = 2..5 (decimating ratios up to M/L < 6): Float32 arithmetic, tapsPerPhi <= 32
 hipError_t launch_opair_f32_s2(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_f32_s3(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
@@ -59,7 +62,7 @@ inline int opair_env_int(const char *name, int dflt)
 }
 }  // namespace
 
-// Covers FIRRational and FIRInterpolator with tapsPerPhi <= 48 (Float64 arithmetic: 32) and M/L < 6 (L >= 2, SMIN = floor(M/L);
+// Covers FIRRational and FIRInterpolator with tapsPerPhi <= 48 (Float32 samples with M < 2L: 64; Float64 arithmetic: 32) and M/L < 6 (L >= 2, SMIN = floor(M/L);
 // SMIN >= 2: Float32 arithmetic and tapsPerPhi <= 32) for Float32 arithmetic (Float32 or ComplexF32 samples, Float32 taps)
 // and Float64 arithmetic on real samples (Float64 x Float64; Float64 taps x Float32 samples).  Returns false otherwise
 // (the caller tries the next kernel).
@@ -71,13 +74,14 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
     const int nc = tk.complex_x ? 2 : 1;
     const long long es = (tk.x_f64 ? 8 : 4) * nc;        // bytes per input sample
 #ifdef MRHIP_PS_FAST_BUILD
-    if (a.T != 24 && !(!tk.r_f64 && (a.T == 36 || a.T == 48))) return false;
+    if (a.T != 24 && !(!tk.r_f64 && (a.T == 36 || a.T == 48 || a.T == 56 || a.T == 64))) return false;
 #endif
-    if (a.T < 1 || a.T > (tk.r_f64 ? 32 : 48)) return false;
+    if (a.T < 1 || a.T > (tk.r_f64 ? 32 : 64)) return false;
     if (a.L < 2 || a.M < 1 || a.zero_start_below > 0) return false;   // (L == 1: the single-column kernels; M == 1: FIRInterpolator)
     const int smin = static_cast<int>(a.M / a.L);        // the two windows of a lane start SMIN or SMIN + 1 samples apart
     if (smin > 5) return false;
     if (smin >= 2 && (tk.r_f64 || a.T > 32)) return false;   // instantiated for Float32 arithmetic, tapsPerPhi <= 32
+    if (a.T > 48 && tk.complex_x) return false;              // 49..64 taps per phase: Float32 samples (ComplexF32 would need > 168 VGPRs)
     const int env_c = opair_env_int("MRHIP_OPAIR_C", 0), env_j = opair_env_int("MRHIP_OPAIR_J", 0), env_ns = opair_env_int("MRHIP_OPAIR_NS", 0);
     // c: lanes = c*L/2 <= 512; c*L and c*M even (a lane owns two outputs; the run base keeps its parity from step to
     // step) => c even, L and M being coprime.  Among the sizes with 3..7 full-ish compute waves take the fullest.
@@ -187,6 +191,8 @@ hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &
     if (pa.r_f64)
         return smin == 0 ? launch_opair_wide_s0(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus)
                          : launch_opair_wide_s1(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus);
+    if (a.T > 48)
+        return smin == 0 ? launch_opair_f32_s0_long(fused, a.T, block, lds, s, a, pa, num_cus) : launch_opair_f32_s1_long(fused, a.T, block, lds, s, a, pa, num_cus);
     switch (smin) {
     case 0: return launch_opair_f32_s0(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
     case 1: return launch_opair_f32_s1(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);

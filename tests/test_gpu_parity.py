@@ -351,7 +351,8 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
              (5, 9, 5 * 13), (4, 7, 4 * 32), (147, 160, 3528), (9, 10, 9 * 7), (31, 32, 31 * 2 - 1),
              (2, 3, 72), (3, 2, 3 * 33), (160, 147, 160 * 48 - 5), (5, 9, 5 * 47), (147, 160, 147 * 40), (7, 5, 7 * 41 - 3),   # 33..48 taps per phase: Float32 arithmetic only
              (441, 160, 441 * 24 - 3), (7, 3, 7 * 24), (5, 2, 5 * 9), (511, 2, 511 * 3), (9, 4, 9 * 32),                      # L >= 2M
-             (160, 441, 160 * 24), (3, 17, 72), (2, 5, 2 * 31), (3, 10, 3 * 8), (2, 9, 64), (2, 11, 2 * 17 - 1), (3, 8, 3 * 32)]   # M >= 2L: Float32 arithmetic, <= 32 taps per phase
+             (160, 441, 160 * 24), (3, 17, 72), (2, 5, 2 * 31), (3, 10, 3 * 8), (2, 9, 64), (2, 11, 2 * 17 - 1), (3, 8, 3 * 32),   # M >= 2L: Float32 arithmetic, <= 32 taps per phase
+             (147, 160, 147 * 56), (160, 147, 160 * 64 - 5), (2, 1, 2 * 50 - 1), (3, 2, 3 * 61)]                                 # 49..64 taps per phase: Float32 samples
     combos = [(np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32)]
     for (L, M, hl) in cases:
         for th, tx in combos:
@@ -359,6 +360,8 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
                 continue                                                # Float64 arithmetic keeps two columns of <= 32 taps
             if M >= 2 * L and th == np.float64:
                 continue                                                # window distances of 2..5 samples: Float32 arithmetic only
+            if -(-hl // L) > 48 and (th, tx) != (np.float32, np.float32):
+                continue                                                # 49..64 taps per phase: Float32 samples and taps
             for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
                 if numerics == pkg.NUMERICS_FUSED and (hl % 2 or th == np.float64 and L % 2):
                     continue                                            # (thin the matrix)
@@ -782,11 +785,11 @@ def test_chunked_streaming_entry_matches_caller_loop(pkg, torch_cuda):
 
 
 def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
-    """Filters the register-resident kernels do not take (tapsPerPhi > 48, or > 32 with Float64 arithmetic, L > 512 phases, hLen > 512 with a decimation above 16) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
+    """Filters the register-resident kernels do not take (tapsPerPhi > 64, > 48 for ComplexF32 samples, or > 32 with Float64 arithmetic, L > 512 phases, hLen > 512 with a decimation above 16) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
     across chunk seams, for every dtype combination, 1..35 channels (all channels-per-lane variants + ragged group)."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
-    cases = [(2, 3, 100, np.float32, np.float32, 35), (3, 2, 200, np.float32, np.complex64, 9), (147, 160, 147 * 50, np.float32, np.float32, 33),
+    cases = [(2, 3, 140, np.float32, np.float32, 35), (3, 2, 200, np.float32, np.complex64, 9), (147, 160, 147 * 70, np.float32, np.float32, 33),
              (2, 3, 72, np.float64, np.float64, 4),
              (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 19, 700, np.float32, np.float32, 5),
              (1, 17, 600, np.float64, np.complex128, 2), (5, 64, 5 * 40, np.float64, np.float32, 32), (4, 7, 4 * 33, np.float32, np.float64, 1)]
