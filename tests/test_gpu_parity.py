@@ -399,16 +399,18 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
 
 def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
     """fir_stream_kernel (FIRStandard / FIRDecimator, Float32 and Float64 arithmetic, loader-wave staging, padded LDS tile,
-    scalar taps): M = 1..16, tap counts 32..512 (whole blocks and ragged), Float32 and ComplexF32, STRICT and FUSED,
+    scalar taps): M = 1..16, 20, 24, 32, 64, tap counts 32..512 (whole blocks and ragged), Float32 and ComplexF32, STRICT and FUSED,
     multi-channel, chunked with 1-sample pieces and pieces shorter than the history (the start-from-zero quirk of the
     Vector seam variant, support.jl:46, applies to the first hLen outputs of EVERY call); inputs contain -0.0, +-Inf,
     NaN.  Bit-exact against the universal kernel, the direct kernel it replaces, and the oracle."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
-    for M in range(1, 17):
+    for M in list(range(1, 17)) + [20, 24, 32, 64]:
         for T in (16, 24, 32, 33, 48, 127, 128, 500, 512):
             if T < 32 and (M > 8 or M == 6):
                 continue                                                # below one block of reads for some of these: the direct kernel's
+            if M > 16 and T not in (128, 512):
+                continue                                                # (a block of reads is up to 128 samples there)
             if M not in (1, 2, 4, 8) and T in (33, 127, 500):
                 continue                                                # (thin the matrix for the later instantiations)
             for th, tx in ((np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32), (np.float64, np.complex64),
@@ -417,6 +419,8 @@ def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
                     continue                                            # (thin the matrix for Float64 arithmetic)
                 if tx == np.complex128 and (T not in (48, 128) or (th == np.float32 and M not in (1, 5))):
                     continue
+                if M * np.dtype(tx).itemsize > 256:
+                    continue                                            # one step of 128 outputs would not fit a 60 KB stage: the tiled kernel's
                 if th == np.float64 and T < 32 and M > 4:
                     continue                                            # below one block of reads for some: the direct kernel's
                 for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
