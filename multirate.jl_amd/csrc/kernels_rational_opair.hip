@@ -52,6 +52,10 @@ hipError_t launch_opair_f32_s4(int nc, bool fused, int T, dim3 block, size_t lds
 hipError_t launch_opair_f32_s5(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_wide_s0(bool x_f64, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_wide_s1(bool x_f64, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+// complex samples with Float64 arithmetic: ComplexF32 samples with Float64 taps (what firdes' Float64 taps and an SDR's
+// ComplexF32 samples promote to) and ComplexF64 samples
+hipError_t launch_opair_cmix_s0(bool x_f64, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_opair_cmix_s1(bool x_f64, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 
 namespace {
 constexpr int kOMaxThreads = 512;
@@ -64,13 +68,12 @@ inline int opair_env_int(const char *name, int dflt)
 
 // Covers FIRRational and FIRInterpolator with tapsPerPhi <= 48 (Float32 samples with M < 2L: 64; Float64 arithmetic: 32) and M/L < 6 (L >= 2, SMIN = floor(M/L);
 // SMIN >= 2: Float32 arithmetic and tapsPerPhi <= 32) for Float32 arithmetic (Float32 or ComplexF32 samples, Float32 taps)
-// and Float64 arithmetic on real samples (Float64 x Float64; Float64 taps x Float32 samples).  Returns false otherwise
+// and Float64 arithmetic (Float64 or ComplexF64 samples; Float64 taps x Float32 or ComplexF32 samples).  Returns false otherwise
 // (the caller tries the next kernel).
 bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {
     if (!opair_env_int("MRHIP_OPAIR", 1)) return false;   // read per call: tests switch kernels at run time
     if (tk.x_f64 && !tk.r_f64) return false;
-    if (tk.r_f64 && tk.complex_x) return false;          // complex samples with Float64 arithmetic: the general kernels
     const int nc = tk.complex_x ? 2 : 1;
     const long long es = (tk.x_f64 ? 8 : 4) * nc;        // bytes per input sample
 #ifdef MRHIP_PS_FAST_BUILD
@@ -188,6 +191,9 @@ hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &
     pa.counters = counters;
     *kname = "rational_opair_kernel";
     const int smin = static_cast<int>(a.M / a.L);
+    if (pa.r_f64 && pa.nc == 2)
+        return smin == 0 ? launch_opair_cmix_s0(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus)
+                         : launch_opair_cmix_s1(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus);
     if (pa.r_f64)
         return smin == 0 ? launch_opair_wide_s0(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus)
                          : launch_opair_wide_s1(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus);

@@ -18,7 +18,7 @@ for (L, M, T) in [(l, m, t) for t in TAPS for (l, m) in RATIOS]:
     h32 = pkg.firdes(T * L, 0.5 / max(L, M), beta=7.8562).astype(np.float32)
     for dt, nch, n, th in ((torch.float32, 64, 1_000_000, np.float32), (torch.float32, 3, 40_000, np.float32), (torch.complex64, 32, 700_000, np.float32),
                            (torch.float32, 1, 3_000_000, np.float32), (torch.float64, 64, 500_000, np.float64), (torch.float64, 2, 30_011, np.float64),
-                           (torch.float32, 64, 500_000, np.float64), (torch.float32, 1, 1_000_000, np.float64)):
+                           (torch.float32, 64, 500_000, np.float64), (torch.float32, 1, 1_000_000, np.float64), (torch.complex64, 32, 400_000, np.float64), (torch.complex128, 24, 300_000, np.float64)):
         h = h32.astype(th)
         if T > 32 and th == np.float64:
             continue                                  # Float64 arithmetic: tapsPerPhi <= 32 on this kernel
@@ -26,6 +26,8 @@ for (L, M, T) in [(l, m, t) for t in TAPS for (l, m) in RATIOS]:
             x = torch.rand((nch, n), device="cuda", dtype=torch.float64) - 0.5
         elif dt == torch.complex64:
             x = torch.view_as_complex(torch.rand((nch, n, 2), device="cuda") - 0.5)
+        elif dt == torch.complex128:
+            x = torch.view_as_complex(torch.rand((nch, n, 2), device="cuda", dtype=torch.float64) - 0.5)
         else:
             x = torch.rand((nch, n), device="cuda") - 0.5
         sizes = [n // 2 + 7, 1, n - n // 2 - 8]
@@ -42,8 +44,8 @@ for (L, M, T) in [(l, m, t) for t in TAPS for (l, m) in RATIOS]:
             ys.append(g.filt(x[:, pos:pos + s])); pos += s
         yg = torch.cat(ys, dim=1)
         os.environ.pop("MRHIP_FORCE_GENERIC", None)
-        a = torch.view_as_real(y) if dt == torch.complex64 else y
-        b = torch.view_as_real(yg) if dt == torch.complex64 else yg
+        a = torch.view_as_real(y) if dt.is_complex else y
+        b = torch.view_as_real(yg) if dt.is_complex else yg
         same = torch.equal(a.view(torch.int32), b.view(torch.int32)) and np.array_equal(f.history.view(np.uint32), g.history.view(np.uint32))
         print(f"{L}//{M} T={T} {dt} taps={np.dtype(th)} nch={nch} n={n} kernel={kn} vs {g.last_kernel_name()}: {'OK' if same else 'MISMATCH'}", flush=True)
         ok = ok and same

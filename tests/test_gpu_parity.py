@@ -340,8 +340,8 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
     """rational_opair_kernel (two adjacent OUTPUTS per lane, window offsets resolved by exact no-op slots): L > M
     ratios (160//147, 3//2, ... and beyond two: 441//160, 7//3, 511//2), M > L ratios (147//160, 5//9, ...) up to
     M/L < 6 (160//441, 3//17, 2//11: window distance SMIN = 2..5), every tapsPerPhi class (odd, even, 1, 32),
-    Float32 / ComplexF32 / Float64 samples, Float32 and Float64 taps (incl. the README's Float64 taps x Float32
-    samples), STRICT and FUSED, multi-channel, chunked with 1-sample and prime pieces; inputs contain -0.0, +-Inf and
+    Float32 / ComplexF32 / Float64 / ComplexF64 samples, Float32 and Float64 taps (incl. the README's Float64 taps x Float32
+    samples and Float64 taps x ComplexF32 samples), STRICT and FUSED, multi-channel, chunked with 1-sample and prime pieces; inputs contain -0.0, +-Inf and
     NaN runs (a skipped slot must not turn into 0*Inf or flip the sign of an all-zero sum).  Bit-exact against the
     universal kernel on all channels and against the oracle on one."""
     torch = torch_cuda
@@ -353,7 +353,7 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
              (441, 160, 441 * 24 - 3), (7, 3, 7 * 24), (5, 2, 5 * 9), (511, 2, 511 * 3), (9, 4, 9 * 32),                      # L >= 2M
              (160, 441, 160 * 24), (3, 17, 72), (2, 5, 2 * 31), (3, 10, 3 * 8), (2, 9, 64), (2, 11, 2 * 17 - 1), (3, 8, 3 * 32),   # M >= 2L: Float32 arithmetic, <= 32 taps per phase
              (147, 160, 147 * 56), (160, 147, 160 * 64 - 5), (2, 1, 2 * 50 - 1), (3, 2, 3 * 61)]                                 # 49..64 taps per phase: Float32 samples
-    combos = [(np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32)]
+    combos = [(np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32), (np.float64, np.complex64), (np.float64, np.complex128)]
     for (L, M, hl) in cases:
         for th, tx in combos:
             if -(-hl // L) > 32 and th == np.float64:
@@ -369,7 +369,7 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
                 h = rng.standard_normal(hl).astype(th)
                 h[rng.integers(0, hl, 3)] = 0.0
                 x = _rand(rng, (nch, 30_011), tx) - 0.5
-                xr = x.view(np.float64 if tx == np.float64 else np.float32)
+                xr = x.view(np.float64 if tx in (np.float64, np.complex128) else np.float32)
                 xr[:, 500:560] = -0.0                                   # an all-(-0) window
                 xr[0, 2000] = np.inf; xr[0, 2100] = -np.inf; xr[nch - 1, 4000:4003] = np.nan
                 xd = torch.from_numpy(x).cuda()
