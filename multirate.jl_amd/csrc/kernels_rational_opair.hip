@@ -40,8 +40,10 @@ namespace mrhip {
 
 // instantiation units (kernels_rational_opair_*.hip): Float32 arithmetic (nc = 1 | 2) and Float64 arithmetic
 // (Float64 samples, or Float32 samples widened: the README's mixed case), one unit per SMIN = floor(M/L)
-hipError_t launch_opair_f32_s0(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
-hipError_t launch_opair_f32_s1(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_opair_f32_s0r(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_opair_f32_s0c(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_opair_f32_s1r(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_opair_f32_s1c(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 // 49..64 taps per phase (Float32 samples, SMIN <= 1: 140-160 VGPRs, one 8-wave workgroup per CU)
 hipError_t launch_opair_f32_s0_long(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_f32_s1_long(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
@@ -200,8 +202,8 @@ hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &
     if (a.T > 48)
         return smin == 0 ? launch_opair_f32_s0_long(fused, a.T, block, lds, s, a, pa, num_cus) : launch_opair_f32_s1_long(fused, a.T, block, lds, s, a, pa, num_cus);
     switch (smin) {
-    case 0: return launch_opair_f32_s0(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
-    case 1: return launch_opair_f32_s1(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
+    case 0: return pa.nc == 2 ? launch_opair_f32_s0c(fused, a.T, block, lds, s, a, pa, num_cus) : launch_opair_f32_s0r(fused, a.T, block, lds, s, a, pa, num_cus);
+    case 1: return pa.nc == 2 ? launch_opair_f32_s1c(fused, a.T, block, lds, s, a, pa, num_cus) : launch_opair_f32_s1r(fused, a.T, block, lds, s, a, pa, num_cus);
     case 2: return launch_opair_f32_s2(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
     case 3: return launch_opair_f32_s3(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
     case 4: return launch_opair_f32_s4(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
