@@ -195,7 +195,10 @@ bool plan_poly_tiled(const TypeKey &tk, const PolyArgs &a, int num_cus, ArbTileA
     long long tile_out = env_tile >= 64 ? env_tile / 64 * 64 : 256;
     // samples a tile of `t` outputs can touch: floor((u_first + (t-1)*M)/L) - floor(u_first/L) + T
     auto span_of = [&](long long t) { return ((t - 1) * a.M + a.L - 1) / a.L + a.T + 1; };
-    const size_t budget = 64 * 1024;                       // two or more workgroups per CU
+    // two or more workgroups per CU when the tap bank leaves room for it; a bank that takes most of that keeps full tiles
+    // and one workgroup per CU instead of shrinking the tile to a quarter of the workgroup (147//160 with 128 taps per
+    // phase: 76 KB of taps)
+    const size_t budget = std::max<size_t>(64 * 1024, std::min<size_t>(bank_bytes + 40 * 1024, 150 * 1024));
     for (;;) {
         const long long max_span = span_of(tile_out);
         const size_t total = bank_bytes + static_cast<size_t>(max_span) * sb * cpl;
