@@ -320,9 +320,11 @@ bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_ho
     const long long groups = (a.nch + cpl - 1) / cpl;
     // tile: a multiple of 256 outputs whose sample span fits the remaining budget
     static const int env_tile = [] { const char *v = std::getenv("MRHIP_ARB_TILE"); return v && *v ? std::atoi(v) : 0; }();
-    // (measured, config 4: with several channels per lane small tiles win -- 6 workgroups per CU)
-    long long tile_out = env_tile >= 256 ? env_tile / 256 * 256 : (cpl >= 4 ? 256 : 1024);
+    // (measured, 256 ch x 2e6, rate pi/3, `scripts/exp_arb_knobs.py`: Float64 arithmetic -- config 4 -- with several channels per
+    //  lane: 256-output tiles 20.4 % of HBM, 1024-output tiles 18.2 %; Float32 arithmetic: 12.9 % against 19.6 %)
+    long long tile_out = env_tile >= 256 ? env_tile / 256 * 256 : (cpl >= 4 && tk.r_f64 ? 256 : 1024);
     const long long want_tiles = 4LL * num_cus;
+    static const int arb_cap_kib = [] { const char *v = std::getenv("MRHIP_ARB_CAP_KIB"); return v && *v ? std::atoi(v) : 36; }();
     while (tile_out > 256 && ((a.n_out + tile_out - 1) / tile_out) * groups < want_tiles) tile_out /= 2;
     for (;;) {
         long long max_span = 0;
@@ -331,7 +333,8 @@ bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_ho
             max_span = std::max<long long>(max_span, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0] + a.T);
         }
         const size_t total = banks_bytes + static_cast<size_t>(max_span) * sb * cpl;
-        if (total <= 64 * 1024 || tile_out == 256) {
+        // Float32 arithmetic: large tiles as long as five workgroups still fit a CU (a decimating rate stretches the span)
+        if (total <= (tk.r_f64 ? 64 : arb_cap_kib) * 1024 || tile_out == 256) {
             if (total > 150 * 1024) return false;
             ArbTileArgs ta{};
             ta.tap_pitch = TP;
