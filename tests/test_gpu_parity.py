@@ -406,23 +406,19 @@ def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
     torch = torch_cuda
     rng = np.random.default_rng(77)
     for M in list(range(1, 17)) + [20, 24, 25, 32, 40, 48, 50, 64]:
-        for T in (16, 24, 32, 33, 48, 127, 128, 500, 512):
-            if T < 32 and (M > 8 or M == 6):
-                continue                                                # below one block of reads for some of these: the direct kernel's
-            if M > 16 and T not in (128, 512):
-                continue                                                # (a block of reads is up to 128 samples there)
-            if M not in (1, 2, 4, 8) and T in (33, 127, 500):
+        for T in (2, 3, 7, 16, 24, 32, 33, 48, 127, 128, 500, 512):
+            if M > 16 and T not in (3, 24, 128, 512):
+                continue
+            if M not in (1, 2, 4, 8) and T in (7, 33, 127, 500):
                 continue                                                # (thin the matrix for the later instantiations)
             for th, tx in ((np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32), (np.float64, np.complex64),
                            (np.float64, np.complex128), (np.float32, np.complex128)):
-                if th == np.float64 and (T in (33, 127, 500) or (M not in (1, 2, 3, 4, 8, 16) and T != 48)):
+                if th == np.float64 and (T in (2, 7, 33, 127, 500) or (M not in (1, 2, 3, 4, 8, 16) and T != 48)):
                     continue                                            # (thin the matrix for Float64 arithmetic)
                 if tx == np.complex128 and (T not in (48, 128) or (th == np.float32 and M not in (1, 5))):
                     continue
                 if M * np.dtype(tx).itemsize > 256:
                     continue                                            # one step of 128 outputs would not fit a 60 KB stage: the tiled kernel's
-                if th == np.float64 and T < 32 and M > 4:
-                    continue                                            # below one block of reads for some: the direct kernel's
                 for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
                     if numerics == pkg.NUMERICS_FUSED and T not in (48, 128):
                         continue
