@@ -1,4 +1,4 @@
-// kernels_fir_stream.hip -- FIRStandard (M = 1) and FIRDecimator (L = 1, M = 2..16, 20, 24, 25, 32, 40, 48, 50, 64), 2 to 16384 taps (as long as a tile fits the LDS),
+// kernels_fir_stream.hip -- FIRStandard (M = 1) and FIRDecimator (L = 1, M = 2..32, 40, 48, 50, 64), 2 to 16384 taps (as long as a tile fits the LDS),
 // with Float32 arithmetic (Float32 or ComplexF32 samples, Float32 taps) and Float64 arithmetic (Float64 or ComplexF64 samples,
 // or Float32 / ComplexF32 samples with Float64 taps): the streaming form of kernels_fir_direct.hip (BASELINE config 3b).  This file holds
 // the planning and the dispatch; the kernel is fir_stream_kernel.inc, instantiated by kernels_fir_stream_{f32,f64,mix}.hip.
@@ -37,7 +37,7 @@ hipError_t launch_fir_stream_f32(int nc, bool fused, dim3 block, size_t lds, hip
 hipError_t launch_fir_stream_f64(int nc, bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_fir_stream_mix(int nc, bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 
-// Covers L == 1, M <= 16 or in {20, 24, 25, 32, 40, 48, 50, 64}, 2 <= T <= 16384, every sample type.  Returns false
+// Covers L == 1, M <= 32 or in {40, 48, 50, 64}, 2 <= T <= 16384, every sample type.  Returns false
 // otherwise (the caller falls back to kernels_fir_direct.hip).
 bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {

@@ -399,13 +399,13 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
 
 def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
     """fir_stream_kernel (FIRStandard / FIRDecimator, Float32 and Float64 arithmetic, loader-wave staging, padded LDS tile,
-    scalar taps): M = 1..16, 20, 24, 25, 32, 40, 48, 50, 64, tap counts 32..512 (whole blocks and ragged), Float32 and ComplexF32, STRICT and FUSED,
+    scalar taps): M = 1..32, 40, 48, 50, 64, tap counts 32..512 (whole blocks and ragged), Float32 and ComplexF32, STRICT and FUSED,
     multi-channel, chunked with 1-sample pieces and pieces shorter than the history (the start-from-zero quirk of the
     Vector seam variant, support.jl:46, applies to the first hLen outputs of EVERY call); inputs contain -0.0, +-Inf,
     NaN.  Bit-exact against the universal kernel, the direct kernel it replaces, and the oracle."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
-    for M in list(range(1, 17)) + [20, 24, 25, 32, 40, 48, 50, 64]:
+    for M in list(range(1, 17)) + [17, 19, 20, 22, 24, 25, 27, 30, 31, 32, 40, 48, 50, 64]:
         for T in (2, 3, 7, 16, 24, 32, 33, 48, 127, 128, 500, 512):
             if M > 16 and T not in (3, 24, 128, 512):
                 continue
