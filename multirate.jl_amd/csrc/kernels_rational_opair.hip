@@ -79,9 +79,9 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
     const int nc = tk.complex_x ? 2 : 1;
     const long long es = (tk.x_f64 ? 8 : 4) * nc;        // bytes per input sample
 #ifdef MRHIP_PS_FAST_BUILD
-    if (a.T != 24 && !(!tk.r_f64 && (a.T == 36 || a.T == 48 || a.T == 56 || a.T == 64))) return false;
+    if (a.T != 24 && !((a.T == 36 || a.T == 48) && !tk.complex_x) && !(!tk.r_f64 && (a.T == 36 || a.T == 48 || a.T == 56 || a.T == 64))) return false;
 #endif
-    if (a.T < 1 || a.T > (tk.r_f64 ? 32 : 64)) return false;
+    if (a.T < 1 || a.T > (tk.r_f64 ? (tk.complex_x ? 32 : 48) : 64)) return false;
     if (a.L < 2 || a.M < 1 || a.zero_start_below > 0) return false;   // (L == 1: the single-column kernels; M == 1: FIRInterpolator)
     const int smin = static_cast<int>(a.M / a.L);        // the two windows of a lane start SMIN or SMIN + 1 samples apart
     if (smin > 5) return false;
@@ -109,6 +109,7 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
             if (static_cast<long long>(c) * a.L / 2 >= 128) { best_c = c; break; }
     if (env_c > 0 && env_c % 2 == 0 && static_cast<long long>(env_c) * a.L / 2 <= kOMaxThreads && static_cast<long long>(env_c) * a.L <= 1024) best_c = env_c;
     if (!best_c) return false;
+    if (tk.r_f64 && a.T > 32 && (static_cast<long long>(best_c) * a.L / 2 + 63) / 64 > 7) return false;   // eight waves at most there (opair_kernel.inc)
     const int c = best_c;
     const long long cM = static_cast<long long>(c) * a.M, cL = static_cast<long long>(c) * a.L;
     const int lanes = static_cast<int>(cL / 2);

@@ -20,8 +20,8 @@ for (L, M, T) in [(l, m, t) for t in TAPS for (l, m) in RATIOS]:
                            (torch.float32, 1, 3_000_000, np.float32), (torch.float64, 64, 500_000, np.float64), (torch.float64, 2, 30_011, np.float64),
                            (torch.float32, 64, 500_000, np.float64), (torch.float32, 1, 1_000_000, np.float64), (torch.complex64, 32, 400_000, np.float64), (torch.complex128, 24, 300_000, np.float64)):
         h = h32.astype(th)
-        if T > 32 and th == np.float64:
-            continue                                  # Float64 arithmetic: tapsPerPhi <= 32 on this kernel
+        if th == np.float64 and (T > 48 or (T > 32 and dt.is_complex)):
+            continue                                  # Float64 arithmetic: tapsPerPhi <= 48 on real samples, <= 32 on complex ones
         if dt == torch.float64:
             x = torch.rand((nch, n), device="cuda", dtype=torch.float64) - 0.5
         elif dt == torch.complex64:

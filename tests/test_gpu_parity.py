@@ -356,8 +356,8 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
     combos = [(np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32), (np.float64, np.complex64), (np.float64, np.complex128)]
     for (L, M, hl) in cases:
         for th, tx in combos:
-            if -(-hl // L) > 32 and th == np.float64:
-                continue                                                # Float64 arithmetic keeps two columns of <= 32 taps
+            if th == np.float64 and (-(-hl // L) > 48 or (-(-hl // L) > 32 and tx in (np.complex64, np.complex128))):
+                continue                                                # Float64 arithmetic: two columns of <= 48 taps (complex samples: 32)
             if M >= 2 * L and th == np.float64:
                 continue                                                # window distances of 2..5 samples: Float32 arithmetic only
             if -(-hl // L) > 48 and (th, tx) != (np.float32, np.float32):
@@ -785,14 +785,14 @@ def test_chunked_streaming_entry_matches_caller_loop(pkg, torch_cuda):
 
 
 def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
-    """Filters the register-resident kernels do not take (tapsPerPhi > 64, > 48 for ComplexF32 samples, or > 32 with Float64 arithmetic, L > 512 phases, hLen > 512 with a decimation that is not instantiated) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
+    """Filters the register-resident kernels do not take (tapsPerPhi > 64, > 48 for ComplexF32 samples or Float64 arithmetic, > 32 for complex samples with Float64 arithmetic, L > 512 phases, hLen > 512 with a decimation that is not instantiated) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
     across chunk seams, for every dtype combination, 1..35 channels (all channels-per-lane variants + ragged group)."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     cases = [(2, 3, 140, np.float32, np.float32, 35), (3, 2, 200, np.float32, np.complex64, 9), (147, 160, 147 * 70, np.float32, np.float32, 33),
-             (2, 3, 72, np.float64, np.float64, 4),
+             (2, 3, 100, np.float64, np.float64, 4),
              (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 35, 700, np.float32, np.float32, 5),
-             (1, 33, 600, np.float64, np.complex128, 2), (5, 64, 5 * 40, np.float64, np.float32, 32), (4, 7, 4 * 33, np.float32, np.float64, 1)]
+             (1, 33, 600, np.float64, np.complex128, 2), (5, 64, 5 * 40, np.float64, np.float32, 32), (4, 7, 4 * 49, np.float32, np.float64, 1)]
     for (L, M, hl, th, tx, nch) in cases:
         h = rng.standard_normal(hl).astype(th)
         x = _rand(rng, (nch, 30_000), tx) - 0.5
