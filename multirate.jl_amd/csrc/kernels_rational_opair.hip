@@ -44,9 +44,9 @@ hipError_t launch_opair_f32_s0r(bool fused, int T, dim3 block, size_t lds, hipSt
 hipError_t launch_opair_f32_s0c(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_f32_s1r(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_f32_s1c(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
-// 49..64 taps per phase (Float32 samples, SMIN <= 1: 140-160 VGPRs, one 8-wave workgroup per CU)
-hipError_t launch_opair_f32_s0_long(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
-hipError_t launch_opair_f32_s1_long(bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+// 49..64 taps per phase (Float32 arithmetic, SMIN <= 1: 140-168 VGPRs, one 8-wave workgroup per CU)
+hipError_t launch_opair_f32_s0_long(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_opair_f32_s1_long(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 // SMIN = 2..5 (decimating ratios up to M/L < 6): Float32 arithmetic, tapsPerPhi <= 32
 hipError_t launch_opair_f32_s2(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_opair_f32_s3(int nc, bool fused, int T, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
@@ -86,7 +86,6 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
     const int smin = static_cast<int>(a.M / a.L);        // the two windows of a lane start SMIN or SMIN + 1 samples apart
     if (smin > 5) return false;
     if (smin >= 2 && (tk.r_f64 || a.T > 32)) return false;   // instantiated for Float32 arithmetic, tapsPerPhi <= 32
-    if (a.T > 48 && tk.complex_x) return false;              // 49..64 taps per phase: Float32 samples (ComplexF32 would need > 168 VGPRs)
     const int env_c = opair_env_int("MRHIP_OPAIR_C", 0), env_j = opair_env_int("MRHIP_OPAIR_J", 0), env_ns = opair_env_int("MRHIP_OPAIR_NS", 0);
     // c: lanes = c*L/2 <= 512; c*L and c*M even (a lane owns two outputs; the run base keeps its parity from step to
     // step) => c even, L and M being coprime.  Among the sizes with 3..7 full-ish compute waves take the fullest.
@@ -201,7 +200,7 @@ hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &
         return smin == 0 ? launch_opair_wide_s0(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus)
                          : launch_opair_wide_s1(pa.x_f64 != 0, fused, a.T, block, lds, s, a, pa, num_cus);
     if (a.T > 48)
-        return smin == 0 ? launch_opair_f32_s0_long(fused, a.T, block, lds, s, a, pa, num_cus) : launch_opair_f32_s1_long(fused, a.T, block, lds, s, a, pa, num_cus);
+        return smin == 0 ? launch_opair_f32_s0_long(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus) : launch_opair_f32_s1_long(pa.nc, fused, a.T, block, lds, s, a, pa, num_cus);
     switch (smin) {
     case 0: return pa.nc == 2 ? launch_opair_f32_s0c(fused, a.T, block, lds, s, a, pa, num_cus) : launch_opair_f32_s0r(fused, a.T, block, lds, s, a, pa, num_cus);
     case 1: return pa.nc == 2 ? launch_opair_f32_s1c(fused, a.T, block, lds, s, a, pa, num_cus) : launch_opair_f32_s1r(fused, a.T, block, lds, s, a, pa, num_cus);

@@ -360,8 +360,8 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
                 continue                                                # Float64 arithmetic: two columns of <= 48 taps (complex samples: 32)
             if M >= 2 * L and th == np.float64:
                 continue                                                # window distances of 2..5 samples: Float32 arithmetic only
-            if -(-hl // L) > 48 and (th, tx) != (np.float32, np.float32):
-                continue                                                # 49..64 taps per phase: Float32 samples and taps
+            if -(-hl // L) > 48 and th != np.float32:
+                continue                                                # 49..64 taps per phase: Float32 arithmetic
             for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
                 if numerics == pkg.NUMERICS_FUSED and (hl % 2 or th == np.float64 and L % 2):
                     continue                                            # (thin the matrix)
@@ -785,7 +785,7 @@ def test_chunked_streaming_entry_matches_caller_loop(pkg, torch_cuda):
 
 
 def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
-    """Filters the register-resident kernels do not take (tapsPerPhi > 64, > 48 for ComplexF32 samples or Float64 arithmetic, > 32 for complex samples with Float64 arithmetic, L > 512 phases, hLen > 512 with a decimation that is not instantiated) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
+    """Filters the register-resident kernels do not take (tapsPerPhi > 64, > 48 for Float64 arithmetic, > 32 for complex samples with Float64 arithmetic, L > 512 phases, hLen > 512 with a decimation that is not instantiated) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
     across chunk seams, for every dtype combination, 1..35 channels (all channels-per-lane variants + ragged group)."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
