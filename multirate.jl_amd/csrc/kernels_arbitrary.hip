@@ -186,12 +186,15 @@ hipError_t launch_arb(bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_
 // then the workgroup walks over ALL channels in groups of CPL: stage the contiguous sample run of the group,
 // one Vector dot per channel (start from zero on the seam, support.jl:46) with the taps read back from LDS.
 // The taps depend on the output index only, so they are evaluated once per 256 outputs x all channels.
-template <typename TX, typename R, int NC, bool FUSED, int CPL>
+// TREG > 0: T <= TREG and the lane keeps its T taps in registers (no tap columns in LDS: 64 KB less per workgroup for 32
+// Float64 taps, twice the resident waves); TREG == 0: tap columns in LDS, any T that fits.
+template <typename TX, typename R, int NC, bool FUSED, int CPL, int TREG>
 __global__ __launch_bounds__(kArbThreads) void farrow_tiled_kernel(FarrowArgs a, ArbTileArgs ta)
 {
     struct alignas(sizeof(TX) * NC) Sample { TX c[NC]; };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    R *const tl = reinterpret_cast<R *>(smem);                                  // taps: [T][256]
+    R *const tl = reinterpret_cast<R *>(smem);                                  // taps: [T][256] (TREG == 0)
+    R treg[TREG > 0 ? TREG : 1];
     Sample *const lx = reinterpret_cast<Sample *>(smem + ta.x_offset_bytes);    // samples: [CPL][max_span]
     const int tid = threadIdx.x;
     const int T = a.T, P = a.polyorder;
@@ -208,11 +211,18 @@ __global__ __launch_bounds__(kArbThreads) void farrow_tiled_kernel(FarrowArgs a,
         if (have) {
             n = a.n_idx[k];
             const double phase = a.acc[k];
-            for (int i = 0; i < T; ++i) {            // Horner in Float64, separately rounded multiply and add
+            auto tap_of = [&](int i) -> R {          // Horner in Float64, separately rounded multiply and add
                 const double *__restrict__ c = a.pnfb + static_cast<long long>(i) * (P + 1);
                 double yv = c[P];
                 for (int j = P - 1; j >= 0; --j) { const double t = phase * yv; yv = c[j] + t; }
-                tl[i * kArbThreads + tid] = a.tap_f32 ? static_cast<R>(static_cast<float>(yv)) : static_cast<R>(yv);
+                return a.tap_f32 ? static_cast<R>(static_cast<float>(yv)) : static_cast<R>(yv);
+            };
+            if constexpr (TREG > 0) {
+#pragma unroll
+                for (int i = 0; i < TREG; ++i)
+                    if (i < T) treg[i] = tap_of(i);
+            } else {
+                for (int i = 0; i < T; ++i) tl[i * kArbThreads + tid] = tap_of(i);
             }
         }
         const bool seam = n < T;                      // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818
@@ -241,7 +251,8 @@ __global__ __launch_bounds__(kArbThreads) void farrow_tiled_kernel(FarrowArgs a,
                 const Sample *wp = lx + (n - n_lo);
                 R acc[CPL][NC];
                 {
-                    const R t = tl[tid];
+                    R t;
+                    if constexpr (TREG > 0) t = treg[0]; else t = tl[tid];
 #pragma unroll
                     for (int cc = 0; cc < CPL; ++cc) {
                         const Sample v = wp[static_cast<size_t>(cc) * ta.max_span];
@@ -252,15 +263,21 @@ __global__ __launch_bounds__(kArbThreads) void farrow_tiled_kernel(FarrowArgs a,
                         }
                     }
                 }
-#pragma unroll 4
-                for (int i = 1; i < T; ++i) {
-                    const R t = tl[i * kArbThreads + tid];
+                auto tap_step = [&](int i, R t) {
 #pragma unroll
                     for (int cc = 0; cc < CPL; ++cc) {
                         const Sample v = wp[static_cast<size_t>(cc) * ta.max_span + i];
 #pragma unroll
                         for (int c = 0; c < NC; ++c) acc[cc][c] = mac<R, FUSED>(t, static_cast<R>(v.c[c]), acc[cc][c]);
                     }
+                };
+                if constexpr (TREG > 0) {
+#pragma unroll
+                    for (int i = 1; i < TREG; ++i)
+                        if (i < T) tap_step(i, treg[i]);        // (wave-uniform)
+                } else {
+#pragma unroll 4
+                    for (int i = 1; i < T; ++i) tap_step(i, tl[i * kArbThreads + tid]);
                 }
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(kArbThreads) void farrow_tiled_kernel(FarrowArgs a,
                 }
             }
         }
-        __syncthreads();   // the tap columns are rewritten by the next tile
+        if constexpr (TREG == 0) __syncthreads();   // the tap columns are rewritten by the next tile
     }
 }
 
@@ -295,8 +312,12 @@ hipError_t launch_farrow_t(bool fused, const FarrowArgs &a, const ArbTileArgs &t
         launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, ta);
         return hipGetLastError();
     };
-    if (ta.cpl == 4) return fused ? go(farrow_tiled_kernel<TX, R, NC, true, 4>) : go(farrow_tiled_kernel<TX, R, NC, false, 4>);
-    return fused ? go(farrow_tiled_kernel<TX, R, NC, true, 1>) : go(farrow_tiled_kernel<TX, R, NC, false, 1>);
+    if (ta.tap_pitch == 1) {     // taps in registers (T <= 32)
+        if (ta.cpl == 4) return fused ? go(farrow_tiled_kernel<TX, R, NC, true, 4, 32>) : go(farrow_tiled_kernel<TX, R, NC, false, 4, 32>);
+        return fused ? go(farrow_tiled_kernel<TX, R, NC, true, 1, 32>) : go(farrow_tiled_kernel<TX, R, NC, false, 1, 32>);
+    }
+    if (ta.cpl == 4) return fused ? go(farrow_tiled_kernel<TX, R, NC, true, 4, 0>) : go(farrow_tiled_kernel<TX, R, NC, false, 4, 0>);
+    return fused ? go(farrow_tiled_kernel<TX, R, NC, true, 1, 0>) : go(farrow_tiled_kernel<TX, R, NC, false, 1, 0>);
 }
 
 }  // namespace
@@ -371,7 +392,9 @@ bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_
     if (!enabled || a.n_out < 1) return false;
     const size_t rs = tk.r_f64 ? 8 : 4;
     const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
-    const size_t taps_bytes = (static_cast<size_t>(a.T) * kArbThreads * rs + 15) / 16 * 16;
+    static const int regs_ok = [] { const char *v = std::getenv("MRHIP_FARROW_REGS"); return !(v && v[0] == '0'); }();
+    const bool in_regs = a.T <= 32 && regs_ok;          // the lane keeps its taps in registers: no tap columns in LDS
+    const size_t taps_bytes = in_regs ? 0 : (static_cast<size_t>(a.T) * kArbThreads * rs + 15) / 16 * 16;
     if (taps_bytes > 96 * 1024) return false;
     const int cpl = a.nch >= 4 ? 4 : 1;
     const long long tile_out = kArbThreads;
@@ -384,6 +407,7 @@ bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_
     if (total > 150 * 1024) return false;
     ArbTileArgs ta{};
     ta.cpl = cpl;
+    ta.tap_pitch = in_regs ? 1 : 0;                   // (FIRFarrow has no tap bank: the field says where the taps live)
     ta.x_offset_bytes = static_cast<int>(taps_bytes);
     ta.max_span = static_cast<int>(max_span);
     ta.tile_out = tile_out;
