@@ -46,10 +46,9 @@ bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs
     if (tk.r_f64 && !stream_env_int("MRHIP_STREAM_F64", 1)) return false;
     const int nc = tk.complex_x ? 2 : 1;
     const long long es = (tk.x_f64 ? 8 : 4) * nc;
-    int pad_every = 0, min_taps = 0;
+    int pad_every = 0, min_taps = 0;   // (min_taps: one block of reads; shorter filters take the kernel's per-sample loop)
     if (a.M > 64 || !(es == 16 ? stream_geometry<16>(static_cast<int>(a.M), &pad_every, &min_taps)
                       : es == 8 ? stream_geometry<8>(static_cast<int>(a.M), &pad_every, &min_taps) : stream_geometry<4>(static_cast<int>(a.M), &pad_every, &min_taps))) return false;
-    (void)min_taps;
     if (a.T < 2 || a.T > 16384) return false;   // (a tile must hold T samples: checked below)
     // compute waves: 3 (+ loader = a 256-thread workgroup) unless overridden; a step is 2 outputs per lane
     int ncw = stream_env_int("MRHIP_STREAM_WAVES", 3);
