@@ -1,5 +1,9 @@
+#!/bin/bash
+# Clock (GRBM_GUI_ACTIVE / 8 / duration) and VALU occupancy of the Float64 and mixed-precision instantiations on launches long
+# enough for the quotient (64 ch x 1e7), with random and zero-filled data.  usage: bash scripts/exp_clk_f64.sh   (on the GPU box)
+set -u
+R="${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 for z in 0 1; do
 rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $R/gpurun_out/s2_clk64_$z -o clk -- python3 $R/scripts/exp_one.py --dtype float64 --long 10000000 --reps 4 --zeros $z > $R/gpurun_out/s2_clk64_$z.log 2>&1
 rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $R/gpurun_out/s2_clkmix_$z -o clk -- python3 $R/scripts/exp_one.py --dtype float32 --taps64 1 --long 10000000 --reps 4 --zeros $z > $R/gpurun_out/s2_clkmix_$z.log 2>&1

@@ -1,4 +1,8 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# rocm-smi clocks / power sampled while the headline launch runs in a loop (and once after it).  usage: bash scripts/exp_smi_sample.sh
+set -u
+R="${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
+cd "$R"
 python3 scripts/exp_one.py --long 100000000 --reps 4000 > gpurun_out/smi_run.log 2>&1 &
 PID=$!
 sleep 30
