@@ -276,6 +276,15 @@ int mrhip_set_timing(mrhip_filter *f, int enabled);
 int mrhip_timing_read(mrhip_filter *f, int64_t *n_launches, double *total_ms);
 /* name of the device kernel the last filt call dispatched (for profiles / logs) */
 const char *mrhip_last_kernel_name(const mrhip_filter *f);
+/* How the phase schedule of a FIRArbitrary / FIRFarrow filter -- update(), src/Filters.jl:663-673 and :780-792 -- has
+ * been evaluated so far.  info[0..n) receives, as far as n reaches:
+ *   [0] 1 if the device evaluation covers this (rate, Nphi), else 0 (the host's serial loop runs)
+ *   [1] candidate values per congruence class G/Umin   [2] candidates per segment
+ *   [3] period of the accumulator's cycle, 0 if none was found (a cycle makes the schedule a closed form)
+ *   [4] outputs scheduled by the host loop             [5] outputs scheduled by the closed form of a cycle
+ *   [6] pieces scheduled and verified on the device    [7] pieces whose verification failed (redone by the host loop)
+ * (diagnostics and tests; results never depend on the path taken) */
+int mrhip_schedule_info(const mrhip_filter *f, int64_t *info, int n);
 
 #ifdef __cplusplus
 }

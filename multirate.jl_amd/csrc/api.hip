@@ -7,7 +7,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
+#include <unordered_map>
 
 #include "mrhip_internal.h"
 
@@ -17,6 +19,35 @@ thread_local LaunchEvents g_launch_events;
 static thread_local std::string g_last_error;
 
 void set_error(const std::string &msg) { g_last_error = msg; }
+
+namespace {
+struct OccKey { const void *fn; int dev; bool operator==(const OccKey &o) const { return fn == o.fn && dev == o.dev; } };
+struct OccKeyHash { size_t operator()(const OccKey &k) const { return std::hash<const void *>()(k.fn) ^ (static_cast<size_t>(k.dev) * 0x9e3779b97f4a7c15ull); } };
+struct OccEntry { unsigned block = 0; size_t lds = ~static_cast<size_t>(0), attr = 0; int per_cu = 0; };
+}  // namespace
+
+hipError_t occupancy_cached(const void *kfn, unsigned block, size_t lds, int *per_cu)
+{
+    static std::mutex m;
+    static std::unordered_map<OccKey, OccEntry, OccKeyHash> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(m);
+    OccEntry &e = cache[OccKey{kfn, dev}];
+    if (lds > 48 * 1024 && lds > e.attr) {            // the limit only ever grows
+        hipError_t err = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (err != hipSuccess) return err;
+        e.attr = lds;
+    }
+    if (e.block != block || e.lds != lds) {
+        int n = 0;
+        hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, static_cast<int>(block), lds);
+        if (err != hipSuccess) return err;
+        e.block = block; e.lds = lds; e.per_cu = n;
+    }
+    *per_cu = e.per_cu;
+    return hipSuccess;
+}
 int fail(int code, const std::string &msg)
 {
     g_last_error = msg;
@@ -312,6 +343,7 @@ int mrhip_create_arbitrary(const void *h, int64_t hLen, int th, double rate, int
     if (!rc) rc = upload_taps(f, f->h_dtaps, &f->d_dtaps);
     if (!rc) rc = alloc_common(f);
     if (rc) { mrhip_destroy(f); return rc; }
+    sched_configure(f);
     *out = f;
     return MRHIP_OK;
 }
@@ -341,6 +373,7 @@ static int create_farrow_common(const std::vector<double> &pnfb_in, int64_t hLen
         rc = fail(MRHIP_ERR_HIP, "uploading the polynomial filter bank failed");
     if (!rc) rc = alloc_common(f);
     if (rc) { mrhip_destroy(f); return rc; }
+    sched_configure(f);
     *out = f;
     return MRHIP_OK;
 }
@@ -425,6 +458,7 @@ void mrhip_destroy(mrhip_filter *f)
         if (p) (void)hipFree(p);
     if (f->pin_n) (void)hipHostFree(f->pin_n);
     if (f->pin_acc) (void)hipHostFree(f->pin_acc);
+    sched_free(f);
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
         if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : {f->sched_copied, f->xs_event, f->ev_in[0], f->ev_in[1], f->ev_k[0], f->ev_k[1], f->ev_out[0], f->ev_out[1]})
@@ -509,6 +543,8 @@ int mrhip_set_state(mrhip_filter *f, int64_t phiIdx, int64_t inputDeficit, doubl
         f->phiIdx = phiIdx;
     }
     f->inputDeficit = inputDeficit;
+    f->sched_cached = false;
+    sched_forget(f);
     return MRHIP_OK;
 }
 
@@ -550,6 +586,7 @@ int mrhip_reset(mrhip_filter *f)
     f->last_stream = s; f->last_stream_valid = true;
     f->phiIdx = 1; f->inputDeficit = 1; f->xIdx = 1; f->phiAcc = 1.0; f->alpha = 0.0;
     f->sched_cached = false;
+    sched_forget(f);
     return MRHIP_OK;
 }
 
@@ -705,19 +742,24 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
     if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {
         // one range [k0, k0+cnt) of this call's outputs: schedule entries are already in the device buffers
         const size_t yelt = dtype_scalar_size(f->ty) * static_cast<size_t>(f->nc);
+        // (d_n, d_acc: the device schedule; n_host: its host copy, or NULL with `spans` = the largest input span of
+        //  the aligned tiles of 256, 512, 1024 outputs when the schedule was evaluated on the device)
+        const void *sched_dn = nullptr, *sched_dacc = nullptr;      // set by the branch that filled them, before its launch_range
+        const int *sched_spans = nullptr;
         auto launch_range = [&](int64_t k0, int64_t cnt, const int32_t *n_host) -> int {
+            if (!sched_dn || !sched_dacc) return fail(MRHIP_ERR_HIP, "no phase schedule on the device (internal)");
             void *yk = static_cast<unsigned char *>(y) + static_cast<size_t>(k0) * yelt;
             if (f->kind == MRHIP_FIR_FARROW) {
                 FarrowArgs fa{};
                 fa.x = x; fa.y = yk; fa.hist = f->d_hist[f->hist_cur]; fa.pnfb = f->d_pnfb;
-                fa.n_idx = static_cast<const int *>(f->d_sched_n) + k0; fa.acc = static_cast<const double *>(f->d_sched_acc) + k0;
+                fa.n_idx = static_cast<const int *>(sched_dn) + k0; fa.acc = static_cast<const double *>(sched_dacc) + k0;
                 fa.x_stride = x_stride; fa.y_stride = y_stride; fa.x_len = x_len; fa.n_out = cnt;
                 fa.T = static_cast<int>(f->T); fa.H = static_cast<int>(f->H); fa.polyorder = static_cast<int>(f->polyorder);
                 fa.tap_f32 = f->th == MRHIP_F32; fa.nch = static_cast<int>(f->nch);
                 if (int rc = timing_mark(f, stream)) return rc;
                 ArbTileArgs fta;
                 size_t flds = 0;
-                if (!f->force_generic && plan_farrow_tiled(tk, fa, n_host, f->num_cus, &fta, &flds))
+                if (!f->force_generic && plan_farrow_tiled(tk, fa, n_host, sched_spans, f->num_cus, &fta, &flds))
                     MRHIP_CHECK_HIP(launch_farrow_tiled(tk, fused, fa, fta, flds, stream, &f->last_kernel, f->num_cus));
                 else
                     MRHIP_CHECK_HIP(launch_farrow(tk, fused, fa, stream, &f->last_kernel));
@@ -725,14 +767,14 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             }
             ArbArgs a{};
             a.x = x; a.y = yk; a.hist = f->d_hist[f->hist_cur]; a.taps = f->d_taps; a.dtaps = f->d_dtaps;
-            a.n_idx = static_cast<const int *>(f->d_sched_n) + k0; a.acc = static_cast<const double *>(f->d_sched_acc) + k0;
+            a.n_idx = static_cast<const int *>(sched_dn) + k0; a.acc = static_cast<const double *>(sched_dacc) + k0;
             a.x_stride = x_stride; a.y_stride = y_stride; a.x_len = x_len; a.n_out = cnt;
             a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H); a.Nphi = static_cast<int>(f->Nphi);
             a.nch = static_cast<int>(f->nch);
             if (int rc = timing_mark(f, stream)) return rc;
             ArbTileArgs ta;
             size_t lds = 0;
-            if (!f->force_generic && plan_arb_tiled(tk, a, n_host, f->num_cus, &ta, &lds))
+            if (!f->force_generic && plan_arb_tiled(tk, a, n_host, sched_spans, f->num_cus, &ta, &lds))
                 MRHIP_CHECK_HIP(launch_arb_tiled(tk, fused, a, ta, lds, stream, &f->last_kernel, f->num_cus));
             else
                 MRHIP_CHECK_HIP(launch_arb_generic(tk, fused, a, stream, &f->last_kernel));
@@ -746,9 +788,30 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             ? static_cast<int64_t>(std::ceil(static_cast<double>(x_len - f->inputDeficit + 1) * f->rate)) + 2 : 0;
         const bool cached = f->sched_cached && f->sched_xlen == x_len && f->sched_acc0 == f->phiAcc && f->sched_deficit0 == f->inputDeficit;
         static const int64_t piece = [] { const char *v = std::getenv("MRHIP_SCHED_PIECE"); return v && *v ? std::atoll(v) : 262144LL; }();
-        if (!cached && est > 2 * piece && y && y_capacity >= est && (f->nch == 1 || y_stride >= est) && est < 0x7fffffffLL) {
+        if (!cached && sched_wants_device(f, est)) {
+            // the schedule is evaluated on the device (arb_schedule.hip): entries, count and end state without the
+            // host's serial loop; ONE filter launch for the whole call
+            SchedResult sr{};
+            if (int rc = sched_run_call(f, x_len, est, &sr)) return rc;
+            n_out = sr.count;
+            if (n_out > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
+            if (n_out > 0) {
+                if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
+                if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
+                MRHIP_CHECK_HIP(hipStreamWaitEvent(stream, f->ds_done, 0));
+                sched_dn = f->ds_n[sr.buf]; sched_dacc = f->ds_acc[sr.buf]; sched_spans = sr.max_span;
+                if (int rc = launch_range(0, n_out, nullptr)) return rc;
+                MRHIP_CHECK_HIP(hipEventRecord(f->ds_read[sr.buf], stream));
+                f->ds_read_valid[sr.buf] = true;
+            }
+            f->ds_cur = sr.buf;
+            f->sched_drift = sr.drift; f->sched_ksteps = sr.ksteps;
+            if (sr.periodic) f->per_pos = sr.per_pos_end;
+            st = sr.end;
+        } else if (!cached && est > 2 * piece && y && y_capacity >= est && (f->nch == 1 || y_stride >= est) && est < 0x7fffffffLL) {
             if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
             if (int rc = ensure_sched_capacity(f, static_cast<size_t>(est))) return rc;
+            sched_dn = f->d_sched_n; sched_dacc = f->d_sched_acc;      // (the buffers may just have been (re)allocated)
             st = ArbState{f->phiAcc, f->phiIdx, f->alpha, f->inputDeficit, f->inputDeficit};   // xIdx starts at inputDeficit (:715)
             bool done = false;
             int64_t k0 = 0;
@@ -795,6 +858,7 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
             if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
             if (int rc = ensure_sched_capacity(f, static_cast<size_t>(n_out))) return rc;
+            sched_dn = f->d_sched_n; sched_dacc = f->d_sched_acc;
             std::memcpy(f->pin_n, f->sched_n.data(), static_cast<size_t>(n_out) * sizeof(int32_t));
             std::memcpy(f->pin_acc, f->sched_acc.data(), static_cast<size_t>(n_out) * sizeof(double));
             MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_sched_n, f->pin_n, static_cast<size_t>(n_out) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
@@ -870,8 +934,7 @@ int mrhip_filt_device_chunked(mrhip_filter *f, const void *x, int64_t x_len, int
     // per-chunk loop: their seam dot product starts from zero (support.jl:46), which is visible per CALL (the sign of an
     // all-(-0) sum); FIRArbitrary/FIRFarrow keep it because their wall time is the host's serial phase recurrence.
     // MRHIP_CHUNKED_PER_CALL=1 forces the per-chunk loop (measurements of genuinely arriving chunks).
-    const char *pcv = std::getenv("MRHIP_CHUNKED_PER_CALL");
-    const bool per_call = pcv && pcv[0] == '1';
+    const bool per_call = MRHIP_ENV_INT("MRHIP_CHUNKED_PER_CALL", 0) == 1;
     int64_t step = chunk;
     if (!per_call && (f->kind == MRHIP_FIR_INTERPOLATOR || f->kind == MRHIP_FIR_RATIONAL) && chunk < x_len) {
         const int64_t total = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len).n_out;
@@ -935,8 +998,8 @@ int mrhip_filt_host(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_str
     if (!guard.ok) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
     const size_t xe = x_elt(f), ye = y_elt(f);
     // MRHIP_HOST_PIECE_KB (tests, tuning): input KiB per piece, read per call
-    const char *pv = std::getenv("MRHIP_HOST_PIECE_KB");
-    const int64_t piece_kb = pv && *pv && std::atoll(pv) > 0 ? std::atoll(pv) : 64 * 1024;
+    const int64_t env_kb = MRHIP_ENV_INT("MRHIP_HOST_PIECE_KB", 0);
+    const int64_t piece_kb = env_kb > 0 ? env_kb : 64 * 1024;
     int64_t piece = (piece_kb << 10) / static_cast<int64_t>(xe * static_cast<size_t>(f->nch));
     piece = std::max<int64_t>(piece, 256);
     const bool pipelined = x_len > piece + piece / 2;
@@ -1049,5 +1112,15 @@ int mrhip_timing_read(mrhip_filter *f, int64_t *n_launches, double *total_ms)
 }
 
 const char *mrhip_last_kernel_name(const mrhip_filter *f) { return f ? f->last_kernel : ""; }
+
+int mrhip_schedule_info(const mrhip_filter *f, int64_t *info, int n)
+{
+    if (!f || !info || n < 0) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    if (f->kind != MRHIP_FIR_ARBITRARY && f->kind != MRHIP_FIR_FARROW) return fail(MRHIP_ERR_INVALID_ARG, "not a FIRArbitrary / FIRFarrow filter");
+    const int64_t v[8] = {f->splan.ok, f->splan.ncand, f->splan.nwin, f->per_valid ? f->per_Q : 0,
+                          f->stat_host_steps, f->stat_periodic_steps, f->stat_device_pieces, f->stat_fallback_pieces};
+    for (int i = 0; i < n && i < 8; ++i) info[i] = v[i];
+    return MRHIP_OK;
+}
 
 }  // extern "C"

@@ -1,0 +1,411 @@
+// arb_schedule.hip -- host side of the device-evaluated phase schedule of FIRArbitrary / FIRFarrow
+// (update(), src/Filters.jl:663-673 and :780-792; device side: kernels_schedule.hip; model: scripts/sched_model.py).
+//
+// One filt! call of x_len samples needs, per output k, the input index n_k and the accumulator acc_k.  Three ways:
+//   HOST      the serial loop of host_logic.cpp (1.3 ns per output): short calls, and whatever the device path does
+//             not cover (rates above ~10 N/32 need more candidates per segment than the tables kernel holds).
+//   PERIODIC  the recurrence is a deterministic map of acc alone, so when the state after the serial prefix equals
+//             -- bit for bit -- a state inside the prefix, the schedule repeats from there on for ever: closed form,
+//             emitted by one trivial kernel, counted on the host, no synchronisation.  (Rates such as 1.0, 3.0, 11/7:
+//             exactly the ones whose phase sits ON the wrap / binade thresholds, where nothing but exact states helps.)
+//   TABLES    everything else: kernels_schedule.hip, piece by piece (sizes grow with the length of the drift
+//             baseline), one host synchronisation per call for the count; a piece whose verification fails is
+//             redone by the host loop.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "mrhip_internal.h"
+
+namespace mrhip {
+namespace {
+
+constexpr int kPerThreads = 256;
+
+// PERIODIC: entry j of the call (j >= 0) is cycle position (pos + j) mod Q
+__global__ __launch_bounds__(kPerThreads) void sched_periodic_kernel(const double *__restrict__ per_acc, const long long *__restrict__ per_xoff,
+                                                                     long long Q, long long XQ, long long pos, long long xbase,
+                                                                     long long n, int *__restrict__ sched_n, double *__restrict__ sched_acc)
+{
+    for (long long j = blockIdx.x * static_cast<long long>(kPerThreads) + threadIdx.x; j < n; j += static_cast<long long>(gridDim.x) * kPerThreads) {
+        const long long t = pos + j, cyc = t / Q, r = t - cyc * Q;
+        sched_n[j] = static_cast<int>(xbase + cyc * XQ + per_xoff[r]);
+        sched_acc[j] = per_acc[r];
+    }
+}
+
+int64_t env_i64(const char *name, int64_t dflt)
+{
+    const char *v = std::getenv(name);
+    return v && *v ? std::atoll(v) : dflt;
+}
+
+double wrap_half(double d, double N)
+{
+    if (d > 0.5 * N) return d - N;
+    if (d < -0.5 * N) return d + N;
+    return d;
+}
+
+// largest n[last] - n[first] over the aligned tiles of 256 << z outputs (tile t = outputs [t*ts, (t+1)*ts) of the call)
+// as far as the host entries [0, cnt) -- outputs [k0, k0 + cnt) -- cover them
+void host_spans(const int32_t *n, int64_t cnt, int64_t k0, int *span)
+{
+    for (int z = 0; z < kSchedSpanSizes; ++z) {
+        const int64_t ts = 256LL << z;
+        for (int64_t t0 = k0 / ts * ts; t0 < k0 + cnt; t0 += ts) {
+            const int64_t first = std::max(t0, k0) - k0, last = std::min(t0 + ts, k0 + cnt) - 1 - k0;
+            if (last > first) span[z] = std::max<int>(span[z], n[last] - n[first]);
+        }
+    }
+}
+
+int ensure_pinned(mrhip_filter *f, size_t n)
+{
+    if (n <= f->pin_cap) return MRHIP_OK;
+    const size_t cap = std::max<size_t>(n + n / 4, 4096);
+    if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
+    MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
+    if (f->pin_n) (void)hipHostFree(f->pin_n);
+    if (f->pin_acc) (void)hipHostFree(f->pin_acc);
+    f->pin_n = f->pin_acc = nullptr;
+    f->pin_cap = 0;
+    MRHIP_CHECK_HIP(hipHostMalloc(&f->pin_n, cap * sizeof(int32_t), hipHostMallocDefault));
+    MRHIP_CHECK_HIP(hipHostMalloc(&f->pin_acc, cap * sizeof(double), hipHostMallocDefault));
+    f->pin_cap = cap;
+    return MRHIP_OK;
+}
+
+int ensure_ds(mrhip_filter *f, int b, size_t n)
+{
+    if (n <= f->ds_cap[b]) return MRHIP_OK;
+    const size_t cap = n + n / 8 + 4096;
+    if (f->ds_read_valid[b]) { MRHIP_CHECK_HIP(hipEventSynchronize(f->ds_read[b])); f->ds_read_valid[b] = false; }
+    MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
+    if (f->ds_n[b]) (void)hipFree(f->ds_n[b]);
+    if (f->ds_acc[b]) (void)hipFree(f->ds_acc[b]);
+    f->ds_n[b] = f->ds_acc[b] = nullptr;
+    f->ds_cap[b] = 0;
+    MRHIP_CHECK_HIP(hipMalloc(&f->ds_n[b], cap * sizeof(int32_t)));
+    MRHIP_CHECK_HIP(hipMalloc(&f->ds_acc[b], cap * sizeof(double)));
+    f->ds_cap[b] = cap;
+    return MRHIP_OK;
+}
+
+int ensure_work(mrhip_filter *f, int64_t groups, int64_t pieces)
+{
+    const SchedPlan &c = f->splan;
+    if (groups > f->ds_work_groups) {
+        MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
+        for (void *p : {static_cast<void *>(f->ds_pathT), static_cast<void *>(f->ds_pathW), static_cast<void *>(f->ds_gtab), static_cast<void *>(f->ds_gstart)})
+            if (p) (void)hipFree(p);
+        f->ds_pathT = nullptr; f->ds_pathW = nullptr; f->ds_gtab = nullptr; f->ds_gstart = nullptr;
+        f->ds_work_groups = 0;
+        const size_t segs = static_cast<size_t>(groups) * 64;
+        MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->ds_pathT), segs * c.nwin * sizeof(double)));
+        MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->ds_pathW), segs * c.nwin * sizeof(int)));
+        MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->ds_gtab), static_cast<size_t>(groups) * c.nwin * sizeof(SchedGroupEntry)));
+        MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->ds_gstart), static_cast<size_t>(groups + 1) * sizeof(SchedGroupStart)));
+        f->ds_work_groups = groups;
+    }
+    if (pieces + 2 > f->ds_state_cap) {
+        MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
+        if (f->ds_state) (void)hipFree(f->ds_state);
+        if (f->ds_pin_state) (void)hipHostFree(f->ds_pin_state);
+        f->ds_state = nullptr; f->ds_pin_state = nullptr; f->ds_state_cap = 0;
+        const int64_t cap = pieces + 64;
+        MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->ds_state), static_cast<size_t>(cap) * sizeof(SchedPieceState)));
+        MRHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&f->ds_pin_state), static_cast<size_t>(cap) * sizeof(SchedPieceState), hipHostMallocDefault));
+        f->ds_state_cap = cap;
+    }
+    if (!f->ds_status) {
+        MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->ds_status), sizeof(SchedStatus)));
+        MRHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&f->ds_pin_status), 2 * sizeof(SchedStatus), hipHostMallocDefault));
+    }
+    return MRHIP_OK;
+}
+
+// upload host entries [0, cnt) of the pinned staging to outputs [k0, k0 + cnt) of schedule buffer b (own_stream)
+int upload_entries(mrhip_filter *f, int b, int64_t k0, int64_t cnt)
+{
+    if (cnt <= 0) return MRHIP_OK;
+    MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<int32_t *>(f->ds_n[b]) + k0, f->pin_n, static_cast<size_t>(cnt) * sizeof(int32_t), hipMemcpyHostToDevice, f->own_stream));
+    MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<double *>(f->ds_acc[b]) + k0, f->pin_acc, static_cast<size_t>(cnt) * sizeof(double), hipMemcpyHostToDevice, f->own_stream));
+    MRHIP_CHECK_HIP(hipEventRecord(f->sched_copied, f->own_stream));
+    f->sched_in_flight = true;
+    return MRHIP_OK;
+}
+
+int wait_pinned_free(mrhip_filter *f)
+{
+    if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
+    return MRHIP_OK;
+}
+
+// x of entry j of a periodic call that starts at cycle position pos with xIdx = x0
+inline int64_t per_x(const mrhip_filter *f, int64_t x0, int64_t j)
+{
+    const int64_t t = f->per_pos + j, cyc = t / f->per_Q, r = t - cyc * f->per_Q;
+    return x0 - f->per_xoff[static_cast<size_t>(f->per_pos)] + cyc * f->per_XQ + f->per_xoff[static_cast<size_t>(r)];
+}
+
+// the state after the prefix equals a state inside it?  (host entries [0, cnt) in the pinned staging; `st` after them)
+int try_find_cycle(mrhip_filter *f, int64_t cnt, const ArbState &st)
+{
+    const double *acc = static_cast<const double *>(f->pin_acc);
+    const int32_t *n = static_cast<const int32_t *>(f->pin_n);
+    int64_t j = cnt - 1;
+    const int64_t lo = std::max<int64_t>(0, cnt - (1 << 16));
+    while (j >= lo && acc[j] != st.acc) --j;
+    if (j < lo) return MRHIP_OK;
+    const int64_t Q = cnt - j;
+    f->per_acc.assign(acc + j, acc + cnt);
+    f->per_xoff.assign(static_cast<size_t>(Q) + 1, 0);
+    for (int64_t i = 0; i < Q; ++i) {
+        const int64_t nxt = i + 1 < Q ? n[j + i + 1] : st.xIdx;
+        f->per_xoff[static_cast<size_t>(i) + 1] = f->per_xoff[static_cast<size_t>(i)] + (nxt - n[j + i]);
+    }
+    f->per_XQ = f->per_xoff[static_cast<size_t>(Q)];
+    if (f->per_XQ < 1) return MRHIP_OK;                 // (cannot happen: a cycle of the phase wraps at least once)
+    f->per_Q = Q;
+    f->per_pos = 0;
+    for (int z = 0; z < kSchedSpanSizes; ++z) {          // largest advance over (256 << z) - 1 steps, from any cycle position
+        const int64_t m = (256LL << z) - 1, full = m / Q, rem = m - full * Q;
+        int64_t best = 0;
+        for (int64_t i = 0; i < Q; ++i) {
+            const int64_t e = i + rem;
+            const int64_t adv = e <= Q ? f->per_xoff[static_cast<size_t>(e)] - f->per_xoff[static_cast<size_t>(i)]
+                                       : f->per_XQ - f->per_xoff[static_cast<size_t>(i)] + f->per_xoff[static_cast<size_t>(e - Q)];
+            best = std::max(best, adv);
+        }
+        f->per_span[z] = static_cast<int>(std::min<int64_t>(full * f->per_XQ + best, 0x7fffffff));
+    }
+    MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
+    if (f->d_per_acc) (void)hipFree(f->d_per_acc);
+    if (f->d_per_xoff) (void)hipFree(f->d_per_xoff);
+    f->d_per_acc = nullptr; f->d_per_xoff = nullptr;
+    MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_per_acc), static_cast<size_t>(Q) * sizeof(double)));
+    MRHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_per_xoff), static_cast<size_t>(Q + 1) * sizeof(long long)));
+    static_assert(sizeof(long long) == sizeof(int64_t), "per_xoff is uploaded as long long");
+    MRHIP_CHECK_HIP(hipMemcpy(f->d_per_acc, f->per_acc.data(), static_cast<size_t>(Q) * sizeof(double), hipMemcpyHostToDevice));
+    MRHIP_CHECK_HIP(hipMemcpy(f->d_per_xoff, f->per_xoff.data(), static_cast<size_t>(Q + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    f->per_valid = true;
+    return MRHIP_OK;
+}
+
+}  // namespace
+
+void sched_configure(mrhip_filter *f)
+{
+    f->splan = make_sched_plan(f->delta, f->Nphi);
+    f->sched_prefix = std::max<int64_t>(env_i64("MRHIP_SCHED_PREFIX", 65536), 0) / kSchedGroup * kSchedGroup;
+    f->sched_pmax = std::max<int64_t>(env_i64("MRHIP_SCHED_PMAX", 1 << 20) / kSchedGroup * kSchedGroup, kSchedGroup);
+    f->sched_device_min = env_i64("MRHIP_SCHED_DEVICE_MIN", 1 << 18);
+    f->sched_corrupt_piece = static_cast<int>(env_i64("MRHIP_SCHED_CORRUPT", -1));
+    if (env_i64("MRHIP_SCHED_DEVICE", 1) == 0) f->splan.ok = 0;
+    f->sched_use_cycle = env_i64("MRHIP_SCHED_CYCLE", 1) != 0;
+}
+
+// the stream position was set from outside (reset, set_state): the drift estimate and a detected cycle no longer apply
+void sched_forget(mrhip_filter *f)
+{
+    f->sched_drift = 0.0;
+    f->sched_ksteps = 0.0;
+    f->per_valid = false;
+}
+
+void sched_free(mrhip_filter *f)
+{
+    for (int b = 0; b < 2; ++b) {
+        if (f->ds_n[b]) (void)hipFree(f->ds_n[b]);
+        if (f->ds_acc[b]) (void)hipFree(f->ds_acc[b]);
+        if (f->ds_read[b]) (void)hipEventDestroy(f->ds_read[b]);
+    }
+    for (void *p : {static_cast<void *>(f->ds_pathT), static_cast<void *>(f->ds_pathW), static_cast<void *>(f->ds_gtab), static_cast<void *>(f->ds_gstart),
+                    static_cast<void *>(f->ds_state), static_cast<void *>(f->ds_status), static_cast<void *>(f->d_per_acc), static_cast<void *>(f->d_per_xoff)})
+        if (p) (void)hipFree(p);
+    if (f->ds_pin_state) (void)hipHostFree(f->ds_pin_state);
+    if (f->ds_pin_status) (void)hipHostFree(f->ds_pin_status);
+    if (f->ds_done) (void)hipEventDestroy(f->ds_done);
+}
+
+bool sched_wants_device(const mrhip_filter *f, int64_t est)
+{
+    return f->splan.ok && est >= f->sched_device_min && est < 0x7fffffffLL;
+}
+
+// Evaluate the schedule of one call (x_len samples from the filter's current state; est = an upper bound of its output
+// count) into schedule buffer out->buf.  The state of the filter is NOT advanced (the caller commits out->end).
+int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, SchedResult *out)
+{
+    const SchedPlan &c = f->splan;
+    hipStream_t s = f->own_stream;
+    const int b = f->ds_cur ^ 1;
+    static const bool prof = env_i64("MRHIP_DEBUG", 0) == 2;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = prof ? now() : 0.0;
+    double t_prefix = 0.0, t_enq = 0.0, t_wait = 0.0;
+    for (int i = 0; i < 2; ++i)
+        if (!f->ds_read[i]) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ds_read[i], hipEventDisableTiming));
+    if (!f->ds_done) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ds_done, hipEventDisableTiming));
+    if (int rc = ensure_ds(f, b, static_cast<size_t>(est + f->sched_pmax + f->sched_prefix + 2 * kSchedGroup))) return rc;
+    if (int rc = ensure_pinned(f, static_cast<size_t>(std::max<int64_t>(f->sched_prefix, f->sched_pmax) + kSchedGroup))) return rc;
+    if (f->ds_read_valid[b]) MRHIP_CHECK_HIP(hipStreamWaitEvent(s, f->ds_read[b], 0));   // the kernel that read this buffer two calls ago
+
+    ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->inputDeficit, f->inputDeficit};   // xIdx starts at inputDeficit (Filters.jl:715)
+    double drift = f->sched_drift, ksteps = f->sched_ksteps;
+    int64_t k = 0;
+    bool done = false;
+    for (int z = 0; z < kSchedSpanSizes; ++z) out->max_span[z] = 0;
+    out->buf = b;
+    auto finish_host_state = [&]() {
+        st.phiIdx = static_cast<int64_t>(std::floor(st.acc));
+        st.alpha = st.acc - static_cast<double>(st.phiIdx);
+        st.inputDeficit = st.xIdx - x_len;
+    };
+
+    // a cycle found earlier still applies only if the stream is exactly where the cycle says it is
+    if (f->per_valid && !(f->per_acc[static_cast<size_t>(f->per_pos)] == st.acc)) f->per_valid = false;
+
+    // ---- serial prefix on the host: short baseline for the drift estimate, cycle detection -----------------
+    if (!f->per_valid && ksteps < static_cast<double>(f->sched_prefix)) {
+        if (int rc = wait_pinned_free(f)) return rc;
+        const double tp0 = prof ? now() : 0.0;
+        const int64_t want = (f->sched_prefix - static_cast<int64_t>(ksteps) + kSchedGroup - 1) / kSchedGroup * kSchedGroup;
+        const double acc_start = st.acc;
+        const int64_t cnt = run_arbitrary_schedule_piece(st, f->delta, f->Nphi, x_len, static_cast<int32_t *>(f->pin_n), static_cast<double *>(f->pin_acc), want, &done);
+        host_spans(static_cast<const int32_t *>(f->pin_n), cnt, 0, out->max_span);
+        if (!done && f->sched_use_cycle)
+            if (int rc = try_find_cycle(f, cnt, st)) return rc;
+        if (int rc = upload_entries(f, b, 0, cnt)) return rc;
+        if (!done) {
+            drift += wrap_half(st.acc - sched_anchor_host(c, acc_start, static_cast<double>(cnt)), c.N);
+            ksteps += static_cast<double>(cnt);
+        }
+        k = cnt;
+        f->stat_host_steps += cnt;
+        if (prof) t_prefix = now() - tp0;
+    }
+
+    // ---- PERIODIC: closed form ------------------------------------------------------------------------------
+    if (!done && f->per_valid) {
+        const int64_t x0 = st.xIdx;
+        // first j with x_j > x_len (x_j never decreases): the number of further outputs
+        int64_t lo = 0, hi = std::max<int64_t>(est - k, 0) + 2;
+        while (per_x(f, x0, hi) <= x_len) hi *= 2;
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (per_x(f, x0, mid) > x_len) hi = mid; else lo = mid + 1;
+        }
+        const int64_t m = lo;
+        if (k + m > static_cast<int64_t>(f->ds_cap[b])) return fail(MRHIP_ERR_INVALID_ARG, "schedule buffer too small for the periodic schedule (internal)");
+        if (m > 0) {
+            const long long blocks = std::min<long long>((m + kPerThreads - 1) / kPerThreads, 4096);
+            hipLaunchKernelGGL(sched_periodic_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kPerThreads), 0, s, f->d_per_acc, f->d_per_xoff,
+                               static_cast<long long>(f->per_Q), static_cast<long long>(f->per_XQ), static_cast<long long>(f->per_pos),
+                               static_cast<long long>(x0 - f->per_xoff[static_cast<size_t>(f->per_pos)]), static_cast<long long>(m),
+                               static_cast<int *>(f->ds_n[b]) + k, static_cast<double *>(f->ds_acc[b]) + k);
+            MRHIP_CHECK_HIP(hipGetLastError());
+        }
+        for (int z = 0; z < kSchedSpanSizes; ++z) out->max_span[z] = std::max(out->max_span[z], f->per_span[z]);
+        st.xIdx = per_x(f, x0, m);
+        out->per_pos_end = (f->per_pos + m) % f->per_Q;
+        st.acc = f->per_acc[static_cast<size_t>(out->per_pos_end)];
+        k += m;
+        done = true;
+        f->stat_periodic_steps += m;
+        out->periodic = true;
+    }
+
+    // ---- TABLES ---------------------------------------------------------------------------------------------
+    std::vector<int64_t> pk0, psteps;
+    while (!done) {
+        pk0.clear(); psteps.clear();
+        const double te0 = prof ? now() : 0.0;
+        int64_t kk = k;
+        double ks = ksteps;
+        while (kk <= est) {
+            int64_t P = kSchedGroup;
+            while (P * 2 <= f->sched_pmax && static_cast<double>(P * 2) <= ks) P *= 2;
+            pk0.push_back(kk); psteps.push_back(P);
+            kk += P; ks += static_cast<double>(P);
+        }
+        const int64_t np = static_cast<int64_t>(pk0.size());
+        if (int rc = ensure_work(f, f->sched_pmax / kSchedGroup, np)) return rc;
+        if (kk > static_cast<int64_t>(f->ds_cap[b])) return fail(MRHIP_ERR_INVALID_ARG, "schedule buffer too small (internal)");
+        SchedStatus *hs = f->ds_pin_status;
+        hs[0] = SchedStatus{};
+        hs[0].fail_piece = kSchedNoFail;
+        f->ds_pin_state[0] = SchedPieceState{st.acc, st.xIdx, drift, ksteps};
+        MRHIP_CHECK_HIP(hipMemcpyAsync(f->ds_status, &hs[0], sizeof(SchedStatus), hipMemcpyHostToDevice, s));
+        MRHIP_CHECK_HIP(hipMemcpyAsync(f->ds_state, f->ds_pin_state, sizeof(SchedPieceState), hipMemcpyHostToDevice, s));
+        for (int64_t p = 0; p < np; ++p) {
+            SchedPieceArgs a{};
+            a.state = f->ds_state; a.status = f->ds_status;
+            a.pathT = f->ds_pathT; a.pathW = f->ds_pathW; a.gtab = f->ds_gtab; a.gstart = f->ds_gstart;
+            a.sched_n = static_cast<int *>(f->ds_n[b]); a.sched_acc = static_cast<double *>(f->ds_acc[b]);
+            a.k0 = pk0[static_cast<size_t>(p)]; a.x_len = x_len;
+            a.piece = static_cast<int>(p); a.ngroups = static_cast<int>(psteps[static_cast<size_t>(p)] / kSchedGroup);
+            a.corrupt_group = f->sched_corrupt_piece == f->stat_device_pieces + p ? 0 : -1;
+            MRHIP_CHECK_HIP(launch_schedule_piece(c, a, s));
+        }
+        MRHIP_CHECK_HIP(hipMemcpyAsync(&hs[1], f->ds_status, sizeof(SchedStatus), hipMemcpyDeviceToHost, s));
+        MRHIP_CHECK_HIP(hipMemcpyAsync(f->ds_pin_state, f->ds_state, static_cast<size_t>(np + 1) * sizeof(SchedPieceState), hipMemcpyDeviceToHost, s));
+        const double te1 = prof ? now() : 0.0;
+        MRHIP_CHECK_HIP(hipStreamSynchronize(s));
+        if (prof) { t_enq += te1 - te0; t_wait += now() - te1; }
+        const SchedStatus &r = hs[1];
+        const SchedPieceState *ps = f->ds_pin_state;
+        if (r.fail_piece != kSchedNoFail) {
+            // piece p did not verify: pieces before it did, so ps[p] is the true state there; redo p with the serial loop
+            const int64_t p = r.fail_piece;
+            f->stat_device_pieces += p + 1;
+            f->stat_fallback_pieces += 1;
+            if (int rc = wait_pinned_free(f)) return rc;
+            ArbState hst{ps[p].acc, 0, 0.0, ps[p].xIdx, 0};
+            const double acc_start = hst.acc;
+            const int64_t cnt = run_arbitrary_schedule_piece(hst, f->delta, f->Nphi, x_len, static_cast<int32_t *>(f->pin_n), static_cast<double *>(f->pin_acc),
+                                                             psteps[static_cast<size_t>(p)], &done);
+            host_spans(static_cast<const int32_t *>(f->pin_n), cnt, pk0[static_cast<size_t>(p)], out->max_span);
+            if (int rc = upload_entries(f, b, pk0[static_cast<size_t>(p)], cnt)) return rc;
+            drift = ps[p].drift; ksteps = ps[p].ksteps;
+            if (!done) {
+                drift += wrap_half(hst.acc - sched_anchor_host(c, acc_start, static_cast<double>(cnt)), c.N);
+                ksteps += static_cast<double>(cnt);
+            }
+            st.acc = hst.acc; st.xIdx = hst.xIdx;
+            k = pk0[static_cast<size_t>(p)] + cnt;
+            f->stat_host_steps += cnt;
+            // (spans of the device pieces before p: every piece reports into the same status word)
+            for (int z = 0; z < kSchedSpanSizes; ++z) out->max_span[z] = std::max(out->max_span[z], r.max_span[z]);
+            continue;
+        }
+        for (int z = 0; z < kSchedSpanSizes; ++z) out->max_span[z] = std::max(out->max_span[z], r.max_span[z]);
+        if (!r.done)                                      // est is an upper bound of the count (Filters.jl:375-381 + 2)
+            return fail(MRHIP_ERR_INVALID_ARG, "phase schedule longer than the output-length bound (internal)");
+        // the drift baseline: the last piece that lies wholly before the call's end
+        int64_t pl = 0;
+        while (pl < np && pk0[static_cast<size_t>(pl)] + psteps[static_cast<size_t>(pl)] <= r.end_k) ++pl;
+        f->stat_device_pieces += std::min<int64_t>(pl + 1, np);
+        drift = ps[pl].drift; ksteps = ps[pl].ksteps;
+        st.acc = r.end_acc; st.xIdx = r.end_xIdx;
+        k = r.end_k;
+        done = true;
+    }
+    finish_host_state();
+    out->count = k;
+    out->end = st;
+    out->drift = drift;
+    out->ksteps = ksteps;
+    // whoever reads the schedule on another stream waits for this event
+    MRHIP_CHECK_HIP(hipEventRecord(f->ds_done, s));
+    if (prof)
+        std::fprintf(stderr, "[mrhip] device schedule: %lld outputs in %.3f ms (host prefix %.3f, enqueue %.3f, wait %.3f)%s\n", static_cast<long long>(k),
+                     (now() - t_begin) * 1e3, t_prefix * 1e3, t_enq * 1e3, t_wait * 1e3, out->periodic ? " periodic" : "");
+    return MRHIP_OK;
+}
+
+}  // namespace mrhip

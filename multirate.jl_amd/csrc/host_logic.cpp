@@ -230,6 +230,20 @@ int64_t run_arbitrary_schedule_piece(ArbState &st, double delta, int64_t Nphi, i
     return count;
 }
 
+// Un-rounded phase after k steps of the recurrence from acc_p (double-double product, folded onto [1, N+1)): what the
+// device schedule (kernels_schedule.hip: sched_anchor) predicts segment starts with.  The host uses it to measure how far
+// the true accumulator drifted from it over a run it evaluated itself.
+double sched_anchor_host(const SchedPlan &c, double acc_p, double k)
+{
+    const double hi = k * c.delta;
+    const double lo = std::fma(k, c.delta, -hi);
+    const double w = std::floor(((acc_p - 1.0) + hi) / c.N);
+    double r = ((acc_p - 1.0) + (hi - w * c.N)) + lo;
+    if (r < 0.0) r += c.N;
+    else if (r >= c.N) r -= c.N;
+    return r + 1.0;
+}
+
 // polyfit(y, polyorder), src/support.jl:85-88: A = [x^p for x in 1:n, p = 0:polyorder]; coefficients = A \ y,
 // i.e. the least-squares solution Julia computes by a QR factorisation of A in Float64.  Restated as a
 // Householder QR (the reference pins no bits here: SURVEY.md 8c -- LAPACK's blocked QR and this one agree

@@ -63,8 +63,11 @@ __global__ __launch_bounds__(kArbThreads) void arb_tiled_kernel(ArbArgs a, ArbTi
     }
 
     for (long long tile = blockIdx.x; tile < ta.total_tiles; tile += gridDim.x) {
-        const int cg = static_cast<int>(tile / ta.tiles_per_channel);                  // channel group
-        const long long tau = tile - static_cast<long long>(cg) * ta.tiles_per_channel;
+        // time-major: the workgroups that run together work on the same stretch of the (shared) phase schedule for
+        // different channel groups, so its entries are read from HBM once
+        const long long ngroups = ta.total_tiles / ta.tiles_per_channel;
+        const long long tau = tile / ngroups;
+        const int cg = static_cast<int>(tile - tau * ngroups);                          // channel group
         const int ch0 = cg * CPL;
         const int nchl = a.nch - ch0 < CPL ? a.nch - ch0 : CPL;                         // channels of this group
         const long long k0 = tau * ta.tile_out;
@@ -146,13 +149,8 @@ template <typename TX, typename R, int NC>
 hipError_t launch_arb(bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s, int num_cus)
 {
     auto go = [&](auto kfn) -> hipError_t {
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               static_cast<int>(lds));
-            if (e != hipSuccess) return e;
-        }
         int per_cu = 0;
-        hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kArbThreads, lds);
+        hipError_t eo = occupancy_cached(reinterpret_cast<const void *>(kfn), kArbThreads, lds, &per_cu);
         if (eo != hipSuccess) return eo;
         if (per_cu < 1) per_cu = 1;
         long long g = static_cast<long long>(num_cus) * per_cu;
@@ -297,13 +295,8 @@ template <typename TX, typename R, int NC>
 hipError_t launch_farrow_t(bool fused, const FarrowArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s, int num_cus)
 {
     auto go = [&](auto kfn) -> hipError_t {
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               static_cast<int>(lds));
-            if (e != hipSuccess) return e;
-        }
         int per_cu = 0;
-        hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kArbThreads, lds);
+        hipError_t eo = occupancy_cached(reinterpret_cast<const void *>(kfn), kArbThreads, lds, &per_cu);
         if (eo != hipSuccess) return eo;
         if (per_cu < 1) per_cu = 1;
         long long g = static_cast<long long>(num_cus) * per_cu;
@@ -322,9 +315,11 @@ hipError_t launch_farrow_t(bool fused, const FarrowArgs &a, const ArbTileArgs &t
 
 }  // namespace
 
-// `n_idx_host` is the host copy of the per-output input indices (non-decreasing).  Returns false when
-// the tap banks plus a useful sample tile do not fit LDS (caller uses the generic kernel).
-bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_host, int num_cus, ArbTileArgs *out, size_t *lds)
+// `n_idx_host` is the host copy of the per-output input indices (non-decreasing); when the schedule was evaluated on
+// the device it is NULL and `spans[z]` holds the largest n[last] - n[first] over the aligned tiles of 256 << z outputs
+// (kernels_schedule.hip).  Returns false when the tap banks plus a useful sample tile do not fit LDS (caller uses the
+// generic kernel).
+bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_host, const int *spans, int num_cus, ArbTileArgs *out, size_t *lds)
 {
     static const int enabled = [] { const char *v = std::getenv("MRHIP_ARB_TILED"); return !(v && v[0] == '0'); }();
     if (!enabled || a.n_out < 1) return false;
@@ -344,14 +339,22 @@ bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_ho
     // (measured, 256 ch x 2e6, rate pi/3, `scripts/exp_arb_knobs.py`: Float64 arithmetic -- config 4 -- with several channels per
     //  lane: 256-output tiles 20.4 % of HBM, 1024-output tiles 18.2 %; Float32 arithmetic: 12.9 % against 19.6 %)
     long long tile_out = env_tile >= 256 ? env_tile / 256 * 256 : (cpl >= 4 && tk.r_f64 ? 256 : 1024);
+    if (!n_idx_host) {                       // device schedule: spans are known for 256, 512, 1024 only
+        if (!spans) return false;
+        tile_out = tile_out >= 1024 ? 1024 : (tile_out >= 512 ? 512 : 256);
+    }
     const long long want_tiles = 4LL * num_cus;
     static const int arb_cap_kib = [] { const char *v = std::getenv("MRHIP_ARB_CAP_KIB"); return v && *v ? std::atoi(v) : 36; }();
     while (tile_out > 256 && ((a.n_out + tile_out - 1) / tile_out) * groups < want_tiles) tile_out /= 2;
     for (;;) {
         long long max_span = 0;
-        for (long long k0 = 0; k0 < a.n_out; k0 += tile_out) {
-            const long long kl = std::min<long long>(k0 + tile_out, a.n_out) - 1;
-            max_span = std::max<long long>(max_span, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0] + a.T);
+        if (n_idx_host) {
+            for (long long k0 = 0; k0 < a.n_out; k0 += tile_out) {
+                const long long kl = std::min<long long>(k0 + tile_out, a.n_out) - 1;
+                max_span = std::max<long long>(max_span, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0] + a.T);
+            }
+        } else {
+            max_span = static_cast<long long>(spans[tile_out == 1024 ? 2 : (tile_out == 512 ? 1 : 0)]) + a.T;
         }
         const size_t total = banks_bytes + static_cast<size_t>(max_span) * sb * cpl;
         // Float32 arithmetic: large tiles as long as five workgroups still fit a CU (a decimating rate stretches the span)
@@ -385,7 +388,7 @@ hipError_t launch_arb_tiled(const TypeKey &tk, bool fused, const ArbArgs &a, con
 }
 
 // FIRFarrow: tap columns of 256 outputs (T*256 elements of R) plus the sample runs of CPL channels must fit LDS.
-bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_idx_host, int num_cus, ArbTileArgs *out, size_t *lds)
+bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_idx_host, const int *spans, int num_cus, ArbTileArgs *out, size_t *lds)
 {
     static const int enabled = [] { const char *v = std::getenv("MRHIP_FARROW_TILED"); return !(v && v[0] == '0'); }();
     (void)num_cus;
@@ -399,9 +402,14 @@ bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_
     const int cpl = a.nch >= 4 ? 4 : 1;
     const long long tile_out = kArbThreads;
     long long max_span = 0;
-    for (long long k0 = 0; k0 < a.n_out; k0 += tile_out) {
-        const long long kl = std::min<long long>(k0 + tile_out, a.n_out) - 1;
-        max_span = std::max<long long>(max_span, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0] + a.T);
+    if (n_idx_host) {
+        for (long long k0 = 0; k0 < a.n_out; k0 += tile_out) {
+            const long long kl = std::min<long long>(k0 + tile_out, a.n_out) - 1;
+            max_span = std::max<long long>(max_span, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0] + a.T);
+        }
+    } else {
+        if (!spans) return false;
+        max_span = static_cast<long long>(spans[0]) + a.T;     // tile_out == 256
     }
     const size_t total = taps_bytes + static_cast<size_t>(max_span) * sb * cpl;
     if (total > 150 * 1024) return false;

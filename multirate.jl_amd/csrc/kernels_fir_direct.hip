@@ -168,13 +168,8 @@ template <typename TX, typename R, int NC>
 hipError_t launch_direct(bool fused, const PolyArgs &a, DirectArgs da, size_t lds, hipStream_t s, int num_cus)
 {
     auto go = [&](auto kfn) -> hipError_t {
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               static_cast<int>(lds));
-            if (e != hipSuccess) return e;
-        }
         int per_cu = 0;
-        hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kDirectThreads, lds);
+        hipError_t eo = occupancy_cached(reinterpret_cast<const void *>(kfn), kDirectThreads, lds, &per_cu);
         if (eo != hipSuccess) return eo;
         if (per_cu < 1) per_cu = 1;
         long long g = static_cast<long long>(num_cus) * per_cu;

@@ -341,14 +341,9 @@ hipError_t launch_T(int T, dim3 grid, dim3 block, size_t lds, hipStream_t s, con
 #define MRHIP_CASE(TT)                                                                              \
     case TT: {                                                                                      \
         auto kfn = poly_phase_stationary_kernel<TT, TX, R, NC, FUSED>;                              \
-        if (lds > 48 * 1024) {                                                                      \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
-            if (e != hipSuccess) return e;                                                          \
-        }                                                                                           \
         /* persistent grid = what is actually co-resident (registers, LDS and waves all count) */   \
         int per_cu = 0;                                                                             \
-        hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, static_cast<int>(block.x), lds); \
+        hipError_t eo = occupancy_cached(reinterpret_cast<const void *>(kfn), block.x, lds, &per_cu); \
         if (eo != hipSuccess) return eo;                                                            \
         if (per_cu < 1) per_cu = 1;                                                                 \
         if (blocks_per_cu_override > 0) per_cu = blocks_per_cu_override;                            \

@@ -61,11 +61,7 @@ hipError_t launch_opair_cmix_s1(bool x_f64, bool fused, int T, dim3 block, size_
 
 namespace {
 constexpr int kOMaxThreads = 512;
-inline int opair_env_int(const char *name, int dflt)
-{
-    const char *v = std::getenv(name);
-    return v && *v ? std::atoi(v) : dflt;
-}
+#define opair_env_int(name, dflt) MRHIP_ENV_INT(name, dflt)   // cached per call site (mrhip_internal.h)
 }  // namespace
 
 // Covers FIRRational and FIRInterpolator with tapsPerPhi <= 48 (Float32 samples with M < 2L: 64; Float64 arithmetic: 32) and M/L < 6 (L >= 2, SMIN = floor(M/L);

@@ -1,0 +1,354 @@
+// kernels_schedule.hip -- the FIRArbitrary / FIRFarrow phase schedule evaluated ON THE DEVICE, exactly.
+//
+// Reference: update(kernel::FIRArbitrary), src/Filters.jl:663-673, and update(kernel::FIRFarrow), :780-792 -- a serial
+// Float64 recurrence   a1 = fl(acc + delta);  if a1 > N: xIdx += floor(fl((a1-1)/N)); acc = mod(a1-1, N) + 1
+// whose roundings the outputs depend on (phiIdx = floor(acc), alpha = acc - phiIdx, Filters.jl:671-672).  The host
+// loop that evaluates it (host_logic.cpp, 1.3 ns per output) bounded BASELINE config 4's wall time in rounds 1-2.
+//
+// The algorithm is modelled, with the argument for its exactness, in scripts/sched_model.py (and run on the CPU
+// against the plain recurrence by tests/test_sched_model.py); in short:
+//   K1  sched_tables_kernel   a piece of the schedule is cut into segments of 64 steps; every segment is run in real
+//                             Float64 arithmetic from each of the NWIN grid values around a predicted start (anchor);
+//                             the end of candidate c is (candidate c', shift) of the next segment, so a segment is a
+//                             map on a finite set; the workgroup composes the maps of its 64 segments (a "group").
+//   K2  sched_chain_kernel    one wave walks the groups' maps from the piece's TRUE start state.
+//   K3  sched_emit_kernel     every segment is re-run from the start the chain gave it, writes the schedule entries
+//                             (1-based input index, accumulator), and must end exactly where the next segment starts.
+// A piece whose every segment verifies IS the serial recurrence (induction from the true start).  Any doubt -- a start
+// off the value grid, a table entry that could not be located, a failed end check -- raises `fail_piece`; the kernels
+// of later pieces then do nothing and the host redoes that piece with its serial loop.  Nothing unverified is used.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "mrhip_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace mrhip {
+namespace {
+
+constexpr int kSeg = kSchedSeg;          // steps per segment
+constexpr int kGroupSegs = 64;           // segments per group (= per workgroup of K1 / K3)
+constexpr int kTabThreads = 256;
+
+// One update() of the reference, in a form whose every operation is exact except the one the reference rounds too
+// (the sum): mod(a1-1, N) == (a1-1) - k*N with k = floor(fl((a1-1)/N)), minus one more N when the rounded quotient
+// overshot an integer (possible for N that is not a power of two; the reference's xIdx step keeps that overshoot,
+// Filters.jl:667, and so does `x` here).  k*N <= a1 < 2^53 is an integer: exact; the difference is a multiple of
+// ulp(a1) no larger than a1: exact.
+__device__ __forceinline__ void sched_step(double &acc, long long &x, const SchedPlan &c)
+{
+    const double a1 = acc + c.delta;                                  // :664
+    if (a1 > c.N) {                                                   // :666
+        const double am1 = a1 - 1.0;
+        const double q = c.pow2 ? am1 * c.invN : am1 / c.N;           // :667 (exact scaling for a power of two)
+        const double k = __builtin_floor(q);
+        double r = am1 - k * c.N;
+        if (r < 0.0) r += c.N;
+        acc = r + 1.0;                                                // :668
+        x += static_cast<long long>(k);
+    } else {
+        acc = a1;
+    }
+}
+
+// Predicted phase after k steps from the piece's start: the un-rounded recurrence (double-double product) plus the
+// drift per step measured so far.  Accuracy only decides how often a start falls outside the candidate window.
+__device__ __forceinline__ double sched_anchor(double acc_p, double k, double slope, const SchedPlan &c)
+{
+    const double hi = k * c.delta;
+    const double lo = __builtin_fma(k, c.delta, -hi);
+    const double w = __builtin_floor(((acc_p - 1.0) + hi) / c.N);
+    double r = ((acc_p - 1.0) + (hi - w * c.N)) + (lo + slope * k);
+    if (r < 0.0) r += c.N;
+    else if (r >= c.N) r -= c.N;
+    return r + 1.0;
+}
+
+__device__ __forceinline__ double sched_base(double anchor, const SchedPlan &c)
+{
+    return __builtin_floor((anchor - c.halfwin) * c.inv_umin) * c.umin;   // window start, on the value grid
+}
+
+// candidate ci of the window: base + ci*umin folded onto a legal state in [1, N+1).  Fold FIRST, then add the offset:
+// base - N is exact and keeps the fine grid next to 1.0.
+__device__ __forceinline__ double sched_cand(double base, int ci, const SchedPlan &c)
+{
+    const double off = static_cast<double>(ci) * c.umin;
+    const double v = base + off;
+    if (v >= c.N + 1.0) return (base - c.N) + off;
+    if (v < 1.0) return (base + c.N) + off;
+    return v;
+}
+
+// T == candidate(ci) + shift, shift a multiple of G; false when T is off the grid or the identity does not hold in
+// Float64 (the shift would cross a binade or the wrap: outside the equivariance argument).
+__device__ __forceinline__ bool sched_locate(double T, double base, const SchedPlan &c, int *ci, double *shift)
+{
+    double d = T - base;
+    if (d > 0.5 * c.N) d = (T - c.N) - base;            // the same point of the phase circle, every step exact
+    else if (d < -0.5 * c.N) d = T - (base - c.N);
+    const double cu = d * c.inv_umin;
+    if (cu != __builtin_floor(cu)) return false;
+    if (cu >= 0.0 && cu < static_cast<double>(c.nwin)) {
+        *ci = static_cast<int>(cu);
+        *shift = 0.0;
+    } else {
+        const double m = __builtin_floor(d * c.inv_G);
+        *ci = static_cast<int>(cu - m * static_cast<double>(c.ncand));
+        *shift = m * c.G;
+    }
+    return sched_cand(base, *ci, c) + *shift == T;
+}
+
+__device__ __forceinline__ bool sched_stop(const SchedStatus *st)
+{
+    return __hip_atomic_load(&st->fail_piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kSchedNoFail ||
+           __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
+// ---- K1: candidate tables of one group (64 segments) per workgroup, composed --------------------------------
+__global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, SchedPieceArgs a)
+{
+    if (sched_stop(a.status)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nwin = c.nwin;
+    double *const eC = reinterpret_cast<double *>(smem);                 // [64][nwin] candidate start value
+    double *const eSh = eC + kGroupSegs * nwin;                          // shift into the next segment's window
+    int *const eW = reinterpret_cast<int *>(eSh + kGroupSegs * nwin);    // xIdx advance over the segment
+    int *const eCn = eW + kGroupSegs * nwin;                             // candidate of the next segment (-1: none)
+
+    const SchedPieceState ps = a.state[a.piece];
+    const double slope = ps.ksteps > 0.0 ? ps.drift / ps.ksteps : 0.0;
+    const int g = blockIdx.x;
+    const long long seg0 = static_cast<long long>(g) * kGroupSegs;
+    const int tasks = kGroupSegs * nwin;
+    for (int t = threadIdx.x; t < tasks; t += kTabThreads) {
+        const int sl = t / nwin, ci = t - sl * nwin;
+        const double k0 = static_cast<double>((seg0 + sl) * kSeg);
+        const double base = sched_base(sched_anchor(ps.acc, k0, slope, c), c);
+        const double base_next = sched_base(sched_anchor(ps.acc, k0 + kSeg, slope, c), c);
+        const double start = sched_cand(base, ci, c);
+        double acc = start;
+        long long x = 0;
+#pragma unroll 4
+        for (int i = 0; i < kSeg; ++i) sched_step(acc, x, c);
+        if (a.corrupt_group == g && sl == 7) acc += c.G;                 // test hook (MRHIP_SCHED_CORRUPT): a wrong table must be caught
+        int cn = -1;
+        double sh = 0.0;
+        if (!sched_locate(acc, base_next, c, &cn, &sh)) cn = -1;
+        eC[t] = start;
+        eSh[t] = sh;
+        eW[t] = static_cast<int>(x);
+        eCn[t] = cn;
+    }
+    __syncthreads();
+    // compose: candidate c0 of the group's first segment walked through the 64 maps; the path is kept for K3
+    for (int c0 = threadIdx.x; c0 < nwin; c0 += kTabThreads) {
+        int ci = c0;
+        double S = 0.0;
+        long long W = 0;
+        bool ok = true;
+        for (int sl = 0; sl < kGroupSegs; ++sl) {
+            const size_t pi = static_cast<size_t>(seg0 + sl) * nwin + c0;
+            a.pathT[pi] = ok ? eC[sl * nwin + ci] + S : __builtin_nan("");
+            a.pathW[pi] = static_cast<int>(W);
+            if (ok) {
+                const int e = sl * nwin + ci;
+                S += eSh[e];
+                W += eW[e];
+                ci = eCn[e];
+                ok = ci >= 0;
+            }
+        }
+        SchedGroupEntry ge;
+        ge.shift = S;
+        ge.advance = static_cast<int>(W);
+        ge.next = ok ? ci : -1;
+        a.gtab[static_cast<size_t>(g) * nwin + c0] = ge;
+    }
+}
+
+// ---- K2: one wave walks the group maps from the piece's true start -------------------------------------------
+__global__ __launch_bounds__(64) void sched_chain_kernel(SchedPlan c, SchedPieceArgs a)
+{
+    if (sched_stop(a.status)) return;
+    const int lane = threadIdx.x;
+    const SchedPieceState ps = a.state[a.piece];
+    const double slope = ps.ksteps > 0.0 ? ps.drift / ps.ksteps : 0.0;
+    int ci = 0;
+    double S = 0.0;
+    bool ok = sched_locate(ps.acc, sched_base(sched_anchor(ps.acc, 0.0, slope, c), c), c, &ci, &S);
+    long long W = 0;
+    const int nwin = c.nwin;
+    for (int g = 0; g < a.ngroups; ++g) {
+        // the whole map of group g in one coalesced load (lane = candidate); the walk itself is a cross-lane read
+        SchedGroupEntry ge{};
+        ge.next = -1;
+        if (lane < nwin) ge = a.gtab[static_cast<size_t>(g) * nwin + lane];
+        if (lane == 0) {
+            SchedGroupStart gs;
+            gs.cand = ok ? ci : -1;
+            gs.shift = S;
+            gs.advance = W;
+            a.gstart[g] = gs;
+        }
+        const int src = ok ? ci : 0;
+        const double gsh = __shfl(ge.shift, src);
+        const int gadv = __shfl(ge.advance, src);
+        const int gnext = __shfl(ge.next, src);
+        if (ok) {
+            S += gsh;
+            W += gadv;
+            ci = gnext;
+            ok = ci >= 0;
+        }
+    }
+    if (lane == 0 && !ok) atomicMin(&a.status->fail_piece, a.piece);
+}
+
+// ---- K3: run every segment from its true start, emit, verify -------------------------------------------------
+__global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, SchedPieceArgs a)
+{
+    if (sched_stop(a.status)) return;
+    __shared__ int s_n[kGroupSegs * (kSeg + 1)];
+    __shared__ double s_acc[kGroupSegs * (kSeg + 1)];
+    __shared__ double s_T[kGroupSegs + 1];
+    __shared__ long long s_X[kGroupSegs + 1];
+
+    const int g = blockIdx.x, sl = threadIdx.x, nwin = c.nwin;
+    const SchedPieceState ps = a.state[a.piece];
+    const SchedGroupStart gs = a.gstart[g];
+    const long long seg = static_cast<long long>(g) * kGroupSegs + sl;
+    bool bad = gs.cand < 0;
+    double T = ps.acc;
+    long long X = ps.xIdx;
+    if (!bad) {
+        const size_t pi = static_cast<size_t>(seg) * nwin + gs.cand;
+        T = a.pathT[pi] + gs.shift;
+        X = ps.xIdx + gs.advance + a.pathW[pi];
+        bad = !(T == T);                                  // NaN: the walk inside the group had no valid entry
+    }
+    s_T[sl] = T;
+    s_X[sl] = X;
+    double acc = T;
+    long long x = X;
+    long long end_k = -1;
+    double end_acc = 0.0;
+    long long end_x = 0;
+    const long long kbase = a.k0 + seg * kSeg;            // step number of this segment's first output within the call
+    long long prev_x = X;
+    for (int i = 0; i < kSeg; ++i) {
+        s_n[sl * (kSeg + 1) + i] = static_cast<int>(x);
+        s_acc[sl * (kSeg + 1) + i] = acc;
+        if (i > 0 && x > a.x_len && prev_x <= a.x_len) { end_k = kbase + i; end_acc = acc; end_x = x; }
+        prev_x = x;
+        sched_step(acc, x, c);
+    }
+    // the next segment's start: the next lane's, or the next group's first segment
+    if (sl == kGroupSegs - 1) {
+        if (g + 1 < a.ngroups) {
+            const SchedGroupStart gn = a.gstart[g + 1];
+            if (gn.cand < 0) bad = true;
+            else {
+                const size_t pn = static_cast<size_t>(seg + 1) * nwin + gn.cand;
+                s_T[kGroupSegs] = a.pathT[pn] + gn.shift;
+                s_X[kGroupSegs] = ps.xIdx + gn.advance + a.pathW[pn];
+            }
+        } else {                                          // last segment of the piece: its end IS the next piece's start
+            s_T[kGroupSegs] = acc;
+            s_X[kGroupSegs] = x;
+        }
+    }
+    __syncthreads();
+    if (!bad && !(acc == s_T[sl + 1] && x == s_X[sl + 1])) bad = true;
+    if (prev_x <= a.x_len && x > a.x_len) { end_k = kbase + kSeg; end_acc = acc; end_x = x; }   // the call ends between two segments
+    if (bad) atomicMin(&a.status->fail_piece, a.piece);
+    if (end_k >= 0) {                                     // unique: xIdx never decreases
+        a.status->end_k = end_k;
+        a.status->end_acc = end_acc;
+        a.status->end_xIdx = end_x;
+        __hip_atomic_store(&a.status->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (sl == kGroupSegs - 1 && g + 1 == a.ngroups) {     // state of the next piece (used only if this piece verified)
+        SchedPieceState ns;
+        ns.acc = acc;
+        ns.xIdx = x;
+        double d = acc - sched_anchor(ps.acc, static_cast<double>(static_cast<long long>(a.ngroups) * kGroupSegs * kSeg), 0.0, c);
+        if (d > 0.5 * c.N) d -= c.N;
+        else if (d < -0.5 * c.N) d += c.N;
+        ns.drift = ps.drift + d;
+        ns.ksteps = ps.ksteps + static_cast<double>(static_cast<long long>(a.ngroups) * kGroupSegs * kSeg);
+        a.state[a.piece + 1] = ns;
+    }
+    // largest input span of the aligned tiles of 256, 512, 1024 outputs inside this group (the filter kernel's planner
+    // sizes its LDS sample tile with them); entries past the call's end count as x_len
+    {
+        int t = sl;
+        for (int z = 0; z < kSchedSpanSizes; ++z) {
+            const int ts = 256 << z, ntile = kGroupSegs * kSeg / ts;
+            if (t < ntile) {
+                const int e0 = t * ts, e1 = e0 + ts - 1;
+                const long long n0 = s_n[(e0 / kSeg) * (kSeg + 1) + e0 % kSeg], n1 = s_n[(e1 / kSeg) * (kSeg + 1) + e1 % kSeg];
+                if (n0 <= a.x_len) atomicMax(&a.status->max_span[z], static_cast<int>((n1 < a.x_len ? n1 : a.x_len) - n0));
+                break;
+            }
+            t -= ntile;
+        }
+    }
+    // coalesced copy of the group's 4096 entries
+    int *__restrict__ gn = a.sched_n + a.k0 + static_cast<long long>(g) * kGroupSegs * kSeg;
+    double *__restrict__ ga = a.sched_acc + a.k0 + static_cast<long long>(g) * kGroupSegs * kSeg;
+    for (int e = sl; e < kGroupSegs * kSeg; e += kGroupSegs) {
+        const int r = e / kSeg, i = e - r * kSeg;
+        gn[e] = s_n[r * (kSeg + 1) + i];
+        ga[e] = s_acc[r * (kSeg + 1) + i];
+    }
+}
+
+}  // namespace
+
+size_t sched_tables_lds(const SchedPlan &c) { return static_cast<size_t>(kGroupSegs) * c.nwin * 24; }
+
+// Enqueue the three kernels of one piece (ngroups * 4096 steps from step a.k0 of the call) on `s`.
+hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hipStream_t s)
+{
+    const size_t lds = sched_tables_lds(c);
+    static size_t lds_attr = 0;                                       // (per process; the attribute only ever grows)
+    if (lds > 48 * 1024 && lds > lds_attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sched_tables_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL(sched_tables_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(kTabThreads), lds, s, c, a);
+    hipLaunchKernelGGL(sched_chain_kernel, dim3(1), dim3(64), 0, s, c, a);
+    hipLaunchKernelGGL(sched_emit_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(kGroupSegs), 0, s, c, a);
+    return hipGetLastError();
+}
+
+// Constants of the parallel evaluation for one (delta, Nphi); plan.ok == 0: the host loop evaluates the schedule.
+SchedPlan make_sched_plan(double delta, int64_t Nphi)
+{
+    SchedPlan c{};
+    c.delta = delta;
+    c.N = static_cast<double>(Nphi);
+    c.invN = 1.0 / c.N;
+    c.pow2 = (Nphi & (Nphi - 1)) == 0;
+    // (the xIdx advance of a 4096-step group is kept in 32 bits: delta / N < 2^18)
+    if (!(delta > 0.0) || !(delta < c.N * 0x1p18) || Nphi > (1 << 24)) return c;
+    const double lo = 1.0 + delta, hi = c.N + 1.0 + delta;
+    c.umin = std::nextafter(lo, INFINITY) - lo;          // ulp(fl(1 + delta)): every value of the recurrence is a multiple
+    const double utop = std::nextafter(hi, INFINITY) - hi;
+    c.G = 2.0 * utop;                                    // shifts by multiples of G commute with every rounding (ties to even)
+    c.inv_umin = 1.0 / c.umin;
+    c.inv_G = 1.0 / c.G;
+    c.ncand = static_cast<int>(c.G / c.umin);
+    c.nwin = std::max(4 * c.ncand, 16);
+    c.halfwin = static_cast<double>(c.nwin / 2) * c.umin;
+    c.ok = c.nwin <= kSchedMaxWin && c.umin <= 0x1p-20;
+    return c;
+}
+
+}  // namespace mrhip

@@ -11,6 +11,7 @@
 #include <hip/hip_ext.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -70,6 +71,76 @@ int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t
                                std::vector<int32_t> *n_idx, std::vector<double> *acc_out);
 int64_t run_arbitrary_schedule_piece(ArbState &st, double delta, int64_t Nphi, int64_t xLen, int32_t *n_idx, double *acc_out,
                                      int64_t max_outputs, bool *done);
+
+// ---------------------------------------------------------------------------------------
+// FIRArbitrary / FIRFarrow phase schedule on the device (kernels_schedule.hip; model: scripts/sched_model.py)
+// ---------------------------------------------------------------------------------------
+constexpr int kSchedSeg = 64;                 // steps per segment
+constexpr int kSchedGroup = 64 * kSchedSeg;   // steps per group (one workgroup): pieces are whole groups
+constexpr int kSchedMaxWin = 64;              // candidates per segment the tables kernel has LDS for
+constexpr int kSchedNoFail = 0x7fffffff;
+constexpr int kSchedSpanSizes = 3;            // tile sizes (256 << i outputs) whose largest input span the emit kernel reports
+
+struct SchedPlan {           // constants of one (delta, Nphi)
+    double delta, N, invN;
+    double umin, inv_umin;   // grid of the values the recurrence can produce
+    double G, inv_G;         // shifts by multiples of G commute with every rounding of the recurrence
+    double halfwin;          // (nwin / 2) * umin
+    int ncand, nwin;         // G / umin; candidates per segment
+    int pow2;                // Nphi is a power of two (the quotient by N is then an exact scaling)
+    int ok;                  // 0: outside what the device evaluation covers (the host loop runs instead)
+};
+struct SchedPieceState {     // true state at the start of a piece + the running drift estimate
+    double acc;
+    long long xIdx;
+    double drift;            // sum over verified pieces of (true end - un-rounded end), phase units
+    double ksteps;           // steps those pieces covered
+};
+struct SchedStatus {
+    int fail_piece;          // kSchedNoFail, or the first piece whose verification failed
+    int done;                // the call's end (first xIdx > x_len) was found
+    long long end_k;         // number of outputs of the call
+    double end_acc;          // state after the last output's update()
+    long long end_xIdx;
+    int max_span[kSchedSpanSizes];   // largest n[last] - n[first] over aligned tiles of 256 << i outputs
+    int pad;
+};
+struct SchedGroupEntry { double shift; int advance; int next; };        // map of one group: candidate -> (next, +shift, +xIdx)
+struct SchedGroupStart { double shift; long long advance; int cand; int pad; };   // true start of a group, as candidate + shift
+struct SchedPieceArgs {
+    SchedPieceState *state;  // [pieces + 1]
+    SchedStatus *status;
+    double *pathT;           // [segments of the piece][nwin]: start value of the segment when the group starts at candidate c0
+    int *pathW;              //                                xIdx advance from the group's start
+    SchedGroupEntry *gtab;   // [groups][nwin]
+    SchedGroupStart *gstart; // [groups]
+    int *sched_n;            // the call's schedule buffers
+    double *sched_acc;
+    long long k0;            // output number of the piece's first step within the call
+    long long x_len;
+    int piece, ngroups;
+    int corrupt_group;       // test hook: -1, or the group whose table is falsified (MRHIP_SCHED_CORRUPT)
+};
+struct SchedResult {         // what sched_run_call (arb_schedule.hip) leaves for the filter kernel's launch
+    int buf;                 // schedule buffer (mrhip_filter::ds_n / ds_acc) that holds entries [0, count)
+    int64_t count;           // outputs of the call
+    ArbState end;            // state after the call (the caller commits it)
+    int max_span[kSchedSpanSizes];
+    double drift, ksteps;    // running drift estimate after the call
+    bool periodic;           // evaluated by the closed form of a detected cycle
+    int64_t per_pos_end;     // ... whose position after the call this is
+};
+SchedPlan make_sched_plan(double delta, int64_t Nphi);
+hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hipStream_t s);
+}  // namespace mrhip
+struct mrhip_filter;
+namespace mrhip {
+void sched_configure(mrhip_filter *f);
+void sched_forget(mrhip_filter *f);
+void sched_free(mrhip_filter *f);
+bool sched_wants_device(const mrhip_filter *f, int64_t est);
+int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, SchedResult *out);
+double sched_anchor_host(const SchedPlan &c, double acc_p, double k);   // un-rounded phase after k steps (host_logic.cpp)
 
 // ---------------------------------------------------------------------------------------
 // device-side parameter blocks
@@ -218,6 +289,25 @@ inline void launch_kernel(F kfn, dim3 grid, dim3 block, size_t lds, hipStream_t 
         hipLaunchKernelGGL(kfn, grid, block, lds, s, args...);
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) + hipOccupancyMaxActiveBlocksPerMultiprocessor, remembered per
+// (kernel, device, block size, LDS bytes): a streaming launch must not pay for them every time (api.hip).
+hipError_t occupancy_cached(const void *kfn, unsigned block, size_t lds, int *per_cu);
+
+// Tuning / test knobs from the environment: read ONCE per process and call site -- a launch must not pay for getenv.
+// MRHIP_ENV_DYNAMIC=1 (set by tests/conftest.py: tests switch kernels between calls) re-reads them on every use.
+inline int env_int_read(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+inline bool env_dynamic()
+{
+    static const bool d = env_int_read("MRHIP_ENV_DYNAMIC", 0) != 0;
+    return d;
+}
+#define MRHIP_ENV_INT(name, dflt) ([]() -> int { static const int v_ = ::mrhip::env_int_read(name, dflt); \
+                                                 return ::mrhip::env_dynamic() ? ::mrhip::env_int_read(name, dflt) : v_; }())
+
 // dtype combination a kernel is instantiated for
 struct TypeKey {
     bool x_f64;      // Tx scalar is double
@@ -232,7 +322,7 @@ struct TypeKey {
 hipError_t launch_poly_generic(const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, hipStream_t s, const char **kname);
 hipError_t launch_farrow(const TypeKey &tk, bool fused, const FarrowArgs &a, hipStream_t s, const char **kname);
-bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_idx_host, int num_cus, ArbTileArgs *out, size_t *lds);
+bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_idx_host, const int *spans, int num_cus, ArbTileArgs *out, size_t *lds);
 hipError_t launch_farrow_tiled(const TypeKey &tk, bool fused, const FarrowArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
                                const char **kname, int num_cus);
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
@@ -247,7 +337,7 @@ hipError_t launch_fir_stream(bool fused, const PolyArgs &a, const PairArgs &pa, 
 bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectArgs *out, size_t *lds);
 hipError_t launch_fir_direct(const TypeKey &tk, bool fused, const PolyArgs &a, const DirectArgs &da, size_t lds, hipStream_t s,
                              const char **kname, int num_cus);
-bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_host, int num_cus, ArbTileArgs *out, size_t *lds);
+bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_host, const int *spans, int num_cus, ArbTileArgs *out, size_t *lds);
 hipError_t launch_arb_tiled(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
                             const char **kname, int num_cus);
 bool plan_poly_tiled(const TypeKey &tk, const PolyArgs &a, int num_cus, ArbTileArgs *out, size_t *lds);
@@ -305,6 +395,36 @@ struct mrhip_filter {
     size_t d_sched_cap = 0;
     hipEvent_t sched_copied = nullptr;
     bool sched_in_flight = false;
+
+    // device-evaluated schedule (arb_schedule.hip, kernels_schedule.hip)
+    mrhip::SchedPlan splan{};
+    int64_t sched_prefix = 65536, sched_pmax = 1 << 20, sched_device_min = 1 << 18;   // MRHIP_SCHED_* (read at create)
+    int sched_corrupt_piece = -1;                 // test hook: falsify the tables of this device piece (counted per filter)
+    bool sched_use_cycle = true;
+    double sched_drift = 0.0, sched_ksteps = 0.0; // running drift estimate of the stream: (true - un-rounded phase) over ksteps steps
+    void *ds_n[2] = {nullptr, nullptr}, *ds_acc[2] = {nullptr, nullptr};   // schedule buffers, alternated per call
+    size_t ds_cap[2] = {0, 0};
+    int ds_cur = 0;
+    hipEvent_t ds_read[2] = {nullptr, nullptr};   // recorded behind the filter kernel that reads the buffer
+    bool ds_read_valid[2] = {false, false};
+    hipEvent_t ds_done = nullptr;                 // recorded on own_stream behind the last write of a call's schedule
+    double *ds_pathT = nullptr;
+    int *ds_pathW = nullptr;
+    mrhip::SchedGroupEntry *ds_gtab = nullptr;
+    mrhip::SchedGroupStart *ds_gstart = nullptr;
+    int64_t ds_work_groups = 0;
+    mrhip::SchedPieceState *ds_state = nullptr, *ds_pin_state = nullptr;
+    int64_t ds_state_cap = 0;
+    mrhip::SchedStatus *ds_status = nullptr, *ds_pin_status = nullptr;
+    // a detected cycle of the accumulator (PERIODIC mode)
+    bool per_valid = false;
+    int64_t per_Q = 0, per_XQ = 0, per_pos = 0;
+    std::vector<double> per_acc;
+    std::vector<int64_t> per_xoff;                // [Q + 1] xIdx advance from cycle position 0
+    int per_span[mrhip::kSchedSpanSizes] = {0, 0, 0};
+    double *d_per_acc = nullptr;
+    long long *d_per_xoff = nullptr;
+    int64_t stat_host_steps = 0, stat_periodic_steps = 0, stat_device_pieces = 0, stat_fallback_pieces = 0;
 
     // host-pointer path staging: two slots each way (H2D of piece i+1 and D2H of piece i-1 overlap the kernel of
     // piece i: copy streams s_in / s_out beside the kernel stream own_stream, ordered by the events below)

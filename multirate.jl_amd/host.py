@@ -107,6 +107,7 @@ ABI = [
     ("mrhip_set_timing", _i, [_vp, _i]),
     ("mrhip_timing_read", _i, [_vp, _pi64, C.POINTER(C.c_double)]),
     ("mrhip_last_kernel_name", C.c_char_p, [_vp]),
+    ("mrhip_schedule_info", _i, [_vp, _pi64, _i]),
 ]
 
 _lib = None
@@ -410,6 +411,14 @@ class FIRFilter:
     def last_kernel_name(self) -> str:
         return self._lib.mrhip_last_kernel_name(self._handle).decode()
 
+    def schedule_info(self) -> dict:
+        """How the phase schedule of this FIRArbitrary / FIRFarrow filter (update(), src/Filters.jl:663-673) has been
+        evaluated so far: on the device, by the closed form of a detected cycle, or by the host's serial loop."""
+        v = (C.c_int64 * 8)()
+        _check(self._lib.mrhip_schedule_info(self._handle, v, 8))
+        keys = ("device_ok", "ncand", "nwin", "period", "host_steps", "periodic_steps", "device_pieces", "fallback_pieces")
+        return dict(zip(keys, (int(a) for a in v)))
+
     # -- bookkeeping (src/Filters.jl:352-422)
     def outputlength(self, inputlength: int) -> int:
         if self._handle is None:
@@ -576,6 +585,9 @@ class FilterCascade:
 
     def _ensure(self, tx, nch: int):
         if self._handle is not None:
+            # the bound cascade only knows the sample type and channel count of its first call: a later call with
+            # another shape must raise like a lone FIRFilter does, not read or write past the caller's buffers
+            self.stages[0]._ensure(np.dtype(tx), nch)
             return
         for f in self.stages:                      # stage i+1's sample type is stage i's output type
             f._ensure(np.dtype(tx), nch)

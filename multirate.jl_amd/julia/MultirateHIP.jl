@@ -329,7 +329,10 @@ mutable struct FilterCascade
     end
 end
 function bind!(c::FilterCascade, ::Type{Tx}, nch::Integer) where {Tx}
-    c.handle == C_NULL || return c
+    if c.handle != C_NULL                   # bound: a later call must have the sample type / channel count of the first
+        bind!(c.stages[1], Tx, nch)         # (errors on a mismatch, like a lone FIRFilter)
+        return c
+    end
     T = Tx
     for f in c.stages                       # stage i+1's sample type is stage i's output type
         bind!(f, T, nch); T = promote_out(eltype(f.h), T)

@@ -6,6 +6,10 @@ import sys
 import numpy as np
 import pytest
 
+# the library reads its tuning / test knobs (MRHIP_OPAIR, MRHIP_STREAM, ...) once per process unless told otherwise; tests
+# switch kernels between calls with monkeypatch.setenv, so they ask for a fresh read every time
+os.environ.setdefault("MRHIP_ENV_DYNAMIC", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -58,6 +58,24 @@ def test_reference_known_answers_on_gpu(pkg, known_answers, torch_cuda):
     assert np.sum(np.concatenate(ys) - pkg.filt(h, x, Fraction(*ka["ratio"]))) == 0.0
 
 
+def test_notebook_farrow_output_length_on_gpu(pkg, O, known_answers, torch_cuda):
+    """The reference's fourth held datum (doc/Polyphase Filtering Explained.ipynb, last cell): 40 samples through
+    FIRFilter(h, float64(pi), 32, 4) give 126 outputs -- FIRFarrow and FIRArbitrary, on the GPU; values == oracle."""
+    ka = known_answers["notebook_farrow"]
+    rate = math.pi
+    t = np.arange(ka["Nx"])
+    x = np.cos(2 * np.pi * ka["xf1"] * t) + 0.5 * np.sin(2 * np.pi * ka["xf2"] * t * np.pi)
+    hLen = ka["tapsPerPhi"] * ka["Nphi"]
+    h = pkg.firdes(hLen, min(0.45 / ka["Nphi"], rate / ka["Nphi"]), beta=7.8562) * ka["Nphi"]
+    ff = pkg.FIRFilter(h, rate, ka["Nphi"], ka["polyorder"])
+    y = ff.filt(x)
+    assert len(y) == ka["len_y"]
+    assert_bit_equal(y, O.FIRFilter(h, rate, ka["Nphi"], tx=np.float64, polyorder=ka["polyorder"], pnfb=ff.pnfb()).filt(x), "notebook farrow")
+    ya = pkg.FIRFilter(h, rate, ka["Nphi"]).filt(x)
+    assert len(ya) == ka["len_y"]
+    assert_bit_equal(ya, O.FIRFilter(h, rate, ka["Nphi"], tx=np.float64).filt(x), "notebook arbitrary")
+
+
 def test_golden_vectors_host_path(pkg, golden, torch_cuda):
     """Every committed fixture through mrhip_filt_host: outputs, per-chunk counts, end state and
     history, all bit-exact."""
@@ -941,6 +959,11 @@ def test_filter_cascade_device_resident(pkg, O, torch_cuda):
                 p = st.filt(p)
             outs.append(p)
         assert_bit_equal(y[c], np.concatenate(outs), f"cascade ch {c}")
+    # a bound cascade refuses another channel count or sample type (it would otherwise read past x / leave rows of y unwritten)
+    with pytest.raises(pkg.MultirateHIPError):
+        casc.filt(torch.zeros((3, 1000), dtype=torch.float32, device="cuda"))
+    with pytest.raises(pkg.MultirateHIPError):
+        casc.filt(torch.zeros((2, 1000), dtype=torch.float64, device="cuda"))
     assert casc.reset().stages[1].state.phiIdx == 1
 
 

@@ -1,0 +1,176 @@
+"""GPU tests of the device-evaluated phase schedule of FIRArbitrary / FIRFarrow (csrc/kernels_schedule.hip,
+csrc/arb_schedule.hip; reference: update(), src/Filters.jl:663-673 and :780-792).
+
+The filter's outputs depend on every schedule entry (input index, phase, alpha of every output), so bit-equal outputs
+and end state against the oracle -- or, at sizes the oracle would take minutes for, against the library's own serial
+host loop (MRHIP_SCHED_DEVICE=0; itself checked against the oracle in test_gpu_parity.py) -- is equality of schedules."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+RATES = [math.pi / 3, 1.0, 0.5, 2.0, 1 / 3, 0.999999, 1.000001, 7.77, 40.0, 0.26, 0.2499, 0.01, 1 / 300, 0.0333, 3.999,
+         1 / 2.123456789, 48000 / 44100, 3.0, 11 / 7, 56 / 37, 2.5]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def _small_pieces(monkeypatch, prefix=4096, pmax=8192, device_min=6000):
+    monkeypatch.setenv("MRHIP_SCHED_PREFIX", str(prefix))
+    monkeypatch.setenv("MRHIP_SCHED_PMAX", str(pmax))
+    monkeypatch.setenv("MRHIP_SCHED_DEVICE_MIN", str(device_min))
+
+
+def _chunks(f, x, sizes):
+    outs, pos = [], 0
+    for s in sizes:
+        outs.append(f.filt(x[..., pos:pos + s]))
+        pos += s
+    return outs
+
+
+def test_device_schedule_vs_oracle_many_rates(pkg, O, torch_cuda, monkeypatch):
+    """15 + 6 rates x 5 Nphi, three calls per stream (so the second and third start from a carried state), pieces small
+    enough that every call spans several of them: outputs and end state bit for bit == oracle."""
+    torch = torch_cuda
+    _small_pieces(monkeypatch)
+    rng = np.random.default_rng(321)
+    seen = dict(device=0, periodic=0, host=0, fallback=0)
+    for rate in RATES:
+        for Nphi in (32, 10, 7, 1, 64):
+            T = 3
+            h = rng.standard_normal(T * Nphi).astype(np.float32)
+            n_out_target = 70_000
+            n = max(int(n_out_target / rate), 400)
+            x = rng.standard_normal(n).astype(np.float32)
+            sizes = [n // 2, 1, n - n // 2 - 1]
+            f = pkg.FIRFilter(h, rate, Nphi)
+            y = np.concatenate([o.cpu().numpy() for o in _chunks(f, torch.from_numpy(x).cuda(), sizes)])
+            fo = O.FIRFilter(h, rate, Nphi, tx=np.float32)
+            yo = np.concatenate(_chunks(fo, x, sizes))
+            assert_bit_equal(y, yo, f"rate={rate} Nphi={Nphi}")
+            assert f.state.phiAccumulator == fo.state.phiAccumulator and f.state.inputDeficit == fo.state.inputDeficit, (rate, Nphi)
+            info = f.schedule_info()
+            seen["device"] += info["device_pieces"] > 0
+            seen["periodic"] += info["periodic_steps"] > 0
+            seen["host"] += info["host_steps"] > 0
+            seen["fallback"] += info["fallback_pieces"]
+            f.close()
+    assert seen["device"] >= 30 and seen["periodic"] >= 5, seen      # both device paths really ran
+    print("schedule paths over the sweep:", seen)
+
+
+def test_farrow_uses_the_same_schedule(pkg, O, torch_cuda, monkeypatch):
+    torch = torch_cuda
+    _small_pieces(monkeypatch)
+    rng = np.random.default_rng(9)
+    for rate in (math.pi / 3, 1.3, 3.0):
+        h = (pkg.firdes(32 * 8, 0.45 / 32, beta=7.8562) * 32).astype(np.float64)
+        x = rng.random(int(60_000 / rate))
+        f = pkg.FIRFilter(h, rate, 32, 4).bind(np.float64)
+        fo = O.FIRFilter(h, rate, 32, tx=np.float64, polyorder=4, pnfb=f.pnfb())
+        y = f.filt(torch.from_numpy(x).cuda()).cpu().numpy()
+        yo = fo.filt(x)
+        assert_bit_equal(y, yo, f"farrow rate={rate}")
+        assert f.state.phiAccumulator == fo.state.phiAccumulator
+        info = f.schedule_info()
+        assert info["device_pieces"] > 0 or info["periodic_steps"] > 0
+        f.close()
+
+
+def test_falsified_table_is_caught_and_the_piece_redone_by_the_host(pkg, O, torch_cuda, monkeypatch):
+    """MRHIP_SCHED_CORRUPT=k falsifies the candidate tables of the k-th device piece: its verification must fail, the
+    host's serial loop must redo exactly that piece, and the result must still be exact."""
+    torch = torch_cuda
+    _small_pieces(monkeypatch)
+    monkeypatch.setenv("MRHIP_SCHED_CORRUPT", "1")
+    rng = np.random.default_rng(3)
+    h = rng.standard_normal(3 * 32).astype(np.float32)
+    x = rng.standard_normal(60_000).astype(np.float32)
+    rate = math.pi / 3
+    f = pkg.FIRFilter(h, rate, 32)
+    y = f.filt(torch.from_numpy(x).cuda()).cpu().numpy()
+    yo = O.FIRFilter(h, rate, 32, tx=np.float32).filt(x)
+    assert_bit_equal(y, yo, "after a forced fallback")
+    info = f.schedule_info()
+    assert info["fallback_pieces"] == 1 and info["device_pieces"] >= 3, info
+    f.close()
+
+
+def test_cycle_shortcut_off_the_tables_still_agree(pkg, O, torch_cuda, monkeypatch):
+    """Rates whose accumulator cycles exactly (phase ON the wrap / binade thresholds every period) through the table
+    path: exact either way -- by verification, or by the host loop where a piece does not verify."""
+    torch = torch_cuda
+    _small_pieces(monkeypatch)
+    monkeypatch.setenv("MRHIP_SCHED_CYCLE", "0")
+    rng = np.random.default_rng(4)
+    for rate, Nphi in ((3.0, 32), (1.0, 32), (56 / 37, 16), (0.75, 32), (2.0, 7)):
+        h = rng.standard_normal(3 * Nphi).astype(np.float32)
+        x = rng.standard_normal(int(50_000 / rate)).astype(np.float32)
+        f = pkg.FIRFilter(h, rate, Nphi)
+        y = f.filt(torch.from_numpy(x).cuda()).cpu().numpy()
+        yo = O.FIRFilter(h, rate, Nphi, tx=np.float32).filt(x)
+        assert_bit_equal(y, yo, f"rate={rate} Nphi={Nphi}")
+        assert f.schedule_info()["periodic_steps"] == 0
+        f.close()
+
+
+def test_set_state_and_reset_drop_the_cycle_and_the_drift_estimate(pkg, O, torch_cuda, monkeypatch):
+    torch = torch_cuda
+    _small_pieces(monkeypatch)
+    rng = np.random.default_rng(6)
+    h = rng.standard_normal(96).astype(np.float32)
+    x = rng.standard_normal(30_000).astype(np.float32)
+    f = pkg.FIRFilter(h, 3.0, 32)
+    fo = O.FIRFilter(h, 3.0, 32, tx=np.float32)
+    xd = torch.from_numpy(x).cuda()
+    assert_bit_equal(f.filt(xd).cpu().numpy(), fo.filt(x), "first")
+    assert f.schedule_info()["period"] == 3
+    for acc in (7.25, 1.0 + 2.0 ** -40 + 2.0 ** -52):       # the second is off the grid of values the recurrence produces
+        f.set_state(1, 2, acc)
+        fo.set_state(1, 2, acc)
+        assert_bit_equal(f.filt(xd).cpu().numpy(), fo.filt(x), f"after set_state({acc!r})")
+        assert f.state.phiAccumulator == fo.state.phiAccumulator
+    f.reset()
+    fo.reset()
+    assert_bit_equal(f.filt(xd).cpu().numpy(), fo.filt(x), "after reset")
+    f.close()
+
+
+@pytest.mark.parametrize("rate,n_out", [(math.pi / 3, 100_000_000), (48000 / 44100, 100_000_000), (7.77, 30_000_000),
+                                        (0.26, 30_000_000), (1 / 2.123456789, 30_000_000), (11 / 7, 30_000_000), (3.0, 30_000_000)])
+def test_long_runs_device_schedule_vs_host_loop(pkg, torch_cuda, monkeypatch, rate, n_out):
+    """1e8 / 3e7 outputs in one call with the default piece sizes: device-evaluated schedule vs the serial host loop,
+    outputs (Float32, 1 channel, 3 taps per phase: every entry matters) and end state bit for bit."""
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n = int(n_out / rate)
+    x = torch.rand(n, generator=g, device="cuda", dtype=torch.float32) - 0.5
+    h = np.random.default_rng(2).standard_normal(96).astype(np.float32)
+    monkeypatch.setenv("MRHIP_SCHED_DEVICE", "0")
+    fh = pkg.FIRFilter(h, rate, 32)
+    yh = fh.filt(x)
+    assert fh.schedule_info()["device_ok"] == 0
+    monkeypatch.delenv("MRHIP_SCHED_DEVICE")
+    fd = pkg.FIRFilter(h, rate, 32)
+    yd = fd.filt(x)
+    info = fd.schedule_info()
+    assert info["device_pieces"] > 0 or info["periodic_steps"] > 0, info
+    assert yd.shape == yh.shape and torch.equal(yd.view(torch.int32), yh.view(torch.int32)), (rate, info)
+    sd, sh = fd.state, fh.state
+    assert (sd.phiAccumulator, sd.inputDeficit, sd.phiIdx) == (sh.phiAccumulator, sh.inputDeficit, sh.phiIdx)
+    # and a second call from the carried state (warm drift estimate: no host prefix any more)
+    yd2, yh2 = fd.filt(x[: n // 7]), fh.filt(x[: n // 7])
+    assert torch.equal(yd2.view(torch.int32), yh2.view(torch.int32))
+    print(f"rate={rate:.6g}: {info}")
+    fd.close()
+    fh.close()

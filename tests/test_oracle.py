@@ -35,6 +35,27 @@ def test_readme_streaming_known_answer(O, known_answers):
     assert np.sum(y - O.filt(h, x, Fraction(*ka["ratio"]))) == ka["sum_diff_vs_stateless"]
 
 
+def test_notebook_farrow_output_length(O, known_answers):
+    """doc/Polyphase Filtering Explained.ipynb, last code cell: filt(FIRFilter(h, float64(pi), 32, 4), x) over 40 samples
+    returns 126 outputs (the cell's stored output is the 126-element time vector, last value 125/pi - 5).  The count is
+    a property of the phase recurrence alone, which FIRFarrow and FIRArbitrary share."""
+    ka = known_answers["notebook_farrow"]
+    rate = math.pi
+    t = np.arange(ka["Nx"])
+    x = np.cos(2 * np.pi * ka["xf1"] * t) + 0.5 * np.sin(2 * np.pi * ka["xf2"] * t * np.pi)
+    hLen = ka["tapsPerPhi"] * ka["Nphi"]
+    k = np.arange(hLen)
+    F = min(0.45 / ka["Nphi"], rate / ka["Nphi"])
+    h = 2 * F * np.sinc(2 * F * (k - (hLen - 1) / 2)) * np.kaiser(hLen, 7.8562) * ka["Nphi"]
+    y_farrow = O.FIRFilter(h, rate, ka["Nphi"], tx=np.float64, polyorder=ka["polyorder"]).filt(x)
+    y_arb = O.FIRFilter(h, rate, ka["Nphi"], tx=np.float64).filt(x)
+    assert len(y_farrow) == ka["len_y"] and len(y_arb) == ka["len_y"]
+    ty = np.arange(len(y_farrow)) / rate - ka["tapsPerPhi"] / 2
+    assert ty[0] == ka["ty_first"] and round(ty[-1], 4) == ka["ty_last_printed"]
+    # the two kernels resample the same signal: they agree to the accuracy of the degree-4 fit
+    assert np.abs(y_farrow - y_arb).max() < 2e-2 * np.abs(y_arb).max()
+
+
 def test_nextphase_table(O, known_answers):
     lo, hi = known_answers["nextphase"]["L_range"]       # test/runtests.jl:423-438
     for L0 in range(lo, hi + 1):
