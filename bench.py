@@ -236,16 +236,40 @@ class Rank:
 
 
 def traffic_for(bytes_per_launch):
-    """PMC-measured HBM bytes of a launch of THIS size (profiles/: separate --pmc passes), or None"""
+    """(PMC-measured HBM bytes of a launch of THIS size, where that number comes from), or (None, None).  The counters
+    need their own rocprofv3 --pmc passes (separate from any trace, MI355X_MICROARCH.md), so this is a RECORDED value
+    from profiles/traffic_latest.json -- measured on the same kernel and launch size by scripts/profile_round.sh, not in
+    this run; `traffic_source` in the JSON line says so."""
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
-            for e in json.load(open(tpath)).get("entries", []):
+            doc = json.load(open(tpath))
+            for e in doc.get("entries", []):
                 if abs(e["algorithmic_bytes_per_launch"] - bytes_per_launch) <= 1e-3 * bytes_per_launch:
-                    return e["hbm_bytes_per_launch"]
+                    src = {"file": "profiles/traffic_latest.json", "from": e.get("source"), "measured": e.get("measured", doc.get("measured")),
+                           "how": "recorded, not measured in this run: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same "
+                                  "kernel and launch size (FETCH_SIZE x2 on gfx950)", "kernel": doc.get("kernel")}
+                    return e["hbm_bytes_per_launch"], src
         except Exception:
-            return None
-    return None
+            return None, None
+    return None, None
+
+
+def config_rows():
+    """Every other BASELINE config on this GPU (and the reference's own FIRArbitrary / FIRFarrow benchmark shape), a few
+    passes each, measured by scripts/bench_configs.py's harness: kernel time from HIP events, wall time with the host."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mrhip_bench_configs", os.path.join(ROOT, "scripts", "bench_configs.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+    out = []
+    for r in bc.run_rows(bc.BENCH_ROWS):
+        out.append({"name": r["config"], "kernel": r["kernel"], "launches_per_pass": r["launches_per_pass"],
+                    "kernel_ms": r["kernel_ms_per_pass"], "wall_ms": r["wall_ms_per_pass_incl_host"],
+                    "Msamples_per_s_in": r["Msamples_per_s_in"], "Msamples_per_s_in_wall": r["Msamples_per_s_in_wall"],
+                    "achieved_GBps": r["algorithmic_GBps"], "frac": r["frac_of_8TBps"], "frac_wall": r["frac_of_8TBps_wall"],
+                    "arith": r["arith"], "TFLOPs": r["TFLOPs"], "strict_valu_frac": r["frac_of_strict_valu"]})
+    return out
 
 
 def run_headline(args, R):
@@ -315,6 +339,7 @@ def run_headline(args, R):
         streamed["whole_step_GBps"] = round(nch * n * BYTES_PER_INPUT_SAMPLE * args.steps / el1 / 1e9, 2)
 
     elapsed = R.max_over_ranks([elapsed])[0]
+    last_kernel = filt.last_kernel_name()
 
     # light sanity check of the timed output against the oracle (checker only, after the timed region)
     if rank == 0 and not args.no_check:
@@ -326,6 +351,13 @@ def run_headline(args, R):
         got = y[nch - 1, :len(yo)].cpu().numpy()
         assert np.array_equal(got.view(np.uint32), yo.view(np.uint32)), "bench output differs from oracle"
 
+    configs = None
+    if world == 1 and chunk == n and not args.no_configs:
+        filt.close()
+        del x, y
+        torch.cuda.empty_cache()
+        configs = config_rows()
+
     total_in = float(nch) * n * args.steps * world
     ms_per_step = elapsed / args.steps * 1e3
     value = total_in / elapsed / 1e6
@@ -334,6 +366,7 @@ def run_headline(args, R):
     achieved = bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
 
     if rank == 0:
+        traffic, traffic_source = traffic_for(bytes_per_launch)
         line = {
             "metric": METRIC,
             "value": round(value, 3), "unit": "Msamples/s (input samples, all channels, all GPUs)",
@@ -347,15 +380,17 @@ def run_headline(args, R):
                        "numerics": args.numerics, "parallelism": f"channel-shard x{world}, no collective",
                        "backend": R.backend if world > 1 else None},
             "output_msamples_s": round(value * L / M, 3),
-            "kernel": filt.last_kernel_name(),
+            "kernel": last_kernel,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_for(bytes_per_launch),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5), "launches_timed": n_launch,
                          "whole_step_GBps": round(nch * n * BYTES_PER_INPUT_SAMPLE / (ms_per_step / 1e3) / 1e9, 2)},
         }
         if streamed is not None:
             line["streamed_1e6_chunks"] = streamed
+        if configs is not None:
+            line["configs"] = configs
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["cpu_baseline_all_cores"] = cpu_baseline(h)
         print(json.dumps(line), flush=True)
@@ -449,7 +484,8 @@ def run_c5(args, R):
             "kernel": sh.filter.last_kernel_name() if sh.filter is not None else None,
             "gather": gather or None,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_for(bytes_per_launch),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_for(bytes_per_launch)[0],
+                         "traffic_source": traffic_for(bytes_per_launch)[1],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5), "launches_timed": n_launch,
                          "note": "rank 0's kernel; per-GPU fraction (every rank runs the same shard size +-1 channel)"},
@@ -471,6 +507,7 @@ def main():
                     "-n: one bracket around every n consecutive launches (0 = every launch when a pass is one call, groups of 10 when it is chunked)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true", help="skip the extra chunked passes reported as `streamed_1e6_chunks`")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs reported as `configs` (N = 1 only)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check (timing experiments)")
     ap.add_argument("--no-gather", action="store_true", help="c5: skip the gather timings")
     args = ap.parse_args()

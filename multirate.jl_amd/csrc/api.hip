@@ -704,14 +704,18 @@ static int ensure_sched_capacity(mrhip_filter *f, size_t n)
     return MRHIP_OK;
 }
 
-int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
-                      int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream_)
+// One launch-sized piece of a filt! call.  `continuation`: the piece continues a call whose earlier samples were already
+// filtered (mrhip_filt_device splits calls longer than a launch can index; mrhip_filt_host cuts a call into staging
+// pieces): the Vector seam's start-from-zero (support.jl:46) then applies to none of its outputs -- in the ONE reference
+// call they all lie past the first hLen samples -- so that a split call equals the unsplit one down to the sign of a zero.
+static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
+                           int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream_, bool continuation)
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
     if (n_written) *n_written = 0;
     if (x_len < 0 || y_capacity < 0) return fail(MRHIP_ERR_INVALID_ARG, "negative length");
     if (x_len > 0 && !x) return fail(MRHIP_ERR_INVALID_ARG, "x is NULL");
-    if (x_len >= 0x7fffffffLL) return fail(MRHIP_ERR_INVALID_ARG, "x_len per call must be < 2^31-1");
+    if (x_len >= 0x7fffffffLL) return fail(MRHIP_ERR_INVALID_ARG, "a launch takes fewer than 2^31-1 samples per channel (internal)");
     if (f->nch > 1 && (x_stride < x_len)) return fail(MRHIP_ERR_INVALID_ARG, "x_stride < x_len");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceGuard guard(f->device);
@@ -884,7 +888,8 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
             a.x = x; a.y = y; a.hist = f->d_hist[f->hist_cur]; a.hist_new = f->d_hist[f->hist_cur ^ 1]; a.taps = f->d_taps;
             a.x_stride = x_stride; a.y_stride = y_stride; a.x_len = x_len; a.n_out = n_out;
             a.u0 = p.phi0 - 1; a.d0 = p.d0;
-            a.zero_start_below = f->kind == MRHIP_FIR_STANDARD ? f->hLen + 1
+            a.zero_start_below = continuation ? 0
+                               : f->kind == MRHIP_FIR_STANDARD ? f->hLen + 1
                                : f->kind == MRHIP_FIR_DECIMATOR ? f->hLen : 0;
             a.L = static_cast<int>(f->L); a.M = static_cast<int>(f->M);
             a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H);
@@ -914,6 +919,47 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
         }
     }
     if (n_written) *n_written = n_out;
+    return MRHIP_OK;
+}
+
+// filt!(buffer, self, x) on device memory.  The reference takes a Vector of any length (Int64 indices); a launch indexes
+// 31 bits, and a FIRArbitrary / FIRFarrow launch holds its phase schedule in device memory, so a long call is cut into
+// launch-sized pieces here -- chunked == unchunked bit for bit (logical window, closed-form / carried state), see
+// filt_device_one for the one place where a piece must know it is not the start of the call.
+int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
+                      int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    if (n_written) *n_written = 0;
+    const bool arb = f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW;
+    // samples per launch: inputs and outputs stay below 2^31; at most 2^24 schedule entries per FIRArbitrary launch
+    const int64_t env_max = MRHIP_ENV_INT("MRHIP_LAUNCH_MAX", 0);              // tests: force the split at small sizes
+    int64_t step = env_max > 0 ? env_max : (1LL << 30);
+    if (f->kind == MRHIP_FIR_INTERPOLATOR) step = std::max<int64_t>(step / f->L, 1);
+    if (arb && env_max <= 0) step = std::max<int64_t>(4096, std::min<int64_t>(step, static_cast<int64_t>(static_cast<double>(1LL << 24) / f->rate)));
+    if (x_len <= step) return filt_device_one(f, x, x_len, x_stride, y, y_capacity, y_stride, n_written, stream, false);
+    if (x_len < 0 || y_capacity < 0) return fail(MRHIP_ERR_INVALID_ARG, "negative length");
+    if (!x) return fail(MRHIP_ERR_INVALID_ARG, "x is NULL");
+    if (stream_is_capturing(static_cast<hipStream_t>(stream)))
+        return fail(MRHIP_ERR_UNSUPPORTED, "a call of this length is issued in several launches with the state advanced in between: not capturable");
+    if (!arb) {   // reference: error() before any work, Filters.jl:460 (Standard), :503 (Interpolator), :550 (Rational)
+        const int64_t total = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len).n_out;
+        if (total > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
+        if (total > 0 && !y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
+        if (f->nch > 1 && y_stride < total) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
+    }
+    const size_t xelt = dtype_scalar_size(f->tx) * static_cast<size_t>(f->nc);
+    const size_t yelt = dtype_scalar_size(f->ty) * static_cast<size_t>(f->nc);
+    int64_t k = 0;
+    for (int64_t a = 0; a < x_len; a += step) {
+        const int64_t len = std::min<int64_t>(step, x_len - a);
+        int64_t got = 0;
+        const int rc = filt_device_one(f, static_cast<const unsigned char *>(x) + static_cast<size_t>(a) * xelt, len, x_stride,
+                                       static_cast<unsigned char *>(y) + static_cast<size_t>(k) * yelt, y_capacity - k, y_stride, &got, stream, a > 0);
+        if (rc) { if (n_written) *n_written = k; return rc; }
+        k += got;
+    }
+    if (n_written) *n_written = k;
     return MRHIP_OK;
 }
 
@@ -1039,7 +1085,7 @@ int mrhip_filt_host(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_str
         const int64_t cap = std::min<int64_t>(y_piece_cap, count - k);
         int64_t nw = 0;
         // (an undersized slot cannot happen: y_piece_cap bounds every piece; the whole call was checked against y_capacity)
-        if (int rc = mrhip_filt_device(f, f->d_xbuf[sl], len, len, f->d_ybuf[sl], cap, std::max<int64_t>(cap, 1), &nw, sk)) {
+        if (int rc = filt_device_one(f, f->d_xbuf[sl], len, len, f->d_ybuf[sl], cap, std::max<int64_t>(cap, 1), &nw, sk, a > 0)) {
             (void)hipStreamSynchronize(f->s_in); (void)hipStreamSynchronize(sk); (void)hipStreamSynchronize(f->s_out);
             if (n_written) *n_written = k;
             return rc;

@@ -202,7 +202,7 @@ void sched_configure(mrhip_filter *f)
 {
     f->splan = make_sched_plan(f->delta, f->Nphi);
     f->sched_prefix = std::max<int64_t>(env_i64("MRHIP_SCHED_PREFIX", 65536), 0) / kSchedGroup * kSchedGroup;
-    f->sched_pmax = std::max<int64_t>(env_i64("MRHIP_SCHED_PMAX", 1 << 20) / kSchedGroup * kSchedGroup, kSchedGroup);
+    f->sched_pmax = std::max<int64_t>(env_i64("MRHIP_SCHED_PMAX", 1 << 22) / kSchedGroup * kSchedGroup, kSchedGroup);
     f->sched_device_min = env_i64("MRHIP_SCHED_DEVICE_MIN", 1 << 18);
     f->sched_corrupt_piece = static_cast<int>(env_i64("MRHIP_SCHED_CORRUPT", -1));
     if (env_i64("MRHIP_SCHED_DEVICE", 1) == 0) f->splan.ok = 0;
@@ -328,8 +328,11 @@ int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, SchedResult *out
         int64_t kk = k;
         double ks = ksteps;
         while (kk <= est) {
+            // a piece may be 16x as long as the drift baseline behind it: the slope error then moves the last segments'
+            // starts out of the candidate window, where the shift argument takes over (exact all the same; rates whose
+            // phase sits ON a threshold -- where it would not hold -- cycle, and took the closed form above)
             int64_t P = kSchedGroup;
-            while (P * 2 <= f->sched_pmax && static_cast<double>(P * 2) <= ks) P *= 2;
+            while (P * 2 <= f->sched_pmax && static_cast<double>(P * 2) <= 16.0 * ks) P *= 2;
             pk0.push_back(kk); psteps.push_back(P);
             kk += P; ks += static_cast<double>(P);
         }

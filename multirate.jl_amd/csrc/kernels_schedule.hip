@@ -30,7 +30,7 @@ namespace {
 
 constexpr int kSeg = kSchedSeg;          // steps per segment
 constexpr int kGroupSegs = 64;           // segments per group (= per workgroup of K1 / K3)
-constexpr int kTabThreads = 256;
+constexpr int kTabThreads = 1024;        // 64 segments x 16 candidates in one round: four waves per SIMD hide the dependent Float64 chain
 
 // One update() of the reference, in a form whose every operation is exact except the one the reference rounds too
 // (the sum): mod(a1-1, N) == (a1-1) - k*N with k = floor(fl((a1-1)/N)), minus one more N when the rounded quotient
@@ -170,42 +170,98 @@ __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, 
     }
 }
 
-// ---- K2: one wave walks the group maps from the piece's true start -------------------------------------------
-__global__ __launch_bounds__(64) void sched_chain_kernel(SchedPlan c, SchedPieceArgs a)
+// ---- K2: the group maps chained from the piece's true start ---------------------------------------------------
+// One workgroup of 16 waves; lane = candidate (nwin <= 64).  Wave w owns a contiguous run of groups:
+//   phase 1  it composes their maps into one (every lane carries its candidate through the run: one cross-lane read
+//            per group, all candidates at once);
+//   phase 2  wave 0 walks the 16 run maps from the true start: every run's start;
+//   phase 3  every wave walks its own groups again from its run's start and writes each group's start.
+// Dependent steps: 2 * ceil(groups / 16) + 16 instead of `groups`.
+constexpr int kChainWaves = 16;
+
+struct ChainState { int ci; double S; long long W; bool ok; };
+
+__device__ __forceinline__ void chain_apply(ChainState &st, const SchedGroupEntry &ge)   // ge = this lane's entry of the group's map
+{
+    const int src = st.ok ? st.ci : 0;
+    const double gsh = __shfl(ge.shift, src);
+    const int gadv = __shfl(ge.advance, src);
+    const int gnext = __shfl(ge.next, src);
+    if (st.ok) {
+        st.S += gsh;
+        st.W += gadv;
+        st.ci = gnext;
+        st.ok = gnext >= 0;
+    }
+}
+
+__global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan c, SchedPieceArgs a)
 {
     if (sched_stop(a.status)) return;
-    const int lane = threadIdx.x;
-    const SchedPieceState ps = a.state[a.piece];
-    const double slope = ps.ksteps > 0.0 ? ps.drift / ps.ksteps : 0.0;
-    int ci = 0;
-    double S = 0.0;
-    bool ok = sched_locate(ps.acc, sched_base(sched_anchor(ps.acc, 0.0, slope, c), c), c, &ci, &S);
-    long long W = 0;
+    __shared__ SchedGroupEntry s_run[kChainWaves][64];      // phase 1 result: the map of every wave's run
+    __shared__ int s_ci[kChainWaves];
+    __shared__ double s_S[kChainWaves];
+    __shared__ long long s_W[kChainWaves];
+    __shared__ int s_ok[kChainWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwin = c.nwin;
-    for (int g = 0; g < a.ngroups; ++g) {
-        // the whole map of group g in one coalesced load (lane = candidate); the walk itself is a cross-lane read
+    const int per = (a.ngroups + kChainWaves - 1) / kChainWaves;
+    const int g0 = wave * per, g1 = g0 + per < a.ngroups ? g0 + per : a.ngroups;
+    auto entry = [&](int g) {
         SchedGroupEntry ge{};
         ge.next = -1;
         if (lane < nwin) ge = a.gtab[static_cast<size_t>(g) * nwin + lane];
-        if (lane == 0) {
-            SchedGroupStart gs;
-            gs.cand = ok ? ci : -1;
-            gs.shift = S;
-            gs.advance = W;
-            a.gstart[g] = gs;
+        return ge;
+    };
+    {   // phase 1: lane's candidate carried through the run
+        ChainState st{lane, 0.0, 0, lane < nwin};
+        int g = g0;
+        for (; g + 4 <= g1; g += 4) {                       // four maps in flight per round of loads
+            const SchedGroupEntry e0 = entry(g), e1 = entry(g + 1), e2 = entry(g + 2), e3 = entry(g + 3);
+            chain_apply(st, e0); chain_apply(st, e1); chain_apply(st, e2); chain_apply(st, e3);
         }
-        const int src = ok ? ci : 0;
-        const double gsh = __shfl(ge.shift, src);
-        const int gadv = __shfl(ge.advance, src);
-        const int gnext = __shfl(ge.next, src);
-        if (ok) {
-            S += gsh;
-            W += gadv;
-            ci = gnext;
-            ok = ci >= 0;
-        }
+        for (; g < g1; ++g) chain_apply(st, entry(g));
+        SchedGroupEntry r;
+        r.shift = st.S;
+        r.advance = static_cast<int>(st.W);
+        r.next = st.ok ? st.ci : -1;
+        s_run[wave][lane] = r;
     }
-    if (lane == 0 && !ok) atomicMin(&a.status->fail_piece, a.piece);
+    __syncthreads();
+    if (wave == 0) {   // phase 2: the runs chained from the piece's true start
+        const SchedPieceState ps = a.state[a.piece];
+        const double slope = ps.ksteps > 0.0 ? ps.drift / ps.ksteps : 0.0;
+        ChainState st{0, 0.0, 0, false};
+        st.ok = sched_locate(ps.acc, sched_base(sched_anchor(ps.acc, 0.0, slope, c), c), c, &st.ci, &st.S);
+        for (int w = 0; w < kChainWaves; ++w) {
+            if (lane == 0) { s_ci[w] = st.ci; s_S[w] = st.S; s_W[w] = st.W; s_ok[w] = st.ok; }
+            if (w * per < a.ngroups) chain_apply(st, s_run[w][lane]);
+        }
+        if (lane == 0 && !st.ok) atomicMin(&a.status->fail_piece, a.piece);
+    }
+    __syncthreads();
+    {   // phase 3: every group's start
+        ChainState st{s_ci[wave], s_S[wave], s_W[wave], s_ok[wave] != 0};
+        auto put = [&](int g) {
+            if (lane == 0) {
+                SchedGroupStart gs;
+                gs.cand = st.ok ? st.ci : -1;
+                gs.shift = st.S;
+                gs.advance = st.W;
+                gs.pad = 0;
+                a.gstart[g] = gs;
+            }
+        };
+        int g = g0;
+        for (; g + 4 <= g1; g += 4) {
+            const SchedGroupEntry e0 = entry(g), e1 = entry(g + 1), e2 = entry(g + 2), e3 = entry(g + 3);
+            put(g); chain_apply(st, e0);
+            put(g + 1); chain_apply(st, e1);
+            put(g + 2); chain_apply(st, e2);
+            put(g + 3); chain_apply(st, e3);
+        }
+        for (; g < g1; ++g) { put(g); chain_apply(st, entry(g)); }
+    }
 }
 
 // ---- K3: run every segment from its true start, emit, verify -------------------------------------------------
@@ -323,7 +379,7 @@ hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hi
         lds_attr = lds;
     }
     hipLaunchKernelGGL(sched_tables_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(kTabThreads), lds, s, c, a);
-    hipLaunchKernelGGL(sched_chain_kernel, dim3(1), dim3(64), 0, s, c, a);
+    hipLaunchKernelGGL(sched_chain_kernel, dim3(1), dim3(kChainWaves * 64), 0, s, c, a);
     hipLaunchKernelGGL(sched_emit_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(kGroupSegs), 0, s, c, a);
     return hipGetLastError();
 }

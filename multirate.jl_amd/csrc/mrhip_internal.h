@@ -267,6 +267,8 @@ struct ArbTileArgs {         // tiling of the FIRArbitrary kernel (kernels_arbit
     int bank_elems;          // elements per tap bank in LDS
     int x_offset_bytes;      // byte offset of the sample tile in LDS
     int max_span;            // samples the largest tile touches
+    int prefetch;            // arb_tiled_kernel: the next tile's samples are loaded into registers a tile ahead
+    int copyb_pad;           // samples between the end of sample copy A and the start of copy B (bank stagger)
     long long tile_out;      // outputs per tile
     long long tiles_per_channel;
     long long total_tiles;
@@ -398,7 +400,7 @@ struct mrhip_filter {
 
     // device-evaluated schedule (arb_schedule.hip, kernels_schedule.hip)
     mrhip::SchedPlan splan{};
-    int64_t sched_prefix = 65536, sched_pmax = 1 << 20, sched_device_min = 1 << 18;   // MRHIP_SCHED_* (read at create)
+    int64_t sched_prefix = 65536, sched_pmax = 1 << 22, sched_device_min = 1 << 18;   // MRHIP_SCHED_* (read at create)
     int sched_corrupt_piece = -1;                 // test hook: falsify the tables of this device piece (counted per filter)
     bool sched_use_cycle = true;
     double sched_drift = 0.0, sched_ksteps = 0.0; // running drift estimate of the stream: (true - un-rounded phase) over ksteps steps

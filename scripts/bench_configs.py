@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Secondary measurements: BASELINE.json configs 1-5 and the non-headline shapes on one MI355X.  Kernel-only figures come
-from the library's HIP-event log; wall figures include the host (Python + library + the serial FIRArbitrary phase
-recurrence).  Every row is priced against BOTH roofs: HBM (8 TB/s) with the algorithmic bytes of SURVEY.md 8d, and
-the vector ALU with the reference's 2 flops per tap -- `frac_of_strict_valu` against the rate of separately rounded
-multiply + add (the default STRICT numerics cannot fuse: half of the FMA peak, 78.6 TF f32 / 39.3 TF f64) and
-`frac_of_fma_valu` against the FMA peak (157.3 TF f32 / 78.6 TF f64, MI355X_MICROARCH.md).  Not the headline bench
-(that is bench.py); used for DESIGN.md's per-kernel table.
+"""Secondary measurements: BASELINE.json configs 1-5, the reference's own Arb-vs-Farrow benchmark shape and the non-headline
+shapes on one MI355X.  Kernel-only figures come from the library's HIP-event log; wall figures include the host (Python +
+library + whatever part of the FIRArbitrary phase schedule runs there).  Every row is priced against BOTH roofs: HBM
+(8 TB/s) with the algorithmic bytes of SURVEY.md 8d, and the vector ALU with the reference's 2 flops per tap --
+`frac_of_strict_valu` against the rate of separately rounded multiply + add (the default STRICT numerics cannot fuse: half
+of the FMA peak, 78.6 TF f32 / 39.3 TF f64) and `frac_of_fma_valu` against the FMA peak (157.3 TF f32 / 78.6 TF f64,
+MI355X_MICROARCH.md).  Not the headline bench (that is bench.py, which imports `run_rows` to put the BASELINE rows into
+its JSON line); used for DESIGN.md's per-kernel table.
 
     python scripts/bench_configs.py [names...] [--numerics fused]
 """
@@ -23,8 +24,9 @@ import torch
 import __graft_entry__ as ge
 
 pkg = ge.load_package()
-dev = torch.device("cuda", 0)
-FUSED = "--numerics" in sys.argv and sys.argv[sys.argv.index("--numerics") + 1] == "fused"
+dev = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+FUSED = __name__ == "__main__" and "--numerics" in sys.argv and sys.argv[sys.argv.index("--numerics") + 1] == "fused"
+EMIT = print                                   # run_rows() points it at a collector
 HBM_GBPS = 8000.0
 FMA_TF = {False: 157.3, True: 78.6}          # vector FMA peak, f32 / f64
 
@@ -38,7 +40,7 @@ def rand(shape, dtype):
 def run(name, h, ratio, nphi, nch, n, dtype, bytes_per_in, flops_per_in, reps=5, chunk=None, polyorder=None, per_call=False, note=None):
     """bytes_per_in / flops_per_in: algorithmic bytes and flops (2 per tap per real component) per input sample per channel"""
     x = rand((nch, n), dtype)
-    f = pkg.FIRFilter(h, ratio, nphi, polyorder, device=0, numerics=pkg.NUMERICS_FUSED if FUSED else pkg.NUMERICS_STRICT)
+    f = pkg.FIRFilter(h, ratio, nphi, polyorder, device=dev.index or 0, numerics=pkg.NUMERICS_FUSED if FUSED else pkg.NUMERICS_STRICT)
     chunk = chunk or n
     f.filt(x[:, :chunk])                       # warm-up + bind
     out_dtype = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
@@ -84,7 +86,7 @@ def run(name, h, ratio, nphi, nch, n, dtype, bytes_per_in, flops_per_in, reps=5,
            "frac_of_strict_valu": round(tflops / (FMA_TF[r_f64] / 2), 4), "frac_of_fma_valu": round(tflops / FMA_TF[r_f64], 4)}
     if note:
         out["note"] = note
-    print(json.dumps(out), flush=True)
+    EMIT(json.dumps(out))
     if per_call:
         os.environ.pop("MRHIP_CHUNKED_PER_CALL", None)
     f.close()
@@ -92,49 +94,88 @@ def run(name, h, ratio, nphi, nch, n, dtype, bytes_per_in, flops_per_in, reps=5,
     torch.cuda.empty_cache()
 
 
-h147 = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
-h128 = pkg.firdes(128, 0.5 / 4, beta=7.8562).astype(np.float32)
-harb = pkg.firdes(32 * 32, 0.45 / 32, beta=7.8562) * 32
-R147 = 147 / 160
+DEFAULT_ROWS = ["c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5", "x160", "xf64", "xmix", "xstd", "x32"]
+# what bench.py reports next to the headline: every BASELINE config on one GPU, the README's mixed precision, the reference's
+# own FIRArbitrary / FIRFarrow benchmark shape
+BENCH_ROWS = ["c2", "c3a", "c3b", "c4", "c4f", "c5", "xmix64", "af"]
 
-which = [a for a in sys.argv[1:] if not a.startswith("--") and a not in ("strict", "fused")] or ["c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5", "x160", "xf64", "xmix", "xstd", "x32"]
-if "c1" in which:
-    run("C1 rational 147//160 f32 1ch x 1e6 (one call)", h147, Fraction(147, 160), 32, 1, 1_000_000, torch.float32, 7.675, 48 * R147)
-if "c2" in which:
-    run("C2 rational 147//160 f32 1ch x 1e8 in 1e6 chunks (resident signal: mrhip_filt_device_chunked)", h147, Fraction(147, 160), 32, 1, 100_000_000, torch.float32, 7.675, 48 * R147, reps=3, chunk=1_000_000)
-if "c2s" in which:
-    run("C2s the same, one launch per arriving 1e6-sample chunk (MRHIP_CHUNKED_PER_CALL=1)", h147, Fraction(147, 160), 32, 1, 100_000_000, torch.float32, 7.675, 48 * R147, reps=2, chunk=1_000_000, per_call=True)
-if "c3a" in which:
-    run("C3a interpolator 4//1 128 taps c64 256ch x 1e6", h128, Fraction(4, 1), 32, 256, 1_000_000, torch.complex64, 40.0, 2 * 2 * 32 * 4)
-if "c3b" in which:
-    run("C3b decimator 1//4 128 taps c64 256ch x 1e6", h128, Fraction(1, 4), 32, 256, 1_000_000, torch.complex64, 10.0, 2 * 2 * 128 / 4)
-if "c4" in which:
-    run("C4 arbitrary pi/3 32x32 taps f64 64ch x 1e7", harb, float(math.pi / 3), 32, 64, 10_000_000, torch.float64, 8 + 8 * math.pi / 3, (2 * 64 + 2) * math.pi / 3, reps=2)
-if "c4f" in which:
-    run("C4f farrow pi/3 32x32 taps polyorder 4 f64 64ch x 1e7", harb, float(math.pi / 3), 32, 64, 10_000_000, torch.float64, 8 + 8 * math.pi / 3, (2 * 32 + 2 * 4 * 32 / 64) * math.pi / 3, reps=2, polyorder=4,
-        note="flops include the Float64 Horner evaluation of the 32 taps of every output index, done once for all 64 channels")
-if "c5" in which:
-    run("C5 rational 147//160 c64 512ch x 1e6 (one GPU's shard of 4096)", h147, Fraction(147, 160), 32, 512, 1_000_000, torch.complex64, 15.35, 2 * 48 * R147)
 
-# shapes outside BASELINE.json (where the non-headline kernels stand)
-if "x160" in which:
-    h160 = pkg.firdes(24 * 160, 0.5 / 160, beta=7.8562).astype(np.float32)
-    run("X rational 160//147 (44.1k->48k) f32 64ch x 1e6", h160, Fraction(160, 147), 32, 64, 1_000_000, torch.float32, 4 + 4 * 160 / 147, 48 * 160 / 147)
-if "xf64" in which:
-    run("X rational 147//160 f64 64ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 64, 1_000_000, torch.float64, 2 * 7.675, 48 * R147)
-if "xmix" in which:
-    # the reference's own published benchmark (README.md:172-193): firdes returns Float64 taps, x = rand(Float32, 1_000_000)
-    # -> Float64 output (Filters.jl:581); 0.0569 s = 17.56 Msamples/s on unnamed 2014 hardware, one channel
-    run("X README mixed precision: 147//160 Float64 taps x Float32 samples -> Float64, 64ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 64, 1_000_000,
-        torch.float32, 4 + 8 * R147, 48 * R147, note="reference README.md:172-193: 17.56 Msamples/s in (0.0569 s for 1e6 samples, 1 channel, Julia 0.3, unnamed 2014 CPU)")
-    run("X README mixed precision, the README's own size: 1ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 1, 1_000_000,
-        torch.float32, 4 + 8 * R147, 48 * R147, note="reference README.md:172-193: 0.0569 s per call = 17.56 Msamples/s")
-if "xstd" in which:
-    run("X standard 1//1 128 taps f32 64ch x 4e6", h128, Fraction(1, 1), 32, 64, 4_000_000, torch.float32, 8.0, 2 * 128)
-if "x32" in which:
-    h32 = pkg.firdes(24 * 3, 0.5 / 3, beta=7.8562).astype(np.float32)
-    run("X rational 3//2 f32 64ch x 1e6", h32, Fraction(3, 2), 32, 64, 1_000_000, torch.float32, 4 + 6, 48 * 1.5)
-    run("X rational 2//3 f32 64ch x 1e6", h32, Fraction(2, 3), 32, 64, 1_000_000, torch.float32, 4 + 8 / 3, 72 * 2 / 3)
-if "xc32" in which:   # the headline's launch size (491 MB) on the ComplexF32 kernel: 32 complex channels x 1e6 per launch
-    run("X rational 147//160 c64 32ch x 2e7 in 1e6 chunks, per call", h147, Fraction(147, 160), 32, 32, 20_000_000, torch.complex64, 15.35, 2 * 48 * R147, reps=3, chunk=1_000_000, per_call=True)
-    run("X rational 147//160 f32 64ch x 2e7 in 1e6 chunks, per call", h147, Fraction(147, 160), 32, 64, 20_000_000, torch.float32, 7.675, 48 * R147, reps=3, chunk=1_000_000, per_call=True)
+def rows(which):
+    h147 = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    h128 = pkg.firdes(128, 0.5 / 4, beta=7.8562).astype(np.float32)
+    harb = pkg.firdes(32 * 32, 0.45 / 32, beta=7.8562) * 32
+    R147 = 147 / 160
+
+    if "c1" in which:
+        run("C1 rational 147//160 f32 1ch x 1e6 (one call)", h147, Fraction(147, 160), 32, 1, 1_000_000, torch.float32, 7.675, 48 * R147)
+    if "c2" in which:
+        run("C2 rational 147//160 f32 1ch x 1e8 in 1e6 chunks (resident signal: mrhip_filt_device_chunked)", h147, Fraction(147, 160), 32, 1, 100_000_000, torch.float32, 7.675, 48 * R147, reps=3, chunk=1_000_000)
+    if "c2s" in which:
+        run("C2s the same, one launch per arriving 1e6-sample chunk (MRHIP_CHUNKED_PER_CALL=1)", h147, Fraction(147, 160), 32, 1, 100_000_000, torch.float32, 7.675, 48 * R147, reps=2, chunk=1_000_000, per_call=True)
+    if "c3a" in which:
+        run("C3a interpolator 4//1 128 taps c64 256ch x 1e6", h128, Fraction(4, 1), 32, 256, 1_000_000, torch.complex64, 40.0, 2 * 2 * 32 * 4)
+    if "c3b" in which:
+        run("C3b decimator 1//4 128 taps c64 256ch x 1e6", h128, Fraction(1, 4), 32, 256, 1_000_000, torch.complex64, 10.0, 2 * 2 * 128 / 4)
+    if "c4" in which:
+        run("C4 arbitrary pi/3 32x32 taps f64 64ch x 1e7", harb, float(math.pi / 3), 32, 64, 10_000_000, torch.float64, 8 + 8 * math.pi / 3, (2 * 64 + 2) * math.pi / 3, reps=2)
+    if "c4f" in which:
+        run("C4f farrow pi/3 32x32 taps polyorder 4 f64 64ch x 1e7", harb, float(math.pi / 3), 32, 64, 10_000_000, torch.float64, 8 + 8 * math.pi / 3, (2 * 32 + 2 * 4 * 32 / 64) * math.pi / 3, reps=2, polyorder=4,
+            note="flops include the Float64 Horner evaluation of the 32 taps of every output index, done once for all 64 channels")
+    if "c5" in which:
+        run("C5 rational 147//160 c64 512ch x 1e6 (one GPU's shard of 4096)", h147, Fraction(147, 160), 32, 512, 1_000_000, torch.complex64, 15.35, 2 * 48 * R147)
+
+    # shapes outside BASELINE.json (where the non-headline kernels stand)
+    if "x160" in which:
+        h160 = pkg.firdes(24 * 160, 0.5 / 160, beta=7.8562).astype(np.float32)
+        run("X rational 160//147 (44.1k->48k) f32 64ch x 1e6", h160, Fraction(160, 147), 32, 64, 1_000_000, torch.float32, 4 + 4 * 160 / 147, 48 * 160 / 147)
+    if "xf64" in which:
+        run("X rational 147//160 f64 64ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 64, 1_000_000, torch.float64, 2 * 7.675, 48 * R147)
+    if "xmix" in which:
+        # the reference's own published benchmark (README.md:172-193): firdes returns Float64 taps, x = rand(Float32, 1_000_000)
+        # -> Float64 output (Filters.jl:581); 0.0569 s = 17.56 Msamples/s on unnamed 2014 hardware, one channel
+        run("X README mixed precision: 147//160 Float64 taps x Float32 samples -> Float64, 64ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 64, 1_000_000,
+            torch.float32, 4 + 8 * R147, 48 * R147, note="reference README.md:172-193: 17.56 Msamples/s in (0.0569 s for 1e6 samples, 1 channel, Julia 0.3, unnamed 2014 CPU)")
+        run("X README mixed precision, the README's own size: 1ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 1, 1_000_000,
+            torch.float32, 4 + 8 * R147, 48 * R147, note="reference README.md:172-193: 0.0569 s per call = 17.56 Msamples/s")
+    if "xstd" in which:
+        run("X standard 1//1 128 taps f32 64ch x 4e6", h128, Fraction(1, 1), 32, 64, 4_000_000, torch.float32, 8.0, 2 * 128)
+    if "x32" in which:
+        h32 = pkg.firdes(24 * 3, 0.5 / 3, beta=7.8562).astype(np.float32)
+        run("X rational 3//2 f32 64ch x 1e6", h32, Fraction(3, 2), 32, 64, 1_000_000, torch.float32, 4 + 6, 48 * 1.5)
+        run("X rational 2//3 f32 64ch x 1e6", h32, Fraction(2, 3), 32, 64, 1_000_000, torch.float32, 4 + 8 / 3, 72 * 2 / 3)
+    if "xc32" in which:   # the headline's launch size (491 MB) on the ComplexF32 kernel: 32 complex channels x 1e6 per launch
+        run("X rational 147//160 c64 32ch x 2e7 in 1e6 chunks, per call", h147, Fraction(147, 160), 32, 32, 20_000_000, torch.complex64, 15.35, 2 * 48 * R147, reps=3, chunk=1_000_000, per_call=True)
+        run("X rational 147//160 f32 64ch x 2e7 in 1e6 chunks, per call", h147, Fraction(147, 160), 32, 64, 20_000_000, torch.float32, 7.675, 48 * R147, reps=3, chunk=1_000_000, per_call=True)
+
+    if "xmix64" in which:
+        run("X README mixed precision: 147//160 Float64 taps x Float32 samples -> Float64, 64ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 64, 1_000_000,
+            torch.float32, 4 + 8 * R147, 48 * R147, note="reference README.md:172-193: 17.56 Msamples/s in (0.0569 s for 1e6 samples, 1 channel, Julia 0.3, unnamed 2014 CPU)")
+    if "af" in which:
+        # examples/Arb-Farrow Speed Comparison.jl:38-54: N𝜙 = 32, 10 taps per phase, polyorder 4, x = rand(Tx, 10_000_000), ONE channel,
+        # rates 1.0 and 1/2.123456789, Tx in (Float32, Float64, Complex64, Complex128); h = firdes(...) .* N𝜙 is Float64 there (the
+        # script's `Th = Float32` is never applied); the reference prints samples/s and records no result
+        haf = pkg.firdes(320, 0.45 / 32, beta=7.8562) * 32
+        for rate in (1.0, 1 / 2.123456789):
+            for dt, sb in ((torch.float32, 4), (torch.float64, 8), (torch.complex64, 8), (torch.complex128, 16)):
+                nc = 2 if dt.is_complex else 1
+                ob = 8 * nc                                   # Float64 taps: the output is Float64 / ComplexF64
+                for kind, po in (("FIRArbitrary", None), ("FIRFarrow", 4)):
+                    fl = (2 * 20 + 2 if po is None else 2 * 10) * nc * rate
+                    run(f"AF {kind} rate {rate:.9g} {str(dt).replace('torch.', '')} 1ch x 1e7 (Arb-Farrow Speed Comparison.jl shape)", haf, float(rate), 32, 1,
+                        10_000_000, dt, sb + ob * rate, fl, reps=2, polyorder=po)
+
+
+def run_rows(which, reps_note=None):
+    """The rows named in `which` as a list of dicts (bench.py)."""
+    global EMIT
+    got = []
+    EMIT = lambda line: got.append(json.loads(line))
+    try:
+        rows(which)
+    finally:
+        EMIT = print
+    return got
+
+
+if __name__ == "__main__":
+    rows([a for a in sys.argv[1:] if not a.startswith("--") and a not in ("strict", "fused")] or DEFAULT_ROWS)

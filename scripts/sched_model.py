@@ -228,7 +228,7 @@ def stream(delta: float, Nphi: int, total_steps: int, acc0: float = 1.0, x0: int
         xs2, accs2 = periodic(accs, xs, x, Q, m + 1)
         return np.concatenate([xs, xs2[:m]]), np.concatenate([accs, accs2[:m]]), float(accs2[m]), int(xs2[m]), stats
     while done < total_steps:
-        P = min(pmax, done, total_steps - done) // LSEG * LSEG
+        P = min(pmax, 16 * done, total_steps - done) // LSEG * LSEG      # a piece up to 16x the drift baseline behind it
         if P == 0 or not plan.ok:
             xs, accs, acc, x = serial(acc, x, delta, Nphi, total_steps - done)
             xs_all.append(xs)
