@@ -567,8 +567,19 @@ int mrhip_set_history(mrhip_filter *f, const void *host_in)
     hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
     if (stream_is_capturing(s)) return fail(MRHIP_ERR_UNSUPPORTED, "set_history while the filter's stream is being captured");
     const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
-    if (bytes) MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_hist[f->hist_cur], host_in, bytes, hipMemcpyHostToDevice, s));
-    MRHIP_CHECK_HIP(hipStreamSynchronize(s));
+    if (bytes && hipMemcpyAsync(f->d_hist[f->hist_cur], host_in, bytes, hipMemcpyHostToDevice, s) != hipSuccess) {
+        // the stream of the filter's last call no longer exists (the caller destroyed it): everything it carried has
+        // either run or gone with it -- order behind the whole device once and carry on on the filter's own stream
+        (void)hipGetLastError();
+        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        s = f->own_stream;
+        MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_hist[f->hist_cur], host_in, bytes, hipMemcpyHostToDevice, s));
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipGetLastError();
+        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        s = f->own_stream;
+    }
     f->last_stream = s; f->last_stream_valid = true;
     return MRHIP_OK;
 }
@@ -581,8 +592,18 @@ int mrhip_reset(mrhip_filter *f)
     // the next filt call is on that stream too, or waits for it (adopt_stream).
     hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
     const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
-    if (bytes) MRHIP_CHECK_HIP(hipMemsetAsync(f->d_hist[f->hist_cur], 0, bytes, s));
-    MRHIP_CHECK_HIP(hipMemsetAsync(f->d_counters, 0, mrhip::kCounterBytes, s));
+    auto zero_on = [&](hipStream_t st) -> hipError_t {
+        if (bytes) { hipError_t e = hipMemsetAsync(f->d_hist[f->hist_cur], 0, bytes, st); if (e != hipSuccess) return e; }
+        return hipMemsetAsync(f->d_counters, 0, mrhip::kCounterBytes, st);
+    };
+    if (zero_on(s) != hipSuccess) {
+        // the stream of the filter's last call no longer exists (torch side streams come and go): like adopt_stream,
+        // order behind the whole device once and carry on on the filter's own stream
+        (void)hipGetLastError();
+        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        s = f->own_stream;
+        MRHIP_CHECK_HIP(zero_on(s));
+    }
     f->last_stream = s; f->last_stream_valid = true;
     f->phiIdx = 1; f->inputDeficit = 1; f->xIdx = 1; f->phiAcc = 1.0; f->alpha = 0.0;
     f->sched_cached = false;
@@ -1071,36 +1092,48 @@ int mrhip_filt_host(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_str
     int64_t k = 0;
     int it = 0;
     bool used[2] = {false, false};
+    // any failure inside the loop: copies that touch the caller's x / y may still be in flight on s_in / s_out, and the
+    // pieces already filtered have advanced the filter -- drain the three streams and report how far the call got
+    auto bail = [&](int rc) -> int {
+        (void)hipStreamSynchronize(f->s_in); (void)hipStreamSynchronize(sk); (void)hipStreamSynchronize(f->s_out);
+        (void)hipGetLastError();
+        if (n_written) *n_written = k;
+        return rc;
+    };
+#define MRHIP_HOSTPATH_HIP(expr)                                                                          \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return bail(fail(MRHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+    } while (0)
     for (int64_t a = 0; a < x_len; a += piece, ++it) {
         const int sl = it & 1;
         const int64_t len = std::min<int64_t>(piece, x_len - a);
         const size_t xrow = static_cast<size_t>(len) * xe;
         // the x slot is free once the kernel of two pieces ago has run; the y slot once its D2H copy has
-        if (used[sl]) MRHIP_CHECK_HIP(hipStreamWaitEvent(f->s_in, f->ev_k[sl], 0));
-        MRHIP_CHECK_HIP(hipMemcpy2DAsync(f->d_xbuf[sl], xrow, static_cast<const unsigned char *>(x) + static_cast<size_t>(a) * xe, x_pitch, xrow,
+        if (used[sl]) MRHIP_HOSTPATH_HIP(hipStreamWaitEvent(f->s_in, f->ev_k[sl], 0));
+        MRHIP_HOSTPATH_HIP(hipMemcpy2DAsync(f->d_xbuf[sl], xrow, static_cast<const unsigned char *>(x) + static_cast<size_t>(a) * xe, x_pitch, xrow,
                                          static_cast<size_t>(f->nch), hipMemcpyHostToDevice, f->s_in));
-        MRHIP_CHECK_HIP(hipEventRecord(f->ev_in[sl], f->s_in));
-        MRHIP_CHECK_HIP(hipStreamWaitEvent(sk, f->ev_in[sl], 0));
-        if (used[sl]) MRHIP_CHECK_HIP(hipStreamWaitEvent(sk, f->ev_out[sl], 0));
+        MRHIP_HOSTPATH_HIP(hipEventRecord(f->ev_in[sl], f->s_in));
+        MRHIP_HOSTPATH_HIP(hipStreamWaitEvent(sk, f->ev_in[sl], 0));
+        if (used[sl]) MRHIP_HOSTPATH_HIP(hipStreamWaitEvent(sk, f->ev_out[sl], 0));
         const int64_t cap = std::min<int64_t>(y_piece_cap, count - k);
         int64_t nw = 0;
         // (an undersized slot cannot happen: y_piece_cap bounds every piece; the whole call was checked against y_capacity)
         if (int rc = filt_device_one(f, f->d_xbuf[sl], len, len, f->d_ybuf[sl], cap, std::max<int64_t>(cap, 1), &nw, sk, a > 0)) {
-            (void)hipStreamSynchronize(f->s_in); (void)hipStreamSynchronize(sk); (void)hipStreamSynchronize(f->s_out);
-            if (n_written) *n_written = k;
-            return rc;
+            return bail(rc);
         }
-        MRHIP_CHECK_HIP(hipEventRecord(f->ev_k[sl], sk));
+        MRHIP_HOSTPATH_HIP(hipEventRecord(f->ev_k[sl], sk));
         if (nw > 0) {
-            MRHIP_CHECK_HIP(hipStreamWaitEvent(f->s_out, f->ev_k[sl], 0));
+            MRHIP_HOSTPATH_HIP(hipStreamWaitEvent(f->s_out, f->ev_k[sl], 0));
             const size_t yrow = static_cast<size_t>(nw) * ye;
-            MRHIP_CHECK_HIP(hipMemcpy2DAsync(static_cast<unsigned char *>(y) + static_cast<size_t>(k) * ye, y_pitch, f->d_ybuf[sl],
+            MRHIP_HOSTPATH_HIP(hipMemcpy2DAsync(static_cast<unsigned char *>(y) + static_cast<size_t>(k) * ye, y_pitch, f->d_ybuf[sl],
                                              static_cast<size_t>(std::max<int64_t>(cap, 1)) * ye, yrow, static_cast<size_t>(f->nch), hipMemcpyDeviceToHost, f->s_out));
         }
-        MRHIP_CHECK_HIP(hipEventRecord(f->ev_out[sl], f->s_out));
+        MRHIP_HOSTPATH_HIP(hipEventRecord(f->ev_out[sl], f->s_out));
         used[sl] = true;
         k += nw;
     }
+#undef MRHIP_HOSTPATH_HIP
     MRHIP_CHECK_HIP(hipStreamSynchronize(f->s_out));
     MRHIP_CHECK_HIP(hipStreamSynchronize(sk));
     if (n_written) *n_written = k;

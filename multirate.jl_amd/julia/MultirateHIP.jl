@@ -13,9 +13,9 @@
 module MultirateHIP
 
 export FIRFilter, FIRKernel, FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary, FIRFarrow,
-       filt, filt!, taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, polyfit,
+       filt, filt!, taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, tapsforphase!, polyfit,
        firdes, firprototype, kaiserlength, kaiser, FIRResponse, LOWPASS, BANDPASS, HIGHPASS, BANDSTOP,
-       FilterCascade, filt_device!, filt_device_chunked!
+       FilterCascade, filt_device!, filt_device_chunked!, scheduleinfo
 
 const libmr = get(ENV, "MRHIP_LIB_PATH", joinpath(@__DIR__, "..", "libmultirate_hip.so"))
 
@@ -123,6 +123,55 @@ function state(f::FIRFilter)
     st[]
 end
 
+# `self.kernel` -- the reference's filter object exposes its kernel struct, and its own example reads and writes the
+# streaming fields through it (examples/FIRFarrow.jl:23,29: `kernel = myfilter.kernel; kernel.inputDeficit += throwaway`).
+# Here the state lives behind the C ABI, so `f.kernel` is a proxy whose fields -- the reference's names, src/Filters.jl:15-147 --
+# read mrhip_get_state and write mrhip_set_state.  (Type the Unicode names as in the reference: \itphi<tab>Idx, \alpha<tab>.)
+struct KernelProxy{Tk<:FIRKernel}
+    filter::FIRFilter{Tk}
+end
+function Base.getproperty(f::FIRFilter, name::Symbol)
+    name === :kernel ? KernelProxy(f) : getfield(f, name)
+end
+Base.propertynames(::FIRFilter) = (fieldnames(FIRFilter)..., :kernel)
+function Base.getproperty(k::KernelProxy, name::Symbol)
+    f = getfield(k, :filter)
+    name === :filter && return f
+    getfield(f, :handle) == C_NULL && error("the kernel fields need a bound filter (call filt once)")
+    st = state(f)
+    name === :inputDeficit ? Int(st.inputDeficit) :
+    name === Symbol("𝜙Idx") ? (f isa FIRFilter{FIRFarrow} ? st.phiAccumulator : Int(st.phiIdx)) :     # FIRFarrow.𝜙Idx is the Float64 phase (:131)
+    name === Symbol("𝜙Accumulator") ? st.phiAccumulator :
+    name === Symbol("α") ? st.alpha :
+    name === Symbol("Δ") ? st.delta :
+    name === :xIdx ? Int(st.xIdx) :
+    name === :rate ? st.rate :
+    name === Symbol("N𝜙") ? Int(st.Nphi) :
+    name === Symbol("tapsPer𝜙") ? Int(st.tapsPerPhi) :
+    name === :hLen ? Int(st.hLen) :
+    name === :interpolation ? Int(st.interpolation) :
+    name === :decimation ? Int(st.decimation) :
+    name === :ratio ? getfield(f, :ratio) :
+    error("the kernel has no field $(name)")
+end
+function Base.setproperty!(k::KernelProxy, name::Symbol, v)
+    f = getfield(k, :filter)
+    getfield(f, :handle) == C_NULL && error("the kernel fields need a bound filter (call filt once)")
+    st = state(f)
+    if name === :inputDeficit
+        setstate!(f, st.phiIdx, Int(v), st.phiAccumulator)
+    elseif name === Symbol("𝜙Idx")
+        f isa FIRFilter{FIRFarrow} ? setstate!(f, 1, st.inputDeficit, Float64(v)) : setstate!(f, Int(v), st.inputDeficit, st.phiAccumulator)
+    elseif name === Symbol("𝜙Accumulator")
+        setstate!(f, st.phiIdx, st.inputDeficit, Float64(v))
+    elseif name === Symbol("α")                        # 𝜙Accumulator = 𝜙Idx + α (Filters.jl:671-672)
+        setstate!(f, st.phiIdx, st.inputDeficit, floor(st.phiAccumulator) + Float64(v))
+    else
+        error("the kernel field $(name) cannot be set")
+    end
+    v
+end
+
 # ---- bookkeeping ---------------------------------------------------------------------------------
 # taps2pfb(h, Nphi)                                        src/Filters.jl:284-298
 function taps2pfb(h::Vector{T}, Nphi::Integer) where {T<:Union{Float32,Float64}}
@@ -165,6 +214,24 @@ function tapsforphase(f::FIRFilter{FIRArbitrary}, phase::Real)
     check(ccall((:mrhip_arbitrary_tapsforphase, libmr), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Cvoid}), f.handle, Float64(phase), taps))
     taps
 end
+# tapsforphase!(buffer, kernel, phase)                     src/Filters.jl:677-688, :764-773 (exported by the reference, Multirate.jl:36)
+function tapsforphase!(buffer::Vector, f::FIRFilter{Tk}, phase::Real) where {Tk<:Union{FIRArbitrary,FIRFarrow}}
+    taps = tapsforphase(f, phase)
+    length(buffer) >= length(taps) || error("buffer is too small")
+    copyto!(buffer, 1, taps, 1, length(taps))
+    buffer
+end
+tapsforphase!(buffer::Vector, k::KernelProxy, phase::Real) = tapsforphase!(buffer, getfield(k, :filter), phase)
+tapsforphase(k::KernelProxy, phase::Real) = tapsforphase(getfield(k, :filter), phase)
+setphase(k::KernelProxy, phi::Real) = setphase(getfield(k, :filter), phi)          # setphase(kernel, 𝜙), Filters.jl:210-232
+
+# How the phase schedule of a FIRArbitrary / FIRFarrow filter has been evaluated so far (mrhip_schedule_info)
+function scheduleinfo(f::FIRFilter{Tk}) where {Tk<:Union{FIRArbitrary,FIRFarrow}}
+    v = zeros(Int64, 8)
+    check(ccall((:mrhip_schedule_info, libmr), Cint, (Ptr{Cvoid}, Ptr{Int64}, Cint), f.handle, v, 8))
+    (device_ok = v[1] != 0, ncand = v[2], nwin = v[3], period = v[4], host_steps = v[5], periodic_steps = v[6], device_pieces = v[7], fallback_pieces = v[8])
+end
+
 # setphase(self::FIRFilter, 𝜙), 𝜙 in [0, 1]                src/Filters.jl:210-235.  The reference's methods for
 # FIRInterpolator/FIRRational read an undefined variable (:212); implemented with the evident intent
 # (𝜙Idx = floor(𝜙*N𝜙)+1 clipped to N𝜙); FIRArbitrary and FIRFarrow as written (:217-229).

@@ -227,12 +227,58 @@ def test_julia_shim_ccalls_match_header():
             n = 0 if not inner else len(re.sub(r"\{[^{}]*\}", "", re.sub(r"\{[^{}]*\}", "", inner)).split(","))
             assert n == arity[name], f"{name}: shim passes {n} arguments, header declares {arity[name]}"
         seen.add(name)
+    # ... and with the header's parameter and return TYPES (Cint <-> int / enum, Int64 <-> int64_t, Cdouble <-> double,
+    # Ptr{...} / Cstring <-> pointer): a swapped Cint / Int64 would pass the arity check and corrupt the call
+    def c_class(t):
+        t = re.sub(r"\bconst\b", "", t).strip()
+        if "*" in t:
+            return "ptr"
+        base = t.split()[0] if t.split() else t
+        return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "double": "f64", "void": "void", "mrhip_status": "i32",
+                "mrhip_dtype": "i32", "mrhip_kind": "i32", "mrhip_numerics": "i32", "size_t": "u64"}[base]
+
+    def jl_class(t):
+        t = t.strip()
+        if t.startswith("Ptr") or t.startswith("Ref") or t == "Cstring":
+            return "ptr"
+        return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Cdouble": "f64", "Float64": "f64", "Cvoid": "void", "Csize_t": "u64"}[t]
+
+    proto = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(mrhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+        ptypes = []
+        if params not in ("", "void"):
+            for prm in params.split(","):
+                prm = prm.strip()
+                ptypes.append(c_class(prm if "*" in prm else " ".join(prm.split()[:-1])))
+        proto[name] = (c_class(ret), ptypes)
+    checked = 0
+    for m in re.finditer(r"ccall\(\(:(mrhip_[a-z0-9_]+), libmr\),\s*(\w+),\s*(\w+|\((?:[^()]|\([^()]*\))*\))", jl):
+        name, ret, argt = m.group(1), m.group(2), m.group(3)
+        if not argt.startswith("("):          # a named tuple of argument types (`args`): resolved below
+            defs = [t for t in re.finditer(r"\b" + argt + r"\s*=\s*(\((?:[^()]|\([^()]*\))*\))", jl) if t.start() < m.start()]
+            assert defs, f"{name}: cannot resolve the argument-type tuple `{argt}`"
+            argt = defs[-1].group(1)                    # the nearest definition above the call
+        inner = argt[1:-1].strip().rstrip(",")
+        flat = re.sub(r"\{[^{}]*\}", "", re.sub(r"\{[^{}]*\}", "", inner))
+        jt = [jl_class(a) for a in flat.split(",")] if flat else []
+        want_ret, want = proto[name]
+        assert jl_class(ret) == want_ret, f"{name}: shim return {ret}, header {want_ret}"
+        assert jt == want, f"{name}: shim argument types {jt}, header {want}"
+        checked += 1
+    assert checked >= 30
     # the shim binds the whole design / cascade / hot-path surface
     for must in ("mrhip_firdes", "mrhip_firdes_kaiser", "mrhip_firprototype", "mrhip_kaiserlength", "mrhip_kaiser",
                  "mrhip_arbitrary_tapsforphase", "mrhip_farrow_tapsforphase", "mrhip_cascade_create", "mrhip_cascade_filt_device",
                  "mrhip_filt_host", "mrhip_filt_device", "mrhip_filt_device_chunked", "mrhip_create_rational",
-                 "mrhip_create_arbitrary", "mrhip_create_farrow", "mrhip_get_state", "mrhip_set_state", "mrhip_reset"):
+                 "mrhip_create_arbitrary", "mrhip_create_farrow", "mrhip_get_state", "mrhip_set_state", "mrhip_reset", "mrhip_schedule_info"):
         assert must in seen, must
+    # the reference's exported names (src/Multirate.jl:26-41) and the kernel-field access of its own example (examples/FIRFarrow.jl:23-30)
+    for name in ("tapsforphase!", "tapsforphase", "setphase", "reset", "outputlength", "inputlength", "taps2pfb", "filt!", "filt", "firdes", "kaiserlength"):
+        assert re.search(r"export[^#]*\b" + re.escape(name), jl, flags=re.S), name
+    assert "Base.getproperty(f::FIRFilter, name::Symbol)" in jl and "name === :kernel" in jl
+    for field in (":inputDeficit", '"𝜙Idx"', '"α"', '"𝜙Accumulator"'):
+        assert field in jl
 
 
 def test_product_path_fails_loudly_without_gpu(pkg):

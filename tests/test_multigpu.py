@@ -33,26 +33,57 @@ def _gpu_count():
 
 
 def _run_ranks(world, backend, channels=37, timeout=600):
+    """All ranks are polled together; output goes to temporary files (a chatty rank cannot stall on a full pipe while another
+    is being drained); on the first non-zero exit the others are ended at once (they would wait at the rendezvous or in a
+    collective until their own timeout) and the failing rank's output is what the assertion shows."""
+    import tempfile
+    import time
     env = dict(os.environ)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                MRHIP_TEST_BACKEND=backend, MRHIP_TEST_CHANNELS=str(channels))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = []
-    for r in range(world):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, WORKER], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
-    try:
-        for p in procs:
-            out, err = p.communicate(timeout=timeout)
-            outs.append((p.returncode, out, err))
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    for rc, out, err in outs:
-        assert rc == 0, f"rank failed (rc={rc}):\n{out}\n{err[-4000:]}"
-    return outs[0][1]
+    procs, files = [], []
+    with tempfile.TemporaryDirectory() as tmp:
+        for r in range(world):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            fo, fe = open(os.path.join(tmp, f"out{r}"), "w+"), open(os.path.join(tmp, f"err{r}"), "w+")
+            files.append((fo, fe))
+            procs.append(subprocess.Popen([sys.executable, WORKER], env=e, stdout=fo, stderr=fe, text=True))
+        deadline = time.monotonic() + timeout
+        failed = None
+        try:
+            pending = set(range(world))
+            while pending and failed is None:
+                for r in sorted(pending):
+                    rc = procs[r].poll()
+                    if rc is None:
+                        continue
+                    pending.discard(r)
+                    if rc != 0:
+                        failed = r
+                        break
+                if time.monotonic() > deadline:
+                    failed = min(pending) if pending else None
+                    break
+                time.sleep(0.05)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        texts = []
+        for fo, fe in files:
+            fo.seek(0); fe.seek(0)
+            texts.append((fo.read(), fe.read()))
+            fo.close(); fe.close()
+    if failed is not None:
+        out, err = texts[failed]
+        raise AssertionError(f"rank {failed} failed or timed out (rc={procs[failed].returncode}):\n{out}\n{err[-4000:]}")
+    return texts[0][0]
 
 
 @pytest.mark.gpu
