@@ -21,7 +21,7 @@ for d in sys.argv[1:]:
         meta = {}
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if not k.startswith(("poly", "arb", "shiftin", "deci", "rational", "fir", "interp", "farrow")):
+            if not k.startswith(("poly", "arb", "shiftin", "deci", "rational", "fir", "interp", "farrow", "sched")):
                 continue
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             # (rocprofv3's VGPR_Count / LDS_Block_Size columns are NOT reported here: for these kernels they read 40 VGPRs
