@@ -187,7 +187,7 @@ int check_create_args(const void *h, int64_t hLen, int th, int tx, int64_t nch, 
 // Kernel selection for the rational family.  Tuned kernels are tried first; the universal
 // one-thread-per-output kernel accepts everything.
 hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s,
-                       const char **kname, bool *did_shiftin)
+                       const char **kname, bool *did_shiftin, unsigned *counters)
 {
     *did_shiftin = false;
     if (!f->force_generic) {
@@ -197,7 +197,7 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
             size_t slds = 0;
             if (plan_fir_stream(tk, a, f->num_cus, &spa, &sblock, &slds)) {
                 *did_shiftin = a.H > 0;          // its loader waves write the call-end history themselves
-                return launch_fir_stream(fused, a, spa, sblock, slds, s, kname, f->num_cus, f->d_counters);
+                return launch_fir_stream(fused, a, spa, sblock, slds, s, kname, f->num_cus, counters);
             }
             DirectArgs da;
             size_t lds = 0;
@@ -210,7 +210,7 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
             size_t lds = 0;
             if (plan_rational_opair(tk, a, f->num_cus, &pa, &block, &lds)) {
                 *did_shiftin = a.H > 0;
-                return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
+                return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, counters);
             }
         }
         TileArgs ta;
@@ -764,6 +764,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
 
     int64_t n_out = 0;
     bool did_shiftin = false;
+    const int hist_next = f->hist_cur ^ 1;
     if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {
         // one range [k0, k0+cnt) of this call's outputs: schedule entries are already in the device buffers
         const size_t yelt = dtype_scalar_size(f->ty) * static_cast<size_t>(f->nc);
@@ -817,19 +818,15 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             // the schedule is evaluated on the device (arb_schedule.hip): entries, count and end state without the
             // host's serial loop; ONE filter launch for the whole call
             SchedResult sr{};
-            if (int rc = sched_run_call(f, x_len, est, &sr)) return rc;
+            if (int rc = sched_run_call(f, x_len, est, stream, &sr)) return rc;
             n_out = sr.count;
             if (n_out > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
             if (n_out > 0) {
                 if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
                 if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
-                MRHIP_CHECK_HIP(hipStreamWaitEvent(stream, f->ds_done, 0));
                 sched_dn = f->ds_n[sr.buf]; sched_dacc = f->ds_acc[sr.buf]; sched_spans = sr.max_span;
                 if (int rc = launch_range(0, n_out, nullptr)) return rc;
-                MRHIP_CHECK_HIP(hipEventRecord(f->ds_read[sr.buf], stream));
-                f->ds_read_valid[sr.buf] = true;
             }
-            f->ds_cur = sr.buf;
             f->sched_drift = sr.drift; f->sched_ksteps = sr.ksteps;
             if (sr.periodic) f->per_pos = sr.per_pos_end;
             st = sr.end;
@@ -906,7 +903,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
             if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
             PolyArgs a{};
-            a.x = x; a.y = y; a.hist = f->d_hist[f->hist_cur]; a.hist_new = f->d_hist[f->hist_cur ^ 1]; a.taps = f->d_taps;
+            a.x = x; a.y = y; a.hist = f->d_hist[f->hist_cur]; a.hist_new = f->d_hist[hist_next]; a.taps = f->d_taps;
             a.x_stride = x_stride; a.y_stride = y_stride; a.x_len = x_len; a.n_out = n_out;
             a.u0 = p.phi0 - 1; a.d0 = p.d0;
             a.zero_start_below = continuation ? 0
@@ -916,7 +913,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H);
             a.nch = static_cast<int>(f->nch);
             if (int rc = timing_mark(f, stream)) return rc;
-            MRHIP_CHECK_HIP(launch_poly(f, tk, fused, a, stream, &f->last_kernel, &did_shiftin));
+            MRHIP_CHECK_HIP(launch_poly(f, tk, fused, a, stream, &f->last_kernel, &did_shiftin, f->d_counters));
             if (int rc = timing_mark(f, stream)) return rc;
         }
         f->phiIdx = p.phi_end;
@@ -926,17 +923,17 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
     // history <- last H samples of [history ; x]   (shiftin!, support.jl:61-80), ping-pong buffers
     if (f->H > 0 && !did_shiftin) {
         HistArgs ha{};
-        ha.x = x; ha.hist_old = f->d_hist[f->hist_cur]; ha.hist_new = f->d_hist[f->hist_cur ^ 1];
+        ha.x = x; ha.hist_old = f->d_hist[f->hist_cur]; ha.hist_new = f->d_hist[hist_next];
         ha.x_stride = x_stride; ha.x_len = x_len; ha.H = static_cast<int>(f->H); ha.nch = static_cast<int>(f->nch);
         MRHIP_CHECK_HIP(launch_shiftin(tk, ha, stream));
     }
     if (f->H > 0) {
         if (capturing) {
-            // a replay reads the slot baked into the node: bring the new history back into it instead of flipping
-            MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_hist[f->hist_cur], f->d_hist[f->hist_cur ^ 1],
+            // a replay reads the slot baked into the node: bring the new history back into it instead of moving on
+            MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_hist[f->hist_cur], f->d_hist[hist_next],
                                            static_cast<size_t>(f->nch) * f->H * x_elt(f), hipMemcpyDeviceToDevice, stream));
         } else {
-            f->hist_cur ^= 1;
+            f->hist_cur = hist_next;
         }
     }
     if (n_written) *n_written = n_out;

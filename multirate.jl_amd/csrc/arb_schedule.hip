@@ -9,8 +9,8 @@
 //             emitted by one trivial kernel, counted on the host, no synchronisation.  (Rates such as 1.0, 3.0, 11/7:
 //             exactly the ones whose phase sits ON the wrap / binade thresholds, where nothing but exact states helps.)
 //   TABLES    everything else: kernels_schedule.hip, piece by piece (sizes grow with the length of the drift
-//             baseline), one host synchronisation per call for the count; a piece whose verification fails is
-//             redone by the host loop.
+//             baseline), one host synchronisation (of the caller's stream) per call for the count; a piece whose
+//             verification fails is redone by the host loop.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -50,12 +50,12 @@ double wrap_half(double d, double N)
     return d;
 }
 
-// largest n[last] - n[first] over the aligned tiles of 256 << z outputs (tile t = outputs [t*ts, (t+1)*ts) of the call)
+// largest n[last] - n[first] over the aligned tiles of kSchedSpanBase << z outputs (tile t = outputs [t*ts, (t+1)*ts) of the call)
 // as far as the host entries [0, cnt) -- outputs [k0, k0 + cnt) -- cover them
 void host_spans(const int32_t *n, int64_t cnt, int64_t k0, int *span)
 {
     for (int z = 0; z < kSchedSpanSizes; ++z) {
-        const int64_t ts = 256LL << z;
+        const int64_t ts = static_cast<int64_t>(kSchedSpanBase) << z;
         for (int64_t t0 = k0 / ts * ts; t0 < k0 + cnt; t0 += ts) {
             const int64_t first = std::max(t0, k0) - k0, last = std::min(t0 + ts, k0 + cnt) - 1 - k0;
             if (last > first) span[z] = std::max<int>(span[z], n[last] - n[first]);
@@ -63,12 +63,12 @@ void host_spans(const int32_t *n, int64_t cnt, int64_t k0, int *span)
     }
 }
 
-int ensure_pinned(mrhip_filter *f, size_t n)
+int ensure_pinned(mrhip_filter *f, size_t n, hipStream_t st)
 {
     if (n <= f->pin_cap) return MRHIP_OK;
     const size_t cap = std::max<size_t>(n + n / 4, 4096);
     if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
-    MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
+    MRHIP_CHECK_HIP(hipStreamSynchronize(st));
     if (f->pin_n) (void)hipHostFree(f->pin_n);
     if (f->pin_acc) (void)hipHostFree(f->pin_acc);
     f->pin_n = f->pin_acc = nullptr;
@@ -79,12 +79,11 @@ int ensure_pinned(mrhip_filter *f, size_t n)
     return MRHIP_OK;
 }
 
-int ensure_ds(mrhip_filter *f, int b, size_t n)
+int ensure_ds(mrhip_filter *f, int b, size_t n, hipStream_t st)
 {
     if (n <= f->ds_cap[b]) return MRHIP_OK;
     const size_t cap = n + n / 8 + 4096;
-    if (f->ds_read_valid[b]) { MRHIP_CHECK_HIP(hipEventSynchronize(f->ds_read[b])); f->ds_read_valid[b] = false; }
-    MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
+    MRHIP_CHECK_HIP(hipStreamSynchronize(st));
     if (f->ds_n[b]) (void)hipFree(f->ds_n[b]);
     if (f->ds_acc[b]) (void)hipFree(f->ds_acc[b]);
     f->ds_n[b] = f->ds_acc[b] = nullptr;
@@ -95,11 +94,11 @@ int ensure_ds(mrhip_filter *f, int b, size_t n)
     return MRHIP_OK;
 }
 
-int ensure_work(mrhip_filter *f, int64_t groups, int64_t pieces)
+int ensure_work(mrhip_filter *f, int64_t groups, int64_t pieces, hipStream_t st)
 {
     const SchedPlan &c = f->splan;
     if (groups > f->ds_work_groups) {
-        MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
+        MRHIP_CHECK_HIP(hipStreamSynchronize(st));
         for (void *p : {static_cast<void *>(f->ds_pathT), static_cast<void *>(f->ds_pathW), static_cast<void *>(f->ds_gtab), static_cast<void *>(f->ds_gstart)})
             if (p) (void)hipFree(p);
         f->ds_pathT = nullptr; f->ds_pathW = nullptr; f->ds_gtab = nullptr; f->ds_gstart = nullptr;
@@ -112,7 +111,7 @@ int ensure_work(mrhip_filter *f, int64_t groups, int64_t pieces)
         f->ds_work_groups = groups;
     }
     if (pieces + 2 > f->ds_state_cap) {
-        MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
+        MRHIP_CHECK_HIP(hipStreamSynchronize(st));
         if (f->ds_state) (void)hipFree(f->ds_state);
         if (f->ds_pin_state) (void)hipHostFree(f->ds_pin_state);
         f->ds_state = nullptr; f->ds_pin_state = nullptr; f->ds_state_cap = 0;
@@ -128,13 +127,13 @@ int ensure_work(mrhip_filter *f, int64_t groups, int64_t pieces)
     return MRHIP_OK;
 }
 
-// upload host entries [0, cnt) of the pinned staging to outputs [k0, k0 + cnt) of schedule buffer b (own_stream)
-int upload_entries(mrhip_filter *f, int b, int64_t k0, int64_t cnt)
+// upload host entries [0, cnt) of the pinned staging to outputs [k0, k0 + cnt) of schedule buffer b
+int upload_entries(mrhip_filter *f, int b, int64_t k0, int64_t cnt, hipStream_t st)
 {
     if (cnt <= 0) return MRHIP_OK;
-    MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<int32_t *>(f->ds_n[b]) + k0, f->pin_n, static_cast<size_t>(cnt) * sizeof(int32_t), hipMemcpyHostToDevice, f->own_stream));
-    MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<double *>(f->ds_acc[b]) + k0, f->pin_acc, static_cast<size_t>(cnt) * sizeof(double), hipMemcpyHostToDevice, f->own_stream));
-    MRHIP_CHECK_HIP(hipEventRecord(f->sched_copied, f->own_stream));
+    MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<int32_t *>(f->ds_n[b]) + k0, f->pin_n, static_cast<size_t>(cnt) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    MRHIP_CHECK_HIP(hipMemcpyAsync(static_cast<double *>(f->ds_acc[b]) + k0, f->pin_acc, static_cast<size_t>(cnt) * sizeof(double), hipMemcpyHostToDevice, st));
+    MRHIP_CHECK_HIP(hipEventRecord(f->sched_copied, st));
     f->sched_in_flight = true;
     return MRHIP_OK;
 }
@@ -153,7 +152,7 @@ inline int64_t per_x(const mrhip_filter *f, int64_t x0, int64_t j)
 }
 
 // the state after the prefix equals a state inside it?  (host entries [0, cnt) in the pinned staging; `st` after them)
-int try_find_cycle(mrhip_filter *f, int64_t cnt, const ArbState &st)
+int try_find_cycle(mrhip_filter *f, int64_t cnt, const ArbState &st, hipStream_t stream)
 {
     const double *acc = static_cast<const double *>(f->pin_acc);
     const int32_t *n = static_cast<const int32_t *>(f->pin_n);
@@ -172,8 +171,8 @@ int try_find_cycle(mrhip_filter *f, int64_t cnt, const ArbState &st)
     if (f->per_XQ < 1) return MRHIP_OK;                 // (cannot happen: a cycle of the phase wraps at least once)
     f->per_Q = Q;
     f->per_pos = 0;
-    for (int z = 0; z < kSchedSpanSizes; ++z) {          // largest advance over (256 << z) - 1 steps, from any cycle position
-        const int64_t m = (256LL << z) - 1, full = m / Q, rem = m - full * Q;
+    for (int z = 0; z < kSchedSpanSizes; ++z) {          // largest advance over (64 << z) - 1 steps, from any cycle position
+        const int64_t m = (static_cast<int64_t>(kSchedSpanBase) << z) - 1, full = m / Q, rem = m - full * Q;
         int64_t best = 0;
         for (int64_t i = 0; i < Q; ++i) {
             const int64_t e = i + rem;
@@ -183,7 +182,7 @@ int try_find_cycle(mrhip_filter *f, int64_t cnt, const ArbState &st)
         }
         f->per_span[z] = static_cast<int>(std::min<int64_t>(full * f->per_XQ + best, 0x7fffffff));
     }
-    MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
+    MRHIP_CHECK_HIP(hipStreamSynchronize(stream));
     if (f->d_per_acc) (void)hipFree(f->d_per_acc);
     if (f->d_per_xoff) (void)hipFree(f->d_per_xoff);
     f->d_per_acc = nullptr; f->d_per_xoff = nullptr;
@@ -222,14 +221,12 @@ void sched_free(mrhip_filter *f)
     for (int b = 0; b < 2; ++b) {
         if (f->ds_n[b]) (void)hipFree(f->ds_n[b]);
         if (f->ds_acc[b]) (void)hipFree(f->ds_acc[b]);
-        if (f->ds_read[b]) (void)hipEventDestroy(f->ds_read[b]);
     }
     for (void *p : {static_cast<void *>(f->ds_pathT), static_cast<void *>(f->ds_pathW), static_cast<void *>(f->ds_gtab), static_cast<void *>(f->ds_gstart),
                     static_cast<void *>(f->ds_state), static_cast<void *>(f->ds_status), static_cast<void *>(f->d_per_acc), static_cast<void *>(f->d_per_xoff)})
         if (p) (void)hipFree(p);
     if (f->ds_pin_state) (void)hipHostFree(f->ds_pin_state);
     if (f->ds_pin_status) (void)hipHostFree(f->ds_pin_status);
-    if (f->ds_done) (void)hipEventDestroy(f->ds_done);
 }
 
 bool sched_wants_device(const mrhip_filter *f, int64_t est)
@@ -239,21 +236,22 @@ bool sched_wants_device(const mrhip_filter *f, int64_t est)
 
 // Evaluate the schedule of one call (x_len samples from the filter's current state; est = an upper bound of its output
 // count) into schedule buffer out->buf.  The state of the filter is NOT advanced (the caller commits out->end).
-int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, SchedResult *out)
+// Everything is enqueued on the CALLER's stream `s`, in front of the filter kernel that reads the schedule.  (Round 3 first ran
+// the schedule on a stream of its own, the two ordered by events: since the host waits for the schedule's count, the event was
+// complete by the time the caller's stream was told to wait for it, the runtime dropped the wait, and the filter kernel -- launched
+// back to back behind the previous call's kernel on a busy queue -- read STALE schedule entries out of one XCD's L2 whenever
+// the same buffer had been read two calls before: whole 4096-entry groups of another call's schedule, intermittently
+// (profiles/r03/experiments.md D).  Producer and consumer in one queue are ordered AND coherent by the kernel boundary.)
+int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, hipStream_t s, SchedResult *out)
 {
     const SchedPlan &c = f->splan;
-    hipStream_t s = f->own_stream;
-    const int b = f->ds_cur ^ 1;
+    const int b = 0;
     static const bool prof = env_i64("MRHIP_DEBUG", 0) == 2;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = prof ? now() : 0.0;
     double t_prefix = 0.0, t_enq = 0.0, t_wait = 0.0;
-    for (int i = 0; i < 2; ++i)
-        if (!f->ds_read[i]) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ds_read[i], hipEventDisableTiming));
-    if (!f->ds_done) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ds_done, hipEventDisableTiming));
-    if (int rc = ensure_ds(f, b, static_cast<size_t>(est + f->sched_pmax + f->sched_prefix + 2 * kSchedGroup))) return rc;
-    if (int rc = ensure_pinned(f, static_cast<size_t>(std::max<int64_t>(f->sched_prefix, f->sched_pmax) + kSchedGroup))) return rc;
-    if (f->ds_read_valid[b]) MRHIP_CHECK_HIP(hipStreamWaitEvent(s, f->ds_read[b], 0));   // the kernel that read this buffer two calls ago
+    if (int rc = ensure_ds(f, b, static_cast<size_t>(est + f->sched_pmax + f->sched_prefix + 2 * kSchedGroup), s)) return rc;
+    if (int rc = ensure_pinned(f, static_cast<size_t>(std::max<int64_t>(f->sched_prefix, f->sched_pmax) + kSchedGroup), s)) return rc;
 
     ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->inputDeficit, f->inputDeficit};   // xIdx starts at inputDeficit (Filters.jl:715)
     double drift = f->sched_drift, ksteps = f->sched_ksteps;
@@ -279,8 +277,8 @@ int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, SchedResult *out
         const int64_t cnt = run_arbitrary_schedule_piece(st, f->delta, f->Nphi, x_len, static_cast<int32_t *>(f->pin_n), static_cast<double *>(f->pin_acc), want, &done);
         host_spans(static_cast<const int32_t *>(f->pin_n), cnt, 0, out->max_span);
         if (!done && f->sched_use_cycle)
-            if (int rc = try_find_cycle(f, cnt, st)) return rc;
-        if (int rc = upload_entries(f, b, 0, cnt)) return rc;
+            if (int rc = try_find_cycle(f, cnt, st, s)) return rc;
+        if (int rc = upload_entries(f, b, 0, cnt, s)) return rc;
         if (!done) {
             drift += wrap_half(st.acc - sched_anchor_host(c, acc_start, static_cast<double>(cnt)), c.N);
             ksteps += static_cast<double>(cnt);
@@ -337,7 +335,7 @@ int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, SchedResult *out
             kk += P; ks += static_cast<double>(P);
         }
         const int64_t np = static_cast<int64_t>(pk0.size());
-        if (int rc = ensure_work(f, f->sched_pmax / kSchedGroup, np)) return rc;
+        if (int rc = ensure_work(f, f->sched_pmax / kSchedGroup, np, s)) return rc;
         if (kk > static_cast<int64_t>(f->ds_cap[b])) return fail(MRHIP_ERR_INVALID_ARG, "schedule buffer too small (internal)");
         SchedStatus *hs = f->ds_pin_status;
         hs[0] = SchedStatus{};
@@ -373,7 +371,7 @@ int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, SchedResult *out
             const int64_t cnt = run_arbitrary_schedule_piece(hst, f->delta, f->Nphi, x_len, static_cast<int32_t *>(f->pin_n), static_cast<double *>(f->pin_acc),
                                                              psteps[static_cast<size_t>(p)], &done);
             host_spans(static_cast<const int32_t *>(f->pin_n), cnt, pk0[static_cast<size_t>(p)], out->max_span);
-            if (int rc = upload_entries(f, b, pk0[static_cast<size_t>(p)], cnt)) return rc;
+            if (int rc = upload_entries(f, b, pk0[static_cast<size_t>(p)], cnt, s)) return rc;
             drift = ps[p].drift; ksteps = ps[p].ksteps;
             if (!done) {
                 drift += wrap_half(hst.acc - sched_anchor_host(c, acc_start, static_cast<double>(cnt)), c.N);
@@ -403,11 +401,10 @@ int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, SchedResult *out
     out->end = st;
     out->drift = drift;
     out->ksteps = ksteps;
-    // whoever reads the schedule on another stream waits for this event
-    MRHIP_CHECK_HIP(hipEventRecord(f->ds_done, s));
     if (prof)
-        std::fprintf(stderr, "[mrhip] device schedule: %lld outputs in %.3f ms (host prefix %.3f, enqueue %.3f, wait %.3f)%s\n", static_cast<long long>(k),
-                     (now() - t_begin) * 1e3, t_prefix * 1e3, t_enq * 1e3, t_wait * 1e3, out->periodic ? " periodic" : "");
+        std::fprintf(stderr, "[mrhip] device schedule: %lld outputs in %.3f ms (host prefix %.3f, enqueue %.3f, wait %.3f)%s spans %d %d %d %d %d\n", static_cast<long long>(k),
+                     (now() - t_begin) * 1e3, t_prefix * 1e3, t_enq * 1e3, t_wait * 1e3, out->periodic ? " periodic" : "",
+                     out->max_span[0], out->max_span[1], out->max_span[2], out->max_span[3], out->max_span[4]);
     return MRHIP_OK;
 }
 

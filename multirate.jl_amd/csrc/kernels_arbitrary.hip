@@ -509,7 +509,7 @@ bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_ho
                     max_span = std::max<long long>(max_span, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0] + a.T);
                 }
             } else {
-                max_span = static_cast<long long>(spans[to == 1024 ? 2 : (to == 512 ? 1 : 0)]) + a.T;
+                max_span = static_cast<long long>(spans[sched_span_index(to)]) + a.T;
             }
             max_span = (max_span + 2) / 2 * 2;           // even (+ room for the pair read of an odd window)
             const int copyb_pad = copies == 2 ? static_cast<int>((128 + 256 - (static_cast<size_t>(max_span) * sb * cpl) % 256) % 256 / sb) : 0;   // samples: copy B starts 128 B (mod 256) after copy A
@@ -572,7 +572,7 @@ bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_
         }
     } else {
         if (!spans) return false;
-        max_span = static_cast<long long>(spans[0]) + a.T;     // tile_out == 256
+        max_span = static_cast<long long>(spans[sched_span_index(tile_out)]) + a.T;
     }
     max_span = (max_span + 2) / 2 * 2;
     const int copyb_pad = copies == 2 ? static_cast<int>((128 + 256 - (static_cast<size_t>(max_span) * sb * cpl) % 256) % 256 / sb) : 0;

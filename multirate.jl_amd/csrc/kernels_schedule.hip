@@ -338,19 +338,18 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
         ns.ksteps = ps.ksteps + static_cast<double>(static_cast<long long>(a.ngroups) * kGroupSegs * kSeg);
         a.state[a.piece + 1] = ns;
     }
-    // largest input span of the aligned tiles of 256, 512, 1024 outputs inside this group (the filter kernel's planner
-    // sizes its LDS sample tile with them); entries past the call's end count as x_len
+    // largest input span of the aligned tiles of 64 ... 1024 outputs inside this group (the filter kernels' planners size
+    // their LDS sample tiles with them); entries past the call's end count as x_len
     {
-        int t = sl;
+        int first_task = 0;
         for (int z = 0; z < kSchedSpanSizes; ++z) {
-            const int ts = 256 << z, ntile = kGroupSegs * kSeg / ts;
-            if (t < ntile) {
+            const int ts = kSchedSpanBase << z, ntile = kGroupSegs * kSeg / ts;
+            for (int t = sl - first_task; t >= 0 && t < ntile; t += kGroupSegs) {      // tasks are dealt round the 64 lanes
                 const int e0 = t * ts, e1 = e0 + ts - 1;
                 const long long n0 = s_n[(e0 / kSeg) * (kSeg + 1) + e0 % kSeg], n1 = s_n[(e1 / kSeg) * (kSeg + 1) + e1 % kSeg];
                 if (n0 <= a.x_len) atomicMax(&a.status->max_span[z], static_cast<int>((n1 < a.x_len ? n1 : a.x_len) - n0));
-                break;
             }
-            t -= ntile;
+            first_task = (first_task + ntile) % kGroupSegs;
         }
     }
     // coalesced copy of the group's 4096 entries

@@ -79,7 +79,9 @@ constexpr int kSchedSeg = 64;                 // steps per segment
 constexpr int kSchedGroup = 64 * kSchedSeg;   // steps per group (one workgroup): pieces are whole groups
 constexpr int kSchedMaxWin = 64;              // candidates per segment the tables kernel has LDS for
 constexpr int kSchedNoFail = 0x7fffffff;
-constexpr int kSchedSpanSizes = 3;            // tile sizes (256 << i outputs) whose largest input span the emit kernel reports
+constexpr int kSchedSpanSizes = 5;            // tile sizes (kSchedSpanBase << i outputs: 64 ... 1024) whose largest input span the emit kernel reports
+constexpr int kSchedSpanBase = 64;
+inline int sched_span_index(long long tile_out) { int z = 0; while (z + 1 < kSchedSpanSizes && (static_cast<long long>(kSchedSpanBase) << z) < tile_out) ++z; return z; }
 
 struct SchedPlan {           // constants of one (delta, Nphi)
     double delta, N, invN;
@@ -102,8 +104,8 @@ struct SchedStatus {
     long long end_k;         // number of outputs of the call
     double end_acc;          // state after the last output's update()
     long long end_xIdx;
-    int max_span[kSchedSpanSizes];   // largest n[last] - n[first] over aligned tiles of 256 << i outputs
-    int pad;
+    int max_span[kSchedSpanSizes];   // largest n[last] - n[first] over aligned tiles of kSchedSpanBase << i outputs
+    int pad[3];
 };
 struct SchedGroupEntry { double shift; int advance; int next; };        // map of one group: candidate -> (next, +shift, +xIdx)
 struct SchedGroupStart { double shift; long long advance; int cand; int pad; };   // true start of a group, as candidate + shift
@@ -139,7 +141,7 @@ void sched_configure(mrhip_filter *f);
 void sched_forget(mrhip_filter *f);
 void sched_free(mrhip_filter *f);
 bool sched_wants_device(const mrhip_filter *f, int64_t est);
-int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, SchedResult *out);
+int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, hipStream_t stream, SchedResult *out);
 double sched_anchor_host(const SchedPlan &c, double acc_p, double k);   // un-rounded phase after k steps (host_logic.cpp)
 
 // ---------------------------------------------------------------------------------------
@@ -404,12 +406,8 @@ struct mrhip_filter {
     int sched_corrupt_piece = -1;                 // test hook: falsify the tables of this device piece (counted per filter)
     bool sched_use_cycle = true;
     double sched_drift = 0.0, sched_ksteps = 0.0; // running drift estimate of the stream: (true - un-rounded phase) over ksteps steps
-    void *ds_n[2] = {nullptr, nullptr}, *ds_acc[2] = {nullptr, nullptr};   // schedule buffers, alternated per call
+    void *ds_n[2] = {nullptr, nullptr}, *ds_acc[2] = {nullptr, nullptr};   // schedule buffers ([0] in use: one stream, in order)
     size_t ds_cap[2] = {0, 0};
-    int ds_cur = 0;
-    hipEvent_t ds_read[2] = {nullptr, nullptr};   // recorded behind the filter kernel that reads the buffer
-    bool ds_read_valid[2] = {false, false};
-    hipEvent_t ds_done = nullptr;                 // recorded on own_stream behind the last write of a call's schedule
     double *ds_pathT = nullptr;
     int *ds_pathW = nullptr;
     mrhip::SchedGroupEntry *ds_gtab = nullptr;
@@ -423,7 +421,7 @@ struct mrhip_filter {
     int64_t per_Q = 0, per_XQ = 0, per_pos = 0;
     std::vector<double> per_acc;
     std::vector<int64_t> per_xoff;                // [Q + 1] xIdx advance from cycle position 0
-    int per_span[mrhip::kSchedSpanSizes] = {0, 0, 0};
+    int per_span[mrhip::kSchedSpanSizes] = {};
     double *d_per_acc = nullptr;
     long long *d_per_xoff = nullptr;
     int64_t stat_host_steps = 0, stat_periodic_steps = 0, stat_device_pieces = 0, stat_fallback_pieces = 0;
