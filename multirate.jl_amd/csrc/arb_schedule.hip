@@ -236,12 +236,9 @@ bool sched_wants_device(const mrhip_filter *f, int64_t est)
 
 // Evaluate the schedule of one call (x_len samples from the filter's current state; est = an upper bound of its output
 // count) into schedule buffer out->buf.  The state of the filter is NOT advanced (the caller commits out->end).
-// Everything is enqueued on the CALLER's stream `s`, in front of the filter kernel that reads the schedule.  (Round 3 first ran
-// the schedule on a stream of its own, the two ordered by events: since the host waits for the schedule's count, the event was
-// complete by the time the caller's stream was told to wait for it, the runtime dropped the wait, and the filter kernel -- launched
-// back to back behind the previous call's kernel on a busy queue -- read STALE schedule entries out of one XCD's L2 whenever
-// the same buffer had been read two calls before: whole 4096-entry groups of another call's schedule, intermittently
-// (profiles/r03/experiments.md D).  Producer and consumer in one queue are ordered AND coherent by the kernel boundary.)
+// Everything is enqueued on the CALLER's stream `s`, in front of the filter kernel that reads the schedule: one queue, no
+// events between producer and consumer, one schedule buffer.  (A stream of its own for the schedule bought nothing: the
+// previous call's persistent filter kernel holds every CU until it ends, profiles/r03/experiments.md B.)
 int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, hipStream_t s, SchedResult *out)
 {
     const SchedPlan &c = f->splan;
@@ -351,6 +348,7 @@ int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, hipStream_t s, S
             a.k0 = pk0[static_cast<size_t>(p)]; a.x_len = x_len;
             a.piece = static_cast<int>(p); a.ngroups = static_cast<int>(psteps[static_cast<size_t>(p)] / kSchedGroup);
             a.corrupt_group = f->sched_corrupt_piece == f->stat_device_pieces + p ? 0 : -1;
+            if (f->sched_corrupt_piece <= -2) a.corrupt_group = f->sched_corrupt_piece;   // test hook: group -v-2 of every piece starts late
             MRHIP_CHECK_HIP(launch_schedule_piece(c, a, s));
         }
         MRHIP_CHECK_HIP(hipMemcpyAsync(&hs[1], f->ds_status, sizeof(SchedStatus), hipMemcpyDeviceToHost, s));

@@ -1,0 +1,400 @@
+// kernels_arb_pipe.hip -- FIRArbitrary (src/Filters.jl:693-742) with Float64 arithmetic over 8-byte samples (Float64,
+// ComplexF32): the hand-scheduled form of arb_tiled_kernel (kernels_arbitrary.hip), same arithmetic, bit-identical results.
+//
+// What bounded arb_tiled_kernel on BASELINE config 4 (PMC, profiles/r03/experiments.md A): the LDS array 67 % active with 48 %
+// of those cycles bank conflicts, and only 4 of 10 VALU instructions outside the dot products... both from leaving the
+// inner loop to the compiler:
+//   * it merges two 8-byte reads of one lane (t[i], t[i + 2] of the unrolled loop) into ds_read2_b64: half rate, and banked
+//     modulo 32 instead of 64;
+//   * the 16-byte sample reads (two copies of the tile, one sample apart) are serviced in lane groups {0-3, 12-15, 20-27}...
+//     (MI355X_MICROARCH.md, LDS): 16 lanes that span 28 outputs, so copy A and copy B, 128 bytes apart, collide;
+//   * every read is waited for right in front of its use.
+// Here every LDS read is an 8-byte ds_read_b64 issued by hand (lane groups {0-31}, {32-63}, 64 banks: the odd tap pitch
+// makes 32 phases 32 different bank pairs, and 32 consecutive outputs at a rate <= 1 touch 32 consecutive samples), ONE copy
+// of the tile, the reads of tap pair i + 1 in flight while pair i is computed (two register sets, counted s_waitcnt
+// lgkmcnt(n): LDS returns in order), two sample buffers in LDS so a tile costs one barrier, and the staging addresses are
+// scalar base + lane offset (no per-element integer division, no 64-bit vector address arithmetic).
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "mrhip_internal.h"
+#include "pair_device.h"
+
+#pragma clang fp contract(off)
+
+namespace mrhip {
+namespace {
+
+using dev::v2u_t;
+
+constexpr int kPipeThreads = 256;
+constexpr int kPipeElems = 8;        // 8-byte samples a thread stages per tile: CPL channels x ROWS rows of 256 samples
+
+template <bool FUSED>
+__device__ __forceinline__ double macd(double t, double x, double acc)
+{
+    if constexpr (FUSED) return __builtin_fma(t, x, acc);
+    const double p = t * x;
+    return acc + p;
+}
+
+template <typename TX, int NC>
+__device__ __forceinline__ double sample_part(v2u_t v, int c)
+{
+    if constexpr (NC == 1) {
+        static_assert(sizeof(TX) == 8, "one 8-byte real sample");
+        return __builtin_bit_cast(double, v);
+    } else {
+        static_assert(sizeof(TX) == 4 && NC == 2, "one ComplexF32 sample");
+        return static_cast<double>(__builtin_bit_cast(float, c == 0 ? v.x : v.y));
+    }
+}
+
+template <typename TX, int NC, bool FUSED, int CPL>
+__global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, ArbTileArgs ta)
+{
+    constexpr int ROWS = kPipeElems / CPL;
+    constexpr int NR = 4 + 2 * CPL;                                  // LDS reads per tap pair
+    static_assert(NR <= 15, "lgkmcnt is a 4-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+    const int tid = threadIdx.x;
+    const int T = a.T, TP = ta.tap_pitch, MS = ta.max_span;
+    double *const lpfb = reinterpret_cast<double *>(smem);
+    double *const ldpfb = lpfb + ta.bank_elems;
+    {   // both tap banks -> LDS once per workgroup: element (phi, i) at phi*TP + i
+        const double *__restrict__ g0 = static_cast<const double *>(a.taps);
+        const double *__restrict__ g1 = static_cast<const double *>(a.dtaps);
+        const int total = a.Nphi * T;
+        for (int e = tid; e < total; e += kPipeThreads) {
+            const int phi = e / T, i = e - phi * T;
+            lpfb[phi * TP + i] = g0[e];
+            ldpfb[phi * TP + i] = g1[e];
+        }
+    }
+    const unsigned xbuf_bytes = static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * 8u;
+    const unsigned lx0 = lds0 + static_cast<unsigned>(ta.x_offset_bytes);        // sample buffer b at lx0 + b*xbuf_bytes: [CPL][MS]
+
+    // tile -> (stretch of 256 outputs tau, channel group cg), time-major: the workgroups that run together share the schedule
+    const int ngroups = static_cast<int>(ta.total_tiles / ta.tiles_per_channel);
+    long long tile = blockIdx.x;
+    if (tile >= ta.total_tiles) return;
+    long long tau = tile / ngroups;
+    int cg = static_cast<int>(tile - tau * ngroups);
+    const long long dtau = gridDim.x / ngroups;
+    const int dcg = static_cast<int>(gridDim.x - dtau * ngroups);
+
+    // n_idx[first output of a tile], by a scalar load issued one tile ahead.  (Left to the compiler it is a vector load
+    // whose wait -- s_waitcnt vmcnt(0) -- also drains the previous tile's output stores: microseconds, at the top of every tile.)
+    auto first_index_issue = [&](long long tau_) -> int {
+        const int *p = a.n_idx + tau_ * kPipeThreads;
+        const unsigned plo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)));
+        const unsigned phi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32));
+        const unsigned long long pu = (static_cast<unsigned long long>(phi) << 32) | plo;
+        int v;
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(pu));
+        return v;                                                // not valid before first_index_wait
+    };
+    auto first_index_wait = [&](int &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); };
+    struct Tile { long long k0, o; int nout, ch0, nchl, n_lo, interior; };
+    auto make_tile = [&](long long tau_, int cg_, int n_lo_) {
+        Tile t;
+        t.ch0 = cg_ * CPL;
+        t.nchl = a.nch - t.ch0 < CPL ? a.nch - t.ch0 : CPL;
+        t.k0 = tau_ * kPipeThreads;
+        const long long rem = a.n_out - t.k0;
+        t.nout = rem < kPipeThreads ? static_cast<int>(rem) : kPipeThreads;
+        t.n_lo = n_lo_;                                          // = n_idx[k0]
+        t.o = static_cast<long long>(t.n_lo) - T;               // x[n_lo - T ...] (0-based); n = 1-based newest sample
+        // every sample of the tile lies inside the signal for every channel of a full group: no per-lane checks
+        t.interior = t.nchl == CPL && t.o >= 0 && t.o + MS <= a.x_len;
+        return t;
+    };
+    // Staging: element j of a thread is sample r*256 + tid of channel cc (j = cc*ROWS + r).  The lane offsets are the same
+    // for every tile (lanes past the span re-read its last sample: same cache line, no branch), the rest of the address is scalar.
+    unsigned soff[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int sidx = r * kPipeThreads + tid;
+        soff[r] = static_cast<unsigned>(sidx < MS ? sidx : MS - 1) * 8u;
+    }
+    unsigned long long pv[kPipeElems];                            // the next tile's samples, as raw 8 bytes
+    auto load_tile = [&](const Tile &t) {
+        if (t.interior) {
+#pragma unroll
+            for (int j = 0; j < kPipeElems; ++j) {
+                // (unconditional, straight-line: a row past the span re-reads the span's last sample -- with a branch per load the
+                // compiler waits for every earlier memory operation, the previous tile's stores included, in front of each)
+                const int cc = j / ROWS, r = j - cc * ROWS;
+                const unsigned char *base = static_cast<const unsigned char *>(a.x) + (static_cast<long long>(t.ch0 + cc) * a.x_stride + t.o) * 8;
+                pv[j] = *reinterpret_cast<const unsigned long long *>(base + soff[r]);
+            }
+        } else {                                                  // the first and last tiles of a channel group: history, zeros
+#pragma unroll
+            for (int j = 0; j < kPipeElems; ++j) {
+                const int cc = j / ROWS, r = j - cc * ROWS;
+                const int sidx = r * kPipeThreads + tid;
+                const long long gi = t.o + sidx;
+                const bool ok = cc < t.nchl && sidx < MS && gi < a.x_len && gi >= -static_cast<long long>(a.H);
+                const unsigned long long *px = static_cast<const unsigned long long *>(a.x) + static_cast<long long>(t.ch0 + cc) * a.x_stride + gi;
+                const unsigned long long *ph = static_cast<const unsigned long long *>(a.hist) + static_cast<long long>(t.ch0 + cc) * a.H + (a.H + gi);
+                const unsigned long long *p = gi >= 0 ? px : ph;
+                const unsigned long long v = *(ok ? p : static_cast<const unsigned long long *>(a.taps));
+                pv[j] = ok ? v : 0ull;
+            }
+        }
+    };
+    auto store_tile = [&](int b) {
+        unsigned long long *const lx = reinterpret_cast<unsigned long long *>(smem + ta.x_offset_bytes + static_cast<size_t>(b) * xbuf_bytes);
+#pragma unroll
+        for (int j = 0; j < kPipeElems; ++j) {
+            const int cc = j / ROWS, r = j - cc * ROWS;
+            const int sidx = r * kPipeThreads + tid;
+            if (r * kPipeThreads < MS && sidx < MS) lx[cc * MS + sidx] = pv[j];
+        }
+    };
+
+    int n_lo0 = first_index_issue(tau);
+    first_index_wait(n_lo0);
+    Tile cur = make_tile(tau, cg, n_lo0);
+    load_tile(cur);
+    int n_pre = 0;
+    double acc_pre = 0.0;
+    if (tid < cur.nout) { n_pre = a.n_idx[cur.k0 + tid]; acc_pre = a.acc[cur.k0 + tid]; }
+    auto step = [&](long long &t_, int &c_) {                    // the tile this workgroup takes after (t_, c_)
+        t_ += dtau; c_ += dcg;
+        if (c_ >= ngroups) { c_ -= ngroups; ++t_; }
+        return t_ * ngroups + c_ < ta.total_tiles;
+    };
+    long long ntau = tau;
+    int ncg = cg;
+    bool have_next = step(ntau, ncg);
+    int n_lo_next = 0;
+    if (have_next) { n_lo_next = first_index_issue(ntau); first_index_wait(n_lo_next); }
+    store_tile(0);
+    __syncthreads();       // the tap banks and the first tile are in LDS
+    int buf = 0;
+
+    for (;;) {
+        // the next tile's loads go out now and land while this tile is computed
+        const int n_mine = n_pre;
+        const double acc_mine = acc_pre;
+        const Tile nxt = make_tile(have_next ? ntau : tau, have_next ? ncg : cg, have_next ? n_lo_next : cur.n_lo);
+        if (have_next) {
+            load_tile(nxt);
+            if (tid < nxt.nout) { n_pre = a.n_idx[nxt.k0 + tid]; acc_pre = a.acc[nxt.k0 + tid]; }
+        }
+        long long n2tau = ntau;
+        int n2cg = ncg;
+        const bool have_next2 = have_next && step(n2tau, n2cg);
+        int n_lo_next2 = 0;
+        if (have_next2) n_lo_next2 = first_index_issue(n2tau);   // waited for behind the barrier at the end of this tile
+
+        double res[CPL][NC];
+        if (tid < cur.nout) {
+            const double phif = __builtin_floor(acc_mine);
+            const double alpha = acc_mine - phif;                 // src/Filters.jl:671-672
+            const int phi = static_cast<int>(phif) - 1;           // 0-based column
+            const int w = n_mine - cur.n_lo;                      // oldest sample of this output's window, within the tile
+            unsigned tpa = lds0 + static_cast<unsigned>(phi * TP) * 8u;                  // taps of this phase
+            unsigned dpa = tpa + static_cast<unsigned>(ta.bank_elems) * 8u;              // ... of the difference bank
+            unsigned sa[CPL];
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) sa[cc] = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w) * 8u;
+            dev::pin(tpa); dev::pin(dpa);                         // (complete addresses in registers: the loop only adds to them)
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) dev::pin(sa[cc]);
+
+            struct Blk { v2u_t t0, t1, d0, d1; v2u_t s0[CPL], s1[CPL]; };
+            auto issue = [&](Blk &b, auto off_c) {              // taps i, i + 1 at byte offset OFF from the running bases
+                constexpr int OFF = decltype(off_c)::value;
+                b.t0 = dev::lds_read_b64<OFF>(tpa); b.t1 = dev::lds_read_b64<OFF + 8>(tpa);
+                b.d0 = dev::lds_read_b64<OFF>(dpa); b.d1 = dev::lds_read_b64<OFF + 8>(dpa);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) { b.s0[cc] = dev::lds_read_b64<OFF>(sa[cc]); b.s1[cc] = dev::lds_read_b64<OFF + 8>(sa[cc]); }
+            };
+            auto landed = [&](Blk &b, auto n_c) {               // at most N later reads still in flight => b has landed
+                constexpr int N = decltype(n_c)::value;
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+                dev::pin(b.t0); dev::pin(b.t1); dev::pin(b.d0); dev::pin(b.d1);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) { dev::pin(b.s0[cc]); dev::pin(b.s1[cc]); }
+            };
+            // -0.0 + p == p for every p (signed zeros, NaN included): starting from -0.0 IS "the first product initialises"
+            double lo[CPL][NC], up[CPL][NC];
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { lo[cc][c] = -0.0; up[cc][c] = -0.0; }
+            }
+            auto compute = [&](const Blk &b) {
+                const double t0 = __builtin_bit_cast(double, b.t0), t1 = __builtin_bit_cast(double, b.t1);
+                const double d0 = __builtin_bit_cast(double, b.d0), d1 = __builtin_bit_cast(double, b.d1);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const double x0 = sample_part<TX, NC>(b.s0[cc], c), x1 = sample_part<TX, NC>(b.s1[cc], c);
+                        lo[cc][c] = macd<FUSED>(t0, x0, lo[cc][c]);
+                        up[cc][c] = macd<FUSED>(d0, x0, up[cc][c]);
+                        lo[cc][c] = macd<FUSED>(t1, x1, lo[cc][c]);
+                        up[cc][c] = macd<FUSED>(d1, x1, up[cc][c]);
+                    }
+                }
+            };
+            auto advance = [&](unsigned bytes) {
+                tpa += bytes; dpa += bytes;
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) sa[cc] += bytes;
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I16 = std::integral_constant<int, 16>;
+            using I32 = std::integral_constant<int, 32>;
+            using INR = std::integral_constant<int, NR>;
+            const int nblk = T >> 1;                             // tap pairs (uniform)
+            if (nblk > 0) {
+                // Straight-line pipeline, no conditional issue (a conditional read makes the two register sets merge through
+                // copies): the pair after the last one is read too -- it lies inside LDS (the next column, the pad behind the
+                // sample buffers) and is never used.
+                Blk A, B;
+                issue(A, I0{});
+                for (int p = 0; p < nblk; p += 2) {              // the bases point at pair p, A holds it
+                    issue(B, I16{});
+                    landed(A, INR{});
+                    compute(A);
+                    issue(A, I32{});
+                    advance(32);
+                    landed(B, INR{});
+                    if (p + 1 < nblk) compute(B);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)");            // the unused last reads
+                dev::pin(A.t0);
+            }
+            if (T & 1) {                                         // odd tapsPerPhi: the last tap alone
+                const int i = T - 1;
+                const unsigned tl = lds0 + static_cast<unsigned>(phi * TP + i) * 8u;
+                v2u_t t = dev::lds_read_b64<0>(tl), d = dev::lds_read_b64<0>(tl + static_cast<unsigned>(ta.bank_elems) * 8u);
+                v2u_t s[CPL];
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc)
+                    s[cc] = dev::lds_read_b64<0>(lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w + i) * 8u);
+                asm volatile("s_waitcnt lgkmcnt(0)");
+                dev::pin(t); dev::pin(d);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) dev::pin(s[cc]);
+                const double tt = __builtin_bit_cast(double, t), dd = __builtin_bit_cast(double, d);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const double x = sample_part<TX, NC>(s[cc], c);
+                        lo[cc][c] = macd<FUSED>(tt, x, lo[cc][c]);
+                        up[cc][c] = macd<FUSED>(dd, x, up[cc][c]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const double prod = up[cc][c] * alpha;                     // Filters.jl:730, Float64 combine
+                    res[cc][c] = lo[cc][c] + prod;
+                }
+            }
+        }
+        // The prefetched samples go to the other buffer BEFORE the outputs are stored: their wait (vmcnt) would otherwise
+        // include the stores.  (The waves still computing this tile do not read that buffer.)
+        asm volatile("" ::: "memory");   // (the LDS writes below stay below the hand-issued reads above: the compiler does not see those as memory operations)
+        if (have_next) { buf ^= 1; store_tile(buf); }
+        if (tid < cur.nout) {
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) {
+                if (cc < cur.nchl) {
+                    double *__restrict__ yc = static_cast<double *>(a.y) + (static_cast<long long>(cur.ch0 + cc) * a.y_stride + cur.k0) * NC;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) yc[tid * NC + c] = res[cc][c];
+                }
+            }
+        }
+        if (!have_next) break;
+        __syncthreads();       // one barrier per tile: the next tile is in LDS, and everyone is done with the buffer written after it
+        if (have_next2) first_index_wait(n_lo_next2);
+        tau = ntau; cg = ncg; cur = nxt;
+        ntau = n2tau; ncg = n2cg; have_next = have_next2; n_lo_next = n_lo_next2;
+    }
+}
+
+template <typename TX, int NC>
+hipError_t launch_pipe_t(bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s, int num_cus)
+{
+    auto go = [&](auto kfn) -> hipError_t {
+        int per_cu = 0;
+        hipError_t eo = occupancy_cached(reinterpret_cast<const void *>(kfn), kPipeThreads, lds, &per_cu);
+        if (eo != hipSuccess) return eo;
+        if (per_cu < 1) per_cu = 1;
+        long long g = static_cast<long long>(num_cus) * per_cu;
+        if (g > ta.total_tiles) g = ta.total_tiles;
+        if (g < 1) g = 1;
+        if (MRHIP_ENV_INT("MRHIP_DEBUG", 0) == 1) {
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kfn));
+            std::fprintf(stderr, "[mrhip] arb_pipe T=%d Nphi=%d cpl=%d grid=%lld lds=%zu occ/CU=%d regs=%d max_span=%d tiles=%lld\n",
+                         a.T, a.Nphi, ta.cpl, g, lds, per_cu, fa.numRegs, ta.max_span, ta.total_tiles);
+        }
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kPipeThreads), lds, s, a, ta);
+        return hipGetLastError();
+    };
+    switch (ta.cpl) {
+    case 4: return fused ? go(arb_pipe_kernel<TX, NC, true, 4>) : go(arb_pipe_kernel<TX, NC, false, 4>);
+    case 2: return fused ? go(arb_pipe_kernel<TX, NC, true, 2>) : go(arb_pipe_kernel<TX, NC, false, 2>);
+    default: return fused ? go(arb_pipe_kernel<TX, NC, true, 1>) : go(arb_pipe_kernel<TX, NC, false, 1>);
+    }
+}
+
+}  // namespace
+
+// Eligible: Float64 arithmetic, 8-byte samples, tiles of 256 outputs whose sample span fits kPipeElems rows of 256 per
+// thread (a decimating rate stretches the span: fewer channels per lane).  `span256` = the largest n[last] - n[first]
+// over the aligned stretches of 256 outputs.
+bool plan_arb_pipe(const TypeKey &tk, const ArbArgs &a, long long span256, ArbTileArgs *out, size_t *lds)
+{
+    if (MRHIP_ENV_INT("MRHIP_ARB_PIPE", 1) == 0) return false;
+    const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
+    if (!tk.r_f64 || sb != 8 || a.n_out < 1) return false;
+    const int TP = a.T | 1;                              // odd column pitch: lanes with different phases read different banks
+    const size_t bank_elems = static_cast<size_t>(a.Nphi) * TP;
+    const size_t banks_bytes = (2 * bank_elems * 8 + 15) / 16 * 16;
+    if (banks_bytes > 96 * 1024) return false;
+    const long long max_span = (span256 + a.T + 1) / 2 * 2;
+    int cpl = a.nch >= 32 ? 4 : (a.nch >= 8 ? 2 : 1);
+    const int env_cpl = MRHIP_ENV_INT("MRHIP_ARB_CPL", 0);
+    if (env_cpl == 1 || env_cpl == 2 || env_cpl == 4) cpl = env_cpl;
+    while (cpl > 1 && max_span > static_cast<long long>(kPipeElems / cpl) * kPipeThreads) cpl /= 2;
+    if (max_span > static_cast<long long>(kPipeElems / cpl) * kPipeThreads) return false;
+    const size_t total = banks_bytes + 2 * static_cast<size_t>(max_span) * cpl * 8 + 64;   // (+ pad: the pipeline reads one tap pair past a window)
+    if (total > 150 * 1024) return false;
+    ArbTileArgs ta{};
+    ta.pipe = 1;
+    ta.cpl = cpl;
+    ta.tap_pitch = TP;
+    ta.bank_elems = static_cast<int>(bank_elems);
+    ta.x_offset_bytes = static_cast<int>(banks_bytes);
+    ta.max_span = static_cast<int>(max_span);
+    ta.tile_out = kPipeThreads;
+    ta.tiles_per_channel = (a.n_out + kPipeThreads - 1) / kPipeThreads;
+    ta.total_tiles = ta.tiles_per_channel * ((a.nch + cpl - 1) / cpl);
+    *out = ta;
+    *lds = total;
+    return true;
+}
+
+hipError_t launch_arb_pipe(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
+                           const char **kname, int num_cus)
+{
+    *kname = "arb_pipe_kernel";
+    return tk.complex_x ? launch_pipe_t<float, 2>(fused, a, ta, lds, s, num_cus) : launch_pipe_t<double, 1>(fused, a, ta, lds, s, num_cus);
+}
+
+}  // namespace mrhip

@@ -477,6 +477,18 @@ bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_ho
     if (!enabled || a.n_out < 1) return false;
     const size_t rs = tk.r_f64 ? 8 : 4;
     const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
+    if (tk.r_f64 && sb == 8) {                           // Float64 arithmetic over 8-byte samples: the hand-pipelined kernel
+        long long span256 = -1;
+        if (n_idx_host) {
+            for (long long k0 = 0; k0 < a.n_out; k0 += 256) {
+                const long long kl = std::min<long long>(k0 + 256, a.n_out) - 1;
+                span256 = std::max<long long>(span256, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0]);
+            }
+        } else if (spans) {
+            span256 = spans[sched_span_index(256)];
+        }
+        if (span256 >= 0 && plan_arb_pipe(tk, a, span256, out, lds)) return true;
+    }
     const int copies = sb >= 16 ? 1 : 2;                 // the sample tile is kept twice, one sample apart (aligned pair reads)
     const int TP = a.T | 1;                              // odd column pitch: lanes with different phases read different banks
     const size_t bank_elems = static_cast<size_t>(a.Nphi) * TP;
@@ -542,6 +554,7 @@ bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_ho
 hipError_t launch_arb_tiled(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
                             const char **kname, int num_cus)
 {
+    if (ta.pipe) return launch_arb_pipe(tk, fused, a, ta, lds, s, kname, num_cus);
     *kname = "arb_tiled_kernel";
     if (!tk.x_f64 && !tk.r_f64) return tk.complex_x ? launch_arb<float, float, 2>(fused, a, ta, lds, s, num_cus) : launch_arb<float, float, 1>(fused, a, ta, lds, s, num_cus);
     if (!tk.x_f64 && tk.r_f64) return tk.complex_x ? launch_arb<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_arb<float, double, 1>(fused, a, ta, lds, s, num_cus);

@@ -102,16 +102,22 @@ __device__ __forceinline__ bool sched_locate(double T, double base, const SchedP
     return sched_cand(base, *ci, c) + *shift == T;
 }
 
-__device__ __forceinline__ bool sched_stop(const SchedStatus *st)
+// A kernel of piece `piece` has nothing to do when an EARLIER piece failed verification or found the end of the call.
+// Within its own piece it must not stop on `done`: the workgroup that holds the call's end can finish before a workgroup
+// of an earlier group (another XCD, running behind) has started, and that group's entries are part of the call.
+// (Round 3's first form returned on any `done`: now and then whole groups of the last piece kept what the buffer held
+// before -- the failure profiles/r03/experiments.md D first took for a cache effect.)
+__device__ __forceinline__ bool sched_stop(const SchedStatus *st, int piece)
 {
-    return __hip_atomic_load(&st->fail_piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kSchedNoFail ||
-           __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const int fp = __hip_atomic_load(&st->fail_piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int dn = __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // 1 + the piece that holds the end
+    return fp != kSchedNoFail || (dn != 0 && dn - 1 < piece);
 }
 
 // ---- K1: candidate tables of one group (64 segments) per workgroup, composed --------------------------------
 __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, SchedPieceArgs a)
 {
-    if (sched_stop(a.status)) return;
+    if (sched_stop(a.status, a.piece)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nwin = c.nwin;
     double *const eC = reinterpret_cast<double *>(smem);                 // [64][nwin] candidate start value
@@ -197,7 +203,7 @@ __device__ __forceinline__ void chain_apply(ChainState &st, const SchedGroupEntr
 
 __global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan c, SchedPieceArgs a)
 {
-    if (sched_stop(a.status)) return;
+    if (sched_stop(a.status, a.piece)) return;
     __shared__ SchedGroupEntry s_run[kChainWaves][64];      // phase 1 result: the map of every wave's run
     __shared__ int s_ci[kChainWaves];
     __shared__ double s_S[kChainWaves];
@@ -267,7 +273,11 @@ __global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan
 // ---- K3: run every segment from its true start, emit, verify -------------------------------------------------
 __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, SchedPieceArgs a)
 {
-    if (sched_stop(a.status)) return;
+    // test hook (MRHIP_SCHED_CORRUPT = -2 - g): group g starts ~0.5 ms late, i.e. after the group that holds the call's end
+    // has set `done` -- it must still write its entries (sched_stop)
+    if (a.corrupt_group <= -2 && static_cast<int>(blockIdx.x) == -a.corrupt_group - 2)
+        for (int i = 0; i < 128; ++i) __builtin_amdgcn_s_sleep(127);
+    if (sched_stop(a.status, a.piece)) return;
     __shared__ int s_n[kGroupSegs * (kSeg + 1)];
     __shared__ double s_acc[kGroupSegs * (kSeg + 1)];
     __shared__ double s_T[kGroupSegs + 1];
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
         a.status->end_k = end_k;
         a.status->end_acc = end_acc;
         a.status->end_xIdx = end_x;
-        __hip_atomic_store(&a.status->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.status->done, a.piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (sl == kGroupSegs - 1 && g + 1 == a.ngroups) {     // state of the next piece (used only if this piece verified)
         SchedPieceState ns;

@@ -100,7 +100,7 @@ struct SchedPieceState {     // true state at the start of a piece + the running
 };
 struct SchedStatus {
     int fail_piece;          // kSchedNoFail, or the first piece whose verification failed
-    int done;                // the call's end (first xIdx > x_len) was found
+    int done;                // != 0: the call's end (first xIdx > x_len) was found, in piece done - 1
     long long end_k;         // number of outputs of the call
     double end_acc;          // state after the last output's update()
     long long end_xIdx;
@@ -271,6 +271,7 @@ struct ArbTileArgs {         // tiling of the FIRArbitrary kernel (kernels_arbit
     int max_span;            // samples the largest tile touches
     int prefetch;            // arb_tiled_kernel: the next tile's samples are loaded into registers a tile ahead
     int copyb_pad;           // samples between the end of sample copy A and the start of copy B (bank stagger)
+    int pipe;                // 1: arb_pipe_kernel (kernels_arb_pipe.hip): one copy, two sample buffers, tiles of 256 outputs
     long long tile_out;      // outputs per tile
     long long tiles_per_channel;
     long long total_tiles;
@@ -342,6 +343,9 @@ bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectAr
 hipError_t launch_fir_direct(const TypeKey &tk, bool fused, const PolyArgs &a, const DirectArgs &da, size_t lds, hipStream_t s,
                              const char **kname, int num_cus);
 bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_host, const int *spans, int num_cus, ArbTileArgs *out, size_t *lds);
+bool plan_arb_pipe(const TypeKey &tk, const ArbArgs &a, long long span256, ArbTileArgs *out, size_t *lds);
+hipError_t launch_arb_pipe(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
+                           const char **kname, int num_cus);
 hipError_t launch_arb_tiled(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
                             const char **kname, int num_cus);
 bool plan_poly_tiled(const TypeKey &tk, const PolyArgs &a, int num_cus, ArbTileArgs *out, size_t *lds);

@@ -515,7 +515,8 @@ def test_arbitrary_tuned_and_generic_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, float(rate), Nphi)
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        assert f.last_kernel_name() == "arb_tiled_kernel"
+        pipe = np.dtype(th) == np.float64 and np.dtype(tx).itemsize == 8     # Float64 arithmetic over 8-byte samples
+        assert f.last_kernel_name() == ("arb_pipe_kernel" if pipe else "arb_tiled_kernel")
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, float(rate), Nphi)
         y_g = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
@@ -1037,3 +1038,52 @@ def test_randomised_stress_short(torch_cuda):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout
+
+
+def test_arb_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
+    """arb_pipe_kernel (Float64 arithmetic, 8-byte samples: hand-pipelined LDS reads, -0.0 accumulator start, two sample
+    buffers): bit-equal to the oracle on some channels and to arb_generic_kernel on all of them, over odd and even
+    tapsPerPhi (the single last tap, T = 1), partial channel groups, rates whose span needs fewer channels per lane or
+    falls back to arb_tiled_kernel, seams with history, signed zeros, and the fused numerics."""
+    torch = torch_cuda
+    rng = np.random.default_rng(4242)
+    seen = set()
+    cases = []
+    for T in (1, 2, 3, 4, 5, 7, 8, 31, 32, 33, 40):
+        cases.append((32, T, math.pi / 3, np.float64, int(rng.choice([1, 3, 9, 33]))))
+    for rate in (0.05, 0.11, 0.26, 0.6, 1.0, 1.9, 3.3):          # (rate = outputs per input: a small one stretches a tile's span)
+        cases.append((32, 12, rate, np.float64, 34))
+        cases.append((10, 6, rate, np.complex64, 9))
+    cases.append((32, 32, math.pi / 3, np.float64, 64))
+    cases.append((32, 32, math.pi / 3, np.complex64, 37))
+    for (Nphi, T, rate, tx, nch) in cases:
+        h = (pkg.firdes(T * Nphi, 0.45 / Nphi, beta=7.0) * Nphi).astype(np.float64)
+        n = (6000 if nch <= 9 else 2500) * (8 if rate < 0.2 else 1)     # (enough outputs per piece for the span to matter)
+        x = _rand(rng, (nch, n), tx) - 0.5
+        x[:, 100:140] = 0.0
+        x[:, 120:130] *= -1.0                                    # -0.0 (and -0.0 - 0.0j)
+        xd = torch.from_numpy(x).cuda()
+        sizes = [n // 2 - 1, 1, 2, n - n // 2 - 2]
+        for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
+            monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+            f = pkg.FIRFilter(h, float(rate), Nphi, numerics=numerics)
+            y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+            seen.add(f.last_kernel_name())
+            monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+            g = pkg.FIRFilter(h, float(rate), Nphi, numerics=numerics)
+            yg = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
+            assert g.last_kernel_name() == "arb_generic_kernel"
+            monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+            tag = f"Nphi={Nphi} T={T} rate={rate} {np.dtype(tx)} nch={nch} numerics={numerics} kernel={f.last_kernel_name()}"
+            assert_bit_equal(y, yg, "pipe vs generic " + tag)
+            assert_bit_equal(f.history, g.history, "history " + tag)
+            O.set_fused(numerics == pkg.NUMERICS_FUSED)
+            try:
+                for c in sorted({0, nch - 1}):
+                    fo = O.FIRFilter(h, float(rate), Nphi, tx=tx)
+                    yo = np.concatenate(_run_chunks(fo, x[c], sizes))
+                    assert_bit_equal(y[c], yo, f"pipe vs oracle ch={c} " + tag)
+            finally:
+                O.set_fused(False)
+            f.close(); g.close()
+    assert "arb_pipe_kernel" in seen and "arb_tiled_kernel" in seen, seen

@@ -174,3 +174,27 @@ def test_long_runs_device_schedule_vs_host_loop(pkg, torch_cuda, monkeypatch, ra
     print(f"rate={rate:.6g}: {info}")
     fd.close()
     fh.close()
+
+
+def test_late_group_of_the_last_piece_still_writes_its_entries(pkg, torch_cuda, monkeypatch):
+    """Regression (round 3): the workgroup that holds the call's end sets `done`; a workgroup of an EARLIER group of the
+    same piece that starts after that must not take it as a reason to return.  The hook delays group 0 of every piece by
+    ~0.5 ms (far longer than the kernel runs)."""
+    torch = torch_cuda
+    rate, n_out = math.pi / 3, 1_000_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(int(n_out / rate), generator=g, device="cuda", dtype=torch.float32) - 0.5
+    h = np.random.default_rng(3).standard_normal(96).astype(np.float32)
+    monkeypatch.setenv("MRHIP_SCHED_DEVICE", "0")
+    fh = pkg.FIRFilter(h, rate, 32)
+    yh = fh.filt(x)
+    monkeypatch.delenv("MRHIP_SCHED_DEVICE")
+    monkeypatch.setenv("MRHIP_SCHED_CORRUPT", "-2")
+    fd = pkg.FIRFilter(h, rate, 32)
+    for _ in range(3):                                           # (the first call also warms the drift estimate)
+        fd.reset(); fh.reset()
+        yd, yh = fd.filt(x), fh.filt(x)
+        info = fd.schedule_info()
+        assert info["device_pieces"] > 0 and info["fallback_pieces"] == 0, info
+        assert torch.equal(yd.view(torch.int32), yh.view(torch.int32))
+    fd.close(); fh.close()
