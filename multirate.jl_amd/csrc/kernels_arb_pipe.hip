@@ -40,6 +40,17 @@ __device__ __forceinline__ double macd(double t, double x, double acc)
     return acc + p;
 }
 
+// A wave-uniform pointer the compiler can no longer fold into vector address arithmetic: base (SGPR pair) + 32-bit lane
+// offset then selects the scalar-base addressing form of global_load / global_store (no 64-bit vector adds per access).
+template <typename P>
+__device__ __forceinline__ P *opaque_uniform(P *p)
+{
+    unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)));
+    unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return reinterpret_cast<P *>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 template <typename TX, int NC>
 __device__ __forceinline__ double sample_part(v2u_t v, int c)
 {
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 // (unconditional, straight-line: a row past the span re-reads the span's last sample -- with a branch per load the
                 // compiler waits for every earlier memory operation, the previous tile's stores included, in front of each)
                 const int cc = j / ROWS, r = j - cc * ROWS;
-                const unsigned char *base = static_cast<const unsigned char *>(a.x) + (static_cast<long long>(t.ch0 + cc) * a.x_stride + t.o) * 8;
+                const unsigned char *base = opaque_uniform(static_cast<const unsigned char *>(a.x) + (static_cast<long long>(t.ch0 + cc) * a.x_stride + t.o) * 8);
                 pv[j] = *reinterpret_cast<const unsigned long long *>(base + soff[r]);
             }
         } else {                                                  // the first and last tiles of a channel group: history, zeros
@@ -312,9 +323,9 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) {
                 if (cc < cur.nchl) {
-                    double *__restrict__ yc = static_cast<double *>(a.y) + (static_cast<long long>(cur.ch0 + cc) * a.y_stride + cur.k0) * NC;
+                    unsigned char *yc = opaque_uniform(reinterpret_cast<unsigned char *>(static_cast<double *>(a.y) + (static_cast<long long>(cur.ch0 + cc) * a.y_stride + cur.k0) * NC));
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) yc[tid * NC + c] = res[cc][c];
+                    for (int c = 0; c < NC; ++c) *reinterpret_cast<double *>(yc + static_cast<unsigned>(tid * NC + c) * 8u) = res[cc][c];
                 }
             }
         }

@@ -562,6 +562,11 @@ hipError_t launch_arb_tiled(const TypeKey &tk, bool fused, const ArbArgs &a, con
     return hipErrorInvalidValue;
 }
 
+// (kernels_farrow_pipe.hip)
+bool plan_farrow_pipe(const TypeKey &tk, const FarrowArgs &a, long long span256, ArbTileArgs *out, size_t *lds);
+hipError_t launch_farrow_pipe(const TypeKey &tk, bool fused, const FarrowArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
+                              const char **kname, int num_cus);
+
 // FIRFarrow: tap columns of 256 outputs (T*256 elements of R) plus the sample runs of CPL channels must fit LDS.
 bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_idx_host, const int *spans, int num_cus, ArbTileArgs *out, size_t *lds)
 {
@@ -570,6 +575,18 @@ bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_
     if (!enabled || a.n_out < 1) return false;
     const size_t rs = tk.r_f64 ? 8 : 4;
     const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
+    if (tk.r_f64 && sb == 8 && a.T <= 32) {              // Float64 arithmetic over 8-byte samples: the hand-pipelined kernel
+        long long span256 = -1;
+        if (n_idx_host) {
+            for (long long k0 = 0; k0 < a.n_out; k0 += 256) {
+                const long long kl = std::min<long long>(k0 + 256, a.n_out) - 1;
+                span256 = std::max<long long>(span256, static_cast<long long>(n_idx_host[kl]) - n_idx_host[k0]);
+            }
+        } else if (spans) {
+            span256 = spans[sched_span_index(256)];
+        }
+        if (span256 >= 0 && plan_farrow_pipe(tk, a, span256, out, lds)) return true;
+    }
     static const int regs_ok = [] { const char *v = std::getenv("MRHIP_FARROW_REGS"); return !(v && v[0] == '0'); }();
     const bool in_regs = a.T <= 32 && regs_ok;          // the lane keeps its taps in registers: no tap columns in LDS
     const size_t taps_bytes = in_regs ? 0 : (static_cast<size_t>(a.T) * kArbThreads * rs + 15) / 16 * 16;
@@ -608,6 +625,7 @@ bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_
 hipError_t launch_farrow_tiled(const TypeKey &tk, bool fused, const FarrowArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
                                const char **kname, int num_cus)
 {
+    if (ta.pipe) return launch_farrow_pipe(tk, fused, a, ta, lds, s, kname, num_cus);
     *kname = "farrow_tiled_kernel";
     if (!tk.x_f64 && !tk.r_f64) return tk.complex_x ? launch_farrow_t<float, float, 2>(fused, a, ta, lds, s, num_cus) : launch_farrow_t<float, float, 1>(fused, a, ta, lds, s, num_cus);
     if (!tk.x_f64 && tk.r_f64) return tk.complex_x ? launch_farrow_t<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_farrow_t<float, double, 1>(fused, a, ta, lds, s, num_cus);

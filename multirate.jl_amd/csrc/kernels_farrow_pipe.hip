@@ -1,0 +1,366 @@
+// kernels_farrow_pipe.hip -- FIRFarrow (src/Filters.jl:764-839) with Float64 arithmetic over 8-byte samples (Float64,
+// ComplexF32) and at most 32 taps: the hand-scheduled form of farrow_tiled_kernel (kernels_arbitrary.hip), same
+// arithmetic, bit-identical results.
+//
+// A workgroup takes 256 consecutive outputs (one per lane).  The lane evaluates ITS taps once (Float64 Horner, separately
+// rounded multiply and add, rounded to the tap type: Polynomials.jl polyval + the store into currentTaps::Vector{Th}) into
+// registers and then walks over all channels, CPL at a time: per channel group the run of samples the 256 outputs touch is
+// staged in LDS and every lane forms CPL dot products.  Per tap and channel that is ONE 8-byte LDS read for one multiply
+// and one add: LDS array and Float64 VALU are equally loaded, so the reads must cost exactly their 2 cycles --
+//   * ds_read_b64 issued by hand (lane groups {0-31}, {32-63}, 64 banks; 32 consecutive outputs at a rate <= 1 touch 32
+//     consecutive samples; the compiler's ds_read2_b64 / two-copy ds_read_b128 forms conflict or run at half rate, see
+//     kernels_arb_pipe.hip), ONE copy of the tile;
+//   * a ring of four register sets of one tap x CPL channels: the reads of the next three taps are in flight while this one is multiplied (counted
+//     s_waitcnt lgkmcnt: LDS returns in order), fully unrolled with immediate offsets;
+//   * two sample buffers: one barrier per channel group; the next group's samples (the next tile's first group behind the
+//     last one) wait in registers while this one is computed; staging addresses are scalar base + lane offset.
+// The accumulators start from -0.0 (x + -0.0 == x for every x: "the first product initialises"), from +0.0 on the seam
+// (support.jl:46: the seam dot starts from zero).
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "mrhip_internal.h"
+#include "pair_device.h"
+
+#pragma clang fp contract(off)
+
+namespace mrhip {
+namespace {
+
+using dev::v2u_t;
+
+constexpr int kFpThreads = 256;
+constexpr int kFpElems = 8;          // 8-byte samples a thread stages per channel group: CPL channels x ROWS rows of 256 samples
+constexpr int kFpSetTaps = 1;        // taps per register set
+constexpr int kFpDepth = 4;          // register sets: the reads of taps i + 1 and i + 2 are in flight while tap i is multiplied
+
+template <bool FUSED>
+__device__ __forceinline__ double fmacd(double t, double x, double acc)
+{
+    if constexpr (FUSED) return __builtin_fma(t, x, acc);
+    const double p = t * x;
+    return acc + p;
+}
+
+// A wave-uniform pointer the compiler can no longer fold into vector address arithmetic: base (SGPR pair) + 32-bit lane
+// offset then selects the scalar-base addressing form of global_load / global_store (no 64-bit vector adds per access).
+template <typename P>
+__device__ __forceinline__ P *opaque_uniform(P *p)
+{
+    unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)));
+    unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return reinterpret_cast<P *>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+template <typename TX, int NC>
+__device__ __forceinline__ double fsample_part(v2u_t v, int c)
+{
+    if constexpr (NC == 1) {
+        static_assert(sizeof(TX) == 8, "one 8-byte real sample");
+        return __builtin_bit_cast(double, v);
+    } else {
+        static_assert(sizeof(TX) == 4 && NC == 2, "one ComplexF32 sample");
+        return static_cast<double>(__builtin_bit_cast(float, c == 0 ? v.x : v.y));
+    }
+}
+
+// EXACT: tapsPerPhi == TREG (no per-tap guards: the unrolled pipeline is one basic block)
+template <typename TX, int NC, bool FUSED, int CPL, int TREG, bool EXACT>
+__global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a, ArbTileArgs ta)
+{
+    constexpr int ROWS = kFpElems / CPL;
+    constexpr int NSETS = (TREG + kFpSetTaps - 1) / kFpSetTaps;
+    constexpr int NR = kFpSetTaps * CPL;                             // LDS reads per register set
+    static_assert(NR * (kFpDepth - 1) <= 15, "lgkmcnt is a 4-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+    const int tid = threadIdx.x;
+    const int T = a.T, P = a.polyorder, MS = ta.max_span;
+    const unsigned xbuf_bytes = static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * 8u;   // sample buffer b at b*xbuf_bytes: [CPL][MS]
+    const long long ntiles = ta.total_tiles;
+    const int ngroups = (a.nch + CPL - 1) / CPL;
+
+    long long tau = blockIdx.x;
+    if (tau >= ntiles) return;
+    // the polynomial coefficients -> LDS once (read from global memory in the Horner loops they are ~160 dependent
+    // vector loads per tile, each waited for: as long as all the dot products of the tile)
+    double *const lcoef = reinterpret_cast<double *>(smem + ta.x_offset_bytes);
+    for (int e = tid; e < T * (P + 1); e += kFpThreads) lcoef[e] = a.pnfb[e];
+
+    // n_idx[first output of a tile] by a scalar load issued a tile ahead (see kernels_arb_pipe.hip)
+    auto first_index_issue = [&](long long tau_) -> int {
+        const int *p = a.n_idx + tau_ * kFpThreads;
+        const unsigned plo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)));
+        const unsigned phi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32));
+        const unsigned long long pu = (static_cast<unsigned long long>(phi) << 32) | plo;
+        int v;
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(pu));
+        return v;                                                // not valid before first_index_wait
+    };
+    auto first_index_wait = [&](int &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); };
+
+    // Staging: element j of a thread is sample r*256 + tid of channel cc (j = cc*ROWS + r); lanes past the span re-read its
+    // last sample (same cache line, no branch)
+    unsigned soff[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int sidx = r * kFpThreads + tid;
+        soff[r] = static_cast<unsigned>(sidx < MS ? sidx : MS - 1) * 8u;
+    }
+    unsigned long long pv[kFpElems];
+    auto load_group = [&](long long o, int ch0) {                  // samples x[o ..] of channels ch0 .. ch0 + CPL - 1
+        const int nchl = a.nch - ch0 < CPL ? a.nch - ch0 : CPL;
+        const bool interior = nchl == CPL && o >= 0 && o + MS <= a.x_len;
+        if (interior) {
+#pragma unroll
+            for (int j = 0; j < kFpElems; ++j) {
+                const int cc = j / ROWS, r = j - cc * ROWS;
+                const unsigned char *base = opaque_uniform(static_cast<const unsigned char *>(a.x) + (static_cast<long long>(ch0 + cc) * a.x_stride + o) * 8);
+                pv[j] = *reinterpret_cast<const unsigned long long *>(base + soff[r]);
+            }
+        } else {                                                  // the first and last tiles, the last channel group: history, zeros
+#pragma unroll
+            for (int j = 0; j < kFpElems; ++j) {
+                const int cc = j / ROWS, r = j - cc * ROWS;
+                const int sidx = r * kFpThreads + tid;
+                const long long gi = o + sidx;
+                const bool ok = cc < nchl && sidx < MS && gi < a.x_len && gi >= -static_cast<long long>(a.H);
+                const unsigned long long *px = static_cast<const unsigned long long *>(a.x) + static_cast<long long>(ch0 + cc) * a.x_stride + gi;
+                const unsigned long long *ph = static_cast<const unsigned long long *>(a.hist) + static_cast<long long>(ch0 + cc) * a.H + (a.H + gi);
+                const unsigned long long *p = gi >= 0 ? px : ph;
+                const unsigned long long v = *(ok ? p : reinterpret_cast<const unsigned long long *>(a.pnfb));
+                pv[j] = ok ? v : 0ull;
+            }
+        }
+    };
+    auto store_group = [&](int b) {
+        unsigned long long *const lx = reinterpret_cast<unsigned long long *>(smem + static_cast<size_t>(b) * xbuf_bytes);
+#pragma unroll
+        for (int j = 0; j < kFpElems; ++j) {
+            const int cc = j / ROWS, r = j - cc * ROWS;
+            const int sidx = r * kFpThreads + tid;
+            if (r * kFpThreads < MS && sidx < MS) lx[cc * MS + sidx] = pv[j];
+        }
+    };
+
+    int n_lo = first_index_issue(tau);
+    first_index_wait(n_lo);
+    int n_pre = 0;
+    double ph_pre = 0.0;
+    {
+        const long long rem = a.n_out - tau * kFpThreads;
+        if (tid < rem) { n_pre = a.n_idx[tau * kFpThreads + tid]; ph_pre = a.acc[tau * kFpThreads + tid]; }
+    }
+    load_group(static_cast<long long>(n_lo) - T, 0);
+    store_group(0);
+    __syncthreads();
+    int buf = 0;
+
+    for (;;) {                                                    // tiles of 256 outputs
+        const long long k0 = tau * kFpThreads;
+        const long long rem = a.n_out - k0;
+        const int nout = rem < kFpThreads ? static_cast<int>(rem) : kFpThreads;
+        const long long o = static_cast<long long>(n_lo) - T;    // x[n_lo - T ...] (0-based); n = 1-based newest sample
+        const long long ntau = tau + gridDim.x;
+        const bool have_next_tile = ntau < ntiles;
+        int n_lo_next = 0;
+        if (have_next_tile) n_lo_next = first_index_issue(ntau);  // waited for in front of its use (the last channel group)
+        const bool have = tid < nout;
+        const int n = n_pre;
+        const double phase = ph_pre;
+        if (have_next_tile) {
+            const long long remn = a.n_out - ntau * kFpThreads;
+            if (tid < remn) { n_pre = a.n_idx[ntau * kFpThreads + tid]; ph_pre = a.acc[ntau * kFpThreads + tid]; }
+        }
+        double treg[TREG];
+        if (have) {
+#pragma unroll
+            for (int i = 0; i < TREG; ++i) {
+                treg[i] = 0.0;
+                if (EXACT || i < T) {                             // Horner in Float64, separately rounded multiply and add
+                    const double *c = lcoef + i * (P + 1);
+                    double yv = c[P];
+                    for (int j = P - 1; j >= 0; --j) { const double t = phase * yv; yv = c[j] + t; }
+                    treg[i] = a.tap_f32 ? static_cast<double>(static_cast<float>(yv)) : yv;
+                }
+            }
+        }
+        const bool seam = n < T;                                  // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818
+        const double acc0 = seam ? 0.0 : -0.0;
+        const int w = have ? n - n_lo : 0;                        // oldest sample of this output's window, within the tile
+
+        for (int cg = 0; cg < ngroups; ++cg) {
+            const int ch0 = cg * CPL;
+            const int nchl = a.nch - ch0 < CPL ? a.nch - ch0 : CPL;
+            const bool last = cg + 1 == ngroups;
+            const bool have_next = !last || have_next_tile;
+            // the next group's loads go out now and land while this group is computed
+            if (!last) {
+                load_group(o, ch0 + CPL);
+            } else if (have_next_tile) {
+                first_index_wait(n_lo_next);
+                load_group(static_cast<long long>(n_lo_next) - T, 0);
+            }
+
+            double res[CPL][NC];
+            if (have) {
+                unsigned sa[CPL];
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+                    sa[cc] = lds0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w) * 8u;
+                    dev::pin(sa[cc]);
+                }
+                struct Set { v2u_t s[kFpSetTaps][CPL]; };
+                auto issue = [&](Set &q, auto set_c) {           // samples w + 2*SET, w + 2*SET + 1 of every channel
+                    constexpr int SET = decltype(set_c)::value;
+                    dev::static_for<0, kFpSetTaps>([&](auto t_c) {
+                        constexpr int TT = decltype(t_c)::value;
+#pragma unroll
+                        for (int cc = 0; cc < CPL; ++cc) q.s[TT][cc] = dev::lds_read_b64<(SET * kFpSetTaps + TT) * 8>(sa[cc]);
+                    });
+                };
+                auto landed = [&](Set &q, auto n_c) {            // at most N later reads still in flight => q has landed
+                    constexpr int N = decltype(n_c)::value;
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+#pragma unroll
+                    for (int t = 0; t < kFpSetTaps; ++t) {
+#pragma unroll
+                        for (int cc = 0; cc < CPL; ++cc) dev::pin(q.s[t][cc]);
+                    }
+                };
+                double acc[CPL][NC];
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[cc][c] = acc0;
+                }
+                auto compute = [&](const Set &q, auto set_c) {
+                    constexpr int SET = decltype(set_c)::value;
+                    dev::static_for<0, kFpSetTaps>([&](auto t_c) {
+                        constexpr int TT = decltype(t_c)::value;
+                        constexpr int I = SET * kFpSetTaps + TT;
+                        if constexpr (I < TREG) {
+                            if (EXACT || I < T) {                 // (uniform)
+#pragma unroll
+                                for (int cc = 0; cc < CPL; ++cc) {
+#pragma unroll
+                                    for (int c = 0; c < NC; ++c)
+                                        acc[cc][c] = fmacd<FUSED>(treg[I], fsample_part<TX, NC>(q.s[TT][cc], c), acc[cc][c]);
+                                }
+                            }
+                        }
+                    });
+                };
+                // straight-line pipeline over a ring of kFpDepth register sets (reads past the window stay inside LDS: the pad
+                // behind the buffers; they are never used)
+                Set ring[kFpDepth];
+                dev::static_for<0, (kFpDepth - 1 < NSETS ? kFpDepth - 1 : NSETS)>([&](auto s_c) { issue(ring[decltype(s_c)::value], s_c); });
+                dev::static_for<0, NSETS>([&](auto s_c) {
+                    constexpr int S = decltype(s_c)::value;
+                    // wait for set S (the sets issued behind it stay in flight), reuse the register set freed one step ago
+                    constexpr int behind = (NSETS - 1 - S) < (kFpDepth - 2) ? (NSETS - 1 - S) : (kFpDepth - 2);
+                    landed(ring[S % kFpDepth], std::integral_constant<int, behind * NR>{});
+                    if constexpr (S + kFpDepth - 1 < NSETS) issue(ring[(S + kFpDepth - 1) % kFpDepth], std::integral_constant<int, S + kFpDepth - 1>{});
+                    compute(ring[S % kFpDepth], s_c);
+                });
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) res[cc][c] = acc[cc][c];
+                }
+            }
+            // The prefetched samples go to the other buffer BEFORE the outputs are stored: their wait (vmcnt) would otherwise
+            // include the stores.  (The waves still computing this group do not read that buffer.)
+            asm volatile("" ::: "memory");   // (the LDS writes below stay below the hand-issued reads above)
+            if (have_next) { buf ^= 1; store_group(buf); }
+            if (have) {
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+                    if (cc < nchl) {
+                        unsigned char *yc = opaque_uniform(reinterpret_cast<unsigned char *>(static_cast<double *>(a.y) + (static_cast<long long>(ch0 + cc) * a.y_stride + k0) * NC));
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) *reinterpret_cast<double *>(yc + static_cast<unsigned>(tid * NC + c) * 8u) = res[cc][c];
+                    }
+                }
+            }
+            if (have_next) __syncthreads();   // one barrier per channel group
+        }
+        if (!have_next_tile) break;
+        tau = ntau;
+        n_lo = n_lo_next;
+    }
+}
+
+template <typename TX, int NC>
+hipError_t launch_fpipe_t(bool fused, const FarrowArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s, int num_cus)
+{
+    auto go = [&](auto kfn) -> hipError_t {
+        int per_cu = 0;
+        hipError_t eo = occupancy_cached(reinterpret_cast<const void *>(kfn), kFpThreads, lds, &per_cu);
+        if (eo != hipSuccess) return eo;
+        if (per_cu < 1) per_cu = 1;
+        long long g = static_cast<long long>(num_cus) * per_cu;
+        if (g > ta.total_tiles) g = ta.total_tiles;
+        if (g < 1) g = 1;
+        if (MRHIP_ENV_INT("MRHIP_DEBUG", 0) == 1) {
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kfn));
+            std::fprintf(stderr, "[mrhip] farrow_pipe T=%d P=%d cpl=%d grid=%lld lds=%zu occ/CU=%d regs=%d max_span=%d tiles=%lld\n",
+                         a.T, a.polyorder, ta.cpl, g, lds, per_cu, fa.numRegs, ta.max_span, ta.total_tiles);
+        }
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kFpThreads), lds, s, a, ta);
+        return hipGetLastError();
+    };
+#define MRHIP_FP_GO(C)                                                                                           \
+    if (a.T == 32) return fused ? go(farrow_pipe_kernel<TX, NC, true, C, 32, true>) : go(farrow_pipe_kernel<TX, NC, false, C, 32, true>);   \
+    return a.T <= 16 ? (fused ? go(farrow_pipe_kernel<TX, NC, true, C, 16, false>) : go(farrow_pipe_kernel<TX, NC, false, C, 16, false>))  \
+                     : (fused ? go(farrow_pipe_kernel<TX, NC, true, C, 32, false>) : go(farrow_pipe_kernel<TX, NC, false, C, 32, false>));
+    switch (ta.cpl) {
+    case 4: MRHIP_FP_GO(4)
+    case 2: MRHIP_FP_GO(2)
+    default: MRHIP_FP_GO(1)
+    }
+#undef MRHIP_FP_GO
+}
+
+}  // namespace
+
+// Eligible: Float64 arithmetic, 8-byte samples, at most 32 taps, tiles of 256 outputs whose sample span fits kFpElems rows
+// of 256 per thread (a decimating rate stretches the span: fewer channels per lane).
+bool plan_farrow_pipe(const TypeKey &tk, const FarrowArgs &a, long long span256, ArbTileArgs *out, size_t *lds)
+{
+    if (MRHIP_ENV_INT("MRHIP_FARROW_PIPE", 1) == 0) return false;
+    const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
+    if (!tk.r_f64 || sb != 8 || a.n_out < 1 || a.T > 32) return false;
+    const long long max_span = (span256 + a.T + 1) / 2 * 2;
+    int cpl = a.nch >= 4 ? 4 : (a.nch >= 2 ? 2 : 1);
+    while (cpl > 1 && max_span > static_cast<long long>(kFpElems / cpl) * kFpThreads) cpl /= 2;
+    if (max_span > static_cast<long long>(kFpElems / cpl) * kFpThreads) return false;
+    // (+ pad: the pipeline reads whole register sets, up to 33 samples from a window's start)
+    const size_t coef_off = 2 * static_cast<size_t>(max_span) * cpl * 8 + 320;
+    const size_t total = coef_off + static_cast<size_t>(a.T) * (a.polyorder + 1) * 8;
+    if (total > 150 * 1024) return false;
+    ArbTileArgs ta{};
+    ta.pipe = 1;
+    ta.cpl = cpl;
+    ta.max_span = static_cast<int>(max_span);
+    ta.x_offset_bytes = static_cast<int>(coef_off);   // (here: where the polynomial coefficients live)
+    ta.tile_out = kFpThreads;
+    ta.tiles_per_channel = (a.n_out + kFpThreads - 1) / kFpThreads;
+    ta.total_tiles = ta.tiles_per_channel;            // a tile covers all channels
+    *out = ta;
+    *lds = total;
+    return true;
+}
+
+hipError_t launch_farrow_pipe(const TypeKey &tk, bool fused, const FarrowArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
+                              const char **kname, int num_cus)
+{
+    *kname = "farrow_pipe_kernel";
+    return tk.complex_x ? launch_fpipe_t<float, 2>(fused, a, ta, lds, s, num_cus) : launch_fpipe_t<double, 1>(fused, a, ta, lds, s, num_cus);
+}
+
+}  // namespace mrhip

@@ -548,7 +548,7 @@ def test_farrow_sweep_bit_exact_with_shared_polynomials(pkg, O, torch_cuda):
         f = pkg.FIRFilter(h, rate, Nphi, order, pnfb=pn)
         outs = [o.cpu().numpy() for o in _run_chunks(f, torch.from_numpy(x).cuda(), sizes)]
         y = np.concatenate(outs, axis=1)
-        assert f.last_kernel_name() in ("farrow_kernel", "farrow_tiled_kernel") and f.kernel_name == "FIRFarrow"
+        assert f.last_kernel_name() in ("farrow_kernel", "farrow_tiled_kernel", "farrow_pipe_kernel") and f.kernel_name == "FIRFarrow"
         assert np.array_equal(f.pnfb(), pn)
         for c in range(nch):
             fo = O.FIRFilter(h, rate, Nphi, tx=tx, polyorder=order, pnfb=pn)
@@ -1087,3 +1087,53 @@ def test_arb_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
                 O.set_fused(False)
             f.close(); g.close()
     assert "arb_pipe_kernel" in seen and "arb_tiled_kernel" in seen, seen
+
+
+def test_farrow_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
+    """farrow_pipe_kernel (Float64 arithmetic, 8-byte samples, at most 32 taps): bit-equal to the oracle on some channels
+    and to the generic farrow_kernel on all of them -- over tap counts on both sides of the 16-tap instantiation, partial
+    channel groups, rates whose span needs fewer channels per lane or falls back, seams, signed zeros, fused numerics."""
+    torch = torch_cuda
+    rng = np.random.default_rng(777)
+    seen = set()
+    cases = []
+    for T in (1, 2, 3, 5, 8, 15, 16, 17, 31, 32):
+        cases.append((32, T, math.pi / 3, np.float64, int(rng.choice([1, 2, 3, 6, 9]))))
+    for rate in (0.05, 0.11, 0.26, 0.6, 1.0, 1.9, 3.3):
+        cases.append((32, 12, rate, np.float64, 13))
+        cases.append((10, 6, rate, np.complex64, 5))
+    cases.append((32, 32, math.pi / 3, np.float64, 64))
+    cases.append((32, 32, math.pi / 3, np.complex64, 37))
+    cases.append((32, 40, math.pi / 3, np.float64, 8))            # more than 32 taps: farrow_tiled_kernel
+    for (Nphi, T, rate, tx, nch) in cases:
+        h = (pkg.firdes(T * Nphi, 0.45 / Nphi, beta=7.0) * Nphi).astype(np.float64)
+        n = (6000 if nch <= 9 else 2500) * (8 if rate < 0.2 else 1)
+        x = _rand(rng, (nch, n), tx) - 0.5
+        x[:, 100:140] = 0.0
+        x[:, 120:130] *= -1.0                                    # -0.0
+        xd = torch.from_numpy(x).cuda()
+        sizes = [n // 2 - 1, 1, 2, n - n // 2 - 2]
+        for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
+            monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+            pn = O.pfb2pnfb(O.taps2pfb(h, Nphi), 4)
+            f = pkg.FIRFilter(h, float(rate), Nphi, 4, pnfb=pn, numerics=numerics)
+            y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+            seen.add(f.last_kernel_name())
+            monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+            g = pkg.FIRFilter(h, float(rate), Nphi, 4, pnfb=pn, numerics=numerics)
+            yg = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
+            assert g.last_kernel_name() == "farrow_kernel"
+            monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+            tag = f"Nphi={Nphi} T={T} rate={rate} {np.dtype(tx)} nch={nch} numerics={numerics} kernel={f.last_kernel_name()}"
+            assert_bit_equal(y, yg, "pipe vs generic " + tag)
+            assert_bit_equal(f.history, g.history, "history " + tag)
+            O.set_fused(numerics == pkg.NUMERICS_FUSED)
+            try:
+                for c in sorted({0, nch - 1}):
+                    fo = O.FIRFilter(h, float(rate), Nphi, tx=tx, polyorder=4, pnfb=pn)
+                    yo = np.concatenate(_run_chunks(fo, x[c], sizes))
+                    assert_bit_equal(y[c], yo, f"pipe vs oracle ch={c} " + tag)
+            finally:
+                O.set_fused(False)
+            f.close(); g.close()
+    assert "farrow_pipe_kernel" in seen and "farrow_tiled_kernel" in seen, seen
