@@ -16,6 +16,21 @@ for d in sys.argv[1:]:
             {"kernel": short(r["Name"]), "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
              "min_us": round(float(r["MinNs"]) / 1e3, 2), "max_us": round(float(r["MaxNs"]) / 1e3, 2),
              "pct": float(r["Percentage"])} for r in rows]
+    # The stats file averages over EVERY launch of the run, warm-up included (the first launches of a process run at lower
+    # clocks); the bench's HIP events bracket only the timed region = the LAST launches.  From the kernel trace, in launch
+    # order: the average of the last 5 launches of each mrhip kernel (bench.py's default --steps) next to the run's average.
+    for f in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
+        runs = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "mrhip" in r["Kernel_Name"]:
+                runs[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        tl = {}
+        for k, v in runs.items():
+            v.sort()
+            dur = [(e - b) / 1e3 for b, e in v]
+            tl[k] = {"launches": len(dur), "all_avg_us": round(sum(dur) / len(dur), 2), "last5_avg_us": round(sum(dur[-5:]) / len(dur[-5:]), 2),
+                     "first3_us": [round(x, 1) for x in dur[:3]]}
+        out.setdefault(d, {})["kernel_trace"] = tl
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         agg = defaultdict(lambda: defaultdict(list))
         meta = {}
