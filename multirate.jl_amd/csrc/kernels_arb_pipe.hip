@@ -32,12 +32,26 @@ using dev::v2u_t;
 constexpr int kPipeThreads = 256;
 constexpr int kPipeElems = 8;        // 8-byte samples a thread stages per tile: CPL channels x ROWS rows of 256 samples
 
-template <bool FUSED>
-__device__ __forceinline__ double macd(double t, double x, double acc)
+template <bool FUSED, typename R>
+__device__ __forceinline__ R macd(R t, R x, R acc)
 {
-    if constexpr (FUSED) return __builtin_fma(t, x, acc);
-    const double p = t * x;
-    return acc + p;
+    if constexpr (FUSED) {
+        if constexpr (sizeof(R) == 4) return __builtin_fmaf(t, x, acc);
+        else return __builtin_fma(t, x, acc);
+    } else {
+        const R p = t * x;
+        return acc + p;
+    }
+}
+
+// a tap as the LDS read delivers it: 8 bytes (Float64 arithmetic) or 4 (Float32)
+template <typename R> struct TapBits { using type = v2u_t; };
+template <> struct TapBits<float> { using type = unsigned; };
+template <typename R, int OFF>
+__device__ __forceinline__ typename TapBits<R>::type lds_read_tap(unsigned byte_addr)
+{
+    if constexpr (sizeof(R) == 8) return dev::lds_read_b64<OFF>(byte_addr);
+    else return dev::lds_read_b32<OFF>(byte_addr);
 }
 
 // A wave-uniform pointer the compiler can no longer fold into vector address arithmetic: base (SGPR pair) + 32-bit lane
@@ -51,19 +65,19 @@ __device__ __forceinline__ P *opaque_uniform(P *p)
     return reinterpret_cast<P *>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
-template <typename TX, int NC>
-__device__ __forceinline__ double sample_part(v2u_t v, int c)
+template <typename TX, typename R, int NC>
+__device__ __forceinline__ R sample_part(v2u_t v, int c)
 {
     if constexpr (NC == 1) {
-        static_assert(sizeof(TX) == 8, "one 8-byte real sample");
+        static_assert(sizeof(TX) == 8 && sizeof(R) == 8, "one 8-byte real sample");
         return __builtin_bit_cast(double, v);
     } else {
         static_assert(sizeof(TX) == 4 && NC == 2, "one ComplexF32 sample");
-        return static_cast<double>(__builtin_bit_cast(float, c == 0 ? v.x : v.y));
+        return static_cast<R>(__builtin_bit_cast(float, c == 0 ? v.x : v.y));
     }
 }
 
-template <typename TX, int NC, bool FUSED, int CPL>
+template <typename TX, typename R, int NC, bool FUSED, int CPL>
 __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, ArbTileArgs ta)
 {
     constexpr int ROWS = kPipeElems / CPL;
@@ -73,11 +87,13 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     const int tid = threadIdx.x;
     const int T = a.T, TP = ta.tap_pitch, MS = ta.max_span;
-    double *const lpfb = reinterpret_cast<double *>(smem);
-    double *const ldpfb = lpfb + ta.bank_elems;
+    constexpr unsigned RS = sizeof(R);                                // bytes per tap
+    using TapReg = typename TapBits<R>::type;
+    R *const lpfb = reinterpret_cast<R *>(smem);
+    R *const ldpfb = lpfb + ta.bank_elems;
     {   // both tap banks -> LDS once per workgroup: element (phi, i) at phi*TP + i
-        const double *__restrict__ g0 = static_cast<const double *>(a.taps);
-        const double *__restrict__ g1 = static_cast<const double *>(a.dtaps);
+        const R *__restrict__ g0 = static_cast<const R *>(a.taps);
+        const R *__restrict__ g1 = static_cast<const R *>(a.dtaps);
         const int total = a.Nphi * T;
         for (int e = tid; e < total; e += kPipeThreads) {
             const int phi = e / T, i = e - phi * T;
@@ -203,14 +219,14 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
         int n_lo_next2 = 0;
         if (have_next2) n_lo_next2 = first_index_issue(n2tau);   // waited for behind the barrier at the end of this tile
 
-        double res[CPL][NC];
+        R res[CPL][NC];
         if (tid < cur.nout) {
             const double phif = __builtin_floor(acc_mine);
             const double alpha = acc_mine - phif;                 // src/Filters.jl:671-672
             const int phi = static_cast<int>(phif) - 1;           // 0-based column
             const int w = n_mine - cur.n_lo;                      // oldest sample of this output's window, within the tile
-            unsigned tpa = lds0 + static_cast<unsigned>(phi * TP) * 8u;                  // taps of this phase
-            unsigned dpa = tpa + static_cast<unsigned>(ta.bank_elems) * 8u;              // ... of the difference bank
+            unsigned tpa = lds0 + static_cast<unsigned>(phi * TP) * RS;                  // taps of this phase
+            unsigned dpa = tpa + static_cast<unsigned>(ta.bank_elems) * RS;              // ... of the difference bank
             unsigned sa[CPL];
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) sa[cc] = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w) * 8u;
@@ -218,11 +234,12 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) dev::pin(sa[cc]);
 
-            struct Blk { v2u_t t0, t1, d0, d1; v2u_t s0[CPL], s1[CPL]; };
+            struct Blk { TapReg t0, t1, d0, d1; v2u_t s0[CPL], s1[CPL]; };
             auto issue = [&](Blk &b, auto off_c) {              // taps i, i + 1 at byte offset OFF from the running bases
                 constexpr int OFF = decltype(off_c)::value;
-                b.t0 = dev::lds_read_b64<OFF>(tpa); b.t1 = dev::lds_read_b64<OFF + 8>(tpa);
-                b.d0 = dev::lds_read_b64<OFF>(dpa); b.d1 = dev::lds_read_b64<OFF + 8>(dpa);
+                constexpr int TOFF = OFF / 8 * static_cast<int>(RS);           // the same tap pair in the tap banks
+                b.t0 = lds_read_tap<R, TOFF>(tpa); b.t1 = lds_read_tap<R, TOFF + static_cast<int>(RS)>(tpa);
+                b.d0 = lds_read_tap<R, TOFF>(dpa); b.d1 = lds_read_tap<R, TOFF + static_cast<int>(RS)>(dpa);
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) { b.s0[cc] = dev::lds_read_b64<OFF>(sa[cc]); b.s1[cc] = dev::lds_read_b64<OFF + 8>(sa[cc]); }
             };
@@ -234,20 +251,20 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 for (int cc = 0; cc < CPL; ++cc) { dev::pin(b.s0[cc]); dev::pin(b.s1[cc]); }
             };
             // -0.0 + p == p for every p (signed zeros, NaN included): starting from -0.0 IS "the first product initialises"
-            double lo[CPL][NC], up[CPL][NC];
+            R lo[CPL][NC], up[CPL][NC];
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) { lo[cc][c] = -0.0; up[cc][c] = -0.0; }
+                for (int c = 0; c < NC; ++c) { lo[cc][c] = static_cast<R>(-0.0); up[cc][c] = static_cast<R>(-0.0); }
             }
             auto compute = [&](const Blk &b) {
-                const double t0 = __builtin_bit_cast(double, b.t0), t1 = __builtin_bit_cast(double, b.t1);
-                const double d0 = __builtin_bit_cast(double, b.d0), d1 = __builtin_bit_cast(double, b.d1);
+                const R t0 = __builtin_bit_cast(R, b.t0), t1 = __builtin_bit_cast(R, b.t1);
+                const R d0 = __builtin_bit_cast(R, b.d0), d1 = __builtin_bit_cast(R, b.d1);
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
-                        const double x0 = sample_part<TX, NC>(b.s0[cc], c), x1 = sample_part<TX, NC>(b.s1[cc], c);
+                        const R x0 = sample_part<TX, R, NC>(b.s0[cc], c), x1 = sample_part<TX, R, NC>(b.s1[cc], c);
                         lo[cc][c] = macd<FUSED>(t0, x0, lo[cc][c]);
                         up[cc][c] = macd<FUSED>(d0, x0, up[cc][c]);
                         lo[cc][c] = macd<FUSED>(t1, x1, lo[cc][c]);
@@ -255,8 +272,8 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                     }
                 }
             };
-            auto advance = [&](unsigned bytes) {
-                tpa += bytes; dpa += bytes;
+            auto advance = [&](unsigned bytes) {                  // `bytes` of samples = bytes / 8 taps
+                tpa += bytes / 8u * RS; dpa += bytes / 8u * RS;
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) sa[cc] += bytes;
             };
@@ -285,8 +302,8 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             }
             if (T & 1) {                                         // odd tapsPerPhi: the last tap alone
                 const int i = T - 1;
-                const unsigned tl = lds0 + static_cast<unsigned>(phi * TP + i) * 8u;
-                v2u_t t = dev::lds_read_b64<0>(tl), d = dev::lds_read_b64<0>(tl + static_cast<unsigned>(ta.bank_elems) * 8u);
+                const unsigned tl = lds0 + static_cast<unsigned>(phi * TP + i) * RS;
+                TapReg t = lds_read_tap<R, 0>(tl), d = lds_read_tap<R, 0>(tl + static_cast<unsigned>(ta.bank_elems) * RS);
                 v2u_t s[CPL];
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc)
@@ -295,12 +312,12 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 dev::pin(t); dev::pin(d);
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) dev::pin(s[cc]);
-                const double tt = __builtin_bit_cast(double, t), dd = __builtin_bit_cast(double, d);
+                const R tt = __builtin_bit_cast(R, t), dd = __builtin_bit_cast(R, d);
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
-                        const double x = sample_part<TX, NC>(s[cc], c);
+                        const R x = sample_part<TX, R, NC>(s[cc], c);
                         lo[cc][c] = macd<FUSED>(tt, x, lo[cc][c]);
                         up[cc][c] = macd<FUSED>(dd, x, up[cc][c]);
                     }
@@ -310,8 +327,8 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             for (int cc = 0; cc < CPL; ++cc) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const double prod = up[cc][c] * alpha;                     // Filters.jl:730, Float64 combine
-                    res[cc][c] = lo[cc][c] + prod;
+                    const double prod = static_cast<double>(up[cc][c]) * alpha;   // Filters.jl:730, Float64 combine, rounded once
+                    res[cc][c] = static_cast<R>(static_cast<double>(lo[cc][c]) + prod);
                 }
             }
         }
@@ -323,9 +340,14 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) {
                 if (cc < cur.nchl) {
-                    unsigned char *yc = opaque_uniform(reinterpret_cast<unsigned char *>(static_cast<double *>(a.y) + (static_cast<long long>(cur.ch0 + cc) * a.y_stride + cur.k0) * NC));
+                    unsigned char *yc = opaque_uniform(reinterpret_cast<unsigned char *>(static_cast<R *>(a.y) + (static_cast<long long>(cur.ch0 + cc) * a.y_stride + cur.k0) * NC));
+                    if constexpr (NC == 2 && sizeof(R) == 4) {     // one ComplexF32 output: one 8-byte store
+                        dev::v2f_t o2 = {res[cc][0], res[cc][1]};
+                        *reinterpret_cast<dev::v2f_t *>(yc + static_cast<unsigned>(tid) * 8u) = o2;
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) *reinterpret_cast<double *>(yc + static_cast<unsigned>(tid * NC + c) * 8u) = res[cc][c];
+                        for (int c = 0; c < NC; ++c) *reinterpret_cast<R *>(yc + static_cast<unsigned>(tid * NC + c) * RS) = res[cc][c];
+                    }
                 }
             }
         }
@@ -337,7 +359,7 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
     }
 }
 
-template <typename TX, int NC>
+template <typename TX, typename R, int NC>
 hipError_t launch_pipe_t(bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s, int num_cus)
 {
     auto go = [&](auto kfn) -> hipError_t {
@@ -358,9 +380,9 @@ hipError_t launch_pipe_t(bool fused, const ArbArgs &a, const ArbTileArgs &ta, si
         return hipGetLastError();
     };
     switch (ta.cpl) {
-    case 4: return fused ? go(arb_pipe_kernel<TX, NC, true, 4>) : go(arb_pipe_kernel<TX, NC, false, 4>);
-    case 2: return fused ? go(arb_pipe_kernel<TX, NC, true, 2>) : go(arb_pipe_kernel<TX, NC, false, 2>);
-    default: return fused ? go(arb_pipe_kernel<TX, NC, true, 1>) : go(arb_pipe_kernel<TX, NC, false, 1>);
+    case 4: return fused ? go(arb_pipe_kernel<TX, R, NC, true, 4>) : go(arb_pipe_kernel<TX, R, NC, false, 4>);
+    case 2: return fused ? go(arb_pipe_kernel<TX, R, NC, true, 2>) : go(arb_pipe_kernel<TX, R, NC, false, 2>);
+    default: return fused ? go(arb_pipe_kernel<TX, R, NC, true, 1>) : go(arb_pipe_kernel<TX, R, NC, false, 1>);
     }
 }
 
@@ -373,10 +395,11 @@ bool plan_arb_pipe(const TypeKey &tk, const ArbArgs &a, long long span256, ArbTi
 {
     if (MRHIP_ENV_INT("MRHIP_ARB_PIPE", 1) == 0) return false;
     const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
-    if (!tk.r_f64 || sb != 8 || a.n_out < 1) return false;
+    if (sb != 8 || a.n_out < 1) return false;              // (Float64 x Float64, ComplexF32 x Float64 taps, ComplexF32 x Float32 taps)
+    const size_t rs = tk.r_f64 ? 8 : 4;
     const int TP = a.T | 1;                              // odd column pitch: lanes with different phases read different banks
     const size_t bank_elems = static_cast<size_t>(a.Nphi) * TP;
-    const size_t banks_bytes = (2 * bank_elems * 8 + 15) / 16 * 16;
+    const size_t banks_bytes = (2 * bank_elems * rs + 15) / 16 * 16;
     if (banks_bytes > 96 * 1024) return false;
     const long long max_span = (span256 + a.T + 1) / 2 * 2;
     int cpl = a.nch >= 32 ? 4 : (a.nch >= 8 ? 2 : 1);
@@ -405,7 +428,8 @@ hipError_t launch_arb_pipe(const TypeKey &tk, bool fused, const ArbArgs &a, cons
                            const char **kname, int num_cus)
 {
     *kname = "arb_pipe_kernel";
-    return tk.complex_x ? launch_pipe_t<float, 2>(fused, a, ta, lds, s, num_cus) : launch_pipe_t<double, 1>(fused, a, ta, lds, s, num_cus);
+    if (!tk.complex_x) return launch_pipe_t<double, double, 1>(fused, a, ta, lds, s, num_cus);
+    return tk.r_f64 ? launch_pipe_t<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_pipe_t<float, float, 2>(fused, a, ta, lds, s, num_cus);
 }
 
 }  // namespace mrhip

@@ -36,12 +36,16 @@ constexpr int kFpElems = 8;          // 8-byte samples a thread stages per chann
 constexpr int kFpSetTaps = 1;        // taps per register set
 constexpr int kFpDepth = 4;          // register sets: the reads of taps i + 1 and i + 2 are in flight while tap i is multiplied
 
-template <bool FUSED>
-__device__ __forceinline__ double fmacd(double t, double x, double acc)
+template <bool FUSED, typename R>
+__device__ __forceinline__ R fmacd(R t, R x, R acc)
 {
-    if constexpr (FUSED) return __builtin_fma(t, x, acc);
-    const double p = t * x;
-    return acc + p;
+    if constexpr (FUSED) {
+        if constexpr (sizeof(R) == 4) return __builtin_fmaf(t, x, acc);
+        else return __builtin_fma(t, x, acc);
+    } else {
+        const R p = t * x;
+        return acc + p;
+    }
 }
 
 // A wave-uniform pointer the compiler can no longer fold into vector address arithmetic: base (SGPR pair) + 32-bit lane
@@ -55,20 +59,21 @@ __device__ __forceinline__ P *opaque_uniform(P *p)
     return reinterpret_cast<P *>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
-template <typename TX, int NC>
-__device__ __forceinline__ double fsample_part(v2u_t v, int c)
+template <typename TX, typename R, int NC>
+__device__ __forceinline__ R fsample_part(v2u_t v, int c)
 {
     if constexpr (NC == 1) {
-        static_assert(sizeof(TX) == 8, "one 8-byte real sample");
+        static_assert(sizeof(TX) == 8 && sizeof(R) == 8, "one 8-byte real sample");
         return __builtin_bit_cast(double, v);
     } else {
         static_assert(sizeof(TX) == 4 && NC == 2, "one ComplexF32 sample");
-        return static_cast<double>(__builtin_bit_cast(float, c == 0 ? v.x : v.y));
+        return static_cast<R>(__builtin_bit_cast(float, c == 0 ? v.x : v.y));
     }
 }
 
 // EXACT: tapsPerPhi == TREG (no per-tap guards: the unrolled pipeline is one basic block)
-template <typename TX, int NC, bool FUSED, int CPL, int TREG, bool EXACT>
+// R = the arithmetic type: Float64, or Float32 (ComplexF32 samples x Float32 taps)
+template <typename TX, typename R, int NC, bool FUSED, int CPL, int TREG, bool EXACT>
 __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a, ArbTileArgs ta)
 {
     constexpr int ROWS = kFpElems / CPL;
@@ -175,21 +180,21 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
             const long long remn = a.n_out - ntau * kFpThreads;
             if (tid < remn) { n_pre = a.n_idx[ntau * kFpThreads + tid]; ph_pre = a.acc[ntau * kFpThreads + tid]; }
         }
-        double treg[TREG];
+        R treg[TREG];
         if (have) {
 #pragma unroll
             for (int i = 0; i < TREG; ++i) {
-                treg[i] = 0.0;
+                treg[i] = static_cast<R>(0);
                 if (EXACT || i < T) {                             // Horner in Float64, separately rounded multiply and add
                     const double *c = lcoef + i * (P + 1);
                     double yv = c[P];
                     for (int j = P - 1; j >= 0; --j) { const double t = phase * yv; yv = c[j] + t; }
-                    treg[i] = a.tap_f32 ? static_cast<double>(static_cast<float>(yv)) : yv;
+                    treg[i] = a.tap_f32 ? static_cast<R>(static_cast<float>(yv)) : static_cast<R>(yv);
                 }
             }
         }
         const bool seam = n < T;                                  // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818
-        const double acc0 = seam ? 0.0 : -0.0;
+        const R acc0 = seam ? static_cast<R>(0.0) : static_cast<R>(-0.0);
         const int w = have ? n - n_lo : 0;                        // oldest sample of this output's window, within the tile
 
         for (int cg = 0; cg < ngroups; ++cg) {
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
                 load_group(static_cast<long long>(n_lo_next) - T, 0);
             }
 
-            double res[CPL][NC];
+            R res[CPL][NC];
             if (have) {
                 unsigned sa[CPL];
 #pragma unroll
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
                         for (int cc = 0; cc < CPL; ++cc) dev::pin(q.s[t][cc]);
                     }
                 };
-                double acc[CPL][NC];
+                R acc[CPL][NC];
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
 #pragma unroll
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
                                 for (int cc = 0; cc < CPL; ++cc) {
 #pragma unroll
                                     for (int c = 0; c < NC; ++c)
-                                        acc[cc][c] = fmacd<FUSED>(treg[I], fsample_part<TX, NC>(q.s[TT][cc], c), acc[cc][c]);
+                                        acc[cc][c] = fmacd<FUSED, R>(treg[I], fsample_part<TX, R, NC>(q.s[TT][cc], c), acc[cc][c]);
                                 }
                             }
                         }
@@ -280,9 +285,14 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
                     if (cc < nchl) {
-                        unsigned char *yc = opaque_uniform(reinterpret_cast<unsigned char *>(static_cast<double *>(a.y) + (static_cast<long long>(ch0 + cc) * a.y_stride + k0) * NC));
+                        unsigned char *yc = opaque_uniform(reinterpret_cast<unsigned char *>(static_cast<R *>(a.y) + (static_cast<long long>(ch0 + cc) * a.y_stride + k0) * NC));
+                        if constexpr (NC == 2 && sizeof(R) == 4) {     // one ComplexF32 output: one 8-byte store
+                            dev::v2f_t o2 = {res[cc][0], res[cc][1]};
+                            *reinterpret_cast<dev::v2f_t *>(yc + static_cast<unsigned>(tid) * 8u) = o2;
+                        } else {
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) *reinterpret_cast<double *>(yc + static_cast<unsigned>(tid * NC + c) * 8u) = res[cc][c];
+                            for (int c = 0; c < NC; ++c) *reinterpret_cast<R *>(yc + static_cast<unsigned>(tid * NC + c) * static_cast<unsigned>(sizeof(R))) = res[cc][c];
+                        }
                     }
                 }
             }
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
     }
 }
 
-template <typename TX, int NC>
+template <typename TX, typename R, int NC>
 hipError_t launch_fpipe_t(bool fused, const FarrowArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s, int num_cus)
 {
     auto go = [&](auto kfn) -> hipError_t {
@@ -315,9 +325,9 @@ hipError_t launch_fpipe_t(bool fused, const FarrowArgs &a, const ArbTileArgs &ta
         return hipGetLastError();
     };
 #define MRHIP_FP_GO(C)                                                                                           \
-    if (a.T == 32) return fused ? go(farrow_pipe_kernel<TX, NC, true, C, 32, true>) : go(farrow_pipe_kernel<TX, NC, false, C, 32, true>);   \
-    return a.T <= 16 ? (fused ? go(farrow_pipe_kernel<TX, NC, true, C, 16, false>) : go(farrow_pipe_kernel<TX, NC, false, C, 16, false>))  \
-                     : (fused ? go(farrow_pipe_kernel<TX, NC, true, C, 32, false>) : go(farrow_pipe_kernel<TX, NC, false, C, 32, false>));
+    if (a.T == 32) return fused ? go(farrow_pipe_kernel<TX, R, NC, true, C, 32, true>) : go(farrow_pipe_kernel<TX, R, NC, false, C, 32, true>);   \
+    return a.T <= 16 ? (fused ? go(farrow_pipe_kernel<TX, R, NC, true, C, 16, false>) : go(farrow_pipe_kernel<TX, R, NC, false, C, 16, false>))  \
+                     : (fused ? go(farrow_pipe_kernel<TX, R, NC, true, C, 32, false>) : go(farrow_pipe_kernel<TX, R, NC, false, C, 32, false>));
     switch (ta.cpl) {
     case 4: MRHIP_FP_GO(4)
     case 2: MRHIP_FP_GO(2)
@@ -334,7 +344,7 @@ bool plan_farrow_pipe(const TypeKey &tk, const FarrowArgs &a, long long span256,
 {
     if (MRHIP_ENV_INT("MRHIP_FARROW_PIPE", 1) == 0) return false;
     const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
-    if (!tk.r_f64 || sb != 8 || a.n_out < 1 || a.T > 32) return false;
+    if (sb != 8 || a.n_out < 1 || a.T > 32) return false;    // (Float64 x Float64, ComplexF32 x Float64 taps, ComplexF32 x Float32 taps)
     const long long max_span = (span256 + a.T + 1) / 2 * 2;
     int cpl = a.nch >= 4 ? 4 : (a.nch >= 2 ? 2 : 1);
     while (cpl > 1 && max_span > static_cast<long long>(kFpElems / cpl) * kFpThreads) cpl /= 2;
@@ -360,7 +370,8 @@ hipError_t launch_farrow_pipe(const TypeKey &tk, bool fused, const FarrowArgs &a
                               const char **kname, int num_cus)
 {
     *kname = "farrow_pipe_kernel";
-    return tk.complex_x ? launch_fpipe_t<float, 2>(fused, a, ta, lds, s, num_cus) : launch_fpipe_t<double, 1>(fused, a, ta, lds, s, num_cus);
+    if (!tk.complex_x) return launch_fpipe_t<double, double, 1>(fused, a, ta, lds, s, num_cus);
+    return tk.r_f64 ? launch_fpipe_t<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_fpipe_t<float, float, 2>(fused, a, ta, lds, s, num_cus);
 }
 
 }  // namespace mrhip

@@ -147,6 +147,16 @@ def rows(which):
         run("X rational 147//160 c64 32ch x 2e7 in 1e6 chunks, per call", h147, Fraction(147, 160), 32, 32, 20_000_000, torch.complex64, 15.35, 2 * 48 * R147, reps=3, chunk=1_000_000, per_call=True)
         run("X rational 147//160 f32 64ch x 2e7 in 1e6 chunks, per call", h147, Fraction(147, 160), 32, 64, 20_000_000, torch.float32, 7.675, 48 * R147, reps=3, chunk=1_000_000, per_call=True)
 
+    if "xarb" in which:   # config 4's shape in the other sample / tap types (which FIRArbitrary / FIRFarrow kernel serves them, and how fast)
+        for th, dt, sb, nm in ((np.float32, torch.float32, 4, "f32 taps x f32"), (np.float32, torch.complex64, 8, "f32 taps x c64"),
+                               (np.float64, torch.float32, 4, "f64 taps x f32"), (np.float64, torch.complex64, 8, "f64 taps x c64"),
+                               (np.float64, torch.complex128, 16, "f64 taps x c128")):
+            nc = 2 if dt.is_complex else 1
+            ob = (8 if th == np.float64 else 4) * nc
+            for kind, po in (("arbitrary", None), ("farrow", 4)):
+                fl = ((2 * 64 + 2) if po is None else (2 * 32 + 2 * 4 * 32 / 64)) * nc * math.pi / 3
+                run(f"X {kind} pi/3 32x32 {nm} 64ch x 4e6", harb.astype(th), float(math.pi / 3), 32, 64, 4_000_000, dt, sb + ob * math.pi / 3, fl, reps=2, polyorder=po)
+
     if "xmix64" in which:
         run("X README mixed precision: 147//160 Float64 taps x Float32 samples -> Float64, 64ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 64, 1_000_000,
             torch.float32, 4 + 8 * R147, 48 * R147, note="reference README.md:172-193: 17.56 Msamples/s in (0.0569 s for 1e6 samples, 1 channel, Julia 0.3, unnamed 2014 CPU)")

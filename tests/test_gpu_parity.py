@@ -515,7 +515,7 @@ def test_arbitrary_tuned_and_generic_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, float(rate), Nphi)
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        pipe = np.dtype(th) == np.float64 and np.dtype(tx).itemsize == 8     # Float64 arithmetic over 8-byte samples
+        pipe = np.dtype(tx).itemsize == 8 and (np.dtype(th) == np.float64 or np.dtype(tx) == np.complex64)   # 8-byte samples
         assert f.last_kernel_name() == ("arb_pipe_kernel" if pipe else "arb_tiled_kernel")
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, float(rate), Nphi)
@@ -1041,7 +1041,7 @@ def test_randomised_stress_short(torch_cuda):
 
 
 def test_arb_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
-    """arb_pipe_kernel (Float64 arithmetic, 8-byte samples: hand-pipelined LDS reads, -0.0 accumulator start, two sample
+    """arb_pipe_kernel (8-byte samples -- Float64, ComplexF32 with Float64 or Float32 taps: hand-pipelined LDS reads, -0.0 accumulator start, two sample
     buffers): bit-equal to the oracle on some channels and to arb_generic_kernel on all of them, over odd and even
     tapsPerPhi (the single last tap, T = 1), partial channel groups, rates whose span needs fewer channels per lane or
     falls back to arb_tiled_kernel, seams with history, signed zeros, and the fused numerics."""
@@ -1050,14 +1050,17 @@ def test_arb_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
     seen = set()
     cases = []
     for T in (1, 2, 3, 4, 5, 7, 8, 31, 32, 33, 40):
-        cases.append((32, T, math.pi / 3, np.float64, int(rng.choice([1, 3, 9, 33]))))
+        cases.append((32, T, math.pi / 3, np.float64, int(rng.choice([1, 3, 9, 33])), np.float64))
+        cases.append((32, T, math.pi / 3, np.complex64, int(rng.choice([1, 3, 9, 33])), np.float32))   # Float32 arithmetic
     for rate in (0.05, 0.11, 0.26, 0.6, 1.0, 1.9, 3.3):          # (rate = outputs per input: a small one stretches a tile's span)
-        cases.append((32, 12, rate, np.float64, 34))
-        cases.append((10, 6, rate, np.complex64, 9))
-    cases.append((32, 32, math.pi / 3, np.float64, 64))
-    cases.append((32, 32, math.pi / 3, np.complex64, 37))
-    for (Nphi, T, rate, tx, nch) in cases:
-        h = (pkg.firdes(T * Nphi, 0.45 / Nphi, beta=7.0) * Nphi).astype(np.float64)
+        cases.append((32, 12, rate, np.float64, 34, np.float64))
+        cases.append((10, 6, rate, np.complex64, 9, np.float64))
+        cases.append((10, 6, rate, np.complex64, 34, np.float32))
+    cases.append((32, 32, math.pi / 3, np.float64, 64, np.float64))
+    cases.append((32, 32, math.pi / 3, np.complex64, 37, np.float64))
+    cases.append((32, 32, math.pi / 3, np.complex64, 37, np.float32))
+    for (Nphi, T, rate, tx, nch, th) in cases:
+        h = (pkg.firdes(T * Nphi, 0.45 / Nphi, beta=7.0) * Nphi).astype(th)
         n = (6000 if nch <= 9 else 2500) * (8 if rate < 0.2 else 1)     # (enough outputs per piece for the span to matter)
         x = _rand(rng, (nch, n), tx) - 0.5
         x[:, 100:140] = 0.0
@@ -1074,7 +1077,7 @@ def test_arb_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
             yg = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
             assert g.last_kernel_name() == "arb_generic_kernel"
             monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
-            tag = f"Nphi={Nphi} T={T} rate={rate} {np.dtype(tx)} nch={nch} numerics={numerics} kernel={f.last_kernel_name()}"
+            tag = f"Nphi={Nphi} T={T} rate={rate} {np.dtype(tx)} x {np.dtype(th)} taps nch={nch} numerics={numerics} kernel={f.last_kernel_name()}"
             assert_bit_equal(y, yg, "pipe vs generic " + tag)
             assert_bit_equal(f.history, g.history, "history " + tag)
             O.set_fused(numerics == pkg.NUMERICS_FUSED)
@@ -1090,7 +1093,7 @@ def test_arb_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
 
 
 def test_farrow_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
-    """farrow_pipe_kernel (Float64 arithmetic, 8-byte samples, at most 32 taps): bit-equal to the oracle on some channels
+    """farrow_pipe_kernel (8-byte samples -- Float64, ComplexF32 with Float64 or Float32 taps --, at most 32 taps): bit-equal to the oracle on some channels
     and to the generic farrow_kernel on all of them -- over tap counts on both sides of the 16-tap instantiation, partial
     channel groups, rates whose span needs fewer channels per lane or falls back, seams, signed zeros, fused numerics."""
     torch = torch_cuda
@@ -1098,15 +1101,18 @@ def test_farrow_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
     seen = set()
     cases = []
     for T in (1, 2, 3, 5, 8, 15, 16, 17, 31, 32):
-        cases.append((32, T, math.pi / 3, np.float64, int(rng.choice([1, 2, 3, 6, 9]))))
+        cases.append((32, T, math.pi / 3, np.float64, int(rng.choice([1, 2, 3, 6, 9])), np.float64))
+        cases.append((32, T, math.pi / 3, np.complex64, int(rng.choice([1, 2, 3, 6, 9])), np.float32))    # Float32 arithmetic
     for rate in (0.05, 0.11, 0.26, 0.6, 1.0, 1.9, 3.3):
-        cases.append((32, 12, rate, np.float64, 13))
-        cases.append((10, 6, rate, np.complex64, 5))
-    cases.append((32, 32, math.pi / 3, np.float64, 64))
-    cases.append((32, 32, math.pi / 3, np.complex64, 37))
-    cases.append((32, 40, math.pi / 3, np.float64, 8))            # more than 32 taps: farrow_tiled_kernel
-    for (Nphi, T, rate, tx, nch) in cases:
-        h = (pkg.firdes(T * Nphi, 0.45 / Nphi, beta=7.0) * Nphi).astype(np.float64)
+        cases.append((32, 12, rate, np.float64, 13, np.float64))
+        cases.append((10, 6, rate, np.complex64, 5, np.float64))
+        cases.append((10, 6, rate, np.complex64, 13, np.float32))
+    cases.append((32, 32, math.pi / 3, np.float64, 64, np.float64))
+    cases.append((32, 32, math.pi / 3, np.complex64, 37, np.float64))
+    cases.append((32, 32, math.pi / 3, np.complex64, 37, np.float32))
+    cases.append((32, 40, math.pi / 3, np.float64, 8, np.float64))            # more than 32 taps: farrow_tiled_kernel
+    for (Nphi, T, rate, tx, nch, th) in cases:
+        h = (pkg.firdes(T * Nphi, 0.45 / Nphi, beta=7.0) * Nphi).astype(th)
         n = (6000 if nch <= 9 else 2500) * (8 if rate < 0.2 else 1)
         x = _rand(rng, (nch, n), tx) - 0.5
         x[:, 100:140] = 0.0
@@ -1124,7 +1130,7 @@ def test_farrow_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
             yg = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
             assert g.last_kernel_name() == "farrow_kernel"
             monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
-            tag = f"Nphi={Nphi} T={T} rate={rate} {np.dtype(tx)} nch={nch} numerics={numerics} kernel={f.last_kernel_name()}"
+            tag = f"Nphi={Nphi} T={T} rate={rate} {np.dtype(tx)} x {np.dtype(th)} taps nch={nch} numerics={numerics} kernel={f.last_kernel_name()}"
             assert_bit_equal(y, yg, "pipe vs generic " + tag)
             assert_bit_equal(f.history, g.history, "history " + tag)
             O.set_fused(numerics == pkg.NUMERICS_FUSED)
