@@ -66,7 +66,7 @@ __device__ __forceinline__ P *opaque_uniform(P *p)
 }
 
 template <typename TX, typename R, int NC>
-__device__ __forceinline__ R sample_part(v2u_t v, int c)
+__device__ __forceinline__ R sample_part(v2u_t v, int c)          // 8-byte sample: component c
 {
     if constexpr (NC == 1) {
         static_assert(sizeof(TX) == 8 && sizeof(R) == 8, "one 8-byte real sample");
@@ -76,12 +76,22 @@ __device__ __forceinline__ R sample_part(v2u_t v, int c)
         return static_cast<R>(__builtin_bit_cast(float, c == 0 ? v.x : v.y));
     }
 }
+template <typename R>
+__device__ __forceinline__ R sample_of_pair(v2u_t v, int which)   // two Float32 samples in one 8-byte read
+{
+    return static_cast<R>(__builtin_bit_cast(float, which == 0 ? v.x : v.y));
+}
 
 template <typename TX, typename R, int NC, bool FUSED, int CPL>
 __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, ArbTileArgs ta)
 {
     constexpr int ROWS = kPipeElems / CPL;
-    constexpr int NR = 4 + 2 * CPL;                                  // LDS reads per tap pair
+    constexpr unsigned SB = sizeof(TX) * NC;                          // bytes per sample: 8, or 4 (Float32)
+    constexpr bool PAIR = SB == 4;                                    // one 8-byte read = the two samples of a tap pair; the tile is
+                                                                      // kept twice, one sample apart (copy B: odd window starts)
+    static_assert(SB == 8 || (SB == 4 && NC == 1), "8-byte samples, or Float32");
+    using StageT = std::conditional_t<SB == 8, unsigned long long, unsigned>;
+    constexpr int NR = 4 + (PAIR ? 1 : 2) * CPL;                      // LDS reads per tap pair
     static_assert(NR <= 15, "lgkmcnt is a 4-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
@@ -101,8 +111,10 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             ldpfb[phi * TP + i] = g1[e];
         }
     }
-    const unsigned xbuf_bytes = static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * 8u;
-    const unsigned lx0 = lds0 + static_cast<unsigned>(ta.x_offset_bytes);        // sample buffer b at lx0 + b*xbuf_bytes: [CPL][MS]
+    const unsigned copy_bytes = static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * SB;
+    const unsigned copyb_off = copy_bytes + static_cast<unsigned>(ta.copyb_pad) * SB;       // copy B behind copy A, 128 B round the banks
+    const unsigned xbuf_bytes = PAIR ? copyb_off + copy_bytes : copy_bytes;
+    const unsigned lx0 = lds0 + static_cast<unsigned>(ta.x_offset_bytes);        // sample buffer b at lx0 + b*xbuf_bytes: [CPL][MS] (x2)
 
     // tile -> (stretch of 256 outputs tau, channel group cg), time-major: the workgroups that run together share the schedule
     const int ngroups = static_cast<int>(ta.total_tiles / ta.tiles_per_channel);
@@ -145,9 +157,9 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int sidx = r * kPipeThreads + tid;
-        soff[r] = static_cast<unsigned>(sidx < MS ? sidx : MS - 1) * 8u;
+        soff[r] = static_cast<unsigned>(sidx < MS ? sidx : MS - 1) * SB;
     }
-    unsigned long long pv[kPipeElems];                            // the next tile's samples, as raw 8 bytes
+    StageT pv[kPipeElems];                                        // the next tile's samples, as raw bits
     auto load_tile = [&](const Tile &t) {
         if (t.interior) {
 #pragma unroll
@@ -155,8 +167,8 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 // (unconditional, straight-line: a row past the span re-reads the span's last sample -- with a branch per load the
                 // compiler waits for every earlier memory operation, the previous tile's stores included, in front of each)
                 const int cc = j / ROWS, r = j - cc * ROWS;
-                const unsigned char *base = opaque_uniform(static_cast<const unsigned char *>(a.x) + (static_cast<long long>(t.ch0 + cc) * a.x_stride + t.o) * 8);
-                pv[j] = *reinterpret_cast<const unsigned long long *>(base + soff[r]);
+                const unsigned char *base = opaque_uniform(static_cast<const unsigned char *>(a.x) + (static_cast<long long>(t.ch0 + cc) * a.x_stride + t.o) * static_cast<long long>(SB));
+                pv[j] = *reinterpret_cast<const StageT *>(base + soff[r]);
             }
         } else {                                                  // the first and last tiles of a channel group: history, zeros
 #pragma unroll
@@ -165,21 +177,25 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 const int sidx = r * kPipeThreads + tid;
                 const long long gi = t.o + sidx;
                 const bool ok = cc < t.nchl && sidx < MS && gi < a.x_len && gi >= -static_cast<long long>(a.H);
-                const unsigned long long *px = static_cast<const unsigned long long *>(a.x) + static_cast<long long>(t.ch0 + cc) * a.x_stride + gi;
-                const unsigned long long *ph = static_cast<const unsigned long long *>(a.hist) + static_cast<long long>(t.ch0 + cc) * a.H + (a.H + gi);
-                const unsigned long long *p = gi >= 0 ? px : ph;
-                const unsigned long long v = *(ok ? p : static_cast<const unsigned long long *>(a.taps));
-                pv[j] = ok ? v : 0ull;
+                const StageT *px = static_cast<const StageT *>(a.x) + static_cast<long long>(t.ch0 + cc) * a.x_stride + gi;
+                const StageT *ph = static_cast<const StageT *>(a.hist) + static_cast<long long>(t.ch0 + cc) * a.H + (a.H + gi);
+                const StageT *p = gi >= 0 ? px : ph;
+                const StageT v = *(ok ? p : static_cast<const StageT *>(a.taps));
+                pv[j] = ok ? v : static_cast<StageT>(0);
             }
         }
     };
     auto store_tile = [&](int b) {
-        unsigned long long *const lx = reinterpret_cast<unsigned long long *>(smem + ta.x_offset_bytes + static_cast<size_t>(b) * xbuf_bytes);
+        StageT *const lx = reinterpret_cast<StageT *>(smem + ta.x_offset_bytes + static_cast<size_t>(b) * xbuf_bytes);
+        StageT *const lxB = reinterpret_cast<StageT *>(smem + ta.x_offset_bytes + static_cast<size_t>(b) * xbuf_bytes + copyb_off);
 #pragma unroll
         for (int j = 0; j < kPipeElems; ++j) {
             const int cc = j / ROWS, r = j - cc * ROWS;
             const int sidx = r * kPipeThreads + tid;
-            if (r * kPipeThreads < MS && sidx < MS) lx[cc * MS + sidx] = pv[j];
+            if (r * kPipeThreads < MS && sidx < MS) {
+                lx[cc * MS + sidx] = pv[j];
+                if constexpr (PAIR) { if (sidx > 0) lxB[cc * MS + sidx - 1] = pv[j]; }        // B[s] = sample s + 1
+            }
         }
     };
 
@@ -229,26 +245,37 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             unsigned dpa = tpa + static_cast<unsigned>(ta.bank_elems) * RS;              // ... of the difference bank
             unsigned sa[CPL];
 #pragma unroll
-            for (int cc = 0; cc < CPL; ++cc) sa[cc] = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w) * 8u;
+            for (int cc = 0; cc < CPL; ++cc) {
+                if constexpr (PAIR) {     // an aligned pair read: even window starts from copy A, odd ones from copy B (= one sample later)
+                    const unsigned odd = static_cast<unsigned>(w) & 1u;
+                    sa[cc] = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + (odd ? copyb_off : 0u) + (static_cast<unsigned>(cc * MS + w) - odd) * SB;
+                } else {
+                    sa[cc] = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w) * SB;
+                }
+            }
             dev::pin(tpa); dev::pin(dpa);                         // (complete addresses in registers: the loop only adds to them)
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) dev::pin(sa[cc]);
 
-            struct Blk { TapReg t0, t1, d0, d1; v2u_t s0[CPL], s1[CPL]; };
+            struct Blk { TapReg t0, t1, d0, d1; v2u_t s0[CPL], s1[PAIR ? 1 : CPL]; };
             auto issue = [&](Blk &b, auto off_c) {              // taps i, i + 1 at byte offset OFF from the running bases
                 constexpr int OFF = decltype(off_c)::value;
                 constexpr int TOFF = OFF / 8 * static_cast<int>(RS);           // the same tap pair in the tap banks
+                constexpr int SOFF = OFF / 8 * static_cast<int>(SB);           // ... in the sample tile
                 b.t0 = lds_read_tap<R, TOFF>(tpa); b.t1 = lds_read_tap<R, TOFF + static_cast<int>(RS)>(tpa);
                 b.d0 = lds_read_tap<R, TOFF>(dpa); b.d1 = lds_read_tap<R, TOFF + static_cast<int>(RS)>(dpa);
 #pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) { b.s0[cc] = dev::lds_read_b64<OFF>(sa[cc]); b.s1[cc] = dev::lds_read_b64<OFF + 8>(sa[cc]); }
+                for (int cc = 0; cc < CPL; ++cc) {
+                    b.s0[cc] = dev::lds_read_b64<SOFF>(sa[cc]);
+                    if constexpr (!PAIR) b.s1[cc] = dev::lds_read_b64<SOFF + 8>(sa[cc]);
+                }
             };
             auto landed = [&](Blk &b, auto n_c) {               // at most N later reads still in flight => b has landed
                 constexpr int N = decltype(n_c)::value;
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
                 dev::pin(b.t0); dev::pin(b.t1); dev::pin(b.d0); dev::pin(b.d1);
 #pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) { dev::pin(b.s0[cc]); dev::pin(b.s1[cc]); }
+                for (int cc = 0; cc < CPL; ++cc) { dev::pin(b.s0[cc]); if constexpr (!PAIR) dev::pin(b.s1[cc]); }
             };
             // -0.0 + p == p for every p (signed zeros, NaN included): starting from -0.0 IS "the first product initialises"
             R lo[CPL][NC], up[CPL][NC];
@@ -264,7 +291,9 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 for (int cc = 0; cc < CPL; ++cc) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
-                        const R x0 = sample_part<TX, R, NC>(b.s0[cc], c), x1 = sample_part<TX, R, NC>(b.s1[cc], c);
+                        R x0, x1;
+                        if constexpr (PAIR) { x0 = sample_of_pair<R>(b.s0[cc], 0); x1 = sample_of_pair<R>(b.s0[cc], 1); }
+                        else { x0 = sample_part<TX, R, NC>(b.s0[cc], c); x1 = sample_part<TX, R, NC>(b.s1[cc], c); }
                         lo[cc][c] = macd<FUSED>(t0, x0, lo[cc][c]);
                         up[cc][c] = macd<FUSED>(d0, x0, up[cc][c]);
                         lo[cc][c] = macd<FUSED>(t1, x1, lo[cc][c]);
@@ -275,7 +304,7 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             auto advance = [&](unsigned bytes) {                  // `bytes` of samples = bytes / 8 taps
                 tpa += bytes / 8u * RS; dpa += bytes / 8u * RS;
 #pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) sa[cc] += bytes;
+                for (int cc = 0; cc < CPL; ++cc) sa[cc] += bytes / 8u * SB;
             };
             using I0 = std::integral_constant<int, 0>;
             using I16 = std::integral_constant<int, 16>;
@@ -304,10 +333,13 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 const int i = T - 1;
                 const unsigned tl = lds0 + static_cast<unsigned>(phi * TP + i) * RS;
                 TapReg t = lds_read_tap<R, 0>(tl), d = lds_read_tap<R, 0>(tl + static_cast<unsigned>(ta.bank_elems) * RS);
-                v2u_t s[CPL];
+                std::conditional_t<PAIR, unsigned, v2u_t> s[CPL];     // (copy A holds every sample at its own index)
 #pragma unroll
-                for (int cc = 0; cc < CPL; ++cc)
-                    s[cc] = dev::lds_read_b64<0>(lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w + i) * 8u);
+                for (int cc = 0; cc < CPL; ++cc) {
+                    const unsigned sad = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w + i) * SB;
+                    if constexpr (PAIR) s[cc] = dev::lds_read_b32<0>(sad);
+                    else s[cc] = dev::lds_read_b64<0>(sad);
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)");
                 dev::pin(t); dev::pin(d);
 #pragma unroll
@@ -317,7 +349,9 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 for (int cc = 0; cc < CPL; ++cc) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
-                        const R x = sample_part<TX, R, NC>(s[cc], c);
+                        R x;
+                        if constexpr (PAIR) x = static_cast<R>(__builtin_bit_cast(float, s[cc]));
+                        else x = sample_part<TX, R, NC>(s[cc], c);
                         lo[cc][c] = macd<FUSED>(tt, x, lo[cc][c]);
                         up[cc][c] = macd<FUSED>(dd, x, up[cc][c]);
                     }
@@ -395,9 +429,10 @@ bool plan_arb_pipe(const TypeKey &tk, const ArbArgs &a, long long span256, ArbTi
 {
     if (MRHIP_ENV_INT("MRHIP_ARB_PIPE", 1) == 0) return false;
     const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
-    if (sb != 8 || a.n_out < 1) return false;              // (Float64 x Float64, ComplexF32 x Float64 taps, ComplexF32 x Float32 taps)
+    if (sb > 8 || a.n_out < 1) return false;               // (Float32 and 8-byte samples; ComplexF64 stays on arb_tiled_kernel)
     const size_t rs = tk.r_f64 ? 8 : 4;
-    const int TP = a.T | 1;                              // odd column pitch: lanes with different phases read different banks
+    const int copies = sb == 4 ? 2 : 1;                    // Float32: the tile twice, one sample apart (aligned pair reads)
+    const int TP = a.T | 1;                                // odd column pitch: lanes with different phases read different banks
     const size_t bank_elems = static_cast<size_t>(a.Nphi) * TP;
     const size_t banks_bytes = (2 * bank_elems * rs + 15) / 16 * 16;
     if (banks_bytes > 96 * 1024) return false;
@@ -407,7 +442,10 @@ bool plan_arb_pipe(const TypeKey &tk, const ArbArgs &a, long long span256, ArbTi
     if (env_cpl == 1 || env_cpl == 2 || env_cpl == 4) cpl = env_cpl;
     while (cpl > 1 && max_span > static_cast<long long>(kPipeElems / cpl) * kPipeThreads) cpl /= 2;
     if (max_span > static_cast<long long>(kPipeElems / cpl) * kPipeThreads) return false;
-    const size_t total = banks_bytes + 2 * static_cast<size_t>(max_span) * cpl * 8 + 64;   // (+ pad: the pipeline reads one tap pair past a window)
+    // copy B starts 128 B (mod 256) behind copy A: the lanes of one read that use it do not land on their neighbours' banks
+    const int copyb_pad = copies == 2 ? static_cast<int>((128 + 256 - (static_cast<size_t>(max_span) * sb * cpl) % 256) % 256 / sb) : 0;
+    const size_t buf_bytes = (static_cast<size_t>(max_span) * cpl * copies + copyb_pad) * sb;
+    const size_t total = banks_bytes + 2 * buf_bytes + 64;   // (+ pad: the pipeline reads one tap pair past a window)
     if (total > 150 * 1024) return false;
     ArbTileArgs ta{};
     ta.pipe = 1;
@@ -416,6 +454,7 @@ bool plan_arb_pipe(const TypeKey &tk, const ArbArgs &a, long long span256, ArbTi
     ta.bank_elems = static_cast<int>(bank_elems);
     ta.x_offset_bytes = static_cast<int>(banks_bytes);
     ta.max_span = static_cast<int>(max_span);
+    ta.copyb_pad = copyb_pad;
     ta.tile_out = kPipeThreads;
     ta.tiles_per_channel = (a.n_out + kPipeThreads - 1) / kPipeThreads;
     ta.total_tiles = ta.tiles_per_channel * ((a.nch + cpl - 1) / cpl);
@@ -428,8 +467,9 @@ hipError_t launch_arb_pipe(const TypeKey &tk, bool fused, const ArbArgs &a, cons
                            const char **kname, int num_cus)
 {
     *kname = "arb_pipe_kernel";
-    if (!tk.complex_x) return launch_pipe_t<double, double, 1>(fused, a, ta, lds, s, num_cus);
-    return tk.r_f64 ? launch_pipe_t<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_pipe_t<float, float, 2>(fused, a, ta, lds, s, num_cus);
+    if (tk.complex_x) return tk.r_f64 ? launch_pipe_t<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_pipe_t<float, float, 2>(fused, a, ta, lds, s, num_cus);
+    if (tk.x_f64) return launch_pipe_t<double, double, 1>(fused, a, ta, lds, s, num_cus);
+    return tk.r_f64 ? launch_pipe_t<float, double, 1>(fused, a, ta, lds, s, num_cus) : launch_pipe_t<float, float, 1>(fused, a, ta, lds, s, num_cus);
 }
 
 }  // namespace mrhip

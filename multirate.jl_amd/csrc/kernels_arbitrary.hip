@@ -477,7 +477,7 @@ bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_ho
     if (!enabled || a.n_out < 1) return false;
     const size_t rs = tk.r_f64 ? 8 : 4;
     const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
-    if (sb == 8) {                                       // 8-byte samples (Float64, ComplexF32): the hand-pipelined kernel
+    if (sb <= 8) {                                       // Float32 and 8-byte samples (Float64, ComplexF32): the hand-pipelined kernel
         long long span256 = -1;
         if (n_idx_host) {
             for (long long k0 = 0; k0 < a.n_out; k0 += 256) {
@@ -575,7 +575,7 @@ bool plan_farrow_tiled(const TypeKey &tk, const FarrowArgs &a, const int32_t *n_
     if (!enabled || a.n_out < 1) return false;
     const size_t rs = tk.r_f64 ? 8 : 4;
     const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
-    if (sb == 8 && a.T <= 32) {                          // 8-byte samples (Float64, ComplexF32): the hand-pipelined kernel
+    if (sb <= 8 && a.T <= 32) {                          // Float32 and 8-byte samples (Float64, ComplexF32): the hand-pipelined kernel
         long long span256 = -1;
         if (n_idx_host) {
             for (long long k0 = 0; k0 < a.n_out; k0 += 256) {

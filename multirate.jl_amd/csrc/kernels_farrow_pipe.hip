@@ -33,7 +33,6 @@ using dev::v2u_t;
 
 constexpr int kFpThreads = 256;
 constexpr int kFpElems = 8;          // 8-byte samples a thread stages per channel group: CPL channels x ROWS rows of 256 samples
-constexpr int kFpSetTaps = 1;        // taps per register set
 constexpr int kFpDepth = 4;          // register sets: the reads of taps i + 1 and i + 2 are in flight while tap i is multiplied
 
 template <bool FUSED, typename R>
@@ -77,14 +76,22 @@ template <typename TX, typename R, int NC, bool FUSED, int CPL, int TREG, bool E
 __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a, ArbTileArgs ta)
 {
     constexpr int ROWS = kFpElems / CPL;
+    constexpr unsigned SB = sizeof(TX) * NC;                          // bytes per sample: 8, or 4 (Float32)
+    constexpr bool PAIR = SB == 4;                                    // one 8-byte read = two Float32 samples: the tile is kept twice, one
+                                                                      // sample apart (copy B serves the odd window starts)
+    static_assert(SB == 8 || (SB == 4 && NC == 1), "8-byte samples, or Float32");
+    using StageT = std::conditional_t<SB == 8, unsigned long long, unsigned>;
+    constexpr int kFpSetTaps = PAIR ? 2 : 1;                          // taps per register set (= per 8-byte read and channel)
     constexpr int NSETS = (TREG + kFpSetTaps - 1) / kFpSetTaps;
-    constexpr int NR = kFpSetTaps * CPL;                             // LDS reads per register set
+    constexpr int NR = CPL;                                          // LDS reads per register set
     static_assert(NR * (kFpDepth - 1) <= 15, "lgkmcnt is a 4-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     const int tid = threadIdx.x;
     const int T = a.T, P = a.polyorder, MS = ta.max_span;
-    const unsigned xbuf_bytes = static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * 8u;   // sample buffer b at b*xbuf_bytes: [CPL][MS]
+    const unsigned copy_bytes = static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * SB;
+    const unsigned copyb_off = copy_bytes + static_cast<unsigned>(ta.copyb_pad) * SB;       // copy B behind copy A, 128 B round the banks
+    const unsigned xbuf_bytes = PAIR ? copyb_off + copy_bytes : copy_bytes;                // sample buffer b at b*xbuf_bytes: [CPL][MS] (x2)
     const long long ntiles = ta.total_tiles;
     const int ngroups = (a.nch + CPL - 1) / CPL;
 
@@ -113,9 +120,9 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int sidx = r * kFpThreads + tid;
-        soff[r] = static_cast<unsigned>(sidx < MS ? sidx : MS - 1) * 8u;
+        soff[r] = static_cast<unsigned>(sidx < MS ? sidx : MS - 1) * SB;
     }
-    unsigned long long pv[kFpElems];
+    StageT pv[kFpElems];
     auto load_group = [&](long long o, int ch0) {                  // samples x[o ..] of channels ch0 .. ch0 + CPL - 1
         const int nchl = a.nch - ch0 < CPL ? a.nch - ch0 : CPL;
         const bool interior = nchl == CPL && o >= 0 && o + MS <= a.x_len;
@@ -123,8 +130,8 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
 #pragma unroll
             for (int j = 0; j < kFpElems; ++j) {
                 const int cc = j / ROWS, r = j - cc * ROWS;
-                const unsigned char *base = opaque_uniform(static_cast<const unsigned char *>(a.x) + (static_cast<long long>(ch0 + cc) * a.x_stride + o) * 8);
-                pv[j] = *reinterpret_cast<const unsigned long long *>(base + soff[r]);
+                const unsigned char *base = opaque_uniform(static_cast<const unsigned char *>(a.x) + (static_cast<long long>(ch0 + cc) * a.x_stride + o) * static_cast<long long>(SB));
+                pv[j] = *reinterpret_cast<const StageT *>(base + soff[r]);
             }
         } else {                                                  // the first and last tiles, the last channel group: history, zeros
 #pragma unroll
@@ -133,21 +140,25 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
                 const int sidx = r * kFpThreads + tid;
                 const long long gi = o + sidx;
                 const bool ok = cc < nchl && sidx < MS && gi < a.x_len && gi >= -static_cast<long long>(a.H);
-                const unsigned long long *px = static_cast<const unsigned long long *>(a.x) + static_cast<long long>(ch0 + cc) * a.x_stride + gi;
-                const unsigned long long *ph = static_cast<const unsigned long long *>(a.hist) + static_cast<long long>(ch0 + cc) * a.H + (a.H + gi);
-                const unsigned long long *p = gi >= 0 ? px : ph;
-                const unsigned long long v = *(ok ? p : reinterpret_cast<const unsigned long long *>(a.pnfb));
-                pv[j] = ok ? v : 0ull;
+                const StageT *px = static_cast<const StageT *>(a.x) + static_cast<long long>(ch0 + cc) * a.x_stride + gi;
+                const StageT *ph = static_cast<const StageT *>(a.hist) + static_cast<long long>(ch0 + cc) * a.H + (a.H + gi);
+                const StageT *p = gi >= 0 ? px : ph;
+                const StageT v = *(ok ? p : reinterpret_cast<const StageT *>(a.pnfb));
+                pv[j] = ok ? v : static_cast<StageT>(0);
             }
         }
     };
     auto store_group = [&](int b) {
-        unsigned long long *const lx = reinterpret_cast<unsigned long long *>(smem + static_cast<size_t>(b) * xbuf_bytes);
+        StageT *const lx = reinterpret_cast<StageT *>(smem + static_cast<size_t>(b) * xbuf_bytes);
+        StageT *const lxB = reinterpret_cast<StageT *>(smem + static_cast<size_t>(b) * xbuf_bytes + copyb_off);
 #pragma unroll
         for (int j = 0; j < kFpElems; ++j) {
             const int cc = j / ROWS, r = j - cc * ROWS;
             const int sidx = r * kFpThreads + tid;
-            if (r * kFpThreads < MS && sidx < MS) lx[cc * MS + sidx] = pv[j];
+            if (r * kFpThreads < MS && sidx < MS) {
+                lx[cc * MS + sidx] = pv[j];
+                if constexpr (PAIR) { if (sidx > 0) lxB[cc * MS + sidx - 1] = pv[j]; }        // B[s] = sample s + 1
+            }
         }
     };
 
@@ -215,26 +226,25 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
                 unsigned sa[CPL];
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
-                    sa[cc] = lds0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w) * 8u;
+                    if constexpr (PAIR) {     // an aligned pair read: even window starts from copy A, odd ones from copy B (= one sample later)
+                        const unsigned odd = static_cast<unsigned>(w) & 1u;
+                        sa[cc] = lds0 + static_cast<unsigned>(buf) * xbuf_bytes + (odd ? copyb_off : 0u) + (static_cast<unsigned>(cc * MS + w) - odd) * SB;
+                    } else {
+                        sa[cc] = lds0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w) * SB;
+                    }
                     dev::pin(sa[cc]);
                 }
-                struct Set { v2u_t s[kFpSetTaps][CPL]; };
-                auto issue = [&](Set &q, auto set_c) {           // samples w + 2*SET, w + 2*SET + 1 of every channel
+                struct Set { v2u_t s[CPL]; };                    // one 8-byte read per channel: one sample, or two Float32 samples
+                auto issue = [&](Set &q, auto set_c) {           // the samples of the taps of register set SET, every channel
                     constexpr int SET = decltype(set_c)::value;
-                    dev::static_for<0, kFpSetTaps>([&](auto t_c) {
-                        constexpr int TT = decltype(t_c)::value;
 #pragma unroll
-                        for (int cc = 0; cc < CPL; ++cc) q.s[TT][cc] = dev::lds_read_b64<(SET * kFpSetTaps + TT) * 8>(sa[cc]);
-                    });
+                    for (int cc = 0; cc < CPL; ++cc) q.s[cc] = dev::lds_read_b64<SET * 8>(sa[cc]);
                 };
                 auto landed = [&](Set &q, auto n_c) {            // at most N later reads still in flight => q has landed
                     constexpr int N = decltype(n_c)::value;
                     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
 #pragma unroll
-                    for (int t = 0; t < kFpSetTaps; ++t) {
-#pragma unroll
-                        for (int cc = 0; cc < CPL; ++cc) dev::pin(q.s[t][cc]);
-                    }
+                    for (int cc = 0; cc < CPL; ++cc) dev::pin(q.s[cc]);
                 };
                 R acc[CPL][NC];
 #pragma unroll
@@ -252,8 +262,12 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
 #pragma unroll
                                 for (int cc = 0; cc < CPL; ++cc) {
 #pragma unroll
-                                    for (int c = 0; c < NC; ++c)
-                                        acc[cc][c] = fmacd<FUSED, R>(treg[I], fsample_part<TX, R, NC>(q.s[TT][cc], c), acc[cc][c]);
+                                    for (int c = 0; c < NC; ++c) {
+                                        R xs;
+                                        if constexpr (PAIR) xs = static_cast<R>(__builtin_bit_cast(float, TT == 0 ? q.s[cc].x : q.s[cc].y));
+                                        else xs = fsample_part<TX, R, NC>(q.s[cc], c);
+                                        acc[cc][c] = fmacd<FUSED, R>(treg[I], xs, acc[cc][c]);
+                                    }
                                 }
                             }
                         }
@@ -344,19 +358,23 @@ bool plan_farrow_pipe(const TypeKey &tk, const FarrowArgs &a, long long span256,
 {
     if (MRHIP_ENV_INT("MRHIP_FARROW_PIPE", 1) == 0) return false;
     const size_t sb = (tk.x_f64 ? 8 : 4) * (tk.complex_x ? 2 : 1);
-    if (sb != 8 || a.n_out < 1 || a.T > 32) return false;    // (Float64 x Float64, ComplexF32 x Float64 taps, ComplexF32 x Float32 taps)
+    if (sb > 8 || a.n_out < 1 || a.T > 32) return false;     // (Float32 and 8-byte samples; ComplexF64 stays on farrow_tiled_kernel)
+    const int copies = sb == 4 ? 2 : 1;                      // Float32: the tile twice, one sample apart (aligned pair reads)
     const long long max_span = (span256 + a.T + 1) / 2 * 2;
     int cpl = a.nch >= 4 ? 4 : (a.nch >= 2 ? 2 : 1);
     while (cpl > 1 && max_span > static_cast<long long>(kFpElems / cpl) * kFpThreads) cpl /= 2;
     if (max_span > static_cast<long long>(kFpElems / cpl) * kFpThreads) return false;
+    const int copyb_pad = copies == 2 ? static_cast<int>((128 + 256 - (static_cast<size_t>(max_span) * sb * cpl) % 256) % 256 / sb) : 0;
+    const size_t buf_bytes = (static_cast<size_t>(max_span) * cpl * copies + copyb_pad) * sb;
     // (+ pad: the pipeline reads whole register sets, up to 33 samples from a window's start)
-    const size_t coef_off = 2 * static_cast<size_t>(max_span) * cpl * 8 + 320;
+    const size_t coef_off = (2 * buf_bytes + 320 + 15) / 16 * 16;
     const size_t total = coef_off + static_cast<size_t>(a.T) * (a.polyorder + 1) * 8;
     if (total > 150 * 1024) return false;
     ArbTileArgs ta{};
     ta.pipe = 1;
     ta.cpl = cpl;
     ta.max_span = static_cast<int>(max_span);
+    ta.copyb_pad = copyb_pad;
     ta.x_offset_bytes = static_cast<int>(coef_off);   // (here: where the polynomial coefficients live)
     ta.tile_out = kFpThreads;
     ta.tiles_per_channel = (a.n_out + kFpThreads - 1) / kFpThreads;
@@ -370,8 +388,9 @@ hipError_t launch_farrow_pipe(const TypeKey &tk, bool fused, const FarrowArgs &a
                               const char **kname, int num_cus)
 {
     *kname = "farrow_pipe_kernel";
-    if (!tk.complex_x) return launch_fpipe_t<double, double, 1>(fused, a, ta, lds, s, num_cus);
-    return tk.r_f64 ? launch_fpipe_t<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_fpipe_t<float, float, 2>(fused, a, ta, lds, s, num_cus);
+    if (tk.complex_x) return tk.r_f64 ? launch_fpipe_t<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_fpipe_t<float, float, 2>(fused, a, ta, lds, s, num_cus);
+    if (tk.x_f64) return launch_fpipe_t<double, double, 1>(fused, a, ta, lds, s, num_cus);
+    return tk.r_f64 ? launch_fpipe_t<float, double, 1>(fused, a, ta, lds, s, num_cus) : launch_fpipe_t<float, float, 1>(fused, a, ta, lds, s, num_cus);
 }
 
 }  // namespace mrhip

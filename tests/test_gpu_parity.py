@@ -515,7 +515,7 @@ def test_arbitrary_tuned_and_generic_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, float(rate), Nphi)
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        pipe = np.dtype(tx).itemsize == 8 and (np.dtype(th) == np.float64 or np.dtype(tx) == np.complex64)   # 8-byte samples
+        pipe = np.dtype(tx).itemsize <= 8                          # Float32 and 8-byte samples; ComplexF64: arb_tiled_kernel
         assert f.last_kernel_name() == ("arb_pipe_kernel" if pipe else "arb_tiled_kernel")
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, float(rate), Nphi)
@@ -1041,7 +1041,7 @@ def test_randomised_stress_short(torch_cuda):
 
 
 def test_arb_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
-    """arb_pipe_kernel (8-byte samples -- Float64, ComplexF32 with Float64 or Float32 taps: hand-pipelined LDS reads, -0.0 accumulator start, two sample
+    """arb_pipe_kernel (Float32, Float64 and ComplexF32 samples with Float64 or Float32 taps: hand-pipelined LDS reads, -0.0 accumulator start, two sample
     buffers): bit-equal to the oracle on some channels and to arb_generic_kernel on all of them, over odd and even
     tapsPerPhi (the single last tap, T = 1), partial channel groups, rates whose span needs fewer channels per lane or
     falls back to arb_tiled_kernel, seams with history, signed zeros, and the fused numerics."""
@@ -1052,13 +1052,18 @@ def test_arb_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
     for T in (1, 2, 3, 4, 5, 7, 8, 31, 32, 33, 40):
         cases.append((32, T, math.pi / 3, np.float64, int(rng.choice([1, 3, 9, 33])), np.float64))
         cases.append((32, T, math.pi / 3, np.complex64, int(rng.choice([1, 3, 9, 33])), np.float32))   # Float32 arithmetic
+        cases.append((32, T, math.pi / 3, np.float32, int(rng.choice([1, 3, 9, 33])), np.float32))     # Float32 samples: pair reads
     for rate in (0.05, 0.11, 0.26, 0.6, 1.0, 1.9, 3.3):          # (rate = outputs per input: a small one stretches a tile's span)
         cases.append((32, 12, rate, np.float64, 34, np.float64))
         cases.append((10, 6, rate, np.complex64, 9, np.float64))
         cases.append((10, 6, rate, np.complex64, 34, np.float32))
+        cases.append((10, 6, rate, np.float32, 34, np.float64))
+        cases.append((32, 7, rate, np.float32, 9, np.float32))
     cases.append((32, 32, math.pi / 3, np.float64, 64, np.float64))
     cases.append((32, 32, math.pi / 3, np.complex64, 37, np.float64))
     cases.append((32, 32, math.pi / 3, np.complex64, 37, np.float32))
+    cases.append((32, 32, math.pi / 3, np.float32, 37, np.float32))
+    cases.append((32, 32, math.pi / 3, np.float32, 64, np.float64))
     for (Nphi, T, rate, tx, nch, th) in cases:
         h = (pkg.firdes(T * Nphi, 0.45 / Nphi, beta=7.0) * Nphi).astype(th)
         n = (6000 if nch <= 9 else 2500) * (8 if rate < 0.2 else 1)     # (enough outputs per piece for the span to matter)
@@ -1093,7 +1098,7 @@ def test_arb_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
 
 
 def test_farrow_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
-    """farrow_pipe_kernel (8-byte samples -- Float64, ComplexF32 with Float64 or Float32 taps --, at most 32 taps): bit-equal to the oracle on some channels
+    """farrow_pipe_kernel (Float32, Float64 and ComplexF32 samples with Float64 or Float32 taps, at most 32 taps): bit-equal to the oracle on some channels
     and to the generic farrow_kernel on all of them -- over tap counts on both sides of the 16-tap instantiation, partial
     channel groups, rates whose span needs fewer channels per lane or falls back, seams, signed zeros, fused numerics."""
     torch = torch_cuda
@@ -1103,13 +1108,18 @@ def test_farrow_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
     for T in (1, 2, 3, 5, 8, 15, 16, 17, 31, 32):
         cases.append((32, T, math.pi / 3, np.float64, int(rng.choice([1, 2, 3, 6, 9])), np.float64))
         cases.append((32, T, math.pi / 3, np.complex64, int(rng.choice([1, 2, 3, 6, 9])), np.float32))    # Float32 arithmetic
+        cases.append((32, T, math.pi / 3, np.float32, int(rng.choice([1, 2, 3, 6, 9])), np.float32))      # Float32 samples: pair reads
     for rate in (0.05, 0.11, 0.26, 0.6, 1.0, 1.9, 3.3):
         cases.append((32, 12, rate, np.float64, 13, np.float64))
         cases.append((10, 6, rate, np.complex64, 5, np.float64))
         cases.append((10, 6, rate, np.complex64, 13, np.float32))
+        cases.append((10, 6, rate, np.float32, 13, np.float64))
+        cases.append((32, 7, rate, np.float32, 5, np.float32))
     cases.append((32, 32, math.pi / 3, np.float64, 64, np.float64))
     cases.append((32, 32, math.pi / 3, np.complex64, 37, np.float64))
     cases.append((32, 32, math.pi / 3, np.complex64, 37, np.float32))
+    cases.append((32, 32, math.pi / 3, np.float32, 37, np.float32))
+    cases.append((32, 32, math.pi / 3, np.float32, 64, np.float64))
     cases.append((32, 40, math.pi / 3, np.float64, 8, np.float64))            # more than 32 taps: farrow_tiled_kernel
     for (Nphi, T, rate, tx, nch, th) in cases:
         h = (pkg.firdes(T * Nphi, 0.45 / Nphi, beta=7.0) * Nphi).astype(th)
