@@ -54,15 +54,19 @@ __device__ __forceinline__ typename TapBits<R>::type lds_read_tap(unsigned byte_
     else return dev::lds_read_b32<OFF>(byte_addr);
 }
 
-// A wave-uniform pointer the compiler can no longer fold into vector address arithmetic: base (SGPR pair) + 32-bit lane
-// offset then selects the scalar-base addressing form of global_load / global_store (no 64-bit vector adds per access).
+// A wave-uniform GLOBAL pointer the compiler can no longer fold into vector address arithmetic: base (SGPR pair) + 32-bit
+// lane offset then selects the scalar-base form of global_load / global_store (no 64-bit vector adds per access).  The result
+// is typed as an address-space-1 pointer: rebuilt from integers as a generic pointer it is accessed with flat_load /
+// flat_store, which also count in lgkmcnt -- the counter the hand-issued LDS pipeline waits on.
 template <typename P>
-__device__ __forceinline__ P *opaque_uniform(P *p)
+using global_ptr = __attribute__((address_space(1))) P *;
+template <typename P>
+__device__ __forceinline__ global_ptr<P> opaque_uniform(P *p)
 {
     unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)));
     unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32));
     asm volatile("" : "+s"(lo), "+s"(hi));
-    return reinterpret_cast<P *>((static_cast<unsigned long long>(hi) << 32) | lo);
+    return reinterpret_cast<global_ptr<P>>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
 template <typename TX, typename R, int NC>
@@ -167,8 +171,8 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 // (unconditional, straight-line: a row past the span re-reads the span's last sample -- with a branch per load the
                 // compiler waits for every earlier memory operation, the previous tile's stores included, in front of each)
                 const int cc = j / ROWS, r = j - cc * ROWS;
-                const unsigned char *base = opaque_uniform(static_cast<const unsigned char *>(a.x) + (static_cast<long long>(t.ch0 + cc) * a.x_stride + t.o) * static_cast<long long>(SB));
-                pv[j] = *reinterpret_cast<const StageT *>(base + soff[r]);
+                const global_ptr<const unsigned char> base = opaque_uniform(static_cast<const unsigned char *>(a.x) + (static_cast<long long>(t.ch0 + cc) * a.x_stride + t.o) * static_cast<long long>(SB));
+                pv[j] = *reinterpret_cast<global_ptr<const StageT>>(base + soff[r]);
             }
         } else {                                                  // the first and last tiles of a channel group: history, zeros
 #pragma unroll
@@ -374,13 +378,13 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) {
                 if (cc < cur.nchl) {
-                    unsigned char *yc = opaque_uniform(reinterpret_cast<unsigned char *>(static_cast<R *>(a.y) + (static_cast<long long>(cur.ch0 + cc) * a.y_stride + cur.k0) * NC));
+                    const global_ptr<unsigned char> yc = opaque_uniform(reinterpret_cast<unsigned char *>(static_cast<R *>(a.y) + (static_cast<long long>(cur.ch0 + cc) * a.y_stride + cur.k0) * NC));
                     if constexpr (NC == 2 && sizeof(R) == 4) {     // one ComplexF32 output: one 8-byte store
                         dev::v2f_t o2 = {res[cc][0], res[cc][1]};
-                        *reinterpret_cast<dev::v2f_t *>(yc + static_cast<unsigned>(tid) * 8u) = o2;
+                        *reinterpret_cast<global_ptr<dev::v2f_t>>(yc + static_cast<unsigned>(tid) * 8u) = o2;
                     } else {
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) *reinterpret_cast<R *>(yc + static_cast<unsigned>(tid * NC + c) * RS) = res[cc][c];
+                        for (int c = 0; c < NC; ++c) *reinterpret_cast<global_ptr<R>>(yc + static_cast<unsigned>(tid * NC + c) * RS) = res[cc][c];
                     }
                 }
             }
