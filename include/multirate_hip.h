@@ -188,6 +188,13 @@ int64_t mrhip_outputlength(const mrhip_filter *f, int64_t inputlength);
  * (== outputlength for the rational family when inputlength >= inputDeficit, else 0; for ARBITRARY it
  * runs the phase recurrence of update(), src/Filters.jl:663-673, without touching the state). */
 int64_t mrhip_next_output_count(const mrhip_filter *f, int64_t inputlength);
+/* Advance the stream state exactly as a filt! call over `inputlength` samples per channel would -- the state updates at
+ * the end of every filt! (src/Filters.jl:472 Standard: none, :515-516 Interpolator, :571-572 Rational, :647-648 Decimator,
+ * :731-735 Arbitrary, :836-838 Farrow) -- WITHOUT data and without touching the history: returns the number of outputs
+ * that call would have written per channel, or -1.  The state machine is data independent, so a stream can be entered
+ * at any sample: advance to it, mrhip_set_history with the tapsPerPhi-1 samples in front of it (support.jl:61-80 is
+ * all a later call sees of the earlier ones), filt from there -- what sharding.py's TimeShardedFilter does per GPU. */
+int64_t mrhip_advance_state(mrhip_filter *f, int64_t inputlength);
 /* replaces inputlength(self::FIRFilter, outputlength), src/Filters.jl:403-422 */
 int64_t mrhip_inputlength(const mrhip_filter *f, int64_t outputlength);
 int mrhip_get_state(const mrhip_filter *f, mrhip_state *st);

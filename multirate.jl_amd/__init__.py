@@ -36,10 +36,10 @@ from .host import (  # noqa: F401
 )
 from .design import (BANDPASS, BANDSTOP, HIGHPASS, LOWPASS, firdes, firprototype, kaiser,  # noqa: F401
                      kaiserlength)
-from .sharding import ChannelShardedFilter, shard_channels  # noqa: F401
+from .sharding import ChannelShardedFilter, TimeShardedFilter, shard_channels, shard_time  # noqa: F401
 
 __all__ = [
     "FIRFilter", "FilterCascade", "filt", "filt_", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
-    "setphase", "tapsforphase", "polyfit", "firdes", "firprototype", "kaiserlength", "kaiser", "LOWPASS", "BANDPASS", "HIGHPASS", "BANDSTOP", "ChannelShardedFilter", "shard_channels", "load_library",
+    "setphase", "tapsforphase", "polyfit", "firdes", "firprototype", "kaiserlength", "kaiser", "LOWPASS", "BANDPASS", "HIGHPASS", "BANDSTOP", "ChannelShardedFilter", "TimeShardedFilter", "shard_channels", "shard_time", "load_library",
     "library_path", "MultirateHIPError", "NUMERICS_STRICT", "NUMERICS_FUSED",
 ]

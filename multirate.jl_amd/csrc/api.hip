@@ -504,6 +504,24 @@ int64_t mrhip_next_output_count(const mrhip_filter *f, int64_t n)
     return plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, n).n_out;
 }
 
+int64_t mrhip_advance_state(mrhip_filter *f, int64_t n)
+{
+    if (!f || n < 0) { (void)fail(MRHIP_ERR_INVALID_ARG, "advance_state: NULL filter or negative length"); return -1; }
+    if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {
+        ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
+        const int64_t total = run_arbitrary_schedule(st, f->delta, f->Nphi, n, nullptr, nullptr);    // (count only: no entries kept)
+        f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;   // Filters.jl:731-735
+        f->inputDeficit = st.inputDeficit;
+        f->sched_cached = false;
+        sched_forget(f);
+        return total;
+    }
+    const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, n);
+    f->phiIdx = p.phi_end;                                              // Filters.jl:515-516, 571-572, 647-648
+    f->inputDeficit = p.d_end;
+    return p.n_out;
+}
+
 int64_t mrhip_inputlength(const mrhip_filter *f, int64_t n)
 {
     if (!f) return -1;

@@ -85,6 +85,7 @@ ABI = [
     ("mrhip_destroy", None, [_vp]),
     ("mrhip_outputlength", _i64, [_vp, _i64]),
     ("mrhip_next_output_count", _i64, [_vp, _i64]),
+    ("mrhip_advance_state", _i64, [_vp, _i64]),
     ("mrhip_inputlength", _i64, [_vp, _i64]),
     ("mrhip_get_state", _i, [_vp, C.POINTER(_State)]),
     ("mrhip_set_state", _i, [_vp, _i64, _i64, _d]),
@@ -441,6 +442,16 @@ class FIRFilter:
         n = self._lib.mrhip_inputlength(self._handle, outputlength)
         if n < 0:
             raise MultirateHIPError(5, "inputlength is not defined for FIRArbitrary in the reference")
+        return n
+
+    def advance_state(self, inputlength: int) -> int:
+        """Advance the stream state as a ``filt`` call over ``inputlength`` samples would, without data and without
+        touching the history; returns the outputs that call would have written (``mrhip_advance_state``)."""
+        if self._handle is None:
+            raise MultirateHIPError(1, "advance_state needs a bound filter (call filt once, or bind())")
+        n = self._lib.mrhip_advance_state(self._handle, int(inputlength))
+        if n < 0:
+            raise MultirateHIPError(1, self._lib.mrhip_last_error().decode("utf-8", "replace"))
         return n
 
     def next_output_count(self, inputlength: int) -> int:

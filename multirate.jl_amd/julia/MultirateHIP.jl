@@ -15,7 +15,7 @@ module MultirateHIP
 export FIRFilter, FIRKernel, FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary, FIRFarrow,
        filt, filt!, taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, tapsforphase!, polyfit,
        firdes, firprototype, kaiserlength, kaiser, FIRResponse, LOWPASS, BANDPASS, HIGHPASS, BANDSTOP,
-       FilterCascade, filt_device!, filt_device_chunked!, scheduleinfo
+       FilterCascade, filt_device!, filt_device_chunked!, scheduleinfo, advancestate!
 
 const libmr = get(ENV, "MRHIP_LIB_PATH", joinpath(@__DIR__, "..", "libmultirate_hip.so"))
 
@@ -187,6 +187,8 @@ nextphase(p::Integer, ratio::Rational) =
 outputlength(f::FIRFilter, n::Integer) = Int(ccall((:mrhip_outputlength, libmr), Int64, (Ptr{Cvoid}, Int64), f.handle, n))
 inputlength(f::FIRFilter, n::Integer) = Int(ccall((:mrhip_inputlength, libmr), Int64, (Ptr{Cvoid}, Int64), f.handle, n))
 nextoutputcount(f::FIRFilter, n::Integer) = Int(ccall((:mrhip_next_output_count, libmr), Int64, (Ptr{Cvoid}, Int64), f.handle, n))
+# advance the stream state as filt! over n samples would, without data (enter a stream at any sample: time-axis sharding)
+advancestate!(f::FIRFilter, n::Integer) = Int(ccall((:mrhip_advance_state, libmr), Int64, (Ptr{Cvoid}, Int64), f.handle, n))
 # reset(self::FIRFilter)                                   src/Filters.jl:256-260
 function reset(f::FIRFilter)
     f.handle == C_NULL || check(ccall((:mrhip_reset, libmr), Cint, (Ptr{Cvoid},), f.handle))

@@ -1,5 +1,14 @@
-"""Channel sharding across GPUs: one process per GPU, channels split contiguously, no exchange
-during compute, one gather of the outputs at the end (BASELINE.json config 5).
+"""Sharding across GPUs: one process per GPU.
+
+``ChannelShardedFilter`` (BASELINE.json config 5): channels split contiguously, no exchange
+during compute, one gather of the outputs at the end.
+
+``TimeShardedFilter``: ONE long stream (every channel of it) split along TIME.  A later ``filt!`` call sees of the earlier
+ones only the stream state and the last ``tapsPerPhi - 1`` samples (``shiftin!``, src/support.jl:61-80), and the state
+machine is data independent -- so rank r can enter the stream at its first sample: advance the state there without data
+(``mrhip_advance_state``), take the ``tapsPerPhi - 1`` samples in front of its slice from rank r-1 (the only exchange of the
+path: one point-to-point halo), and filter its slice.  The result is what a caller's chunk loop with those boundaries
+produces, bit for bit; outputs are then gathered along time.
 
 Channels are fully independent in the reference (each FIRFilter owns its history; only the
 read-only taps are shared), so rank r simply owns channels [start, start+count) and builds an
@@ -155,3 +164,123 @@ class ChannelShardedFilter:
         dist.all_gather_into_tensor(out, pad, group=self.group)
         out = out.view(self.world_size, cmax, -1)
         return torch.cat([out[r, :c] for r, c in enumerate(counts)], dim=0)
+
+
+def shard_time(n: int, world_size: int, rank: int, multiple: int = 1):
+    """Contiguous split of ``n`` samples along time; slice boundaries are multiples of ``multiple`` (e.g. the decimation,
+    so that every slice but the last yields whole output blocks).  Returns (start, count)."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad world_size / rank")
+    multiple = max(1, int(multiple))
+    blocks = -(-n // multiple)
+    base, extra = divmod(blocks, world_size)
+    b0 = rank * base + min(rank, extra)
+    b1 = b0 + base + (1 if rank < extra else 0)
+    start, end = min(b0 * multiple, n), min(b1 * multiple, n)
+    return start, end - start
+
+
+class TimeShardedFilter:
+    """One stream of ``n_total`` samples per channel, of which this rank filters the samples ``[start, start + count)``.
+
+    ``filter_factory()`` must return an object with ``filt(x)``, ``reset()``, ``advance_state(n)``, ``set_history(h)``
+    and ``historyLen`` (the HIP-backed ``FIRFilter`` by default; tests inject a CPU model).  Every slice but the first
+    must be at least ``historyLen`` samples long (its successor's history comes from it alone).
+    """
+
+    def __init__(self, h, ratio, n_total: int, *, Nphi: int = 32, polyorder=None, numerics: Optional[int] = None,
+                 rank: Optional[int] = None, world_size: Optional[int] = None, device: Optional[int] = None,
+                 multiple: int = 1, filter_factory: Optional[Callable] = None, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        if world_size is None:
+            world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rank, self.world_size, self.n_total = rank, world_size, int(n_total)
+        self.slices = [shard_time(self.n_total, world_size, r, multiple) for r in range(world_size)]
+        self.start, self.count = self.slices[rank]
+        if filter_factory is None:
+            from .host import FIRFilter, NUMERICS_STRICT
+
+            def filter_factory():
+                import torch
+                dev = device if device is not None else torch.cuda.current_device()
+                return FIRFilter(h, ratio, Nphi, polyorder, device=dev,
+                                 numerics=NUMERICS_STRICT if numerics is None else numerics)
+        self.filter = filter_factory()
+
+    def local_slice(self, x_global):
+        """The samples of a (..., n_total) global array that belong to this rank."""
+        return x_global[..., self.start:self.start + self.count]
+
+    def _exchange_halo(self, x_local, H):
+        """The last H samples of every slice go to the next rank (point to point); returns this rank's history
+        (channels, H) as a tensor, or None for rank 0 (the stream's own zero history)."""
+        import torch
+        dist = self._dist
+        if self.world_size == 1 or not dist.is_initialized() or H == 0:
+            return None
+        x2 = x_local.reshape(-1, x_local.shape[-1])
+        # the message lives where the backend moves it: device memory for nccl (RCCL over xGMI), host memory otherwise
+        # (the history is handed to the filter as a host array anyway)
+        wire = x2.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        real = (lambda t: (torch.view_as_real(t.contiguous()).reshape(t.shape[0], -1) if t.is_complex() else t.contiguous()).to(wire))
+        reqs, recv = [], None
+        if self.rank + 1 < self.world_size and self.slices[self.rank + 1][1] > 0:
+            if self.count < H and self.rank > 0:
+                raise ValueError(f"time slice of rank {self.rank} ({self.count} samples) is shorter than the filter history ({H})")
+            tail = x2[:, -H:] if self.count >= H else torch.cat([torch.zeros((x2.shape[0], H - self.count), dtype=x2.dtype, device=x2.device), x2], dim=1)
+            reqs.append(dist.isend(real(tail), dst=self.rank + 1, group=self.group))
+        if self.rank > 0 and self.count > 0:
+            recv = torch.empty((x2.shape[0], H * (2 if x2.is_complex() else 1)), dtype=x2.real.dtype if x2.is_complex() else x2.dtype, device=wire)
+            reqs.append(dist.irecv(recv, src=self.rank - 1, group=self.group))
+        for r in reqs:
+            r.wait()
+        if recv is None:
+            return None
+        return torch.view_as_complex(recv.reshape(recv.shape[0], H, 2)) if x2.is_complex() else recv
+
+    def filt(self, x_local):
+        """Filter this rank's slice ``x_local`` (..., count) of the stream.  One halo message per neighbour pair."""
+        f = self.filter
+        if self.count == 0:
+            return f.filt(x_local)                       # nothing to do: an empty output of the right type
+        if hasattr(f, "bind") and getattr(f, "_handle", True) is None:
+            import numpy as np_
+            nch = 1 if x_local.ndim == 1 else int(x_local.shape[0])
+            f.bind(np_.dtype(str(x_local.dtype).replace("torch.", "")), nch)
+        f.reset()
+        f.advance_state(self.start)                      # the stream state at this slice's first sample
+        hist = self._exchange_halo(x_local, int(f.historyLen))
+        if hist is not None:
+            f.set_history(hist.cpu().numpy())
+        return f.filt(x_local)
+
+    def gather(self, y_local, dst: int = 0):
+        """Concatenate the per-rank outputs along time on ``dst`` (variable lengths: the counts are exchanged first);
+        returns the (..., n_out_total) tensor there and None elsewhere."""
+        import torch
+        dist = self._dist
+        if self.world_size == 1 or not dist.is_initialized():
+            return y_local
+        y2 = y_local.reshape(-1, y_local.shape[-1]).contiguous()
+        lens = torch.zeros(self.world_size, dtype=torch.int64, device=y2.device)
+        lens[self.rank] = y2.shape[1]
+        dist.all_reduce(lens, group=self.group)
+        lens = [int(v) for v in lens.tolist()]
+        lmax = max(lens)
+        cplx = y2.is_complex()
+        yr = torch.view_as_real(y2).reshape(y2.shape[0], -1) if cplx else y2
+        w = 2 if cplx else 1
+        pad = torch.zeros((yr.shape[0], lmax * w), dtype=yr.dtype, device=yr.device)
+        pad[:, : yr.shape[1]] = yr
+        if self.rank == dst:
+            parts = [torch.empty_like(pad) for _ in range(self.world_size)]
+            dist.gather(pad, parts, dst=dst, group=self.group)
+            out = torch.cat([p[:, : n * w] for p, n in zip(parts, lens)], dim=1)
+            out = torch.view_as_complex(out.reshape(out.shape[0], -1, 2)) if cplx else out
+            return out.reshape(*y_local.shape[:-1], out.shape[-1])
+        dist.gather(pad, None, dst=dst, group=self.group)
+        return None

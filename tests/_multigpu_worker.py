@@ -31,6 +31,9 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = ge.load_package()
 
+    if os.environ.get("MRHIP_TEST_MODE", "channels") == "time":
+        return time_sharded(pkg, O, dist, torch, rank, world, backend, dev_index, dev)
+
     L, M = 147, 160
     h = pkg.firdes(24 * L, 0.5 / L, beta=7.8562).astype(np.float32)
     rng = np.random.default_rng(1234)                 # every rank draws the same global signal
@@ -64,6 +67,45 @@ def main():
     assert int(formed.item()) == world
     if rank == 0:
         print(f"MULTIGPU_OK ranks={int(formed.item())} backend={backend} channels={nch} shard0={sf.count}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def time_sharded(pkg, O, dist, torch, rank, world, backend, dev_index, dev):
+    """ONE stream per channel split along time over the ranks (TimeShardedFilter): state entered with mrhip_advance_state,
+    a tapsPerPhi-1 halo from the left neighbour; the result must be the chunk loop's with the same boundaries."""
+    import math
+    rng = np.random.default_rng(99)
+    n = int(os.environ.get("MRHIP_TEST_SAMPLES", "200000"))
+    cases = [(Fraction(147, 160), pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32), np.float32, 3, 160),
+             (Fraction(1, 4), pkg.firdes(128, 0.125, beta=7.0).astype(np.float32), np.complex64, 2, 4),
+             (Fraction(4, 1), pkg.firdes(128, 0.125, beta=7.0).astype(np.float32), np.float32, 2, 1),
+             (Fraction(1, 1), pkg.firdes(65, 0.2, beta=7.0).astype(np.float64), np.float64, 1, 1),
+             (float(math.pi / 3), (pkg.firdes(32 * 12, 0.45 / 32, beta=7.0) * 32).astype(np.float32), np.float32, 2, 1)]
+    for ratio, h, tx, nch, mult in cases:
+        x = rng.standard_normal((nch, n)).astype(np.float32)
+        if np.dtype(tx).kind == "c":
+            x = (x + 1j * rng.standard_normal((nch, n)).astype(np.float32))
+        x = x.astype(tx)
+        ts = pkg.TimeShardedFilter(h, ratio, n, device=dev_index, multiple=mult)
+        assert (ts.rank, ts.world_size) == (rank, world)
+        xl = torch.from_numpy(np.ascontiguousarray(ts.local_slice(x))).to(dev)
+        y_local = ts.filt(xl)
+        full = ts.gather(y_local if backend == "nccl" else y_local.cpu(), dst=0)
+        if rank == 0:
+            for c in (0, nch - 1):
+                fo = O.FIRFilter(h, ratio, 32, tx=tx) if isinstance(ratio, float) else O.FIRFilter(h, ratio, tx=tx)
+                ref = np.concatenate([fo.filt(x[c, a:a + m]) for a, m in ts.slices])
+                got = full[c].cpu().numpy()
+                assert got.shape == ref.shape and got.dtype == ref.dtype, (ratio, got.shape, ref.shape, got.dtype, ref.dtype)
+                assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), f"time-sharded {ratio} channel {c} differs from the chunk loop"
+        else:
+            assert full is None
+        ts.filter.close()
+    formed = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(formed)
+    if rank == 0:
+        print(f"MULTIGPU_OK ranks={int(formed.item())} backend={backend} mode=time cases={len(cases)}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

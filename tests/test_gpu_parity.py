@@ -1153,3 +1153,35 @@ def test_farrow_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
                 O.set_fused(False)
             f.close(); g.close()
     assert "farrow_pipe_kernel" in seen and "farrow_tiled_kernel" in seen, seen
+
+
+def test_advance_state_equals_filtering(pkg, O, torch_cuda):
+    """mrhip_advance_state(n): the state a filt! call over n samples leaves, without data -- for every kind, from a fresh and
+    from an advanced state; the history is untouched; a stream entered that way (advance + set_history + filt) continues
+    bit for bit."""
+    torch = torch_cuda
+    rng = np.random.default_rng(2024)
+    cases = [(Fraction(147, 160), 147 * 8), (Fraction(1, 4), 64), (Fraction(5, 1), 60), (Fraction(1, 1), 33), (Fraction(3, 17), 51),
+             (float(math.pi / 3), 32 * 6), (0.2345, 32 * 6), (3.0, 32 * 4)]
+    for ratio, hl in cases:
+        h = rng.standard_normal(hl).astype(np.float32)
+        x = rng.standard_normal(5000).astype(np.float32)
+        for farrow in ((False, True) if isinstance(ratio, float) else (False,)):
+            mk = (lambda: pkg.FIRFilter(h, ratio, 32, 3)) if farrow else (lambda: pkg.FIRFilter(h, ratio, 32) if isinstance(ratio, float) else pkg.FIRFilter(h, ratio))
+            a, b = mk(), mk()
+            a.bind(np.float32); b.bind(np.float32)
+            if farrow:
+                b.close(); b = pkg.FIRFilter(h, ratio, 32, 3, pnfb=a.pnfb()); b.bind(np.float32)
+            pos = 0
+            for n in (0, 1, 7, 1234, 3000):
+                ya = a.filt(x[pos:pos + n])
+                hist_before = b.history.copy()
+                cnt = b.advance_state(n)
+                assert cnt == len(ya), (ratio, farrow, n, cnt, len(ya))
+                sa, sb = a.state, b.state
+                assert (sa.phiIdx, sa.inputDeficit, sa.phiAccumulator) == (sb.phiIdx, sb.inputDeficit, sb.phiAccumulator), (ratio, farrow, n)
+                assert_bit_equal(b.history, hist_before, "advance_state must not touch the history")
+                pos += n
+            b.set_history(a.history)                       # enter the stream here
+            assert_bit_equal(b.filt(x[pos:]), a.filt(x[pos:]), f"entered stream {ratio} farrow={farrow}")
+            a.close(); b.close()

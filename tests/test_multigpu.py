@@ -32,7 +32,7 @@ def _gpu_count():
     return torch.cuda.device_count()
 
 
-def _run_ranks(world, backend, channels=37, timeout=600):
+def _run_ranks(world, backend, channels=37, timeout=600, mode="channels"):
     """All ranks are polled together; output goes to temporary files (a chatty rank cannot stall on a full pipe while another
     is being drained); on the first non-zero exit the others are ended at once (they would wait at the rendezvous or in a
     collective until their own timeout) and the failing rank's output is what the assertion shows."""
@@ -40,7 +40,7 @@ def _run_ranks(world, backend, channels=37, timeout=600):
     import time
     env = dict(os.environ)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
-               MRHIP_TEST_BACKEND=backend, MRHIP_TEST_CHANNELS=str(channels))
+               MRHIP_TEST_BACKEND=backend, MRHIP_TEST_CHANNELS=str(channels), MRHIP_TEST_MODE=mode)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs, files = [], []
     with tempfile.TemporaryDirectory() as tmp:
@@ -107,6 +107,21 @@ def test_sharded_hip_filter_two_ranks_one_gpu_gloo(channels):
         pytest.skip("needs a GPU")
     out = _run_ranks(2, "gloo", channels=channels)
     assert "MULTIGPU_OK ranks=2 backend=gloo" in out
+
+
+@pytest.mark.gpu
+def test_time_sharded_hip_filter():
+    """One long stream split along TIME over the ranks (every filter kind): advance_state + halo + filt == the chunk loop.
+    RCCL over all GPUs of the box when there are several, else two ranks on one GPU over gloo."""
+    n = _gpu_count()
+    if n < 1:
+        pytest.skip("needs a GPU")
+    backend, world = ("nccl", min(n, 8)) if n >= 2 else ("gloo", 2)
+    out = _run_ranks(world, backend, mode="time")
+    assert f"MULTIGPU_OK ranks={world} backend={backend} mode=time" in out
+    if backend == "nccl":        # the host-staged variant too
+        out = _run_ranks(2, "gloo", mode="time")
+        assert "MULTIGPU_OK ranks=2 backend=gloo mode=time" in out
 
 
 def _bench(args, backend, timeout=900):
