@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--arb", type=float, default=None, help="fraction of FIRArbitrary / FIRFarrow cases (default 0.15)")
     ap.add_argument("--big", action="store_true", help="long launches: 32-96 channels x 0.5-4e6 samples, ratios the pair kernels take "
                     "(dynamic scheduling, two-stage tiles)")
     args = ap.parse_args()
@@ -41,7 +42,7 @@ def main():
     for case in range(args.cases):
         if time.time() - t0 > args.seconds:
             break
-        arbitrary = rng.random() < 0.15
+        arbitrary = rng.random() < (args.arb if args.arb is not None else 0.15)
         th = rng.choice([np.float32, np.float32, np.float64])
         tx = rng.choice([np.float32, np.float32, np.complex64, np.float64, np.complex128])
         if th == np.float64 and tx in (np.float32, np.complex64) and rng.random() < 0.5:
@@ -67,6 +68,12 @@ def main():
             mk = lambda: pkg.FIRFilter(h, ratio, nphi)
             mko = lambda: O.FIRFilter(h, ratio, nphi, tx=tx)
             desc = f"arbitrary rate={ratio} Nphi={nphi} hLen={len(h)}"
+            if rng.random() < 0.5 and T > 1:      # FIRFarrow: one polynomial bank (fitted by the oracle) for all three filters
+                order = int(rng.integers(0, 6))
+                pn = O.pfb2pnfb(O.taps2pfb(h, nphi), order)
+                mk = lambda: pkg.FIRFilter(h, ratio, nphi, order, pnfb=pn)
+                mko = lambda: O.FIRFilter(h, ratio, nphi, tx=tx, polyorder=order, pnfb=pn)
+                desc = f"farrow rate={ratio} Nphi={nphi} hLen={len(h)} order={order}"
         else:
             kind = rng.choice(["rational", "rational", "near1", "interp", "decim", "standard", "h147"])
             if args.big:
