@@ -625,7 +625,10 @@ int mrhip_reset(mrhip_filter *f)
     f->last_stream = s; f->last_stream_valid = true;
     f->phiIdx = 1; f->inputDeficit = 1; f->xIdx = 1; f->phiAcc = 1.0; f->alpha = 0.0;
     f->sched_cached = false;
-    sched_forget(f);
+    // The stream restarts from the constructor state, i.e. on the very trajectory the device schedule's drift-per-step
+    // estimate was measured on: keep it (no serial host prefix, full-size pieces at once; every piece is verified
+    // anyway).  A stream that was found to cycle re-enters its cycle somewhere else: forget that (the prefix finds it again).
+    if (f->per_valid || MRHIP_ENV_INT("MRHIP_SCHED_KEEP_DRIFT", 1) == 0) sched_forget(f);
     return MRHIP_OK;
 }
 

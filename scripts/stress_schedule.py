@@ -84,6 +84,13 @@ def main():
             info = fd.schedule_info()
             ok = all(a.shape == b.shape and torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(yd, yh))
             ok = ok and (sd.phiAccumulator, sd.inputDeficit, sd.phiIdx) == (sh.phiAccumulator, sh.inputDeficit, sh.phiIdx)
+            if rng.random() < 0.5:                # the same stream again after reset(): the drift estimate is kept
+                fd.reset()
+                yd2 = [fd.filt(p) for p in pieces]
+                ok = ok and all(a.shape == b.shape and torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(yd2, yh))
+                sd = fd.state
+                ok = ok and (sd.phiAccumulator, sd.inputDeficit, sd.phiIdx) == (sh.phiAccumulator, sh.inputDeficit, sh.phiIdx)
+                info = fd.schedule_info()
             if not ok:
                 bad += 1
                 print(f"MISMATCH case {case}: rate={rate!r} nphi={nphi} farrow={farrow} {tx} n_in={n_in} cuts={cuts} knobs={knobs} info={info}", flush=True)
