@@ -97,7 +97,7 @@ def run(name, h, ratio, nphi, nch, n, dtype, bytes_per_in, flops_per_in, reps=5,
 DEFAULT_ROWS = ["c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5", "x160", "xf64", "xmix", "xstd", "x32"]
 # what bench.py reports next to the headline: every BASELINE config on one GPU, the README's mixed precision, the reference's
 # own FIRArbitrary / FIRFarrow benchmark shape
-BENCH_ROWS = ["c2", "c3a", "c3b", "c4", "c4f", "c5", "xmix64", "af"]
+BENCH_ROWS = ["c2", "c3a", "c3b", "c4", "c4f", "c5", "xmix64", "af", "xarb"]
 
 
 def rows(which):
