@@ -76,7 +76,10 @@ __device__ __forceinline__ R fsample_part(v2u_t v, int c)
 
 // EXACT: tapsPerPhi == TREG (no per-tap guards: the unrolled pipeline is one basic block)
 // R = the arithmetic type: Float64, or Float32 (ComplexF32 samples x Float32 taps)
-template <typename TX, typename R, int NC, bool FUSED, int CPL, int TREG, bool EXACT>
+// DMA: the sample rows go HBM -> LDS by LDS-DMA (global_load_lds, 16 bytes per lane, no staging registers, no ds_write); the
+// rows then have a pitch of whole 16-byte chunks.  First / last tiles and partial channel groups are staged synchronously
+// through registers.
+template <typename TX, typename R, int NC, bool FUSED, int CPL, int TREG, bool EXACT, bool DMA>
 __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a, ArbTileArgs ta)
 {
     constexpr int ROWS = kFpElems / CPL;
@@ -93,9 +96,11 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     const int tid = threadIdx.x;
     const int T = a.T, P = a.polyorder, MS = ta.max_span;
-    const unsigned copy_bytes = static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * SB;
+    const int RP = DMA ? ta.bank_elems : MS;                         // row pitch in samples (DMA: whole 16-byte chunks)
+    // one copy of the tile: [CPL][RP]; DMA rounds it up to whole 1 KiB wave transfers
+    const unsigned copy_bytes = DMA ? static_cast<unsigned>(ta.tap_pitch) * 1024u : static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * SB;
     const unsigned copyb_off = copy_bytes + static_cast<unsigned>(ta.copyb_pad) * SB;       // copy B behind copy A, 128 B round the banks
-    const unsigned xbuf_bytes = PAIR ? copyb_off + copy_bytes : copy_bytes;                // sample buffer b at b*xbuf_bytes: [CPL][MS] (x2)
+    const unsigned xbuf_bytes = PAIR ? copyb_off + copy_bytes : copy_bytes;                // sample buffer b at b*xbuf_bytes (x2)
     const long long ntiles = ta.total_tiles;
     const int ngroups = (a.nch + CPL - 1) / CPL;
 
@@ -126,10 +131,38 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
         const int sidx = r * kFpThreads + tid;
         soff[r] = static_cast<unsigned>(sidx < MS ? sidx : MS - 1) * SB;
     }
+    // DMA: a wave transfer moves 64 chunks of 16 bytes to 1 KiB of LDS; chunk c = slot*64 + lane is chunk c % row_chunks of row
+    // c / row_chunks (chunks past the tile re-read chunk 0: they land in the padding behind the rows)
+    constexpr int DSL = 4;                                            // slots per wave and copy (4 waves: 16 KiB per copy)
+    unsigned dvoff[DSL];
+    const int row_chunks = RP * static_cast<int>(SB) / 16, nslots = ta.tap_pitch;
+    if constexpr (DMA) {
+#pragma unroll
+        for (int q = 0; q < DSL; ++q) {
+            const int c = ((tid >> 6) + 4 * q) * 64 + (tid & 63);
+            const int cc = c / row_chunks, k = c - cc * row_chunks;
+            dvoff[q] = cc < CPL ? static_cast<unsigned>(cc) * static_cast<unsigned>(a.x_stride) * SB + static_cast<unsigned>(k) * 16u : 0u;
+        }
+    }
+    auto dma_ok = [&](long long o, int ch0) {                      // every chunk of every row (and of copy B) lies inside the signal
+        return a.nch - ch0 >= CPL && o >= 0 && o + RP + (PAIR ? 1 : 0) <= a.x_len;
+    };
+    auto dma_group = [&](long long o, int ch0, int b) {
+        const global_ptr<const unsigned char> base = opaque_uniform(static_cast<const unsigned char *>(a.x) + (static_cast<long long>(ch0) * a.x_stride + o) * static_cast<long long>(SB));
+        unsigned char *const dst = smem + static_cast<size_t>(b) * xbuf_bytes;
+#pragma unroll
+        for (int q = 0; q < DSL; ++q) {
+            const int slot = (tid >> 6) + 4 * q;                   // (wave-uniform)
+            if (slot < nslots) {
+                dev::dma16((const void *)(base + dvoff[q]), dst + static_cast<size_t>(slot) * 1024);
+                if constexpr (PAIR) dev::dma16((const void *)(base + dvoff[q] + SB), dst + copyb_off + static_cast<size_t>(slot) * 1024);   // B[s] = sample s + 1
+            }
+        }
+    };
     StageT pv[kFpElems];
     auto load_group = [&](long long o, int ch0) {                  // samples x[o ..] of channels ch0 .. ch0 + CPL - 1
         const int nchl = a.nch - ch0 < CPL ? a.nch - ch0 : CPL;
-        const bool interior = nchl == CPL && o >= 0 && o + MS <= a.x_len;
+        const bool interior = !DMA && nchl == CPL && o >= 0 && o + MS <= a.x_len;
         if (interior) {
 #pragma unroll
             for (int j = 0; j < kFpElems; ++j) {
@@ -160,8 +193,8 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
             const int cc = j / ROWS, r = j - cc * ROWS;
             const int sidx = r * kFpThreads + tid;
             if (r * kFpThreads < MS && sidx < MS) {
-                lx[cc * MS + sidx] = pv[j];
-                if constexpr (PAIR) { if (sidx > 0) lxB[cc * MS + sidx - 1] = pv[j]; }        // B[s] = sample s + 1
+                lx[cc * RP + sidx] = pv[j];
+                if constexpr (PAIR) { if (sidx > 0) lxB[cc * RP + sidx - 1] = pv[j]; }        // B[s] = sample s + 1
             }
         }
     };
@@ -174,7 +207,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
         const long long rem = a.n_out - tau * kFpThreads;
         if (tid < rem) { n_pre = a.n_idx[tau * kFpThreads + tid]; ph_pre = a.acc[tau * kFpThreads + tid]; }
     }
-    load_group(static_cast<long long>(n_lo) - T, 0);
+    load_group(static_cast<long long>(n_lo) - T, 0);                // (the first group: through registers in either form)
     store_group(0);
     __syncthreads();
     int buf = 0;
@@ -218,11 +251,21 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
             const bool last = cg + 1 == ngroups;
             const bool have_next = !last || have_next_tile;
             // the next group's loads go out now and land while this group is computed
-            if (!last) {
-                load_group(o, ch0 + CPL);
-            } else if (have_next_tile) {
+            long long o_nx = o;
+            int ch_nx = ch0 + CPL;
+            if (last && have_next_tile) {
                 first_index_wait(n_lo_next);
-                load_group(static_cast<long long>(n_lo_next) - T, 0);
+                o_nx = static_cast<long long>(n_lo_next) - T;
+                ch_nx = 0;
+            }
+            bool by_dma = false;                                  // (uniform)
+            if (have_next) {
+                if constexpr (DMA) {
+                    by_dma = dma_ok(o_nx, ch_nx);
+                    if (by_dma) dma_group(o_nx, ch_nx, buf ^ 1);
+                } else {
+                    load_group(o_nx, ch_nx);
+                }
             }
 
             R res[CPL][NC];
@@ -232,9 +275,9 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
                 for (int cc = 0; cc < CPL; ++cc) {
                     if constexpr (PAIR) {     // an aligned pair read: even window starts from copy A, odd ones from copy B (= one sample later)
                         const unsigned odd = static_cast<unsigned>(w) & 1u;
-                        sa[cc] = lds0 + static_cast<unsigned>(buf) * xbuf_bytes + (odd ? copyb_off : 0u) + (static_cast<unsigned>(cc * MS + w) - odd) * SB;
+                        sa[cc] = lds0 + static_cast<unsigned>(buf) * xbuf_bytes + (odd ? copyb_off : 0u) + (static_cast<unsigned>(cc * RP + w) - odd) * SB;
                     } else {
-                        sa[cc] = lds0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w) * SB;
+                        sa[cc] = lds0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * RP + w) * SB;
                     }
                     dev::pin(sa[cc]);
                 }
@@ -298,7 +341,19 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
             // The prefetched samples go to the other buffer BEFORE the outputs are stored: their wait (vmcnt) would otherwise
             // include the stores.  (The waves still computing this group do not read that buffer.)
             asm volatile("" ::: "memory");   // (the LDS writes below stay below the hand-issued reads above)
-            if (have_next) { buf ^= 1; store_group(buf); }
+            if (have_next) {
+                buf ^= 1;
+                if constexpr (DMA) {
+                    if (by_dma) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's transfers have landed (the barrier below: everyone's)
+                    } else {                                                  // a first / last tile, a partial channel group: synchronously
+                        load_group(o_nx, ch_nx);
+                        store_group(buf);
+                    }
+                } else {
+                    store_group(buf);
+                }
+            }
             if (have) {
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
@@ -342,14 +397,21 @@ hipError_t launch_fpipe_t(bool fused, const FarrowArgs &a, const ArbTileArgs &ta
         launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kFpThreads), lds, s, a, ta);
         return hipGetLastError();
     };
-#define MRHIP_FP_GO(C)                                                                                           \
-    if (a.T == 32) return fused ? go(farrow_pipe_kernel<TX, R, NC, true, C, 32, true>) : go(farrow_pipe_kernel<TX, R, NC, false, C, 32, true>);   \
-    return a.T <= 16 ? (fused ? go(farrow_pipe_kernel<TX, R, NC, true, C, 16, false>) : go(farrow_pipe_kernel<TX, R, NC, false, C, 16, false>))  \
-                     : (fused ? go(farrow_pipe_kernel<TX, R, NC, true, C, 32, false>) : go(farrow_pipe_kernel<TX, R, NC, false, C, 32, false>));
+#define MRHIP_FP_GO(C, D)                                                                                         \
+    if (a.T == 32) return fused ? go(farrow_pipe_kernel<TX, R, NC, true, C, 32, true, D>) : go(farrow_pipe_kernel<TX, R, NC, false, C, 32, true, D>);   \
+    return a.T <= 16 ? (fused ? go(farrow_pipe_kernel<TX, R, NC, true, C, 16, false, D>) : go(farrow_pipe_kernel<TX, R, NC, false, C, 16, false, D>))  \
+                     : (fused ? go(farrow_pipe_kernel<TX, R, NC, true, C, 32, false, D>) : go(farrow_pipe_kernel<TX, R, NC, false, C, 32, false, D>));
+    if (ta.prefetch) {      // LDS-DMA staging
+        switch (ta.cpl) {
+        case 4: MRHIP_FP_GO(4, true)
+        case 2: MRHIP_FP_GO(2, true)
+        default: MRHIP_FP_GO(1, true)
+        }
+    }
     switch (ta.cpl) {
-    case 4: MRHIP_FP_GO(4)
-    case 2: MRHIP_FP_GO(2)
-    default: MRHIP_FP_GO(1)
+    case 4: MRHIP_FP_GO(4, false)
+    case 2: MRHIP_FP_GO(2, false)
+    default: MRHIP_FP_GO(1, false)
     }
 #undef MRHIP_FP_GO
 }
@@ -368,8 +430,18 @@ bool plan_farrow_pipe(const TypeKey &tk, const FarrowArgs &a, long long span256,
     int cpl = a.nch >= 4 ? 4 : (a.nch >= 2 ? 2 : 1);
     while (cpl > 1 && max_span > static_cast<long long>(kFpElems / cpl) * kFpThreads) cpl /= 2;
     if (max_span > static_cast<long long>(kFpElems / cpl) * kFpThreads) return false;
-    const int copyb_pad = copies == 2 ? static_cast<int>((128 + 256 - (static_cast<size_t>(max_span) * sb * cpl) % 256) % 256 / sb) : 0;
-    const size_t buf_bytes = (static_cast<size_t>(max_span) * cpl * copies + copyb_pad) * sb;
+    // LDS-DMA staging: rows of whole 16-byte chunks, a copy rounded up to whole 1 KiB wave transfers, at most 16 of them;
+    // the lane offsets of the transfers are 32-bit: the channels of a group must lie within 2 GiB of each other
+    const long long row_chunks = (max_span * static_cast<long long>(sb) + 15) / 16;
+    const long long nslots = (row_chunks * cpl + 63) / 64;
+    const bool dma = MRHIP_ENV_INT("MRHIP_PIPE_DMA", 1) != 0 && nslots <= 16 &&
+                     static_cast<double>(cpl) * static_cast<double>(a.x_stride) * static_cast<double>(sb) < 2147483648.0;
+    int copyb_pad = copies == 2 ? static_cast<int>((128 + 256 - (static_cast<size_t>(max_span) * sb * cpl) % 256) % 256 / sb) : 0;
+    size_t buf_bytes = (static_cast<size_t>(max_span) * cpl * copies + copyb_pad) * sb;
+    if (dma) {
+        copyb_pad = copies == 2 ? static_cast<int>(128 / sb) : 0;            // (a copy is a multiple of 1 KiB)
+        buf_bytes = static_cast<size_t>(nslots) * 1024 * copies + copyb_pad * sb;
+    }
     // (+ pad: the pipeline reads whole register sets, up to 33 samples from a window's start)
     const size_t coef_off = (2 * buf_bytes + 320 + 15) / 16 * 16;
     const size_t total = coef_off + static_cast<size_t>(a.T) * (a.polyorder + 1) * 8;
@@ -379,6 +451,9 @@ bool plan_farrow_pipe(const TypeKey &tk, const FarrowArgs &a, long long span256,
     ta.cpl = cpl;
     ta.max_span = static_cast<int>(max_span);
     ta.copyb_pad = copyb_pad;
+    ta.prefetch = dma ? 1 : 0;
+    ta.bank_elems = static_cast<int>(row_chunks * 16 / static_cast<long long>(sb));   // (here: the row pitch in samples under DMA staging)
+    ta.tap_pitch = static_cast<int>(nslots);                                         // (here: 1 KiB transfers per copy)
     ta.x_offset_bytes = static_cast<int>(coef_off);   // (here: where the polynomial coefficients live)
     ta.tile_out = kFpThreads;
     ta.tiles_per_channel = (a.n_out + kFpThreads - 1) / kFpThreads;
