@@ -86,7 +86,10 @@ __device__ __forceinline__ R sample_of_pair(v2u_t v, int which)   // two Float32
     return static_cast<R>(__builtin_bit_cast(float, which == 0 ? v.x : v.y));
 }
 
-template <typename TX, typename R, int NC, bool FUSED, int CPL>
+// DMA: the sample rows go HBM -> LDS by LDS-DMA (global_load_lds, 16 bytes per lane: no staging registers, no ds_write); the
+// rows then have a pitch of whole 16-byte chunks.  First / last tiles and partial channel groups are staged synchronously
+// through registers.
+template <typename TX, typename R, int NC, bool FUSED, int CPL, bool DMA>
 __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, ArbTileArgs ta)
 {
     constexpr int ROWS = kPipeElems / CPL;
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             ldpfb[phi * TP + i] = g1[e];
         }
     }
-    const unsigned copy_bytes = static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * SB;
+    const int RP = DMA ? ta.row_pitch : MS;                          // row pitch in samples (DMA: whole 16-byte chunks)
+    const unsigned copy_bytes = DMA ? static_cast<unsigned>(ta.dma_slots) * 1024u : static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * SB;
     const unsigned copyb_off = copy_bytes + static_cast<unsigned>(ta.copyb_pad) * SB;       // copy B behind copy A, 128 B round the banks
     const unsigned xbuf_bytes = PAIR ? copyb_off + copy_bytes : copy_bytes;
     const unsigned lx0 = lds0 + static_cast<unsigned>(ta.x_offset_bytes);        // sample buffer b at lx0 + b*xbuf_bytes: [CPL][MS] (x2)
@@ -129,18 +133,21 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
     const long long dtau = gridDim.x / ngroups;
     const int dcg = static_cast<int>(gridDim.x - dtau * ngroups);
 
-    // n_idx[first output of a tile], by a scalar load issued one tile ahead.  (Left to the compiler it is a vector load
-    // whose wait -- s_waitcnt vmcnt(0) -- also drains the previous tile's output stores: microseconds, at the top of every tile.)
-    auto first_index_issue = [&](long long tau_) -> int {
+    // n_idx[first output of a tile].  In the tile loop it is loaded TWO tiles ahead by an ordinary load and taken over into a scalar
+    // behind the staging wait at the end of a tile, where nothing is in flight any more: left to a load at the top of the tile the
+    // compiler waits s_waitcnt vmcnt(0) there -- the previous tile's output stores included, microseconds per tile.  (Round 3 first
+    // issued it as an asynchronous s_load_dword from inline assembly and waited a tile later: the compiler, which takes an asm
+    // output for valid at once, spilled and re-used that SGPR while the load was still in flight, and the landing data overwrote
+    // whatever lived there -- whole tiles of zeros in workgroups that take more than one tile, for some instantiations only.)
+    auto first_index_sync = [&](long long tau_) -> int {
         const int *p = a.n_idx + tau_ * kPipeThreads;
         const unsigned plo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)));
         const unsigned phi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32));
         const unsigned long long pu = (static_cast<unsigned long long>(phi) << 32) | plo;
         int v;
-        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(pu));
-        return v;                                                // not valid before first_index_wait
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pu));   // (valid when the statement ends)
+        return v;
     };
-    auto first_index_wait = [&](int &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); };
     struct Tile { long long k0, o; int nout, ch0, nchl, n_lo, interior; };
     auto make_tile = [&](long long tau_, int cg_, int n_lo_) {
         Tile t;
@@ -163,9 +170,37 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
         const int sidx = r * kPipeThreads + tid;
         soff[r] = static_cast<unsigned>(sidx < MS ? sidx : MS - 1) * SB;
     }
+    // DMA: a wave transfer moves 64 chunks of 16 bytes to 1 KiB of LDS; chunk c = slot*64 + lane is chunk c % row_chunks of row
+    // c / row_chunks (chunks past the tile re-read chunk 0: they land in the padding behind the rows)
+    constexpr int DSL = 4;                                            // slots per wave and copy (4 waves: 16 KiB per copy)
+    unsigned dvoff[DSL];
+    const int row_chunks = RP * static_cast<int>(SB) / 16, nslots = ta.dma_slots;
+    if constexpr (DMA) {
+#pragma unroll
+        for (int q = 0; q < DSL; ++q) {
+            const int c = ((tid >> 6) + 4 * q) * 64 + (tid & 63);
+            const int cc = c / row_chunks, k = c - cc * row_chunks;
+            dvoff[q] = cc < CPL ? static_cast<unsigned>(cc) * static_cast<unsigned>(a.x_stride) * SB + static_cast<unsigned>(k) * 16u : 0u;
+        }
+    }
+    auto dma_ok = [&](const Tile &t) {                              // every chunk of every row (and of copy B) lies inside the signal
+        return t.nchl == CPL && t.o >= 0 && t.o + RP + (PAIR ? 1 : 0) <= a.x_len;
+    };
+    auto dma_tile = [&](const Tile &t, int b) {
+        const global_ptr<const unsigned char> base = opaque_uniform(static_cast<const unsigned char *>(a.x) + (static_cast<long long>(t.ch0) * a.x_stride + t.o) * static_cast<long long>(SB));
+        unsigned char *const dst = smem + ta.x_offset_bytes + static_cast<size_t>(b) * xbuf_bytes;
+#pragma unroll
+        for (int q = 0; q < DSL; ++q) {
+            const int slot = (tid >> 6) + 4 * q;                   // (wave-uniform)
+            if (slot < nslots) {
+                dev::dma16((const void *)(base + dvoff[q]), dst + static_cast<size_t>(slot) * 1024);
+                if constexpr (PAIR) dev::dma16((const void *)(base + dvoff[q] + SB), dst + copyb_off + static_cast<size_t>(slot) * 1024);   // B[s] = sample s + 1
+            }
+        }
+    };
     StageT pv[kPipeElems];                                        // the next tile's samples, as raw bits
     auto load_tile = [&](const Tile &t) {
-        if (t.interior) {
+        if (!DMA && t.interior) {
 #pragma unroll
             for (int j = 0; j < kPipeElems; ++j) {
                 // (unconditional, straight-line: a row past the span re-reads the span's last sample -- with a branch per load the
@@ -197,14 +232,13 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             const int cc = j / ROWS, r = j - cc * ROWS;
             const int sidx = r * kPipeThreads + tid;
             if (r * kPipeThreads < MS && sidx < MS) {
-                lx[cc * MS + sidx] = pv[j];
-                if constexpr (PAIR) { if (sidx > 0) lxB[cc * MS + sidx - 1] = pv[j]; }        // B[s] = sample s + 1
+                lx[cc * RP + sidx] = pv[j];
+                if constexpr (PAIR) { if (sidx > 0) lxB[cc * RP + sidx - 1] = pv[j]; }        // B[s] = sample s + 1
             }
         }
     };
 
-    int n_lo0 = first_index_issue(tau);
-    first_index_wait(n_lo0);
+    const int n_lo0 = first_index_sync(tau);
     Tile cur = make_tile(tau, cg, n_lo0);
     load_tile(cur);
     int n_pre = 0;
@@ -219,7 +253,7 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
     int ncg = cg;
     bool have_next = step(ntau, ncg);
     int n_lo_next = 0;
-    if (have_next) { n_lo_next = first_index_issue(ntau); first_index_wait(n_lo_next); }
+    if (have_next) n_lo_next = first_index_sync(ntau);
     store_tile(0);
     __syncthreads();       // the tap banks and the first tile are in LDS
     int buf = 0;
@@ -229,15 +263,21 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
         const int n_mine = n_pre;
         const double acc_mine = acc_pre;
         const Tile nxt = make_tile(have_next ? ntau : tau, have_next ? ncg : cg, have_next ? n_lo_next : cur.n_lo);
+        bool by_dma = false;                                      // (uniform)
         if (have_next) {
-            load_tile(nxt);
+            if constexpr (DMA) {
+                by_dma = dma_ok(nxt);
+                if (by_dma) dma_tile(nxt, buf ^ 1);
+            } else {
+                load_tile(nxt);
+            }
             if (tid < nxt.nout) { n_pre = a.n_idx[nxt.k0 + tid]; acc_pre = a.acc[nxt.k0 + tid]; }
         }
         long long n2tau = ntau;
         int n2cg = ncg;
         const bool have_next2 = have_next && step(n2tau, n2cg);
-        int n_lo_next2 = 0;
-        if (have_next2) n_lo_next2 = first_index_issue(n2tau);   // waited for behind the barrier at the end of this tile
+        int first2 = 0;                                         // n_idx[first output] of the tile after the next: taken over below
+        if (have_next2) first2 = a.n_idx[n2tau * kPipeThreads];
 
         R res[CPL][NC];
         if (tid < cur.nout) {
@@ -252,9 +292,9 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             for (int cc = 0; cc < CPL; ++cc) {
                 if constexpr (PAIR) {     // an aligned pair read: even window starts from copy A, odd ones from copy B (= one sample later)
                     const unsigned odd = static_cast<unsigned>(w) & 1u;
-                    sa[cc] = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + (odd ? copyb_off : 0u) + (static_cast<unsigned>(cc * MS + w) - odd) * SB;
+                    sa[cc] = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + (odd ? copyb_off : 0u) + (static_cast<unsigned>(cc * RP + w) - odd) * SB;
                 } else {
-                    sa[cc] = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w) * SB;
+                    sa[cc] = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * RP + w) * SB;
                 }
             }
             dev::pin(tpa); dev::pin(dpa);                         // (complete addresses in registers: the loop only adds to them)
@@ -340,7 +380,7 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 std::conditional_t<PAIR, unsigned, v2u_t> s[CPL];     // (copy A holds every sample at its own index)
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
-                    const unsigned sad = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * MS + w + i) * SB;
+                    const unsigned sad = lx0 + static_cast<unsigned>(buf) * xbuf_bytes + static_cast<unsigned>(cc * RP + w + i) * SB;
                     if constexpr (PAIR) s[cc] = dev::lds_read_b32<0>(sad);
                     else s[cc] = dev::lds_read_b64<0>(sad);
                 }
@@ -373,7 +413,21 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
         // The prefetched samples go to the other buffer BEFORE the outputs are stored: their wait (vmcnt) would otherwise
         // include the stores.  (The waves still computing this tile do not read that buffer.)
         asm volatile("" ::: "memory");   // (the LDS writes below stay below the hand-issued reads above: the compiler does not see those as memory operations)
-        if (have_next) { buf ^= 1; store_tile(buf); }
+        if (have_next) {
+            buf ^= 1;
+            if constexpr (DMA) {
+                if (by_dma) {
+                    // this wave's transfers and its schedule entries have landed (the barrier below: everyone's)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(n_pre), "+v"(acc_pre)::"memory");
+                } else {                                              // a first / last tile, a partial channel group: synchronously
+                    load_tile(nxt);
+                    store_tile(buf);
+                }
+            } else {
+                store_tile(buf);
+            }
+        }
+        const int n_lo_next2 = __builtin_amdgcn_readfirstlane(first2);   // (its load has landed with the staging loads above)
         if (tid < cur.nout) {
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) {
@@ -391,13 +445,12 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
         }
         if (!have_next) break;
         __syncthreads();       // one barrier per tile: the next tile is in LDS, and everyone is done with the buffer written after it
-        if (have_next2) first_index_wait(n_lo_next2);
         tau = ntau; cg = ncg; cur = nxt;
         ntau = n2tau; ncg = n2cg; have_next = have_next2; n_lo_next = n_lo_next2;
     }
 }
 
-template <typename TX, typename R, int NC>
+template <typename TX, typename R, int NC, bool DMA>
 hipError_t launch_pipe_t(bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s, int num_cus)
 {
     auto go = [&](auto kfn) -> hipError_t {
@@ -418,9 +471,12 @@ hipError_t launch_pipe_t(bool fused, const ArbArgs &a, const ArbTileArgs &ta, si
         return hipGetLastError();
     };
     switch (ta.cpl) {
-    case 4: return fused ? go(arb_pipe_kernel<TX, R, NC, true, 4>) : go(arb_pipe_kernel<TX, R, NC, false, 4>);
-    case 2: return fused ? go(arb_pipe_kernel<TX, R, NC, true, 2>) : go(arb_pipe_kernel<TX, R, NC, false, 2>);
-    default: return fused ? go(arb_pipe_kernel<TX, R, NC, true, 1>) : go(arb_pipe_kernel<TX, R, NC, false, 1>);
+    case 4:
+        // (four ComplexF32 channels per lane with Float64 arithmetic and register staging would spill: never planned, not built)
+        if constexpr (!DMA && NC == 2 && sizeof(R) == 8) return hipErrorInvalidValue;
+        else return fused ? go(arb_pipe_kernel<TX, R, NC, true, 4, DMA>) : go(arb_pipe_kernel<TX, R, NC, false, 4, DMA>);
+    case 2: return fused ? go(arb_pipe_kernel<TX, R, NC, true, 2, DMA>) : go(arb_pipe_kernel<TX, R, NC, false, 2, DMA>);
+    default: return fused ? go(arb_pipe_kernel<TX, R, NC, true, 1, DMA>) : go(arb_pipe_kernel<TX, R, NC, false, 1, DMA>);
     }
 }
 
@@ -447,8 +503,21 @@ bool plan_arb_pipe(const TypeKey &tk, const ArbArgs &a, long long span256, ArbTi
     while (cpl > 1 && max_span > static_cast<long long>(kPipeElems / cpl) * kPipeThreads) cpl /= 2;
     if (max_span > static_cast<long long>(kPipeElems / cpl) * kPipeThreads) return false;
     // copy B starts 128 B (mod 256) behind copy A: the lanes of one read that use it do not land on their neighbours' banks
-    const int copyb_pad = copies == 2 ? static_cast<int>((128 + 256 - (static_cast<size_t>(max_span) * sb * cpl) % 256) % 256 / sb) : 0;
-    const size_t buf_bytes = (static_cast<size_t>(max_span) * cpl * copies + copyb_pad) * sb;
+    // LDS-DMA staging: rows of whole 16-byte chunks, a copy rounded up to whole 1 KiB wave transfers, at most 16 of them;
+    // the lane offsets of the transfers are 32-bit: the channels of a group must lie within 2 GiB of each other
+    const long long row_chunks = (max_span * static_cast<long long>(sb) + 15) / 16;
+    const long long nslots = (row_chunks * cpl + 63) / 64;
+    const bool dma = MRHIP_ENV_INT("MRHIP_PIPE_DMA", 1) != 0 && nslots <= 16 &&
+                     static_cast<double>(cpl) * static_cast<double>(a.x_stride) * static_cast<double>(sb) < 2147483648.0;
+    // (register staging of four ComplexF32 channels with Float64 arithmetic does not fit 128 VGPRs: that instantiation spills, and
+    //  a spilled register of the hand-issued LDS pipeline would be saved before its data has landed -- two channels per lane then)
+    if (!dma && tk.complex_x && tk.r_f64 && cpl > 2) cpl = 2;
+    int copyb_pad = copies == 2 ? static_cast<int>((128 + 256 - (static_cast<size_t>(max_span) * sb * cpl) % 256) % 256 / sb) : 0;
+    size_t buf_bytes = (static_cast<size_t>(max_span) * cpl * copies + copyb_pad) * sb;
+    if (dma) {
+        copyb_pad = copies == 2 ? static_cast<int>(128 / sb) : 0;            // (a copy is a multiple of 1 KiB)
+        buf_bytes = static_cast<size_t>(nslots) * 1024 * copies + copyb_pad * sb;
+    }
     const size_t total = banks_bytes + 2 * buf_bytes + 64;   // (+ pad: the pipeline reads one tap pair past a window)
     if (total > 150 * 1024) return false;
     ArbTileArgs ta{};
@@ -459,6 +528,9 @@ bool plan_arb_pipe(const TypeKey &tk, const ArbArgs &a, long long span256, ArbTi
     ta.x_offset_bytes = static_cast<int>(banks_bytes);
     ta.max_span = static_cast<int>(max_span);
     ta.copyb_pad = copyb_pad;
+    ta.prefetch = dma ? 1 : 0;
+    ta.row_pitch = static_cast<int>(row_chunks * 16 / static_cast<long long>(sb));
+    ta.dma_slots = static_cast<int>(nslots);
     ta.tile_out = kPipeThreads;
     ta.tiles_per_channel = (a.n_out + kPipeThreads - 1) / kPipeThreads;
     ta.total_tiles = ta.tiles_per_channel * ((a.nch + cpl - 1) / cpl);
@@ -471,9 +543,13 @@ hipError_t launch_arb_pipe(const TypeKey &tk, bool fused, const ArbArgs &a, cons
                            const char **kname, int num_cus)
 {
     *kname = "arb_pipe_kernel";
-    if (tk.complex_x) return tk.r_f64 ? launch_pipe_t<float, double, 2>(fused, a, ta, lds, s, num_cus) : launch_pipe_t<float, float, 2>(fused, a, ta, lds, s, num_cus);
-    if (tk.x_f64) return launch_pipe_t<double, double, 1>(fused, a, ta, lds, s, num_cus);
-    return tk.r_f64 ? launch_pipe_t<float, double, 1>(fused, a, ta, lds, s, num_cus) : launch_pipe_t<float, float, 1>(fused, a, ta, lds, s, num_cus);
+#define MRHIP_AP_GO(D)                                                                                                           \
+    if (tk.complex_x) return tk.r_f64 ? launch_pipe_t<float, double, 2, D>(fused, a, ta, lds, s, num_cus) : launch_pipe_t<float, float, 2, D>(fused, a, ta, lds, s, num_cus);   \
+    if (tk.x_f64) return launch_pipe_t<double, double, 1, D>(fused, a, ta, lds, s, num_cus);                                          \
+    return tk.r_f64 ? launch_pipe_t<float, double, 1, D>(fused, a, ta, lds, s, num_cus) : launch_pipe_t<float, float, 1, D>(fused, a, ta, lds, s, num_cus);
+    if (ta.prefetch) { MRHIP_AP_GO(true) }
+    MRHIP_AP_GO(false)
+#undef MRHIP_AP_GO
 }
 
 }  // namespace mrhip

@@ -96,9 +96,9 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     const int tid = threadIdx.x;
     const int T = a.T, P = a.polyorder, MS = ta.max_span;
-    const int RP = DMA ? ta.bank_elems : MS;                         // row pitch in samples (DMA: whole 16-byte chunks)
+    const int RP = DMA ? ta.row_pitch : MS;                         // row pitch in samples (DMA: whole 16-byte chunks)
     // one copy of the tile: [CPL][RP]; DMA rounds it up to whole 1 KiB wave transfers
-    const unsigned copy_bytes = DMA ? static_cast<unsigned>(ta.tap_pitch) * 1024u : static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * SB;
+    const unsigned copy_bytes = DMA ? static_cast<unsigned>(ta.dma_slots) * 1024u : static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * SB;
     const unsigned copyb_off = copy_bytes + static_cast<unsigned>(ta.copyb_pad) * SB;       // copy B behind copy A, 128 B round the banks
     const unsigned xbuf_bytes = PAIR ? copyb_off + copy_bytes : copy_bytes;                // sample buffer b at b*xbuf_bytes (x2)
     const long long ntiles = ta.total_tiles;
@@ -111,17 +111,17 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
     double *const lcoef = reinterpret_cast<double *>(smem + ta.x_offset_bytes);
     for (int e = tid; e < T * (P + 1); e += kFpThreads) lcoef[e] = a.pnfb[e];
 
-    // n_idx[first output of a tile] by a scalar load issued a tile ahead (see kernels_arb_pipe.hip)
-    auto first_index_issue = [&](long long tau_) -> int {
+    // n_idx[first output of a tile]: loaded two tiles ahead by an ordinary load, taken over into a scalar behind the first staging
+    // wait of a tile (see kernels_arb_pipe.hip: an asynchronous s_load from inline assembly is not safe, the compiler re-uses its SGPR)
+    auto first_index_sync = [&](long long tau_) -> int {
         const int *p = a.n_idx + tau_ * kFpThreads;
         const unsigned plo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)));
         const unsigned phi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32));
         const unsigned long long pu = (static_cast<unsigned long long>(phi) << 32) | plo;
         int v;
-        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(pu));
-        return v;                                                // not valid before first_index_wait
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pu));   // (valid when the statement ends)
+        return v;
     };
-    auto first_index_wait = [&](int &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); };
 
     // Staging: element j of a thread is sample r*256 + tid of channel cc (j = cc*ROWS + r); lanes past the span re-read its
     // last sample (same cache line, no branch)
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
     // c / row_chunks (chunks past the tile re-read chunk 0: they land in the padding behind the rows)
     constexpr int DSL = 4;                                            // slots per wave and copy (4 waves: 16 KiB per copy)
     unsigned dvoff[DSL];
-    const int row_chunks = RP * static_cast<int>(SB) / 16, nslots = ta.tap_pitch;
+    const int row_chunks = RP * static_cast<int>(SB) / 16, nslots = ta.dma_slots;
     if constexpr (DMA) {
 #pragma unroll
         for (int q = 0; q < DSL; ++q) {
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
         }
     };
 
-    int n_lo = first_index_issue(tau);
-    first_index_wait(n_lo);
+    int n_lo = first_index_sync(tau);
+    int n_lo_next = tau + gridDim.x < ntiles ? first_index_sync(tau + gridDim.x) : 0;
     int n_pre = 0;
     double ph_pre = 0.0;
     {
@@ -219,8 +219,10 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
         const long long o = static_cast<long long>(n_lo) - T;    // x[n_lo - T ...] (0-based); n = 1-based newest sample
         const long long ntau = tau + gridDim.x;
         const bool have_next_tile = ntau < ntiles;
-        int n_lo_next = 0;
-        if (have_next_tile) n_lo_next = first_index_issue(ntau);  // waited for in front of its use (the last channel group)
+        const long long n2tau = ntau + gridDim.x;
+        int first2 = 0;                                           // n_idx[first output] of the tile after the next: taken over below
+        if (n2tau < ntiles) first2 = a.n_idx[n2tau * kFpThreads];
+        int n_lo_next2 = 0;
         const bool have = tid < nout;
         const int n = n_pre;
         const double phase = ph_pre;
@@ -254,15 +256,15 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
             long long o_nx = o;
             int ch_nx = ch0 + CPL;
             if (last && have_next_tile) {
-                first_index_wait(n_lo_next);
                 o_nx = static_cast<long long>(n_lo_next) - T;
                 ch_nx = 0;
             }
             bool by_dma = false;                                  // (uniform)
             if (have_next) {
                 if constexpr (DMA) {
-                    by_dma = dma_ok(o_nx, ch_nx);
+                    by_dma = dma_ok(o_nx, ch_nx) && !(ta.pipe & 2);
                     if (by_dma) dma_group(o_nx, ch_nx, buf ^ 1);
+                    if (by_dma && (ta.pipe & 4)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
                 } else {
                     load_group(o_nx, ch_nx);
                 }
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
                     store_group(buf);
                 }
             }
+            if (cg == 0) n_lo_next2 = __builtin_amdgcn_readfirstlane(first2);   // (its load has landed with the staging above)
             if (have) {
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
@@ -374,6 +377,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
         if (!have_next_tile) break;
         tau = ntau;
         n_lo = n_lo_next;
+        n_lo_next = n_lo_next2;
     }
 }
 
@@ -447,13 +451,13 @@ bool plan_farrow_pipe(const TypeKey &tk, const FarrowArgs &a, long long span256,
     const size_t total = coef_off + static_cast<size_t>(a.T) * (a.polyorder + 1) * 8;
     if (total > 150 * 1024) return false;
     ArbTileArgs ta{};
-    ta.pipe = 1;
+    ta.pipe = 1 | MRHIP_ENV_INT("MRHIP_FP_DEBUG", 0);
     ta.cpl = cpl;
     ta.max_span = static_cast<int>(max_span);
     ta.copyb_pad = copyb_pad;
     ta.prefetch = dma ? 1 : 0;
-    ta.bank_elems = static_cast<int>(row_chunks * 16 / static_cast<long long>(sb));   // (here: the row pitch in samples under DMA staging)
-    ta.tap_pitch = static_cast<int>(nslots);                                         // (here: 1 KiB transfers per copy)
+    ta.row_pitch = static_cast<int>(row_chunks * 16 / static_cast<long long>(sb));
+    ta.dma_slots = static_cast<int>(nslots);
     ta.x_offset_bytes = static_cast<int>(coef_off);   // (here: where the polynomial coefficients live)
     ta.tile_out = kFpThreads;
     ta.tiles_per_channel = (a.n_out + kFpThreads - 1) / kFpThreads;

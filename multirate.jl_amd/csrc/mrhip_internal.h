@@ -272,6 +272,8 @@ struct ArbTileArgs {         // tiling of the FIRArbitrary kernel (kernels_arbit
     int prefetch;            // arb_tiled_kernel: the next tile's samples are loaded into registers a tile ahead
     int copyb_pad;           // samples between the end of sample copy A and the start of copy B (bank stagger)
     int pipe;                // 1: arb_pipe_kernel (kernels_arb_pipe.hip): one copy, two sample buffers, tiles of 256 outputs
+    int row_pitch;           // pipe kernels with LDS-DMA staging (prefetch = 1): samples between the rows of a tile (whole 16-byte chunks)
+    int dma_slots;           //   ... and 1 KiB wave transfers per copy of the tile
     long long tile_out;      // outputs per tile
     long long tiles_per_channel;
     long long total_tiles;

@@ -1,0 +1,52 @@
+"""Properties of the built device code that the hand-scheduled kernels rely on (CPU only: reads the objects the build made).
+
+The pipe kernels (kernels_arb_pipe.hip, kernels_farrow_pipe.hip) issue their LDS reads from inline assembly and wait for them
+with counted s_waitcnt: between issue and wait the destination registers are NOT valid, which the compiler does not know.  A
+register spill inside that window would save a register before its data has landed (round 3 met the same hazard with an
+asynchronous s_load).  So no instantiation of these kernels may use scratch memory at all."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "multirate.jl_amd", "csrc")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernel_scratch(obj):
+    """{kernel name: private_segment_fixed_size} of the gfx950 code object bundled in a host object file."""
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, os.path.basename(obj))
+        shutil.copy(obj, local)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], cwd=tmp, capture_output=True, text=True, timeout=300, check=True)
+        cos = [f for f in os.listdir(tmp) if "amdgcn" in f]
+        assert cos, "no device code object bundled in " + obj
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, cos[0])], capture_output=True, text=True, timeout=300, check=True).stdout
+    out = {}
+    for entry in notes.split("\n  - .agpr_count")[1:]:
+        name = re.search(r"\n    \.name:\s+(\S+)", entry)
+        size = re.search(r"\n    \.private_segment_fixed_size:\s+(\d+)", entry)
+        if name and size:
+            out[name.group(1)] = int(size.group(1))
+    return out
+
+
+@pytest.mark.parametrize("src,kernel", [("kernels_arb_pipe.hip", "arb_pipe_kernel"), ("kernels_farrow_pipe.hip", "farrow_pipe_kernel")])
+def test_pipe_kernels_use_no_scratch(pkg, src, kernel):
+    obj = os.path.join(CSRC, "build", src + ".o")
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("no built object (the library came prebuilt) or no llvm tools")
+    if os.path.getmtime(obj) < os.path.getmtime(os.path.join(CSRC, src)):
+        pytest.skip("object older than its source")
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    # the flag that keeps the Float32 instantiations within their register budget
+    assert re.search(r"kernels_arb_pipe\.hip\.o[^\n]*kernels_farrow_pipe\.hip\.o[^\n]*-fno-slp-vectorize", mk), \
+        "Makefile no longer builds the pipe kernels with -fno-slp-vectorize"
+    sizes = {k: v for k, v in _kernel_scratch(obj).items() if kernel in k}
+    assert len(sizes) >= 12, f"expected the instantiations of {kernel} in the object, found {len(sizes)}"
+    spilling = {k: v for k, v in sizes.items() if v != 0}
+    assert not spilling, f"{kernel}: instantiations with scratch (register spills next to hand-issued LDS reads): {list(spilling.items())[:6]}"

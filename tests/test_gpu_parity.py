@@ -1077,6 +1077,14 @@ def test_arb_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
             f = pkg.FIRFilter(h, float(rate), Nphi, numerics=numerics)
             y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
             seen.add(f.last_kernel_name())
+            if nch >= 33 and numerics == pkg.NUMERICS_STRICT:        # the register-staged form of the same kernel (LDS-DMA staging off)
+                monkeypatch.setenv("MRHIP_PIPE_DMA", "0")
+                f0 = pkg.FIRFilter(h, float(rate), Nphi, numerics=numerics)
+                y0 = torch.cat(_run_chunks(f0, xd, sizes), dim=-1).cpu().numpy()
+                monkeypatch.delenv("MRHIP_PIPE_DMA")
+                assert f0.last_kernel_name() == f.last_kernel_name()
+                assert_bit_equal(y0, y, "DMA staging off vs on")
+                f0.close()
             monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
             g = pkg.FIRFilter(h, float(rate), Nphi, numerics=numerics)
             yg = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
@@ -1135,6 +1143,14 @@ def test_farrow_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
             f = pkg.FIRFilter(h, float(rate), Nphi, 4, pnfb=pn, numerics=numerics)
             y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
             seen.add(f.last_kernel_name())
+            if nch >= 13 and numerics == pkg.NUMERICS_STRICT:        # the register-staged form of the same kernel (LDS-DMA staging off)
+                monkeypatch.setenv("MRHIP_PIPE_DMA", "0")
+                f0 = pkg.FIRFilter(h, float(rate), Nphi, 4, pnfb=pn, numerics=numerics)
+                y0 = torch.cat(_run_chunks(f0, xd, sizes), dim=-1).cpu().numpy()
+                monkeypatch.delenv("MRHIP_PIPE_DMA")
+                assert f0.last_kernel_name() == f.last_kernel_name()
+                assert_bit_equal(y0, y, "DMA staging off vs on")
+                f0.close()
             monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
             g = pkg.FIRFilter(h, float(rate), Nphi, 4, pnfb=pn, numerics=numerics)
             yg = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
@@ -1185,3 +1201,44 @@ def test_advance_state_equals_filtering(pkg, O, torch_cuda):
             b.set_history(a.history)                       # enter the stream here
             assert_bit_equal(b.filt(x[pos:]), a.filt(x[pos:]), f"entered stream {ratio} farrow={farrow}")
             a.close(); b.close()
+
+
+def test_pipe_kernels_many_tiles_per_workgroup(pkg, O, torch_cuda, monkeypatch):
+    """Calls long enough that every persistent workgroup of arb_pipe_kernel / farrow_pipe_kernel takes several tiles (the short
+    sweeps above give each workgroup one): few channels (1, 2, 4 channels per lane), tap counts on both sides of the 32-tap
+    instantiations, LDS-DMA staging on and off -- against the tiled kernels, bit for bit.  Regression: round 3's first form
+    prefetched a tile's first index with an asynchronous s_load from inline assembly; the compiler re-used that SGPR while the
+    load was in flight and whole tiles came out as zeros, for some instantiations only."""
+    torch = torch_cuda
+    rng = np.random.default_rng(808)
+    nphi, n_in = 8, 200_000
+    seen = set()
+    for farrow in (False, True):
+        for rate in (7.7, math.pi / 3):
+            for T, tx, th in ((17, np.float64, np.float32), (32, np.float64, np.float64), (25, np.complex64, np.float32), (32, np.float32, np.float32)):
+                h = rng.standard_normal(T * nphi).astype(th)
+                pn = O.pfb2pnfb(O.taps2pfb(h, nphi), 3) if farrow else None
+                for nch in (1, 2, 3, 5):
+                    x = _rand(rng, (nch, n_in), tx) - 0.5
+                    xd = torch.from_numpy(x).cuda()
+                    mk = (lambda: pkg.FIRFilter(h, rate, nphi, 3, pnfb=pn)) if farrow else (lambda: pkg.FIRFilter(h, rate, nphi))
+                    outs = {}
+                    for name, env in (("pipe", {}), ("pipe, register staging", {"MRHIP_PIPE_DMA": "0"}),
+                                      ("tiled", {"MRHIP_FARROW_PIPE": "0", "MRHIP_ARB_PIPE": "0"})):
+                        for k, v in env.items():
+                            monkeypatch.setenv(k, v)
+                        f = mk()
+                        y = f.filt(xd).cpu().numpy()          # (on the host before the filter goes away)
+                        outs[name] = (y, f.last_kernel_name())
+                        f.close()
+                        for k in env:
+                            monkeypatch.delenv(k)
+                    want, kt = outs["tiled"]
+                    assert kt in ("arb_tiled_kernel", "farrow_tiled_kernel"), kt
+                    assert want.shape[1] > 768 * 256          # more tiles than workgroups
+                    for name in ("pipe", "pipe, register staging"):
+                        got, kn = outs[name]
+                        seen.add(kn)
+                        assert kn in ("arb_pipe_kernel", "farrow_pipe_kernel"), kn
+                        assert_bit_equal(got, want, f"{name} vs {kt}: farrow={farrow} rate={rate} T={T} {np.dtype(tx)} x {np.dtype(th)} taps nch={nch}")
+    assert seen == {"arb_pipe_kernel", "farrow_pipe_kernel"}
