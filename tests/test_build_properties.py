@@ -51,3 +51,18 @@ def test_pipe_kernels_use_no_scratch(pkg, src, kernel):
     assert len(sizes) >= 12, f"expected the instantiations of {kernel} in the object, found {len(sizes)}"
     spilling = {k: v for k, v in sizes.items() if v != 0}
     assert not spilling, f"{kernel}: instantiations with scratch or AccVGPRs (registers parked next to hand-issued LDS reads): {list(spilling.items())[:6]}"
+
+
+@pytest.mark.gpu
+def test_instantiations_with_scratch_are_bit_exact_on_the_gpu():
+    """The older hand-scheduled kernels (output-pair, streaming) have instantiations that do use scratch memory: each one, read
+    from the built objects, runs against the universal kernel bit for bit (scripts/check_spilling_instantiations.py)."""
+    import glob
+    import sys
+    if not glob.glob(os.path.join(CSRC, "build", "kernels_*.hip.o")) or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("no built objects on this box (the library came prebuilt) or no llvm tools")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_spilling_instantiations.py")], capture_output=True, text=True, timeout=900)
+    tail = "\n".join(p.stdout.splitlines()[-6:])
+    assert p.returncode == 0, tail + p.stderr[-2000:]
+    m = re.search(r"instantiations with scratch: (\d+) mismatches: (\d+)", p.stdout)
+    assert m and int(m.group(2)) == 0, tail
