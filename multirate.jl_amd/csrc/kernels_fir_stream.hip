@@ -1,4 +1,4 @@
-// kernels_fir_stream.hip -- FIRStandard (M = 1) and FIRDecimator (L = 1, M = 2..32, 40, 48, 50, 64), 2 to 16384 taps (as long as a tile fits the LDS),
+// kernels_fir_stream.hip -- FIRStandard (M = 1) and FIRDecimator (L = 1, M = 2..32, 40, 48, 50, 64; real Float32: every M up to 64 but 36 and 38), 2 to 16384 taps (as long as a tile fits the LDS),
 // with Float32 arithmetic (Float32 or ComplexF32 samples, Float32 taps) and Float64 arithmetic (Float64 or ComplexF64 samples,
 // or Float32 / ComplexF32 samples with Float64 taps): the streaming form of kernels_fir_direct.hip (BASELINE config 3b).  This file holds
 // the planning and the dispatch; the kernel is fir_stream_kernel.inc, instantiated by kernels_fir_stream_{f32,f64,mix}.hip.
@@ -37,7 +37,7 @@ hipError_t launch_fir_stream_f32(int nc, bool fused, dim3 block, size_t lds, hip
 hipError_t launch_fir_stream_f64(int nc, bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_fir_stream_mix(int nc, bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 
-// Covers L == 1, M <= 32 or in {40, 48, 50, 64}, 2 <= T <= 16384, every sample type.  Returns false
+// Covers L == 1, M <= 32 or in {40, 48, 50, 64} (real Float32 samples and taps: every M <= 64 but 36 and 38), 2 <= T <= 16384, every sample type.  Returns false
 // otherwise (the caller falls back to kernels_fir_direct.hip).
 bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {
@@ -47,8 +47,9 @@ bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs
     const int nc = tk.complex_x ? 2 : 1;
     const long long es = (tk.x_f64 ? 8 : 4) * nc;
     int pad_every = 0, min_taps = 0;   // (min_taps: one block of reads; shorter filters take the kernel's per-sample loop)
-    if (a.M > 64 || !(es == 16 ? stream_geometry<16>(static_cast<int>(a.M), &pad_every, &min_taps)
-                      : es == 8 ? stream_geometry<8>(static_cast<int>(a.M), &pad_every, &min_taps) : stream_geometry<4>(static_cast<int>(a.M), &pad_every, &min_taps))) return false;
+    const bool f32a = !tk.r_f64 && !tk.complex_x;          // (real Float32 samples x Float32 taps: more decimations are instantiated)
+    if (a.M > 64 || !(es == 16 ? stream_geometry<16>(static_cast<int>(a.M), f32a, &pad_every, &min_taps)
+                      : es == 8 ? stream_geometry<8>(static_cast<int>(a.M), f32a, &pad_every, &min_taps) : stream_geometry<4>(static_cast<int>(a.M), f32a, &pad_every, &min_taps))) return false;
     if (a.T < 2 || a.T > 16384) return false;   // (a tile must hold T samples: checked below)
     // compute waves: 3 (+ loader = a 256-thread workgroup) unless overridden; a step is 2 outputs per lane
     int ncw = stream_env_int("MRHIP_STREAM_WAVES", 3);

@@ -810,7 +810,7 @@ def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
     rng = np.random.default_rng(77)
     cases = [(2, 3, 140, np.float32, np.float32, 35), (3, 2, 200, np.float32, np.complex64, 9), (147, 160, 147 * 70, np.float32, np.float32, 33),
              (2, 3, 100, np.float64, np.float64, 4),
-             (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 35, 700, np.float32, np.float32, 5),
+             (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 36, 700, np.float32, np.float32, 5),
              (1, 33, 600, np.float64, np.complex128, 2), (5, 64, 5 * 40, np.float64, np.float32, 32), (4, 7, 4 * 49, np.float32, np.float64, 1)]
     for (L, M, hl, th, tx, nch) in cases:
         h = rng.standard_normal(hl).astype(th)
@@ -1242,3 +1242,31 @@ def test_pipe_kernels_many_tiles_per_workgroup(pkg, O, torch_cuda, monkeypatch):
                         assert kn in ("arb_pipe_kernel", "farrow_pipe_kernel"), kn
                         assert_bit_equal(got, want, f"{name} vs {kt}: farrow={farrow} rate={rate} T={T} {np.dtype(tx)} x {np.dtype(th)} taps nch={nch}")
     assert seen == {"arb_pipe_kernel", "farrow_pipe_kernel"}
+
+
+def test_stream_kernel_decimations_33_to_63_real_float32(pkg, O, torch_cuda, monkeypatch):
+    """fir_stream_kernel's extra instantiations for real Float32 samples and taps (every decimation up to 64 except 36 and 38,
+    which stay on fir_direct_kernel like the ComplexF32 ones): against the oracle and the universal kernel, chunked."""
+    torch = torch_cuda
+    rng = np.random.default_rng(3363)
+    for M in (33, 35, 37, 44, 49, 52, 57, 63, 36, 38):
+        for hl in (M + 3, 128):
+            h = rng.standard_normal(hl).astype(np.float32)
+            nch, n = 7, 90_001
+            x = rng.standard_normal((nch, n)).astype(np.float32)
+            xd = torch.from_numpy(x).cuda()
+            sizes = [40_000, 1, n - 40_001]
+            monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+            f = pkg.FIRFilter(h, Fraction(1, M))
+            y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+            assert f.last_kernel_name() == ("fir_direct_kernel" if M in (36, 38) else "fir_stream_kernel"), (M, f.last_kernel_name())
+            monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+            g = pkg.FIRFilter(h, Fraction(1, M))
+            yg = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
+            monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+            assert_bit_equal(y, yg, f"1//{M} hLen={hl} vs universal kernel")
+            fo = O.FIRFilter(h, Fraction(1, M), tx=np.float32)
+            yo = np.concatenate(_run_chunks(fo, x[nch - 1], sizes))
+            assert_bit_equal(y[nch - 1], yo, f"1//{M} hLen={hl} vs oracle")
+            assert_bit_equal(f.history, g.history, "history")
+            f.close(); g.close()
