@@ -2,7 +2,7 @@
 """Randomised parity stress (GPU box): random kinds / ratios / tap counts / dtypes / channel counts / chunkings,
 every tuned kernel against the universal kernel (all channels) and against the CPU oracle (two channels), bit for bit.
 
-    python scripts/stress_random.py [--cases 300] [--seed 1] [--seconds 240]
+    python tests/stress_random.py [--cases 300] [--seed 1] [--seconds 240]
 Prints one line per failure and a per-kernel tally; exit code 1 on any mismatch."""
 import argparse
 import math
@@ -11,7 +11,7 @@ import sys
 import time
 from fractions import Fraction
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (tests/ -> repo root)
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -1029,7 +1029,7 @@ def test_long_launch_two_stage_tiles_match_generic(pkg, O, torch_cuda, monkeypat
 
 
 def test_randomised_stress_short(torch_cuda):
-    """scripts/stress_random.py (random kinds / ratios / tap counts / dtypes / channels / chunkings; every tuned kernel
+    """tests/stress_random.py (random kinds / ratios / tap counts / dtypes / channels / chunkings; every tuned kernel
     against the universal kernel and the oracle, bit for bit) on a fixed seed, as a child process."""
     import subprocess
     import sys
