@@ -356,7 +356,10 @@ def run_headline(args, R):
         filt.close()
         del x, y
         torch.cuda.empty_cache()
-        configs = config_rows()
+        try:
+            configs = config_rows()
+        except Exception as e:       # the headline line is the contract: a failing side measurement must not take it down
+            configs = [{"name": "configs failed", "error": f"{type(e).__name__}: {e}"}]
 
     total_in = float(nch) * n * args.steps * world
     ms_per_step = elapsed / args.steps * 1e3
