@@ -262,9 +262,8 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
             bool by_dma = false;                                  // (uniform)
             if (have_next) {
                 if constexpr (DMA) {
-                    by_dma = dma_ok(o_nx, ch_nx) && !(ta.pipe & 2);
+                    by_dma = dma_ok(o_nx, ch_nx);
                     if (by_dma) dma_group(o_nx, ch_nx, buf ^ 1);
-                    if (by_dma && (ta.pipe & 4)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
                 } else {
                     load_group(o_nx, ch_nx);
                 }
@@ -451,7 +450,7 @@ bool plan_farrow_pipe(const TypeKey &tk, const FarrowArgs &a, long long span256,
     const size_t total = coef_off + static_cast<size_t>(a.T) * (a.polyorder + 1) * 8;
     if (total > 150 * 1024) return false;
     ArbTileArgs ta{};
-    ta.pipe = 1 | MRHIP_ENV_INT("MRHIP_FP_DEBUG", 0);
+    ta.pipe = 1;
     ta.cpl = cpl;
     ta.max_span = static_cast<int>(max_span);
     ta.copyb_pad = copyb_pad;

@@ -1034,7 +1034,7 @@ def test_randomised_stress_short(torch_cuda):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_random.py"), "--cases", "160", "--seed", "11", "--seconds", "90"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_random.py"), "--cases", "160", "--seed", "11", "--seconds", "90"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout
