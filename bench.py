@@ -394,8 +394,20 @@ def run_headline(args, R):
             line["streamed_1e6_chunks"] = streamed
         if configs is not None:
             line["configs"] = configs
+            # the BASELINE rows once more, compact and inside `roofline` (a record that keeps only the parsed top-level keys,
+            # or only the end of the line, still carries them): name -> kernel ms, wall ms, fraction of the HBM roof
+            base = {}
+            for r in configs:
+                nm = r.get("name", "")
+                if nm[:3] in ("C2 ", "C3a", "C3b", "C4 ", "C4f", "C5 "):
+                    base[nm.split()[0]] = {"kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "wall_ms": r["wall_ms"], "frac": r["frac"],
+                                           "frac_wall": r["frac_wall"]}
+            line["roofline"]["baseline_configs"] = base
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["cpu_baseline_all_cores"] = cpu_baseline(h)
+        # `configs` (long) goes LAST so that its BASELINE rows -- the last of it -- end the line
+        if "configs" in line:
+            line["configs"] = line.pop("configs")
         print(json.dumps(line), flush=True)
 
 

@@ -206,6 +206,9 @@ int mrhip_set_state(mrhip_filter *f, int64_t phiIdx, int64_t inputDeficit, doubl
  * host buffer laid out [nchannels][historyLen] in sample_dtype.  Synchronous. */
 int mrhip_get_history(mrhip_filter *f, void *host_out);
 int mrhip_set_history(mrhip_filter *f, const void *host_in);
+/* the same from DEVICE memory on f's device, asynchronous on `stream` (ordered behind the filter's earlier calls and ahead of
+ * its next one): a halo that arrived over RCCL goes into the filter without touching the host (sharding.py). */
+int mrhip_set_history_device(mrhip_filter *f, const void *device_in, void *stream);
 /* replaces reset(self::FIRFilter), src/Filters.jl:256-260: zero history; state back to the
  * constructor's (the reference resets 𝜙Idx only and is broken for FIRArbitrary, :247-253). */
 int mrhip_reset(mrhip_filter *f);
@@ -226,9 +229,38 @@ int mrhip_get_taps(mrhip_filter *f, int which, void *host_out);
  * pure function of (state, x_len) and is valid on return even though the kernels are only
  * enqueued: the call is asynchronous on `stream` (a hipStream_t, NULL = default stream).
  * A short input (x_len < inputDeficit) is not an error: history is shifted, inputDeficit
- * reduced, *n_written = 0 (:543-547, :638-643, :705-709). */
+ * reduced, *n_written = 0 (:543-547, :638-643, :705-709).
+ * On a stream that is being captured into a HIP graph the call takes the device-planned path of mrhip_filt_device_async
+ * (same buffer rule); *n_written then is the count of the FIRST replay (rational family) or -1 (FIRArbitrary / FIRFarrow:
+ * read it with mrhip_sync_state after a replay). */
 int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
                       int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream);
+/* filt!(buffer, self, x) with NOTHING returned to the host: the call is planned ON THE DEVICE.  The reference mutates
+ * 𝜙Idx / inputDeficit / 𝜙Accumulator at the end of every filt! (src/Filters.jl:571-572, 627-628, 734-735, update() :663-673);
+ * here that state has a device-resident record per filter that every call keeps current in stream order.  This entry reads
+ * the record in a one-lane plan kernel in front of the filter kernel (FIRArbitrary / FIRFarrow: in the kernels that evaluate
+ * the phase schedule), advances it there, and never makes the host wait -- so a loop of such calls only enqueues, and the
+ * same calls captured into a HIP graph replay correctly at ANY fixed chunk size and for every kind (mrhip_filt_device on a
+ * capturing stream takes this path by itself).  The count is data independent but state dependent, so:
+ *   - y_capacity (and y_stride for nchannels > 1) must be at least mrhip_outputlength_bound(x_len), else
+ *     MRHIP_ERR_BUFFER_TOO_SMALL and nothing is enqueued (the reference's filt sizes its buffer from outputlength the same
+ *     way, src/Filters.jl:744-751);
+ *   - *count_out, if not NULL, must be DEVICE-ACCESSIBLE memory (hipMalloc or hipHostMalloc): the per-channel output count
+ *     is stored there in stream order; mrhip_sync_state returns the last call's count as well;
+ *   - the host-side view of the state (mrhip_get_state, outputlength, ...) re-reads the record when next asked, which
+ *     waits for the filter's stream (after a capture: for the device).
+ * A call longer than one launch (2^30 samples; 2^24 / rate for FIRArbitrary) is MRHIP_ERR_UNSUPPORTED here. */
+int mrhip_filt_device_async(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
+                            int64_t y_capacity, int64_t y_stride, int64_t *count_out, void *stream);
+/* the largest per-channel output count a call of `inputlength` samples can have whatever the stream state: outputlength
+ * (src/Filters.jl:352-385) evaluated for 𝜙Idx = inputDeficit = 1 (+ 2 for FIRArbitrary / FIRFarrow, whose outputlength is
+ * an estimate, :375-381) */
+int64_t mrhip_outputlength_bound(const mrhip_filter *f, int64_t inputlength);
+/* wait for everything the filter has enqueued (after a HIP-graph capture of one of its calls: for the device -- replays run
+ * on streams the library never saw) and take the device-resident stream state over into the host object;
+ * *last_n_written (optional) receives the per-channel count of the last call.  Returns the status of a device-planned call
+ * that failed since the last mrhip_sync_state, once. */
+int mrhip_sync_state(mrhip_filter *f, int64_t *last_n_written);
 /* Streaming helper: exactly the sequence of filt!(buffer, self, x[a:a+chunk]) calls a caller would make
  * over consecutive `chunk`-sample pieces of a device-resident signal, issued back to back by the library (one host
  * call instead of x_len/chunk).  Output k of piece i lands right after the outputs of piece i-1 in y; *n_written is the

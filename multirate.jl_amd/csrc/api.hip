@@ -127,7 +127,7 @@ int alloc_common(mrhip_filter *f)
     }
     MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->sched_copied, hipEventDisableTiming));
     MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->xs_event, hipEventDisableTiming));
-    return MRHIP_OK;
+    return rec_alloc(f);              // the stream state on the device (stream_state.hip), constructor state
 }
 
 // Is `stream` being captured into a HIP graph?  (The legacy null stream cannot be; while another stream captures in
@@ -187,15 +187,17 @@ int check_create_args(const void *h, int64_t hLen, int th, int tx, int64_t nch, 
 // Kernel selection for the rational family.  Tuned kernels are tried first; the universal
 // one-thread-per-output kernel accepts everything.
 hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s,
-                       const char **kname, bool *did_shiftin, unsigned *counters)
+                       const char **kname, bool *did_shiftin, unsigned *counters, bool *rec_written)
 {
     *did_shiftin = false;
+    *rec_written = false;             // the pair kernels and the universal kernel file the call's end state in the device record
     if (!f->force_generic) {
         if (a.L == 1) {
             PairArgs spa;
             dim3 sblock;
             size_t slds = 0;
             if (plan_fir_stream(tk, a, f->num_cus, &spa, &sblock, &slds)) {
+                *rec_written = true;
                 *did_shiftin = a.H > 0;          // its loader waves write the call-end history themselves
                 return launch_fir_stream(fused, a, spa, sblock, slds, s, kname, f->num_cus, counters);
             }
@@ -209,6 +211,7 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
             dim3 block;
             size_t lds = 0;
             if (plan_rational_opair(tk, a, f->num_cus, &pa, &block, &lds)) {
+                *rec_written = true;
                 *did_shiftin = a.H > 0;
                 return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, counters);
             }
@@ -225,6 +228,7 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
                 return launch_poly_tiled(tk, fused, a, tt, tl, s, kname, f->num_cus);
         }
     }
+    *rec_written = true;
     return launch_poly_generic(tk, fused, a, s, kname);
 }
 
@@ -450,6 +454,7 @@ void mrhip_destroy(mrhip_filter *f)
 {
     if (!f) return;
     DeviceGuard guard(f->device);
+    if (f->captured) (void)hipDeviceSynchronize();   // replays of a graph that holds this filter's calls ran on streams the library never saw
     (void)drain_filter(f);                       // this filter's work only; other streams of the process keep running
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
         if (st) (void)hipStreamSynchronize(st);
@@ -459,6 +464,7 @@ void mrhip_destroy(mrhip_filter *f)
     if (f->pin_n) (void)hipHostFree(f->pin_n);
     if (f->pin_acc) (void)hipHostFree(f->pin_acc);
     sched_free(f);
+    rec_free(f);
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
         if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : {f->sched_copied, f->xs_event, f->ev_in[0], f->ev_in[1], f->ev_k[0], f->ev_k[1], f->ev_out[0], f->ev_out[1]})
@@ -467,9 +473,34 @@ void mrhip_destroy(mrhip_filter *f)
     delete f;
 }
 
+// The host's state written into the device record, in stream order behind whatever the filter enqueued last (the stream of
+// its last call; when that stream no longer exists -- torch side streams come and go -- behind the whole device, on the
+// filter's own stream).
+static int push_state(mrhip_filter *f)
+{
+    hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
+    if (rec_push(f, s) != MRHIP_OK) {
+        (void)hipGetLastError();
+        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        s = f->own_stream;
+        if (int rc = rec_push(f, s)) return rc;
+    }
+    f->last_stream = s; f->last_stream_valid = true;
+    return MRHIP_OK;
+}
+
+// the host's copy of the stream state is stale after calls nobody collected (asynchronous calls, graph replays)
+static int fresh(const mrhip_filter *f)
+{
+    if (f->mirror_valid) return MRHIP_OK;
+    DeviceGuard guard(f->device);
+    return rec_pull(const_cast<mrhip_filter *>(f));
+}
+
 int64_t mrhip_outputlength(const mrhip_filter *f, int64_t n)
 {
     if (!f) return -1;
+    if (f->kind != MRHIP_FIR_STANDARD && f->kind != MRHIP_FIR_INTERPOLATOR && fresh(f)) return -1;
     switch (f->kind) {
     case MRHIP_FIR_STANDARD: return n;                                                   // Filters.jl:359
     case MRHIP_FIR_INTERPOLATOR: return f->L * n;                                        // :363
@@ -499,6 +530,7 @@ static int64_t arb_schedule(mrhip_filter *f, int64_t x_len, ArbState *end_state)
 int64_t mrhip_next_output_count(const mrhip_filter *f, int64_t n)
 {
     if (!f || n < 0) return -1;
+    if (fresh(f)) return -1;
     if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW)   // the schedule is cached for the filt call that normally follows
         return arb_schedule(const_cast<mrhip_filter *>(f), n, nullptr);
     return plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, n).n_out;
@@ -507,24 +539,32 @@ int64_t mrhip_next_output_count(const mrhip_filter *f, int64_t n)
 int64_t mrhip_advance_state(mrhip_filter *f, int64_t n)
 {
     if (!f || n < 0) { (void)fail(MRHIP_ERR_INVALID_ARG, "advance_state: NULL filter or negative length"); return -1; }
+    if (fresh(f)) return -1;
+    DeviceGuard guard(f->device);
+    hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
+    if (stream_is_capturing(s)) { (void)fail(MRHIP_ERR_UNSUPPORTED, "advance_state while the filter's stream is being captured"); return -1; }
+    int64_t total;
     if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {
         ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
-        const int64_t total = run_arbitrary_schedule(st, f->delta, f->Nphi, n, nullptr, nullptr);    // (count only: no entries kept)
+        total = run_arbitrary_schedule(st, f->delta, f->Nphi, n, nullptr, nullptr);    // (count only: no entries kept)
         f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;   // Filters.jl:731-735
         f->inputDeficit = st.inputDeficit;
         f->sched_cached = false;
         sched_forget(f);
-        return total;
+    } else {
+        const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, n);
+        f->phiIdx = p.phi_end;                                              // Filters.jl:515-516, 571-572, 647-648
+        f->inputDeficit = p.d_end;
+        total = p.n_out;
     }
-    const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, n);
-    f->phiIdx = p.phi_end;                                              // Filters.jl:515-516, 571-572, 647-648
-    f->inputDeficit = p.d_end;
-    return p.n_out;
+    if (push_state(f)) return -1;                                           // the device record follows, in stream order
+    return total;
 }
 
 int64_t mrhip_inputlength(const mrhip_filter *f, int64_t n)
 {
     if (!f) return -1;
+    if (fresh(f)) return -1;
     switch (f->kind) {
     case MRHIP_FIR_STANDARD: return n;                                                    // Filters.jl:403
     case MRHIP_FIR_INTERPOLATOR: return inputlength_ratio(n, f->L, 1, 1);                 // :407
@@ -538,6 +578,7 @@ int64_t mrhip_inputlength(const mrhip_filter *f, int64_t n)
 int mrhip_get_state(const mrhip_filter *f, mrhip_state *st)
 {
     if (!f || !st) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    if (int rc = fresh(f)) return rc;
     st->kind = f->kind; st->tap_dtype = f->th; st->sample_dtype = f->tx; st->output_dtype = f->ty;
     st->nchannels = f->nch; st->hLen = f->hLen; st->interpolation = f->L; st->decimation = f->M;
     st->Nphi = f->Nphi; st->tapsPerPhi = f->T; st->historyLen = f->H;
@@ -550,6 +591,9 @@ int mrhip_set_state(mrhip_filter *f, int64_t phiIdx, int64_t inputDeficit, doubl
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
     if (inputDeficit < 1) return fail(MRHIP_ERR_INVALID_ARG, "inputDeficit must be >= 1");
+    DeviceGuard guard(f->device);
+    hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
+    if (stream_is_capturing(s)) return fail(MRHIP_ERR_UNSUPPORTED, "set_state while the filter's stream is being captured");
     if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {
         if (!(phiAccumulator >= 1.0) || !(phiAccumulator < static_cast<double>(f->Nphi) + 1.0))
             return fail(MRHIP_ERR_INVALID_ARG, "phiAccumulator must be in [1, Nphi+1)");
@@ -563,7 +607,10 @@ int mrhip_set_state(mrhip_filter *f, int64_t phiIdx, int64_t inputDeficit, doubl
     f->inputDeficit = inputDeficit;
     f->sched_cached = false;
     sched_forget(f);
-    return MRHIP_OK;
+    // the device record follows in stream order (behind the calls already enqueued, like the reference's assignment
+    // behind the calls already made); whatever asynchronous calls left in the host's copy is overwritten with it
+    f->mirror_valid = true;
+    return push_state(f);
 }
 
 int mrhip_get_history(mrhip_filter *f, void *host_out)
@@ -602,6 +649,18 @@ int mrhip_set_history(mrhip_filter *f, const void *host_in)
     return MRHIP_OK;
 }
 
+int mrhip_set_history_device(mrhip_filter *f, const void *dev_in, void *stream_)
+{
+    if (!f || !dev_in) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    DeviceGuard guard(f->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (stream_is_capturing(stream)) return fail(MRHIP_ERR_UNSUPPORTED, "set_history while the stream is being captured");
+    if (int rc = adopt_stream(f, stream)) return rc;          // behind the filter's earlier launches, ahead of its next one
+    const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
+    if (bytes) MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_hist[f->hist_cur], dev_in, bytes, hipMemcpyDeviceToDevice, stream));
+    return MRHIP_OK;
+}
+
 int mrhip_reset(mrhip_filter *f)
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
@@ -625,11 +684,14 @@ int mrhip_reset(mrhip_filter *f)
     f->last_stream = s; f->last_stream_valid = true;
     f->phiIdx = 1; f->inputDeficit = 1; f->xIdx = 1; f->phiAcc = 1.0; f->alpha = 0.0;
     f->sched_cached = false;
+    f->mirror_valid = true;
     // The stream restarts from the constructor state, i.e. on the very trajectory the device schedule's drift-per-step
     // estimate was measured on: keep it (no serial host prefix, full-size pieces at once; every piece is verified
-    // anyway).  A stream that was found to cycle re-enters its cycle somewhere else: forget that (the prefix finds it again).
-    if (f->per_valid || MRHIP_ENV_INT("MRHIP_SCHED_KEEP_DRIFT", 1) == 0) sched_forget(f);
-    return MRHIP_OK;
+    // anyway).  A stream that was found to cycle re-enters its cycle where the constructor state sits on it -- when it does
+    // (rate 1.0: the cycle IS that state); otherwise forget the cycle (the prefix finds it again).
+    if (f->per_valid && f->per_reset_pos >= 0 && MRHIP_ENV_INT("MRHIP_SCHED_KEEP_DRIFT", 1) != 0) f->per_pos = f->per_reset_pos;
+    else if (f->per_valid || MRHIP_ENV_INT("MRHIP_SCHED_KEEP_DRIFT", 1) == 0) sched_forget(f);
+    return rec_push(f, s);            // the device record: constructor state, in stream order behind the zeroing
 }
 
 int mrhip_set_numerics(mrhip_filter *f, int numerics)
@@ -746,12 +808,69 @@ static int ensure_sched_capacity(mrhip_filter *f, size_t n)
     return MRHIP_OK;
 }
 
+// a-priori bound of n[last] - n[first] over `m` consecutive outputs of FIRArbitrary / FIRFarrow: every update() advances
+// xIdx by floor((phase + delta) / N) (Filters.jl:666-668), so m - 1 steps advance it by at most (m - 1) / rate + 1; one more
+// for the roundings of the Float64 recurrence.  Sizes the LDS sample tiles of a call whose schedule is still on its way.
+static void span_bounds(double rate, int *spans)
+{
+    for (int z = 0; z < kSchedSpanSizes; ++z) {
+        const double m = static_cast<double>((static_cast<long long>(kSchedSpanBase) << z) - 1);
+        const double b = std::floor(m / rate) + 2.0;
+        spans[z] = b < 2.0e9 ? static_cast<int>(b) : 0x7fffffff;
+    }
+}
+
+// the largest output count a call of x_len samples can have, whatever the stream state (what y must hold for a call
+// that is planned on the device)
+static int64_t output_bound(const mrhip_filter *f, int64_t x_len)
+{
+    switch (f->kind) {
+    case MRHIP_FIR_STANDARD: return x_len;
+    case MRHIP_FIR_INTERPOLATOR: return f->L * x_len;
+    case MRHIP_FIR_DECIMATOR: return outputlength_ratio(x_len, 1, f->M, 1);
+    case MRHIP_FIR_RATIONAL: return outputlength_ratio(x_len, f->L, f->M, 1);
+    default: return x_len > 0 ? static_cast<int64_t>(std::ceil(static_cast<double>(x_len) * f->rate)) + 2 : 0;   // Filters.jl:375-381 with inputDeficit = 1, + 2
+    }
+}
+
+// Kernel selection for a DEVICE-PLANNED call of the rational family: the kernels that read the call record (the two pair
+// kernels and the universal one); `a` holds the upper bounds the launch is sized with.  *P receives the outputs per step
+// the plan kernel needs for the pair kernels' step walk.
+static hipError_t launch_poly_dyn(mrhip_filter *f, const TypeKey &tk, bool fused, const PolyArgs &a, int64_t x_len, long long y_capacity,
+                                  long long *count_dev, hipStream_t s, const char **kname, bool *did_shiftin)
+{
+    *did_shiftin = false;
+    if (!f->force_generic) {
+        PairArgs pa;
+        dim3 block;
+        size_t lds = 0;
+        if (a.L == 1 && plan_fir_stream(tk, a, f->num_cus, &pa, &block, &lds)) {
+            hipError_t e = launch_poly_plan(f, x_len, pa.P, y_capacity, count_dev, s);
+            if (e != hipSuccess) return e;
+            *did_shiftin = a.H > 0;
+            return launch_fir_stream(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
+        }
+        if (a.L > 1 && plan_rational_opair(tk, a, f->num_cus, &pa, &block, &lds)) {
+            hipError_t e = launch_poly_plan(f, x_len, pa.P, y_capacity, count_dev, s);
+            if (e != hipSuccess) return e;
+            *did_shiftin = a.H > 0;
+            return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
+        }
+    }
+    hipError_t e = launch_poly_plan(f, x_len, 1, y_capacity, count_dev, s);
+    if (e != hipSuccess) return e;
+    return launch_poly_generic(tk, fused, a, s, kname);
+}
+
 // One launch-sized piece of a filt! call.  `continuation`: the piece continues a call whose earlier samples were already
 // filtered (mrhip_filt_device splits calls longer than a launch can index; mrhip_filt_host cuts a call into staging
 // pieces): the Vector seam's start-from-zero (support.jl:46) then applies to none of its outputs -- in the ONE reference
 // call they all lie past the first hLen samples -- so that a split call equals the unsplit one down to the sign of a zero.
+// `async`: nobody waits for this call (mrhip_filt_device_async): it is planned on the device from the device-resident
+// stream state, like every call that is being captured into a HIP graph.
 static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
-                           int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream_, bool continuation)
+                           int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream_, bool continuation,
+                           bool async = false, long long *count_dev = nullptr)
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
     if (n_written) *n_written = 0;
@@ -764,36 +883,46 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
     if (!guard.ok) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
     const TypeKey tk = type_key(f);
     const bool fused = f->numerics == MRHIP_NUMERICS_FUSED;
-    if (x_len == 0) return MRHIP_OK;   // nothing to do: zero outputs, history and state unchanged
+    const bool arb = f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW;
 
-    // Stream capture (HIP graphs).  A captured call is replayed with the arguments baked in at capture time -- the
-    // call-start (phiIdx, inputDeficit), the history slot -- while the host object is NOT advanced by a replay.  So a
-    // call may only be captured if it leaves the integer state where it found it (x_len a multiple of the decimation
-    // for the rational family); its history is written back into the slot it was read from, and every replay then
-    // continues the stream exactly like the next call of a plain loop would.  Anything else would replay stale
-    // state silently, and is refused.
+    // Stream capture (HIP graphs).  A captured call is replayed with the arguments baked in at capture time while the
+    // host object is NOT advanced by a replay: so it is planned ON THE DEVICE -- a one-lane plan kernel in front of the
+    // filter kernel reads the stream state from the device record, leaves count and call-start state in the call record
+    // the filter kernel reads, and advances the record -- and every replay continues the stream like the next call of a
+    // plain loop, at ANY fixed chunk size and for every kind.  The history is written back into the slot it was read
+    // from (the slot is baked in too).  The host fields move on as a shadow of ONE replay (so that the calls of a capture
+    // see each other) and are re-read from the device before they are next used.
     const bool capturing = stream_is_capturing(stream);
-    if (capturing) {
-        if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW)
-            return fail(MRHIP_ERR_UNSUPPORTED, "FIRArbitrary/FIRFarrow calls cannot be captured in a HIP graph (the phase schedule is uploaded per call)");
-        const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len);
-        if (p.short_input || p.phi_end != p.phi0 || p.d_end != p.d0)
-            return fail(MRHIP_ERR_UNSUPPORTED, "a captured filt! call must leave (phiIdx, inputDeficit) unchanged (x_len a multiple of the decimation): a replay would reuse the capture-time state");
-    } else if (int rc = adopt_stream(f, stream)) {
-        return rc;
+    const bool dev_planned = async || capturing;
+    if (!dev_planned && !f->mirror_valid)
+        if (int rc = rec_pull(f)) return rc;
+    if (x_len == 0) {                  // nothing to do: zero outputs, history and state unchanged
+        if (count_dev) MRHIP_CHECK_HIP(hipMemsetAsync(count_dev, 0, sizeof(long long), stream));
+        return MRHIP_OK;
+    }
+    if (!capturing)
+        if (int rc = adopt_stream(f, stream)) return rc;
+    const int64_t bound = output_bound(f, x_len);
+    if (dev_planned) {
+        if (y_capacity < bound)
+            return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small: a call planned on the device (mrhip_filt_device_async, HIP-graph capture) needs room for mrhip_outputlength_bound(x_len) outputs");
+        if (bound > 0 && !y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
+        if (f->nch > 1 && y_stride < bound) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output bound");
     }
 
     int64_t n_out = 0;
     bool did_shiftin = false;
+    bool rec_current = false;          // the device record has (or will have, in stream order) this call's end state
     const int hist_next = f->hist_cur ^ 1;
-    if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {
+    if (arb) {
         // one range [k0, k0+cnt) of this call's outputs: schedule entries are already in the device buffers
         const size_t yelt = dtype_scalar_size(f->ty) * static_cast<size_t>(f->nc);
         // (d_n, d_acc: the device schedule; n_host: its host copy, or NULL with `spans` = the largest input span of
-        //  the aligned tiles of 256, 512, 1024 outputs when the schedule was evaluated on the device)
+        //  the aligned tiles of 64 ... 1024 outputs when the schedule is evaluated on the device; dyn: the count comes
+        //  from the call record, cnt is its upper bound)
         const void *sched_dn = nullptr, *sched_dacc = nullptr;      // set by the branch that filled them, before its launch_range
         const int *sched_spans = nullptr;
-        auto launch_range = [&](int64_t k0, int64_t cnt, const int32_t *n_host) -> int {
+        auto launch_range = [&](int64_t k0, int64_t cnt, const int32_t *n_host, const DevCall *dyn) -> int {
             if (!sched_dn || !sched_dacc) return fail(MRHIP_ERR_HIP, "no phase schedule on the device (internal)");
             void *yk = static_cast<unsigned char *>(y) + static_cast<size_t>(k0) * yelt;
             if (f->kind == MRHIP_FIR_FARROW) {
@@ -803,6 +932,8 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 fa.x_stride = x_stride; fa.y_stride = y_stride; fa.x_len = x_len; fa.n_out = cnt;
                 fa.T = static_cast<int>(f->T); fa.H = static_cast<int>(f->H); fa.polyorder = static_cast<int>(f->polyorder);
                 fa.tap_f32 = f->th == MRHIP_F32; fa.nch = static_cast<int>(f->nch);
+                fa.seam_below = continuation ? 0 : static_cast<int>(f->T);
+                fa.dyn = dyn;
                 if (int rc = timing_mark(f, stream)) return rc;
                 ArbTileArgs fta;
                 size_t flds = 0;
@@ -818,6 +949,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             a.x_stride = x_stride; a.y_stride = y_stride; a.x_len = x_len; a.n_out = cnt;
             a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H); a.Nphi = static_cast<int>(f->Nphi);
             a.nch = static_cast<int>(f->nch);
+            a.dyn = dyn;
             if (int rc = timing_mark(f, stream)) return rc;
             ArbTileArgs ta;
             size_t lds = 0;
@@ -829,28 +961,62 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         };
         ArbState st;
         // Upper bound of the output count (the reference's outputlength estimate, Filters.jl:375-381, + 2 for the
-        // rounding of its Float64 recurrence).  With room for it in y, the serial host recurrence is PIPELINED with
-        // the GPU: every piece of the schedule is uploaded and its kernel launched while the next piece is computed.
-        const int64_t est = x_len >= f->inputDeficit
-            ? static_cast<int64_t>(std::ceil(static_cast<double>(x_len - f->inputDeficit + 1) * f->rate)) + 2 : 0;
-        const bool cached = f->sched_cached && f->sched_xlen == x_len && f->sched_acc0 == f->phiAcc && f->sched_deficit0 == f->inputDeficit;
+        // rounding of its Float64 recurrence); without the host's copy of the state: for inputDeficit = 1.
+        const int64_t est = dev_planned ? bound
+            : (x_len >= f->inputDeficit ? static_cast<int64_t>(std::ceil(static_cast<double>(x_len - f->inputDeficit + 1) * f->rate)) + 2 : 0);
+        const bool cached = !dev_planned && f->sched_cached && f->sched_xlen == x_len && f->sched_acc0 == f->phiAcc && f->sched_deficit0 == f->inputDeficit;
         static const int64_t piece = [] { const char *v = std::getenv("MRHIP_SCHED_PIECE"); return v && *v ? std::atoll(v) : 262144LL; }();
-        if (!cached && sched_wants_device(f, est)) {
-            // the schedule is evaluated on the device (arb_schedule.hip): entries, count and end state without the
-            // host's serial loop; ONE filter launch for the whole call
-            SchedResult sr{};
-            if (int rc = sched_run_call(f, x_len, est, stream, &sr)) return rc;
-            n_out = sr.count;
-            if (n_out > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
-            if (n_out > 0) {
-                if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
-                if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
-                sched_dn = f->ds_n[sr.buf]; sched_dacc = f->ds_acc[sr.buf]; sched_spans = sr.max_span;
-                if (int rc = launch_range(0, n_out, nullptr)) return rc;
+        if (dev_planned || (!cached && sched_wants_device(f, est))) {
+            // The schedule is evaluated on the device (arb_schedule.hip), in front of ONE filter launch that takes the
+            // output count from the call record: nothing waits in the middle of the call.  A caller that wants the count
+            // (the reference's filt! returns it) collects it from the pinned mirror once the schedule's last kernel has
+            // run -- by then the filter kernel is already queued behind it.
+            if (est >= 0x7fffffffLL) return fail(MRHIP_ERR_INVALID_ARG, "call too long for one launch (internal)");
+            int spans[kSchedSpanSizes];
+            span_bounds(f->rate, spans);
+            SchedOut so{};
+            if (int rc = sched_enqueue(f, x_len, est, dev_planned ? y_capacity : INT64_MAX, count_dev, !dev_planned, stream, &so)) return rc;   // (a call that is waited for checks the count against the room itself)
+            sched_dn = f->ds_n[so.buf]; sched_dacc = f->ds_acc[so.buf]; sched_spans = spans;
+            const bool room = y && y_capacity >= est && (f->nch == 1 || y_stride >= est);
+            bool launched = false;
+            if (so.pending && room && est > 0) {
+                if (int rc = launch_range(0, est, nullptr, f->d_call)) return rc;
+                launched = true;
             }
-            f->sched_drift = sr.drift; f->sched_ksteps = sr.ksteps;
-            if (sr.periodic) f->per_pos = sr.per_pos_end;
-            st = sr.end;
+            rec_current = so.pending;
+            if (dev_planned) {
+                // nobody collects: the host's copy of the state is stale from here on (a capture additionally moves it on
+                // as the shadow of one replay -- not for these kinds: their state is the device's alone)
+                f->mirror_valid = false;
+                n_out = -1;
+                st = ArbState{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
+            } else {
+                for (;;) {
+                    bool relaunch = false;
+                    if (int rc = sched_collect(f, x_len, est, INT64_MAX, count_dev, stream, &so, &relaunch)) return rc;
+                    if (!relaunch) break;
+                    rec_current = so.pending;
+                    if (so.pending && room) { if (int rc = launch_range(0, est, nullptr, f->d_call)) return rc; }
+                    else launched = false;
+                }
+                n_out = so.count;
+                st = so.end;
+                // (rec_current: the FINISH kernel wrote the record; a call the host evaluated itself pushes it below)
+                if (n_out > y_capacity) {
+                    if (rec_current) {      // the record moved on with the schedule: take the stream back to the call's start
+                        f->sched_cached = false;
+                        (void)rec_push(f, stream);
+                    }
+                    return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
+                }
+                if (n_out > 0 && !launched) {
+                    if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
+                    if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
+                    if (int rc = launch_range(0, n_out, nullptr, nullptr)) return rc;
+                }
+                f->sched_drift = so.drift; f->sched_ksteps = so.ksteps;
+                if (so.periodic || f->per_valid) f->per_pos = so.per_pos_end;
+            }
         } else if (!cached && est > 2 * piece && y && y_capacity >= est && (f->nch == 1 || y_stride >= est) && est < 0x7fffffffLL) {
             if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
             if (int rc = ensure_sched_capacity(f, static_cast<size_t>(est))) return rc;
@@ -883,7 +1049,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                         hipMemcpyAsync(static_cast<double *>(f->d_sched_acc) + k0, pa, static_cast<size_t>(cnt) * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess)
                         return bail(fail(MRHIP_ERR_HIP, "uploading the phase schedule failed"));
                     const double t2 = prof ? now() : 0;
-                    if (int rc = launch_range(k0, cnt, pn)) return bail(rc);
+                    if (int rc = launch_range(k0, cnt, pn, nullptr)) return bail(rc);
                     if (prof) { t_rec += t1 - t0; t_copy += t2 - t1; t_launch += now() - t2; }
                     k0 += cnt;
                 }
@@ -908,13 +1074,43 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_sched_acc, f->pin_acc, static_cast<size_t>(n_out) * sizeof(double), hipMemcpyHostToDevice, stream));
             MRHIP_CHECK_HIP(hipEventRecord(f->sched_copied, stream));
             f->sched_in_flight = true;
-            if (int rc = launch_range(0, n_out, f->sched_n.data())) return rc;
+            if (int rc = launch_range(0, n_out, f->sched_n.data(), nullptr)) return rc;
         }
         }
         // commit the post-call state (Filters.jl:731-735)
-        f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;
-        f->inputDeficit = st.inputDeficit;
+        if (!dev_planned) {
+            f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;
+            f->inputDeficit = st.inputDeficit;
+        }
         f->sched_cached = false;
+    } else if (dev_planned) {
+        PolyArgs a{};
+        a.x = x; a.y = y; a.hist = f->d_hist[f->hist_cur]; a.hist_new = f->d_hist[hist_next]; a.taps = f->d_taps;
+        a.x_stride = x_stride; a.y_stride = y_stride; a.x_len = x_len;
+        a.n_out = std::max<int64_t>(bound, 1);                          // upper bounds: the plan kernel leaves the call's own values in the call record
+        a.u0 = 0; a.d0 = 1;
+        a.zero_start_below = continuation ? 0
+                           : f->kind == MRHIP_FIR_STANDARD ? f->hLen + 1
+                           : f->kind == MRHIP_FIR_DECIMATOR ? f->hLen : 0;
+        a.L = static_cast<int>(f->L); a.M = static_cast<int>(f->M);
+        a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H);
+        a.nch = static_cast<int>(f->nch);
+        a.rec = f->d_rec; a.dyn = f->d_call;
+        if (int rc = timing_mark(f, stream)) return rc;
+        MRHIP_CHECK_HIP(launch_poly_dyn(f, tk, fused, a, x_len, y_capacity, count_dev, stream, &f->last_kernel, &did_shiftin));
+        if (int rc = timing_mark(f, stream)) return rc;
+        rec_current = true;
+        if (f->mirror_valid || capturing) {
+            // the shadow of ONE execution: exact while the host knew the state when the capture (or the run of
+            // asynchronous calls) began; re-read from the device before it is next used either way
+            const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len);
+            n_out = p.n_out;
+            f->phiIdx = p.phi_end;
+            f->inputDeficit = p.d_end;
+        } else {
+            n_out = -1;
+        }
+        f->mirror_valid = false;
     } else {
         const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len);
         n_out = p.n_out;
@@ -933,13 +1129,17 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             a.L = static_cast<int>(f->L); a.M = static_cast<int>(f->M);
             a.T = static_cast<int>(f->T); a.H = static_cast<int>(f->H);
             a.nch = static_cast<int>(f->nch);
+            a.rec = f->d_rec; a.dyn = nullptr; a.phi_end = p.phi_end; a.d_end = p.d_end;
             if (int rc = timing_mark(f, stream)) return rc;
-            MRHIP_CHECK_HIP(launch_poly(f, tk, fused, a, stream, &f->last_kernel, &did_shiftin, f->d_counters));
+            MRHIP_CHECK_HIP(launch_poly(f, tk, fused, a, stream, &f->last_kernel, &did_shiftin, f->d_counters, &rec_current));
             if (int rc = timing_mark(f, stream)) return rc;
         }
         f->phiIdx = p.phi_end;
         f->inputDeficit = p.d_end;
     }
+    // the device record follows every call in stream order: a call whose kernels did not file its end state pushes it
+    if (!rec_current && (f->kind != MRHIP_FIR_STANDARD && f->kind != MRHIP_FIR_INTERPOLATOR))
+        if (int rc = rec_push(f, stream, -1, std::max<int64_t>(n_out, 0))) return rc;
 
     // history <- last H samples of [history ; x]   (shiftin!, support.jl:61-80), ping-pong buffers
     if (f->H > 0 && !did_shiftin) {
@@ -957,6 +1157,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             f->hist_cur = hist_next;
         }
     }
+    if (capturing) f->captured = true;
     if (n_written) *n_written = n_out;
     return MRHIP_OK;
 }
@@ -965,22 +1166,27 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
 // 31 bits, and a FIRArbitrary / FIRFarrow launch holds its phase schedule in device memory, so a long call is cut into
 // launch-sized pieces here -- chunked == unchunked bit for bit (logical window, closed-form / carried state), see
 // filt_device_one for the one place where a piece must know it is not the start of the call.
-int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
-                      int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream)
+static int filt_device_any(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
+                           int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream, bool async, long long *count_dev)
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
     if (n_written) *n_written = 0;
     const bool arb = f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW;
-    // samples per launch: inputs and outputs stay below 2^31; at most 2^24 schedule entries per FIRArbitrary launch
+    // samples per launch: inputs AND outputs stay below 2^31 (FIRInterpolator and FIRRational with L > M write more than
+    // they read); at most 2^24 schedule entries per FIRArbitrary launch
     const int64_t env_max = MRHIP_ENV_INT("MRHIP_LAUNCH_MAX", 0);              // tests: force the split at small sizes
     int64_t step = env_max > 0 ? env_max : (1LL << 30);
-    if (f->kind == MRHIP_FIR_INTERPOLATOR) step = std::max<int64_t>(step / f->L, 1);
+    if (env_max <= 0 && (f->kind == MRHIP_FIR_INTERPOLATOR || f->kind == MRHIP_FIR_RATIONAL) && f->L > f->M)
+        step = std::max<int64_t>(static_cast<int64_t>((static_cast<__int128>(step) * f->M) / f->L), 1);
+    if (f->kind == MRHIP_FIR_INTERPOLATOR && env_max > 0) step = std::max<int64_t>(step / f->L, 1);
     if (arb && env_max <= 0) step = std::max<int64_t>(4096, std::min<int64_t>(step, static_cast<int64_t>(static_cast<double>(1LL << 24) / f->rate)));
-    if (x_len <= step) return filt_device_one(f, x, x_len, x_stride, y, y_capacity, y_stride, n_written, stream, false);
+    if (x_len <= step) return filt_device_one(f, x, x_len, x_stride, y, y_capacity, y_stride, n_written, stream, false, async, count_dev);
     if (x_len < 0 || y_capacity < 0) return fail(MRHIP_ERR_INVALID_ARG, "negative length");
     if (!x) return fail(MRHIP_ERR_INVALID_ARG, "x is NULL");
-    if (stream_is_capturing(static_cast<hipStream_t>(stream)))
-        return fail(MRHIP_ERR_UNSUPPORTED, "a call of this length is issued in several launches with the state advanced in between: not capturable");
+    if (async || stream_is_capturing(static_cast<hipStream_t>(stream)))
+        return fail(MRHIP_ERR_UNSUPPORTED, "a call of this length is issued in several launches whose places in y depend on the counts of the earlier ones: neither capturable nor asynchronous");
+    if (!f->mirror_valid)
+        if (int rc = rec_pull(f)) return rc;
     if (!arb) {   // reference: error() before any work, Filters.jl:460 (Standard), :503 (Interpolator), :550 (Rational)
         const int64_t total = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len).n_out;
         if (total > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
@@ -999,6 +1205,41 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
         k += got;
     }
     if (n_written) *n_written = k;
+    return MRHIP_OK;
+}
+
+int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
+                      int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream)
+{
+    return filt_device_any(f, x, x_len, x_stride, y, y_capacity, y_stride, n_written, stream, false, nullptr);
+}
+
+int mrhip_filt_device_async(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
+                            int64_t y_capacity, int64_t y_stride, int64_t *count_out, void *stream)
+{
+    static_assert(sizeof(long long) == sizeof(int64_t), "the count is written by the device as a long long");
+    return filt_device_any(f, x, x_len, x_stride, y, y_capacity, y_stride, nullptr, stream, true, reinterpret_cast<long long *>(count_out));
+}
+
+int64_t mrhip_outputlength_bound(const mrhip_filter *f, int64_t inputlength)
+{
+    if (!f || inputlength < 0) return -1;
+    return output_bound(f, inputlength);
+}
+
+int mrhip_sync_state(mrhip_filter *f, int64_t *last_n_written)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    DeviceGuard guard(f->device);
+    if (int rc = rec_pull(f)) return rc;
+    const DevStream r = *f->h_rec;
+    if (last_n_written) *last_n_written = r.n_written;
+    if (r.error != 0) {
+        hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
+        if (int rc = rec_push(f, s)) return rc;                     // (clears the sticky error; the state stays)
+        return fail(r.error, r.error == MRHIP_ERR_BUFFER_TOO_SMALL ? "buffer is too small (a device-planned call clipped its outputs)"
+                                                                   : "a device-planned call failed (the stream was moved off the cycle its schedule relies on, or its schedule overran the bound)");
+    }
     return MRHIP_OK;
 }
 

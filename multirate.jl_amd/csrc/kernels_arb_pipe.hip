@@ -125,7 +125,9 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
     const unsigned lx0 = lds0 + static_cast<unsigned>(ta.x_offset_bytes);        // sample buffer b at lx0 + b*xbuf_bytes: [CPL][MS] (x2)
 
     // tile -> (stretch of 256 outputs tau, channel group cg), time-major: the workgroups that run together share the schedule
-    const int ngroups = static_cast<int>(ta.total_tiles / ta.tiles_per_channel);
+    long long ngroups_ll;
+    tiles_take_dyn(a.n_out, ta, ngroups_ll, a.dyn);                 // (a device-planned call: the count from the call record)
+    const int ngroups = static_cast<int>(ngroups_ll);
     long long tile = blockIdx.x;
     if (tile >= ta.total_tiles) return;
     long long tau = tile / ngroups;

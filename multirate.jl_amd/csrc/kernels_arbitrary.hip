@@ -81,7 +81,8 @@ __global__ __launch_bounds__(kArbThreads, 4) void arb_tiled_kernel(ArbArgs a, Ar
             ldpfb[phi * TP + i] = g1[e];
         }
     }
-    const long long ngroups = ta.total_tiles / ta.tiles_per_channel;
+    long long ngroups;
+    tiles_take_dyn(a.n_out, ta, ngroups, a.dyn);                    // (a device-planned call: the count from the call record)
 
     // tile -> (first output, last output, channel group, first sample, span)
     struct TileInfo { long long k0, klast, o; int ch0, nchl, span; long long n_lo; };
@@ -315,6 +316,10 @@ __global__ __launch_bounds__(kArbThreads, 3) void farrow_tiled_kernel(FarrowArgs
     Sample *const lxB = lxA + (SPR == 2 ? CPL * MS + ta.copyb_pad : 0);         // the same, one sample later, 128 B round the banks
     const int tid = threadIdx.x;
     const int T = a.T, P = a.polyorder;
+    {
+        long long ngroups;
+        tiles_take_dyn(a.n_out, ta, ngroups, a.dyn);                // (a device-planned call: the count from the call record)
+    }
 
     for (long long tile = blockIdx.x; tile < ta.total_tiles; tile += gridDim.x) {
         const long long k0 = tile * ta.tile_out;
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(kArbThreads, 3) void farrow_tiled_kernel(FarrowArgs
                 for (int i = 0; i < T; ++i) tl[i * kArbThreads + tid] = tap_of(i);
             }
         }
-        const bool seam = n < T;                      // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818
+        const bool seam = n < a.seam_below;           // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818 (never in a piece that continues a call)
         const int w = have ? static_cast<int>(n - n_lo) : 0;
         const bool oddw = SPR == 2 && (w & 1);
         const Sample *const wp = oddw ? lxB + (w - 1) : lxA + w;

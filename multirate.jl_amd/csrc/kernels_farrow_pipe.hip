@@ -101,6 +101,10 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
     const unsigned copy_bytes = DMA ? static_cast<unsigned>(ta.dma_slots) * 1024u : static_cast<unsigned>(CPL) * static_cast<unsigned>(MS) * SB;
     const unsigned copyb_off = copy_bytes + static_cast<unsigned>(ta.copyb_pad) * SB;       // copy B behind copy A, 128 B round the banks
     const unsigned xbuf_bytes = PAIR ? copyb_off + copy_bytes : copy_bytes;                // sample buffer b at b*xbuf_bytes (x2)
+    {
+        long long ngroups;
+        tiles_take_dyn(a.n_out, ta, ngroups, a.dyn);                // (a device-planned call: the count from the call record)
+    }
     const long long ntiles = ta.total_tiles;
     const int ngroups = (a.nch + CPL - 1) / CPL;
 
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
                 }
             }
         }
-        const bool seam = n < T;                                  // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818
+        const bool seam = n < a.seam_below;                       // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818 (never in a piece that continues a call)
         const R acc0 = seam ? static_cast<R>(0.0) : static_cast<R>(-0.0);
         const int w = have ? n - n_lo : 0;                        // oldest sample of this output's window, within the tile
 

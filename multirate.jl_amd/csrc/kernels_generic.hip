@@ -47,6 +47,10 @@ template <typename TX, typename R, int NC, bool FUSED>
 __global__ __launch_bounds__(256) void poly_generic_kernel(PolyArgs a)
 {
     const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (a.dyn) { a.n_out = a.dyn->n_out; a.u0 = a.dyn->u0; a.d0 = a.dyn->d0; }       // a device-planned call (mrhip_internal.h: DevCall)
+    else if (a.rec && k == 0 && blockIdx.y == 0) {                                    // the host planned it: file the end state
+        a.rec->phiIdx = a.phi_end; a.rec->inputDeficit = a.d_end; a.rec->n_written = a.n_out; a.rec->calls += 1;
+    }
     if (k >= a.n_out) return;
     const R *__restrict__ taps = static_cast<const R *>(a.taps);
     for (int ch = blockIdx.y; ch < a.nch; ch += gridDim.y) {
@@ -91,6 +95,7 @@ template <typename TX, typename R, int NC, bool FUSED>
 __global__ __launch_bounds__(256) void arb_generic_kernel(ArbArgs a)
 {
     const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (a.dyn) a.n_out = a.dyn->n_out;              // a device-planned call: the count the schedule's FINISH kernel left
     if (k >= a.n_out) return;
     const long long n = a.n_idx[k];
     const double pacc = a.acc[k];
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(256) void farrow_kernel(FarrowArgs a)
     R *const tl = reinterpret_cast<R *>(farrow_smem);
     const int tid = threadIdx.x, bs = blockDim.x;
     const long long k = static_cast<long long>(blockIdx.x) * bs + tid;
+    if (a.dyn) a.n_out = a.dyn->n_out;             // a device-planned call
     if (k >= a.n_out) return;                      // no barriers below: each thread only reads its own LDS column
     const long long n = a.n_idx[k];
     const double phase = a.acc[k];
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(256) void farrow_kernel(FarrowArgs a)
     if constexpr (CACHE)
         for (int i = 0; i < a.T; ++i) tl[i * bs + tid] = tap(i);
     const long long base = n - a.T;
-    const bool seam = n < a.T;                     // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818
+    const bool seam = n < a.seam_below;            // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818 (never in a piece that continues a call)
     for (int ch = blockIdx.y; ch < a.nch; ch += gridDim.y) {
         const TX *__restrict__ xc = static_cast<const TX *>(a.x) + static_cast<long long>(ch) * a.x_stride * NC;
         const TX *__restrict__ hc = static_cast<const TX *>(a.hist) + static_cast<long long>(ch) * a.H * NC;
@@ -216,7 +222,7 @@ hipError_t dispatch_types(const TypeKey &tk, F &&f)
 
 inline dim3 grid_for(long long n_out, int nch)
 {
-    const long long bx = (n_out + 255) / 256;
+    const long long bx = n_out > 0 ? (n_out + 255) / 256 : 1;
     return dim3(static_cast<unsigned>(bx), static_cast<unsigned>(nch < 65535 ? nch : 65535), 1);
 }
 
@@ -224,7 +230,7 @@ inline dim3 grid_for(long long n_out, int nch)
 
 hipError_t launch_poly_generic(const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s, const char **kname)
 {
-    if (a.n_out <= 0) return hipSuccess;
+    if (a.n_out <= 0 && !a.dyn) return hipSuccess;
     if ((a.n_out + 255) / 256 > 0x7fffffffLL) return hipErrorInvalidValue;
     *kname = "poly_generic_kernel";
     return dispatch_types(tk, [&]<typename TX, typename R, int NC>() -> hipError_t {
@@ -236,7 +242,7 @@ hipError_t launch_poly_generic(const TypeKey &tk, bool fused, const PolyArgs &a,
 
 hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, hipStream_t s, const char **kname)
 {
-    if (a.n_out <= 0) return hipSuccess;
+    if (a.n_out <= 0 && !a.dyn) return hipSuccess;
     if ((a.n_out + 255) / 256 > 0x7fffffffLL) return hipErrorInvalidValue;
     *kname = "arb_generic_kernel";
     return dispatch_types(tk, [&]<typename TX, typename R, int NC>() -> hipError_t {
@@ -248,7 +254,7 @@ hipError_t launch_arb_generic(const TypeKey &tk, bool fused, const ArbArgs &a, h
 
 hipError_t launch_farrow(const TypeKey &tk, bool fused, const FarrowArgs &a, hipStream_t s, const char **kname)
 {
-    if (a.n_out <= 0) return hipSuccess;
+    if (a.n_out <= 0 && !a.dyn) return hipSuccess;
     *kname = "farrow_kernel";
     return dispatch_types(tk, [&]<typename TX, typename R, int NC>() -> hipError_t {
         // block size: as many outputs as keep one LDS column of T taps per thread within 64 KiB
@@ -258,7 +264,7 @@ hipError_t launch_farrow(const TypeKey &tk, bool fused, const FarrowArgs &a, hip
         if (bs > 256) bs = 256;
         if (!cache) bs = 256;
         const size_t lds = cache ? static_cast<size_t>(per_thread) * bs : 0;
-        const long long bx = (a.n_out + bs - 1) / bs;
+        const long long bx = std::max<long long>((a.n_out + bs - 1) / bs, 1);
         if (bx > 0x7fffffffLL) return hipErrorInvalidValue;
         // channels are split over blockIdx.y only as far as needed to fill the machine: the taps are
         // evaluated once per (output, blockIdx.y)

@@ -372,7 +372,108 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
     }
 }
 
+// ---- BEGIN / FINISH: the one-lane kernels round the pieces of a call (mrhip_internal.h: SchedBeginArgs) ----------------
+__global__ __launch_bounds__(64) void sched_begin_kernel(SchedBeginArgs a, long long x_len, long long k_first)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    SchedPieceState ps;
+    if (a.use_host) { ps.acc = a.acc; ps.xIdx = a.xIdx; ps.drift = a.drift; ps.ksteps = a.ksteps; }
+    else { const DevStream r = *a.rec; ps.acc = r.acc; ps.xIdx = r.inputDeficit; ps.drift = r.drift; ps.ksteps = r.ksteps; }   // xIdx starts at inputDeficit, Filters.jl:715
+    SchedStatus st{};
+    st.fail_piece = kSchedNoFail;
+    if (ps.xIdx > x_len) {            // not one output (Filters.jl:705-709): the call ends before its first entry
+        st.done = 1;
+        st.end_k = k_first;
+        st.end_acc = ps.acc;
+        st.end_xIdx = ps.xIdx;
+    }
+    *a.status = st;
+    a.state[0] = ps;
+}
+
+__global__ __launch_bounds__(64) void sched_finish_kernel(SchedPlan c, SchedFinishArgs a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DevStream r = *a.rec;
+    const SchedStatus st = *a.status;
+    const int fail = st.fail_piece;
+    DevCall call{};
+    r.sched_fail = kSchedNoFail;
+    if (fail != kSchedNoFail && !a.serial_fallback) {
+        // the host waits for this call anyway: it redoes the piece with its own serial loop and continues from there
+        // (arb_schedule.hip: sched_collect); nothing of the stream state moves, the filter kernel finds no outputs
+        r.sched_fail = fail;
+        *a.fail_state = a.state[fail];
+        call.n_out = 0;
+        *a.call = call;
+        *a.rec = r;
+        *a.mirror = r;
+        if (a.count_out) *a.count_out = 0;
+        return;
+    }
+    long long n_out, end_x;
+    double end_acc, drift, ksteps;
+    if (fail == kSchedNoFail && st.done) {
+        n_out = st.end_k; end_acc = st.end_acc; end_x = st.end_xIdx;
+        // the drift baseline: the state behind the last piece that lies wholly before the call's end
+        long long kk = a.k_first;
+        double ks = a.ks_first;
+        int pl = 0;
+        for (; pl < a.np; ++pl) {
+            const long long P = sched_piece_steps(ks, a.pmax);
+            if (kk + P > n_out) break;
+            kk += P; ks += static_cast<double>(P);
+        }
+        drift = a.state[pl].drift; ksteps = a.state[pl].ksteps;
+    } else {
+        // the serial recurrence, from the verified start of the piece that failed (or from behind the last piece when the
+        // pieces did not reach the call's end) to the end of the call: exact, and slow -- one lane
+        const int p0 = fail != kSchedNoFail ? fail : a.np;
+        long long k = a.k_first;
+        double ks = a.ks_first;
+        for (int p = 0; p < p0; ++p) { const long long P = sched_piece_steps(ks, a.pmax); k += P; ks += static_cast<double>(P); }
+        const SchedPieceState ps = a.state[p0];
+        double acc = ps.acc;
+        long long x = ps.xIdx;
+        const long long k_start = k;
+        while (x <= a.x_len && k < a.est) {
+            a.sched_n[k] = static_cast<int>(x);
+            a.sched_acc[k] = acc;
+            ++k;
+            sched_step(acc, x, c);
+        }
+        if (x <= a.x_len) r.error = MRHIP_ERR_INVALID_ARG;        // est is an upper bound of the count: cannot happen
+        n_out = k; end_acc = acc; end_x = x;
+        drift = ps.drift; ksteps = ps.ksteps;
+        r.fallback_steps += k - k_start;
+    }
+    call.n_out = n_out;
+    if (n_out > a.y_capacity) { call.n_out = a.y_capacity; r.error = MRHIP_ERR_BUFFER_TOO_SMALL; }
+    call.k_done = n_out;
+    r.acc = end_acc;
+    r.inputDeficit = end_x - a.x_len;                            // Filters.jl:734
+    r.drift = drift; r.ksteps = ksteps;
+    r.n_written = call.n_out;
+    r.calls += 1;
+    *a.call = call;
+    *a.rec = r;
+    *a.mirror = r;
+    if (a.count_out) *a.count_out = call.n_out;
+}
+
 }  // namespace
+
+hipError_t launch_sched_begin(const SchedBeginArgs &a, long long x_len, long long k_first, hipStream_t s)
+{
+    hipLaunchKernelGGL(sched_begin_kernel, dim3(1), dim3(64), 0, s, a, x_len, k_first);
+    return hipGetLastError();
+}
+
+hipError_t launch_sched_finish(const SchedPlan &c, const SchedFinishArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(sched_finish_kernel, dim3(1), dim3(64), 0, s, c, a);
+    return hipGetLastError();
+}
 
 size_t sched_tables_lds(const SchedPlan &c) { return static_cast<size_t>(kGroupSegs) * c.nwin * 24; }
 
@@ -380,12 +481,10 @@ size_t sched_tables_lds(const SchedPlan &c) { return static_cast<size_t>(kGroupS
 hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hipStream_t s)
 {
     const size_t lds = sched_tables_lds(c);
-    static size_t lds_attr = 0;                                       // (per process; the attribute only ever grows)
-    if (lds > 48 * 1024 && lds > lds_attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sched_tables_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    {   // the dynamic-LDS attribute is per device: remembered per (kernel, device) like every other launch's
+        int per_cu = 0;
+        hipError_t e = occupancy_cached(reinterpret_cast<const void *>(sched_tables_kernel), kTabThreads, lds, &per_cu);
         if (e != hipSuccess) return e;
-        lds_attr = lds;
     }
     hipLaunchKernelGGL(sched_tables_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(kTabThreads), lds, s, c, a);
     hipLaunchKernelGGL(sched_chain_kernel, dim3(1), dim3(kChainWaves * 64), 0, s, c, a);

@@ -123,17 +123,47 @@ struct SchedPieceArgs {
     int piece, ngroups;
     int corrupt_group;       // test hook: -1, or the group whose table is falsified (MRHIP_SCHED_CORRUPT)
 };
-struct SchedResult {         // what sched_run_call (arb_schedule.hip) leaves for the filter kernel's launch
-    int buf;                 // schedule buffer (mrhip_filter::ds_n / ds_acc) that holds entries [0, count)
-    int64_t count;           // outputs of the call
-    ArbState end;            // state after the call (the caller commits it)
-    int max_span[kSchedSpanSizes];
-    double drift, ksteps;    // running drift estimate after the call
-    bool periodic;           // evaluated by the closed form of a detected cycle
-    int64_t per_pos_end;     // ... whose position after the call this is
-};
 SchedPlan make_sched_plan(double delta, int64_t Nphi);
 hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hipStream_t s);
+// The two one-lane kernels round the pieces of a call (kernels_schedule.hip).  BEGIN arms the status word and writes the
+// call-start state of piece 0 -- from the device record, or from the host's values when it just evaluated a prefix itself.
+// FINISH turns the pieces' verdict into the call's result: output count into the DevCall the filter kernel reads (clamped
+// to the caller's room in y), end state and drift estimate into the record and its pinned mirror.  A piece that did not
+// verify is either reported (the host redoes it and continues: the call is waited for anyway) or, for a call nobody
+// waits for, redone on the spot by the serial recurrence, from that piece's verified start state to the end of the call.
+struct DevStream;
+struct DevCall;
+struct SchedBeginArgs {
+    DevStream *rec;
+    SchedStatus *status;
+    SchedPieceState *state;
+    int use_host;                 // 1: (acc, xIdx, drift, ksteps) below are the state at schedule entry k_first
+    double acc; long long xIdx; double drift, ksteps;
+};
+struct SchedFinishArgs {
+    DevStream *rec, *mirror;
+    DevCall *call;
+    SchedStatus *status;
+    SchedPieceState *state;       // [pieces + 1]
+    SchedPieceState *fail_state;  // pinned: the verified start state of a piece that failed (for the host's redo)
+    int *sched_n; double *sched_acc;
+    long long *count_out;         // optional, device-accessible: receives the call's output count
+    long long k_first;            // schedule entry the first piece starts at (> 0 behind a host prefix)
+    double ks_first;              // the drift baseline the host sized the pieces with (piece sizes are recomputed from it)
+    long long pmax, est, x_len, y_capacity;
+    int np;                       // pieces enqueued
+    int serial_fallback;          // redo a failed piece (and everything behind it) here instead of reporting it
+};
+hipError_t launch_sched_begin(const SchedBeginArgs &a, long long x_len, long long k_first, hipStream_t s);
+hipError_t launch_sched_finish(const SchedPlan &c, const SchedFinishArgs &a, hipStream_t s);
+// piece sizes of a call: piece i covers steps [k, k + P), P the largest power-of-two multiple of a group that is at most
+// pmax and at most 16x the drift baseline behind it (one rule for the host that enqueues and the kernel that sums up)
+__host__ __device__ inline long long sched_piece_steps(double ks, long long pmax)
+{
+    long long P = kSchedGroup;
+    while (P * 2 <= pmax && static_cast<double>(P * 2) <= 16.0 * ks) P *= 2;
+    return P;
+}
 }  // namespace mrhip
 struct mrhip_filter;
 namespace mrhip {
@@ -141,8 +171,80 @@ void sched_configure(mrhip_filter *f);
 void sched_forget(mrhip_filter *f);
 void sched_free(mrhip_filter *f);
 bool sched_wants_device(const mrhip_filter *f, int64_t est);
-int sched_run_call(mrhip_filter *f, int64_t x_len, int64_t est, hipStream_t stream, SchedResult *out);
+// Enqueue the schedule of one call on `s` (see arb_schedule.hip).  host_ok: the host's copy of the stream state is exact
+// and may be used (serial prefix, closed form of a cycle); otherwise everything is taken from the device record.
+struct SchedOut {
+    int buf = 0;                  // schedule buffer that will hold the entries
+    bool host_known = false;      // the host evaluated the whole call itself: count / end are final, nothing to collect
+    bool pending = false;         // a FINISH kernel will deliver the result into the mirror (ev_rec)
+    int64_t count = 0;
+    ArbState end;
+    bool periodic = false;
+    int64_t per_pos_end = 0;
+    double drift = 0.0, ksteps = 0.0;
+    // for a host redo after a failed piece: what was enqueued
+    std::vector<int64_t> pk0, psteps;
+    int64_t k_first = 0;
+};
+int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, bool host_ok, hipStream_t s, SchedOut *out);
+int sched_collect(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, hipStream_t s, SchedOut *io, bool *relaunch);
+// stream_state.hip: the device record
+int rec_alloc(mrhip_filter *f);
+void rec_free(mrhip_filter *f);
+// write the host's state into the device record (and its mirror), in stream order on `s`; call_n_out >= 0 also arms the
+// DevCall with that output count (a call the host evaluated, whose filter kernel reads the DevCall)
+int rec_push(mrhip_filter *f, hipStream_t s, long long call_n_out = -1, long long n_written = -1);
+// wait for everything enqueued on the filter's behalf and take the device record over into the host fields
+int rec_pull(mrhip_filter *f);
+hipError_t launch_poly_plan(mrhip_filter *f, int64_t x_len, long long P, long long y_capacity, long long *count_out, hipStream_t s);
 double sched_anchor_host(const SchedPlan &c, double acc_p, double k);   // un-rounded phase after k steps (host_logic.cpp)
+
+// ---------------------------------------------------------------------------------------
+// the stream state ON THE DEVICE (stream_state.hip)
+// ---------------------------------------------------------------------------------------
+// The reference mutates 𝜙Idx / inputDeficit / 𝜙Accumulator at the end of every filt! (src/Filters.jl:571-572, 627-628,
+// 734-735, update() :663-673).  Here that state has a device-resident record per filter, kept current IN STREAM ORDER by
+// every call: a call the host planned writes the end state it computed (carried in the kernel arguments: one lane of the
+// filter kernel, or stream_set_kernel); a DEVICE-PLANNED call (mrhip_filt_device_async, every call captured into a HIP
+// graph, every FIRArbitrary / FIRFarrow call whose schedule the device evaluates) reads the record in a one-lane plan
+// kernel, leaves what its filter kernel needs in a DevCall, and advances the record there -- so a replayed graph continues
+// the stream by itself, and the host learns counts and state from a pinned mirror of the record, never by waiting in the
+// middle of a call.
+struct DevStream {
+    long long phiIdx, inputDeficit;   // 1-based, reference field names
+    double acc;                       // 𝜙Accumulator
+    double drift, ksteps;             // FIRArbitrary / FIRFarrow: running drift estimate of the device schedule
+    long long per_pos;                // ... position in a detected cycle of the accumulator
+    long long n_written;              // outputs per channel of the last call
+    long long calls;                  // filt! calls completed on this stream
+    long long fallback_steps;         // schedule steps redone by the serial loop on the device
+    int error;                        // sticky until read: mrhip_status of a device-planned call (buffer too small, ...)
+    int sched_fail;                   // the last call's first schedule piece that did not verify (kSchedNoFail: none)
+};
+struct DevCall {                      // what the kernels of ONE device-planned call read
+    long long n_out;                  // outputs per channel
+    long long u0, d0;                 // rational family: phi0 - 1, inputDeficit at call start
+    unsigned steps_per_channel, total_steps, spc_magic, pad0;   // pair kernels: the step walk for this n_out
+    long long per_pos, per_xbase;     // PERIODIC schedule: cycle position / x offset at the call's first entry
+    long long k_done;                 // schedule entries valid so far (a call whose schedule is continued after a host redo)
+};
+// Closed form of the rational loop (host_logic.cpp: plan_rational), usable on both sides
+struct CallPlanPOD { long long n_out, phi0, d0, phi_end, d_end; int short_input; };
+__host__ __device__ inline CallPlanPOD plan_rational_pod(int kind, long long L, long long M, long long phiIdx, long long inputDeficit, long long xLen)
+{
+    CallPlanPOD p{0, 1, 1, 1, 1, 0};
+    if (kind == MRHIP_FIR_STANDARD) { p.n_out = xLen; return p; }
+    if (kind == MRHIP_FIR_INTERPOLATOR) { p.n_out = L * xLen; return p; }
+    p.phi0 = kind == MRHIP_FIR_DECIMATOR ? 1 : phiIdx;
+    p.d0 = inputDeficit;
+    if (xLen < inputDeficit) { p.short_input = 1; p.n_out = 0; p.phi_end = phiIdx; p.d_end = inputDeficit - xLen; return p; }
+    const long long a = (xLen - inputDeficit + 1) * L - p.phi0 + 1;          // outputlength_ratio, Filters.jl:352-357
+    p.n_out = a >= 0 ? (a + M - 1) / M : -((-a) / M);
+    const long long u_end = (p.phi0 - 1) + p.n_out * M;
+    p.phi_end = u_end % L + 1;
+    p.d_end = p.d0 + u_end / L - xLen;
+    return p;
+}
 
 // ---------------------------------------------------------------------------------------
 // device-side parameter blocks
@@ -163,6 +265,12 @@ struct PolyArgs {            // rational family: STANDARD / DECIMATOR / INTERPOL
                                  // (support.jl:46; STANDARD: hLen+1, DECIMATOR: hLen, else 0)
     int L, M, T, H;
     int nch;
+    // the device-resident stream state (see DevStream).  dyn == NULL: the host planned this call; `rec` (if set) receives
+    // the end state (phi_end, d_end) and n_out from one lane of the kernel.  dyn != NULL: n_out, u0, d0 (and the step walk of
+    // the pair kernels) are read from *dyn, which the call's plan kernel filled; the values above are upper bounds.
+    DevStream *rec;
+    const DevCall *dyn;
+    long long phi_end, d_end;
 };
 
 struct ArbArgs {             // FIRArbitrary
@@ -178,6 +286,7 @@ struct ArbArgs {             // FIRArbitrary
     long long n_out;
     int T, H, Nphi;
     int nch;
+    const DevCall *dyn;      // != NULL: n_out is read from it (a device-planned call; the value above is an upper bound)
 };
 
 struct FarrowArgs {          // FIRFarrow
@@ -193,6 +302,9 @@ struct FarrowArgs {          // FIRFarrow
     int T, H, polyorder;
     int tap_f32;             // currentTaps is a Vector{Float32}: round every evaluated tap to Float32
     int nch;
+    int seam_below;          // outputs whose 1-based input index n < this start from +0 (support.jl:46): T, or 0 for a
+                             // piece that continues a call (mrhip_filt_device splits long calls)
+    const DevCall *dyn;      // != NULL: n_out is read from it
 };
 
 struct HistArgs {            // shiftin! (src/support.jl:61-80) for every channel
@@ -278,6 +390,19 @@ struct ArbTileArgs {         // tiling of the FIRArbitrary kernel (kernels_arbit
     long long tiles_per_channel;
     long long total_tiles;
 };
+
+// A device-planned FIRArbitrary / FIRFarrow call (ArbArgs::dyn / FarrowArgs::dyn): the output count comes from the call
+// record (the schedule's FINISH kernel left it there) and the tiling follows it; the launch was sized with upper bounds.
+// `ngroups` = channel groups per stretch of outputs (tiles that share one stretch of the schedule).
+__device__ __forceinline__ void tiles_take_dyn(long long &n_out, ArbTileArgs &ta, long long &ngroups, const DevCall *dyn)
+{
+    ngroups = ta.tiles_per_channel > 0 ? ta.total_tiles / ta.tiles_per_channel : 1;
+    if (dyn) {
+        n_out = dyn->n_out;
+        ta.tiles_per_channel = (n_out + ta.tile_out - 1) / ta.tile_out;
+        ta.total_tiles = ta.tiles_per_channel * ngroups;
+    }
+}
 
 // Every compute kernel is launched through launch_kernel().  Optional timing mode MRHIP_TIMING_ATTACH=1
 // (api.hip:timing_mark): a start/stop event pair armed by api.hip is attached to the next kernel's own dispatch
@@ -389,6 +514,16 @@ struct mrhip_filter {
     int64_t phiIdx = 1, inputDeficit = 1, xIdx = 1;
     double rate = 0.0, phiAcc = 1.0, alpha = 0.0, delta = 0.0;
 
+    // the stream state on the device (DevStream above; stream_state.hip).  The host fields above mirror it exactly while
+    // mirror_valid; device-planned calls whose result the host has not yet collected (mrhip_filt_device_async, calls
+    // captured into a HIP graph) clear the flag, mrhip_sync_state / any call that needs the state restores it.
+    mrhip::DevStream *d_rec = nullptr;      // device
+    mrhip::DevCall *d_call = nullptr;       // device: the call record of the filter's current device-planned call
+    mrhip::DevStream *h_rec = nullptr;      // pinned host memory the plan kernels mirror the record into
+    bool mirror_valid = true;
+    bool captured = false;                  // a call went into a HIP graph: replays advance the record behind the host's back
+    hipEvent_t ev_rec = nullptr;            // recorded behind a plan kernel: the mirror holds that call's result once it fires
+
     // FIRArbitrary schedule staging
     std::vector<int32_t> sched_n;
     std::vector<double> sched_acc;
@@ -408,7 +543,7 @@ struct mrhip_filter {
 
     // device-evaluated schedule (arb_schedule.hip, kernels_schedule.hip)
     mrhip::SchedPlan splan{};
-    int64_t sched_prefix = 65536, sched_pmax = 1 << 22, sched_device_min = 1 << 18;   // MRHIP_SCHED_* (read at create)
+    int64_t sched_prefix = 65536, sched_pmax = 1 << 22, sched_device_min = 1 << 16;   // MRHIP_SCHED_* (read at create)
     int sched_corrupt_piece = -1;                 // test hook: falsify the tables of this device piece (counted per filter)
     bool sched_use_cycle = true;
     double sched_drift = 0.0, sched_ksteps = 0.0; // running drift estimate of the stream: (true - un-rounded phase) over ksteps steps
@@ -424,7 +559,7 @@ struct mrhip_filter {
     mrhip::SchedStatus *ds_status = nullptr, *ds_pin_status = nullptr;
     // a detected cycle of the accumulator (PERIODIC mode)
     bool per_valid = false;
-    int64_t per_Q = 0, per_XQ = 0, per_pos = 0;
+    int64_t per_Q = 0, per_XQ = 0, per_pos = 0, per_reset_pos = -1;
     std::vector<double> per_acc;
     std::vector<int64_t> per_xoff;                // [Q + 1] xIdx advance from cycle position 0
     int per_span[mrhip::kSchedSpanSizes] = {};

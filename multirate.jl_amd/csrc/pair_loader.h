@@ -24,6 +24,21 @@ __device__ __forceinline__ TileAt pair_tile_at(const PairArgs &pa, unsigned g, u
     return TileAt{static_cast<int>(q), static_cast<int>(r), static_cast<int>(umin(jt, spc - r))};
 }
 
+// A device-planned call (PolyArgs::dyn, mrhip_internal.h: DevCall): the output count, the call-start (u0, d0) and the step
+// walk come from the record the call's plan kernel filled; the kernel arguments hold upper bounds the launch was sized with.
+__device__ __forceinline__ void pair_take_dyn(PolyArgs &a, PairArgs &pa)
+{
+    if (a.dyn) {
+        const DevCall *__restrict__ d = a.dyn;
+        a.n_out = d->n_out; a.u0 = d->u0; a.d0 = d->d0;
+        pa.o0 = d->d0 - a.T;
+        pa.steps_per_channel = d->steps_per_channel;
+        pa.total_steps = d->total_steps;
+        pa.spc_magic = d->spc_magic;
+        pa.steps_per_group = (pa.total_steps + static_cast<unsigned>(pa.ngroups) - 1u) / static_cast<unsigned>(pa.ngroups);
+    }
+}
+
 // The whole life of the loader wave (the last wave of the workgroup).  A tile of jt steps needs
 // jt * pa.cM + pa.tail samples of one channel; NC = components per sample (1: Float32, 2: ComplexF32 / one Float64).
 template <int NC>
@@ -176,6 +191,14 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
             for (int k = 0; k < pa.ngroups; ++k) pa.counters[k * 64] = 0u;
             *done = 0u;
         }
+    }
+    // the stream state on the device (mrhip_internal.h: DevStream): a call the host planned carries its end state
+    // (Filters.jl:571-572, 627-628) in the arguments and one lane files it; a device-planned call's plan kernel already has
+    if (blockIdx.x == 0 && lane == 0 && a.rec && !a.dyn) {
+        a.rec->phiIdx = a.phi_end;
+        a.rec->inputDeficit = a.d_end;
+        a.rec->n_written = a.n_out;
+        a.rec->calls += 1;
     }
     // shiftin! (support.jl:61-80), fused: hist_new <- last H samples of [hist ; x] for the channels this
     // workgroup is responsible for (round-robin); hist_new is the other ping-pong buffer, nobody reads it

@@ -95,6 +95,10 @@ ABI = [
     ("mrhip_set_numerics", _i, [_vp, _i]),
     ("mrhip_get_taps", _i, [_vp, _i, _vp]),
     ("mrhip_filt_device", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
+    ("mrhip_filt_device_async", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
+    ("mrhip_outputlength_bound", _i64, [_vp, _i64]),
+    ("mrhip_sync_state", _i, [_vp, _pi64]),
+    ("mrhip_set_history_device", _i, [_vp, _vp, _vp]),
     ("mrhip_filt_device_chunked", _i, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
     ("mrhip_filt_host", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64]),
     ("mrhip_synchronize", _i, [_vp, _vp]),
@@ -509,6 +513,58 @@ class FIRFilter:
         cap = buffer.shape[-1]
         _check(self._lib.mrhip_filt_host(self._handle, _ptr(x), n, n, _ptr(buffer), cap, cap, C.byref(nw)))
         return nw.value
+
+    def outputlength_bound(self, inputlength: int) -> int:
+        """The largest per-channel output count a call of ``inputlength`` samples can have whatever the stream state
+        (``mrhip_outputlength_bound``): the room ``filt_into_async`` -- and every call captured into a HIP graph -- needs."""
+        if self._handle is None:
+            raise MultirateHIPError(1, "outputlength_bound needs a bound filter (call filt once, or bind())")
+        return self._lib.mrhip_outputlength_bound(self._handle, int(inputlength))
+
+    def filt_into_async(self, buffer, x, count=None) -> None:
+        """filt!(buffer, self, x) planned ON THE DEVICE from the device-resident stream state (``mrhip_filt_device_async``):
+        nothing is returned and the host never waits, so a loop of such calls only enqueues -- and captures into a HIP
+        graph at any fixed chunk size, for every kind.  ``buffer`` must hold ``outputlength_bound(n)`` samples per channel;
+        ``count`` (optional) is a one-element int64 CUDA tensor that receives the per-channel output count in stream order.
+        ``sync_state()`` returns the last call's count and brings the host-side view of the state up to date."""
+        if not _is_torch(x) or not x.is_cuda:
+            raise MultirateHIPError(1, "filt_into_async takes torch device tensors")
+        if x.stride(-1) != 1 or buffer.stride(-1) != 1:
+            raise MultirateHIPError(1, "x and buffer must be contiguous along time (planar channels)")
+        nch, n, _ = self._shape(x)
+        self._ensure(_torch_np_dtype(x.dtype), nch)
+        if _torch_np_dtype(buffer.dtype) != self.output_dtype:
+            raise MultirateHIPError(1, f"buffer dtype must be {self.output_dtype}")
+        if buffer.ndim != x.ndim or (x.ndim == 2 and buffer.shape[0] != nch):
+            raise MultirateHIPError(1, "buffer must have one row per channel")
+        cap = buffer.shape[-1]
+        xs = x.stride(0) if x.ndim == 2 and nch > 1 else n
+        ys = buffer.stride(0) if buffer.ndim == 2 and nch > 1 else cap
+        cptr = None
+        if count is not None:
+            if not (_is_torch(count) and count.is_cuda and count.dtype == torch.int64 and count.numel() >= 1):
+                raise MultirateHIPError(1, "count must be an int64 CUDA tensor")
+            cptr = C.c_void_p(count.data_ptr())
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(self._lib.mrhip_filt_device_async(self._handle, C.c_void_p(x.data_ptr()), n, xs, C.c_void_p(buffer.data_ptr()),
+                                                 cap, ys, cptr, C.c_void_p(stream)))
+
+    def sync_state(self) -> int:
+        """Wait for the filter's enqueued calls (after a graph capture: for the device) and take the device-resident
+        stream state over into the host object; returns the per-channel output count of the last call
+        (``mrhip_sync_state``).  Raises if a device-planned call failed since the last ``sync_state``."""
+        nw = C.c_int64(0)
+        _check(self._lib.mrhip_sync_state(self._handle, C.byref(nw)))
+        return nw.value
+
+    def set_history_device(self, hist) -> None:
+        """FIRFilter.history from a torch CUDA tensor, asynchronously on the current stream (``mrhip_set_history_device``)."""
+        if not _is_torch(hist) or not hist.is_cuda or not hist.is_contiguous():
+            raise MultirateHIPError(1, "set_history_device takes a contiguous torch CUDA tensor")
+        if _torch_np_dtype(hist.dtype) != self._tx or hist.numel() != self._nch * self.historyLen:
+            raise MultirateHIPError(1, f"history must hold {self._nch} x {self.historyLen} samples of {self._tx}")
+        stream = torch.cuda.current_stream(hist.device).cuda_stream
+        _check(self._lib.mrhip_set_history_device(self._handle, C.c_void_p(hist.data_ptr()), C.c_void_p(stream)))
 
     def filt_into_chunked(self, buffer, x, chunk: int) -> int:
         """The loop ``for a in range(0, n, chunk): filt!(buffer[k:], self, x[a:a+chunk])`` issued by the library in one

@@ -361,6 +361,28 @@ function filt_device!(f::FIRFilter, yptr::Ptr{Cvoid}, ycap::Integer, ystride::In
     Int(nw[])
 end
 
+# filt! planned ON THE DEVICE from the device-resident stream state (mrhip_filt_device_async): nothing comes back, the host
+# never waits; the same call captured into a HIP graph replays at any fixed chunk size, for every kind.  ycap must be at
+# least outputlengthbound(f, xlen); countptr (optional) is device-accessible memory for the per-channel output count.
+function filt_device_async!(f::FIRFilter, yptr::Ptr{Cvoid}, ycap::Integer, ystride::Integer, xptr::Ptr{Cvoid}, xlen::Integer,
+                            xstride::Integer, ::Type{Tx}, nch::Integer; countptr::Ptr{Int64} = Ptr{Int64}(C_NULL), stream::Ptr{Cvoid} = C_NULL) where {Tx}
+    bind!(f, Tx, nch)
+    check(ccall((:mrhip_filt_device_async, libmr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Cvoid}),
+                f.handle, xptr, xlen, xstride, yptr, ycap, ystride, countptr, stream))
+    nothing
+end
+outputlengthbound(f::FIRFilter, n::Integer) = Int(ccall((:mrhip_outputlength_bound, libmr), Int64, (Ptr{Cvoid}, Int64), f.handle, n))
+# wait for the filter's enqueued calls, bring the host-side view of the state up to date; returns the last call's count
+function syncstate!(f::FIRFilter)
+    nw = Ref{Int64}(0)
+    check(ccall((:mrhip_sync_state, libmr), Cint, (Ptr{Cvoid}, Ptr{Int64}), f.handle, nw))
+    Int(nw[])
+end
+# FIRFilter.history from device memory (a halo received over RCCL), asynchronous on `stream`
+sethistorydevice!(f::FIRFilter, histptr::Ptr{Cvoid}; stream::Ptr{Cvoid} = C_NULL) =
+    check(ccall((:mrhip_set_history_device, libmr), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), f.handle, histptr, stream))
+
 # The streaming loop `for each chunk: filt!(view(y, k+1:...), f, view(x, a+1:a+chunk))` over a device-resident signal,
 # issued by the library in one call (mrhip_filt_device_chunked): same outputs, same end state.
 function filt_device_chunked!(f::FIRFilter, yptr::Ptr{Cvoid}, ycap::Integer, ystride::Integer, xptr::Ptr{Cvoid}, xlen::Integer,

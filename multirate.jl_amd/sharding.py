@@ -181,11 +181,19 @@ def shard_time(n: int, world_size: int, rank: int, multiple: int = 1):
 
 
 class TimeShardedFilter:
-    """One stream of ``n_total`` samples per channel, of which this rank filters the samples ``[start, start + count)``.
+    """One stream cut into blocks of ``n_total`` samples per channel; of every block this rank filters the samples
+    ``[start, start + count)``.  Successive ``filt`` calls continue the stream block after block (``reset()`` starts over).
+
+    Per call the state enters this rank's slice without data (``advance_state`` over the samples the other ranks own) and
+    the ``historyLen`` samples in front of the slice arrive from the rank before it -- for rank 0 of a later block: from
+    the LAST rank's slice of the block before -- one point-to-point message per neighbour pair, a ring.  Over RCCL the halo
+    stays in device memory end to end (``set_history_device``); over gloo it travels through host memory.
 
     ``filter_factory()`` must return an object with ``filt(x)``, ``reset()``, ``advance_state(n)``, ``set_history(h)``
-    and ``historyLen`` (the HIP-backed ``FIRFilter`` by default; tests inject a CPU model).  Every slice but the first
-    must be at least ``historyLen`` samples long (its successor's history comes from it alone).
+    and ``historyLen`` (the HIP-backed ``FIRFilter`` by default; tests inject a CPU model).  Every slice that has a
+    non-empty successor must be at least ``historyLen`` samples long (its successor's history comes from it alone), except
+    rank 0's in the first block (the stream's own zero history pads it): checked identically on every rank BEFORE any
+    message is posted, so that a bad split raises everywhere instead of leaving a neighbour waiting.
     """
 
     def __init__(self, h, ratio, n_total: int, *, Nphi: int = 32, polyorder=None, numerics: Optional[int] = None,
@@ -210,52 +218,88 @@ class TimeShardedFilter:
                 return FIRFilter(h, ratio, Nphi, polyorder, device=dev,
                                  numerics=NUMERICS_STRICT if numerics is None else numerics)
         self.filter = filter_factory()
+        self.blocks = 0            # blocks filtered so far (0: the next call starts the stream)
+        self._tail = None          # the last rank keeps the tail of its slice for rank 0's next block
 
     def local_slice(self, x_global):
         """The samples of a (..., n_total) global array that belong to this rank."""
         return x_global[..., self.start:self.start + self.count]
 
+    def reset(self):
+        """Start the stream over (every rank)."""
+        self.filter.reset()
+        self.blocks = 0
+        self._tail = None
+        return self
+
+    def _ring(self):
+        """(ranks with samples, in order): the halo travels from each to the next, and from the last to the first"""
+        return [r for r in range(self.world_size) if self.slices[r][1] > 0]
+
     def _exchange_halo(self, x_local, H):
-        """The last H samples of every slice go to the next rank (point to point); returns this rank's history
-        (channels, H) as a tensor, or None for rank 0 (the stream's own zero history)."""
+        """The last H samples of every owner's slice go to the next owner (point to point), the last owner's to the first
+        for the NEXT block; returns this rank's history (channels, H) as a tensor in the wire's memory, or None when the
+        history is the stream's own (first block of the first owner; a single rank)."""
         import torch
         dist = self._dist
-        if self.world_size == 1 or not dist.is_initialized() or H == 0:
+        owners = self._ring()
+        if self.world_size == 1 or not dist.is_initialized() or H == 0 or len(owners) < 2 or self.count == 0:
             return None
         x2 = x_local.reshape(-1, x_local.shape[-1])
         # the message lives where the backend moves it: device memory for nccl (RCCL over xGMI), host memory otherwise
-        # (the history is handed to the filter as a host array anyway)
         wire = x2.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
         real = (lambda t: (torch.view_as_real(t.contiguous()).reshape(t.shape[0], -1) if t.is_complex() else t.contiguous()).to(wire))
+        me = owners.index(self.rank)
+        first, last = me == 0, me == len(owners) - 1
+        tail = real(x2[:, -H:])
         reqs, recv = [], None
-        if self.rank + 1 < self.world_size and self.slices[self.rank + 1][1] > 0:
-            if self.count < H and self.rank > 0:
-                raise ValueError(f"time slice of rank {self.rank} ({self.count} samples) is shorter than the filter history ({H})")
-            tail = x2[:, -H:] if self.count >= H else torch.cat([torch.zeros((x2.shape[0], H - self.count), dtype=x2.dtype, device=x2.device), x2], dim=1)
-            reqs.append(dist.isend(real(tail), dst=self.rank + 1, group=self.group))
-        if self.rank > 0 and self.count > 0:
+        send_now = None
+        if not last:
+            send_now = tail                                  # this block's slice feeds the next owner's slice of this block
+        elif self.blocks > 0:
+            send_now = self._tail                            # the last owner: its PREVIOUS block's tail feeds the first owner now
+        if send_now is not None:
+            reqs.append(dist.isend(send_now, dst=owners[(me + 1) % len(owners)], group=self.group))
+        if not first or self.blocks > 0:
             recv = torch.empty((x2.shape[0], H * (2 if x2.is_complex() else 1)), dtype=x2.real.dtype if x2.is_complex() else x2.dtype, device=wire)
-            reqs.append(dist.irecv(recv, src=self.rank - 1, group=self.group))
+            reqs.append(dist.irecv(recv, src=owners[(me - 1) % len(owners)], group=self.group))
         for r in reqs:
             r.wait()
+        if last:
+            self._tail = tail
         if recv is None:
             return None
         return torch.view_as_complex(recv.reshape(recv.shape[0], H, 2)) if x2.is_complex() else recv
 
     def filt(self, x_local):
-        """Filter this rank's slice ``x_local`` (..., count) of the stream.  One halo message per neighbour pair."""
+        """Filter this rank's slice ``x_local`` (..., count) of the next block of the stream.  One halo message per
+        neighbour pair."""
         f = self.filter
+        H = int(f.historyLen)
+        if self.world_size > 1 and len(self._ring()) > 1:
+            for r in self._ring():
+                if self.slices[r][1] < H:
+                    raise ValueError(f"time slice of rank {r} ({self.slices[r][1]} samples) is shorter than the filter history ({H}): "
+                                     f"its successor's history comes from it alone")
         if self.count == 0:
+            self.blocks += 1
             return f.filt(x_local)                       # nothing to do: an empty output of the right type
         if hasattr(f, "bind") and getattr(f, "_handle", True) is None:
             import numpy as np_
             nch = 1 if x_local.ndim == 1 else int(x_local.shape[0])
             f.bind(np_.dtype(str(x_local.dtype).replace("torch.", "")), nch)
-        f.reset()
-        f.advance_state(self.start)                      # the stream state at this slice's first sample
-        hist = self._exchange_halo(x_local, int(f.historyLen))
+        # the stream state at this slice's first sample: over the samples the ranks before it own (first block), then
+        # over everybody else's samples between this rank's slices of consecutive blocks
+        skip = self.start if self.blocks == 0 else self.n_total - self.count
+        if skip > 0:
+            f.advance_state(skip)
+        hist = self._exchange_halo(x_local, H)
         if hist is not None:
-            f.set_history(hist.cpu().numpy())
+            if hist.is_cuda and hasattr(f, "set_history_device"):
+                f.set_history_device(hist.contiguous())   # the halo never leaves the device (RCCL)
+            else:
+                f.set_history(hist.cpu().numpy())
+        self.blocks += 1
         return f.filt(x_local)
 
     def gather(self, y_local, dst: int = 0):

@@ -84,6 +84,20 @@ struct mro_filter {
 static int g_mro_fused = 0;
 void mro_set_fused(int fused) { g_mro_fused = fused ? 1 : 0; }
 
+/* mod(x, y) of update() (src/Filters.jl:668, :786) for x >= 0, y > 0.  Form 0 (default): the exact floating-point remainder,
+ * what Julia >= 0.4 computes for these operands (its mod() is rem() plus a sign fix-up).  Form 1: rem(y + rem(x, y), y), the
+ * expression older Base versions used for floats -- the reference is Julia-0.3 code and nothing in this tree says which one
+ * its Base had.  The two differ only when y + rem(x, y) is not representable, i.e. by one rounding of that sum
+ * (tests/test_oracle.py::test_mod_form_of_julia_0_3_quantified states how often and by how much). */
+static int g_mro_mod_form = 0;
+void mro_set_mod_form(int form) { g_mro_mod_form = form ? 1 : 0; }
+static double mro_mod_pos(double x, double y)
+{
+    const double r = fmod(x, y);
+    if (!g_mro_mod_form) return r;
+    return fmod(y + r, y);
+}
+
 static size_t dtype_scalar_size(int dt) { return (dt == MRO_F32 || dt == MRO_C64) ? 4 : 8; }
 static int dtype_is_complex(int dt) { return dt == MRO_C64 || dt == MRO_C128; }
 static int dtype_is_f64(int dt) { return dt == MRO_F64 || dt == MRO_C128; }
@@ -287,7 +301,7 @@ void mro_update_farrow(mro_filter *k)
     k->phiAccumulator += k->delta;
     if (k->phiAccumulator > Nphi) {
         k->xIdx += (long)floor((k->phiAccumulator - 1.0) / Nphi);
-        k->phiAccumulator = fmod(k->phiAccumulator - 1.0, Nphi) + 1.0;
+        k->phiAccumulator = mro_mod_pos(k->phiAccumulator - 1.0, Nphi) + 1.0;
     }
     farrow_taps(k, k->phiAccumulator);
     k->phiIdx = (long)floor(k->phiAccumulator);           /* bookkeeping only (state snapshots) */
@@ -313,7 +327,7 @@ void mro_update_arbitrary(mro_filter *k)
     k->phiAccumulator += k->delta;
     if (k->phiAccumulator > Nphi) {
         k->xIdx += (long)floor((k->phiAccumulator - 1.0) / Nphi);
-        k->phiAccumulator = fmod(k->phiAccumulator - 1.0, Nphi) + 1.0;
+        k->phiAccumulator = mro_mod_pos(k->phiAccumulator - 1.0, Nphi) + 1.0;
     }
     k->phiIdx = (long)floor(k->phiAccumulator);
     k->alpha = k->phiAccumulator - (double)k->phiIdx;

@@ -33,6 +33,7 @@ typedef struct {
 } mro_state;
 
 int mro_output_dtype(int th, int tx);
+void mro_set_mod_form(int form); /* 0: exact remainder (default); 1: rem(y + rem(x, y), y), see multirate_oracle.c */
 void mro_set_fused(int fused);   /* 1: one fma per tap (checker for MRHIP_NUMERICS_FUSED); 0: the reference's arithmetic */
 void mro_shiftin(void *a, long aLen, const void *b, long bLen, size_t elsize);
 long mro_nextphase(long currentphase, long interpolation, long decimation);

@@ -71,6 +71,7 @@ def lib():
         L.mro_get_current_taps.argtypes = [vp, vp]
         L.mro_destroy.argtypes = [vp]
         L.mro_set_fused.argtypes = [ci]
+        L.mro_set_mod_form.argtypes = [ci]
         L.mro_outputlength.restype = cl
         L.mro_outputlength.argtypes = [vp, cl]
         L.mro_inputlength.restype = cl
@@ -104,6 +105,12 @@ def set_fused(fused: bool):
     """Process-wide: True makes every dot product use one fma per tap (checker for the library's opt-in
     NUMERICS_FUSED mode); False (default) is the reference's separately rounded multiply and add."""
     lib().mro_set_fused(1 if fused else 0)
+
+
+def set_mod_form(julia03: bool):
+    """Process-wide: the float mod() of update() (src/Filters.jl:668) as rem(y + rem(x, y), y) (True: the form older Julia
+    Base versions used) instead of the exact remainder (False, default: Julia >= 0.4)."""
+    lib().mro_set_mod_form(1 if julia03 else 0)
 
 
 def _ptr(a: np.ndarray):

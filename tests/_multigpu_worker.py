@@ -89,18 +89,22 @@ def time_sharded(pkg, O, dist, torch, rank, world, backend, dev_index, dev):
         x = x.astype(tx)
         ts = pkg.TimeShardedFilter(h, ratio, n, device=dev_index, multiple=mult)
         assert (ts.rank, ts.world_size) == (rank, world)
-        xl = torch.from_numpy(np.ascontiguousarray(ts.local_slice(x))).to(dev)
-        y_local = ts.filt(xl)
-        full = ts.gather(y_local if backend == "nccl" else y_local.cpu(), dst=0)
-        if rank == 0:
-            for c in (0, nch - 1):
-                fo = O.FIRFilter(h, ratio, 32, tx=tx) if isinstance(ratio, float) else O.FIRFilter(h, ratio, tx=tx)
-                ref = np.concatenate([fo.filt(x[c, a:a + m]) for a, m in ts.slices])
-                got = full[c].cpu().numpy()
-                assert got.shape == ref.shape and got.dtype == ref.dtype, (ratio, got.shape, ref.shape, got.dtype, ref.dtype)
-                assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), f"time-sharded {ratio} channel {c} differs from the chunk loop"
-        else:
-            assert full is None
+        # two consecutive blocks of the stream: the second enters with the state and the halo the first left (the last
+        # rank's tail feeds rank 0); over RCCL the halo stays in device memory (mrhip_set_history_device)
+        fos = {c: (O.FIRFilter(h, ratio, 32, tx=tx) if isinstance(ratio, float) else O.FIRFilter(h, ratio, tx=tx)) for c in (0, nch - 1)}
+        for blk in range(2):
+            xb = x if blk == 0 else (np.roll(x, 101, axis=1) * np.float32(0.75)).astype(tx)
+            xl = torch.from_numpy(np.ascontiguousarray(ts.local_slice(xb))).to(dev)
+            y_local = ts.filt(xl)
+            full = ts.gather(y_local if backend == "nccl" else y_local.cpu(), dst=0)
+            if rank == 0:
+                for c in (0, nch - 1):
+                    ref = np.concatenate([fos[c].filt(xb[c, a:a + m]) for a, m in ts.slices])
+                    got = full[c].cpu().numpy()
+                    assert got.shape == ref.shape and got.dtype == ref.dtype, (ratio, got.shape, ref.shape, got.dtype, ref.dtype)
+                    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), f"time-sharded {ratio} block {blk} channel {c} differs from the chunk loop"
+            else:
+                assert full is None
         ts.filter.close()
     formed = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(formed)

@@ -1,0 +1,219 @@
+"""GPU tests of the device-resident stream state (csrc/stream_state.hip, include/multirate_hip.h: mrhip_filt_device_async,
+mrhip_sync_state): the reference mutates 𝜙Idx / inputDeficit / 𝜙Accumulator at the end of every filt!
+(src/Filters.jl:571-572, 627-628, 734-735, update() :663-673); here a device record carries them, so that
+
+* a streaming loop captured into a HIP graph replays correctly at ANY fixed chunk size -- also chunk sizes
+  that advance (𝜙Idx, inputDeficit) every call, and FIRArbitrary / FIRFarrow, whose output count varies from call to call;
+* calls can be issued without the host ever waiting in their middle.
+
+Bar: outputs, per-call counts and end state bit for bit equal to the oracle's chunk loop."""
+import math
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def _tdtype(torch, d):
+    return {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+            np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}[np.dtype(d)]
+
+
+def _graph_stream(torch, f, x_all, chunk, nrep, ncalls=1):
+    """Capture `ncalls` consecutive filt! calls of `chunk` samples each into ONE graph (static input / output / count
+    buffers), replay it `nrep` times with fresh input copied in front of every replay, collect what each call wrote."""
+    nch = x_all.shape[0]
+    bound = f.outputlength_bound(chunk)
+    xs = torch.zeros((nch, chunk * ncalls), dtype=x_all.dtype, device="cuda")
+    ys = torch.zeros((ncalls, nch, bound), dtype=_tdtype(torch, f.output_dtype), device="cuda")
+    cnt = torch.zeros(ncalls, dtype=torch.int64, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=s):
+        for i in range(ncalls):
+            f.filt_into_async(ys[i], xs[:, i * chunk:(i + 1) * chunk], cnt[i:i + 1])
+    outs, counts = [], []
+    pos = 0
+    for rep in range(nrep):
+        xs.copy_(x_all[:, pos:pos + chunk * ncalls])
+        pos += chunk * ncalls
+        g.replay()
+        torch.cuda.synchronize()
+        c = cnt.cpu().tolist()
+        for i in range(ncalls):
+            outs.append(ys[i, :, :c[i]].cpu().numpy().copy())
+            counts.append(c[i])
+    return outs, counts
+
+
+def _oracle_chunks(fo, x, chunk, n):
+    return [fo.filt(x[i * chunk:(i + 1) * chunk]) for i in range(n)]
+
+
+def test_graph_capture_rational_chunk_that_advances_the_state(pkg, O, torch_cuda):
+    """147//160 (the headline shape) with chunk 999 983 -- prime, so (𝜙Idx, inputDeficit) differ at every call and the
+    count alternates between two values: 50 replays of a captured call == the oracle's chunk loop, end state included."""
+    torch = torch_cuda
+    L, M, chunk, nrep, nch = 147, 160, 999_983, 50, 2
+    h = pkg.firdes(24 * L, 0.5 / L, beta=7.8562).astype(np.float32)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand((nch, chunk * nrep), generator=gen, device="cuda", dtype=torch.float32) - 0.5
+    f = pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nch)
+    outs, counts = _graph_stream(torch, f, x, chunk, nrep)
+    assert f.last_kernel_name() == "rational_opair_kernel"
+    assert len(set(counts)) == 2, counts                      # the state really moves
+    xh = x.cpu().numpy()
+    for c in (0, nch - 1):
+        fo = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
+        yo = _oracle_chunks(fo, xh[c], chunk, nrep)
+        assert counts == [len(v) for v in yo]
+        assert_bit_equal(np.concatenate([o[c] for o in outs]), np.concatenate(yo), f"channel {c}")
+    last = f.sync_state()
+    assert last == counts[-1]
+    st, so = f.state, fo.state
+    assert (st.phiIdx, st.inputDeficit) == (so.phiIdx, so.inputDeficit)
+    assert_bit_equal(f.history.reshape(nch, -1)[nch - 1], fo.history, "history after the replays")
+    # a plain call continues the stream the replays left
+    tail = torch.rand((nch, 12_345), generator=gen, device="cuda", dtype=torch.float32) - 0.5
+    assert_bit_equal(f.filt(tail).cpu().numpy()[nch - 1], fo.filt(tail.cpu().numpy()[nch - 1]), "plain call after the replays")
+    f.close()
+
+
+@pytest.mark.parametrize("L,M,tx,chunk,ncalls", [(1, 4, np.complex64, 10_007, 3), (3, 17, np.float64, 4_099, 2), (1, 1, np.float32, 5_001, 2),
+                                                 (4, 1, np.float32, 3_001, 2), (2, 13, np.float32, 7_919, 1)])
+def test_graph_capture_other_rational_kinds(pkg, O, torch_cuda, L, M, tx, chunk, ncalls):
+    """FIRDecimator (inputDeficit moves), FIRRational on other kernels (2//13 has no device-planned tuned kernel: the
+    universal kernel serves it), FIRStandard / FIRInterpolator (no state), several calls per graph."""
+    torch = torch_cuda
+    nrep, nch = 12, 2
+    rng = np.random.default_rng(L * 100 + M)
+    h = rng.standard_normal(96 if L > 1 else 64).astype(np.float32)
+    n = chunk * ncalls * nrep
+    xh = (rng.standard_normal((nch, n)) + (1j * rng.standard_normal((nch, n)) if np.issubdtype(tx, np.complexfloating) else 0)).astype(tx)
+    x = torch.from_numpy(xh).cuda()
+    f = pkg.FIRFilter(h, Fraction(L, M)).bind(tx, nch)
+    outs, counts = _graph_stream(torch, f, x, chunk, nrep, ncalls)
+    fo = O.FIRFilter(h, Fraction(L, M), tx=tx)
+    yo = _oracle_chunks(fo, xh[1], chunk, ncalls * nrep)
+    assert counts == [len(v) for v in yo]
+    assert_bit_equal(np.concatenate([o[1] for o in outs]), np.concatenate(yo), f"{L}//{M} {tx}")
+    f.sync_state()
+    assert (f.state.phiIdx, f.state.inputDeficit) == (fo.state.phiIdx, fo.state.inputDeficit)
+    f.close()
+
+
+@pytest.mark.parametrize("kind", ["arbitrary", "farrow"])
+@pytest.mark.parametrize("rate", [math.pi / 3, 1 / 2.123456789, 3.0])
+def test_graph_capture_arbitrary_and_farrow(pkg, O, torch_cuda, kind, rate):
+    """FIRArbitrary / FIRFarrow: the phase schedule, the output count and the accumulator all live on the device, so a
+    captured call replays: 50 replays == the oracle's chunk loop (outputs, counts, 𝜙Accumulator, inputDeficit).  Rate 3.0
+    cycles: the closed form of its cycle is evaluated on the device too."""
+    torch = torch_cuda
+    chunk, nrep, nch, Nphi = 100_003, 52, 2, 32
+    h = (pkg.firdes(Nphi * 8, 0.45 / Nphi, beta=7.8562) * Nphi)
+    rng = np.random.default_rng(17)
+    xh = rng.random((nch, chunk * nrep))
+    x = torch.from_numpy(xh).cuda()
+    po = 4 if kind == "farrow" else None
+    f = pkg.FIRFilter(h, rate, Nphi, po).bind(np.float64, nch)
+    fo = O.FIRFilter(h, rate, Nphi, tx=np.float64, polyorder=po, pnfb=f.pnfb()) if po else O.FIRFilter(h, rate, Nphi, tx=np.float64)
+    # The stream starts with a plain call and an asynchronous one of the captured size: the schedule's work buffers are
+    # allocated by the first call of a size (allocations cannot be captured), and the plain call's serial prefix is what
+    # finds a cycle of the accumulator (rate 3.0).  The graph then takes the stream over where they left it.
+    y0 = f.filt(x[:, :chunk])
+    assert_bit_equal(y0.cpu().numpy()[1], fo.filt(xh[1, :chunk]), "first plain call")
+    yb = torch.empty((nch, f.outputlength_bound(chunk)), dtype=torch.float64, device="cuda")
+    f.filt_into_async(yb, x[:, chunk:2 * chunk])
+    n1 = f.sync_state()
+    assert_bit_equal(yb[1, :n1].cpu().numpy(), fo.filt(xh[1, chunk:2 * chunk]), "first asynchronous call")
+    nrep -= 2
+    x, xh = x[:, 2 * chunk:], xh[:, 2 * chunk:]
+    outs, counts = _graph_stream(torch, f, x, chunk, nrep)
+    if rate == 3.0:
+        assert f.schedule_info()["period"] == 3
+    yo = _oracle_chunks(fo, xh[1], chunk, nrep)
+    assert counts == [len(v) for v in yo], (counts[:5], [len(v) for v in yo][:5])
+    assert_bit_equal(np.concatenate([o[1] for o in outs]), np.concatenate(yo), f"{kind} rate={rate}")
+    assert f.sync_state() == counts[-1]
+    st, so = f.state, fo.state
+    assert (st.phiAccumulator, st.inputDeficit) == (so.phiAccumulator, so.inputDeficit)
+    # and the stream goes on with plain calls
+    tail = rng.random((nch, 5_000))
+    assert_bit_equal(f.filt(torch.from_numpy(tail).cuda()).cpu().numpy()[1], fo.filt(tail[1]), "plain call after the replays")
+    f.close()
+
+
+@pytest.mark.parametrize("kind", ["rational", "decimator", "arbitrary", "farrow"])
+def test_async_calls_never_wait_and_match_the_plain_loop(pkg, O, torch_cuda, kind):
+    """mrhip_filt_device_async outside a graph: a loop of ragged calls that only enqueues (counts land in a device
+    array), then ONE sync_state; == the same loop of plain calls; set_state / reset in between follow in stream order."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    nch = 3
+    if kind == "rational":
+        h, ratio, tx, po = rng.standard_normal(24 * 7).astype(np.float32), Fraction(7, 9), np.float32, None
+    elif kind == "decimator":
+        h, ratio, tx, po = rng.standard_normal(40).astype(np.float32), Fraction(1, 5), np.complex64, None
+    else:
+        h, ratio, tx, po = (pkg.firdes(32 * 6, 0.45 / 32, beta=7.0) * 32).astype(np.float32), 0.8123, np.float32, (3 if kind == "farrow" else None)
+    sizes = [40_001, 3, 17_777, 1, 65_536, 29_999, 2, 50_000]
+    n = sum(sizes)
+    xh = rng.standard_normal((nch, n)).astype(np.float32)
+    if np.issubdtype(tx, np.complexfloating):
+        xh = (xh + 1j * rng.standard_normal((nch, n))).astype(tx)
+    x = torch.from_numpy(xh).cuda()
+    f = pkg.FIRFilter(h, ratio, 32, po).bind(tx, nch)
+    g = pkg.FIRFilter(h, ratio, 32, po, pnfb=f.pnfb() if po else None).bind(tx, nch)
+    for rnd in range(2):
+        cnt = torch.zeros(len(sizes), dtype=torch.int64, device="cuda")
+        ys, pos = [], 0
+        for i, s in enumerate(sizes):
+            y = torch.empty((nch, f.outputlength_bound(s)), dtype=_tdtype(torch, f.output_dtype), device="cuda")
+            f.filt_into_async(y, x[:, pos:pos + s], cnt[i:i + 1])
+            ys.append(y)
+            pos += s
+        last = f.sync_state()
+        c = cnt.cpu().tolist()
+        assert last == c[-1]
+        ref = [g.filt(x[:, a:a + s]) for a, s in zip(np.cumsum([0] + sizes[:-1]), sizes)]
+        assert c == [r.shape[1] for r in ref], (kind, c, [r.shape[1] for r in ref])
+        for y, r, k in zip(ys, ref, c):
+            assert torch.equal(torch.view_as_real(y[:, :k].contiguous()).view(torch.int32) if y.is_complex() else y[:, :k].contiguous().view(torch.int32),
+                               torch.view_as_real(r.contiguous()).view(torch.int32) if r.is_complex() else r.contiguous().view(torch.int32))
+        sf, sg = f.state, g.state
+        assert (sf.phiIdx, sf.inputDeficit, sf.phiAccumulator) == (sg.phiIdx, sg.inputDeficit, sg.phiAccumulator)
+        assert_bit_equal(f.history, g.history, "history")
+        if rnd == 0:                      # move both streams, asynchronously for f
+            if kind in ("arbitrary", "farrow"):
+                f.set_state(1, 2, 7.25); g.set_state(1, 2, 7.25)
+            else:
+                f.reset(); g.reset()
+    f.close(); g.close()
+
+
+def test_async_call_needs_room_for_the_bound(pkg, torch_cuda):
+    torch = torch_cuda
+    h = np.ones(24 * 3, dtype=np.float32)
+    f = pkg.FIRFilter(h, Fraction(3, 5)).bind(np.float32, 1)
+    x = torch.zeros(1000, dtype=torch.float32, device="cuda")
+    assert f.outputlength_bound(1000) == 600
+    with pytest.raises(pkg.MultirateHIPError) as ei:
+        f.filt_into_async(torch.empty(599, dtype=torch.float32, device="cuda"), x)
+    assert ei.value.code == 2
+    st = f.state
+    assert (st.phiIdx, st.inputDeficit) == (1, 1)
+    f.filt_into_async(torch.empty(600, dtype=torch.float32, device="cuda"), x)
+    assert f.sync_state() == 600
+    f.close()

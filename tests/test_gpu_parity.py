@@ -835,11 +835,11 @@ def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
 
 def test_hip_graph_capture_of_fixed_chunk_streaming(pkg, torch_cuda):
     """filt! on a caller stream only enqueues kernels, so a fixed-chunk streaming loop can be captured
-    in a HIP graph.  With chunk % M == 0 the (phiIdx, inputDeficit) state is the same at every call; a captured call
-    writes its history back into the slot it read, so any number of calls per graph (here an ODD one) replays
-    correctly: every replay continues the stream exactly like the plain loop would (history carried on the device).
-    Calls that would advance the integer state, and FIRArbitrary calls, are refused during capture instead of
-    replaying stale state."""
+    in a HIP graph -- here through the plain entry (mrhip_filt_device on a capturing stream), an ODD number of calls per
+    graph: a captured call is planned on the device from the device-resident stream state and writes its history back
+    into the slot it read, so every replay continues the stream exactly like the plain loop would.  (Chunk sizes that
+    advance the state, FIRArbitrary and FIRFarrow: tests/test_gpu_device_state.py.)  A filter whose schedule buffers do
+    not exist yet cannot allocate them inside a capture: refused, capture intact."""
     torch = torch_cuda
     L, M, chunk, ncalls, nch = 147, 160, 16_000, 3, 3
     h = pkg.firdes(24 * L, 0.5 / L, beta=7.8562).astype(np.float32)
@@ -852,7 +852,6 @@ def test_hip_graph_capture_of_fixed_chunk_streaming(pkg, torch_cuda):
         for i in range(ncalls):
             assert flt.filt_into(y[:, i * nout:(i + 1) * nout], x[:, i * chunk:(i + 1) * chunk]) == nout
 
-    bad = pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nch)
     harb = (pkg.firdes(32 * 8, 0.45 / 32, beta=7.0) * 32).astype(np.float32)
     arb = pkg.FIRFilter(harb, 0.77, 32).bind(np.float32, nch)
     y_bad = torch.zeros((nch, nout + 64), dtype=torch.float32, device="cuda")
@@ -861,12 +860,9 @@ def test_hip_graph_capture_of_fixed_chunk_streaming(pkg, torch_cuda):
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.graph(g, stream=s):
         loop(f, y_g)
-        for flt, xx in ((bad, x[:, :chunk + 7]), (arb, x[:, :chunk])):       # refused, state untouched, capture intact
-            st0 = (flt.state.phiIdx, flt.state.inputDeficit, flt.state.phiAccumulator)
-            with pytest.raises(pkg.MultirateHIPError) as ei:
-                flt.filt_into(y_bad, xx)
-            assert ei.value.code == 5
-            assert (flt.state.phiIdx, flt.state.inputDeficit, flt.state.phiAccumulator) == st0
+        with pytest.raises(pkg.MultirateHIPError) as ei:                 # cold FIRArbitrary: refused, capture intact
+            arb.filt_into(y_bad, x[:, :chunk])
+        assert ei.value.code == 5
     ref = pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nch)
     y_ref = torch.empty_like(y_g)
     for replay in range(4):                      # pass 0 starts from the zero history, the others continue the stream
@@ -877,6 +873,7 @@ def test_hip_graph_capture_of_fixed_chunk_streaming(pkg, torch_cuda):
     assert f.last_kernel_name() == "rational_opair_kernel"
     # the host object follows the replays: its history is the device's, so a plain call continues the stream too
     assert_bit_equal(f.history, ref.history, "history after the replays")
+    assert (arb.state.phiAccumulator, arb.state.inputDeficit) == (1.0, 1)
 
 
 def test_calls_on_different_streams_are_ordered(pkg, O, torch_cuda):

@@ -151,3 +151,51 @@ def test_bench_direct_launch_spawns_its_own_ranks():
     assert line["n_gpus"] == world and line["scaling"] == "strong"
     assert line["config"]["channels_per_gpu"] == 64 // world
     assert set(line["gather"]) == {"root", "all"} and line["gather"]["root"]["ms"] > 0
+
+
+@pytest.mark.gpu
+def test_config5_eight_way_shards_on_the_hip_filter(pkg, O):
+    """BASELINE config 5 as the 8-GPU node will run it: 4096 ComplexF32 channels in EIGHT contiguous shards of 512, each
+    through the real HIP filter behind ChannelShardedFilter (rank r of world 8) -- here one after the other on the one
+    GPU of the box, because eight processes on one card exceed the box's process guard (the collectives of the eight-rank
+    split are rehearsed over gloo on the CPU: tests/test_sharding_gloo.py).  The channels either side of every rank
+    boundary against the oracle, two calls per shard (state and history carried per shard)."""
+    import torch
+    from fractions import Fraction
+    import numpy as np
+    L, M, nch, n, cut = 147, 160, 4096, 24_000, 9_001
+    h = pkg.firdes(24 * L, 0.5 / L, beta=7.8562).astype(np.float32)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.view_as_complex(torch.rand((nch, n, 2), generator=g, device="cuda", dtype=torch.float32) - 0.5)
+    shards = []
+    for r in range(8):
+        sf = pkg.ChannelShardedFilter(h, Fraction(L, M), nch, rank=r, world_size=8, device=0)
+        assert (sf.start, sf.count) == (512 * r, 512)
+        xl = sf.local_slice(x)
+        shards.append(torch.cat([sf.filt(xl[:, :cut]), sf.filt(xl[:, cut:])], dim=1))
+        assert sf.filter.last_kernel_name() == "rational_opair_kernel"
+        sf.filter.close()
+    y = torch.cat(shards, dim=0)
+    assert y.shape == (nch, (n * L + M - 1) // M)
+    for c in (0, 511, 512, 1023, 1024, 3583, 3584, 4095):
+        fo = O.FIRFilter(h, Fraction(L, M), tx=np.complex64)
+        xc = x[c].cpu().numpy()
+        ref = np.concatenate([fo.filt(xc[:cut]), fo.filt(xc[cut:])])
+        assert np.array_equal(y[c].cpu().numpy().view(np.uint32), ref.view(np.uint32)), f"channel {c}"
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_on_one_gpu_at_config5_channel_count():
+    """`bench.py --gpus 4` (headline) and `--config c5` with all 4096 channels (reduced samples) started directly: four ranks
+    share the box's GPU over gloo (the most the process guard leaves room for next to this pytest process)."""
+    n = _gpu_count()
+    if n < 1:
+        pytest.skip("needs a GPU")
+    if n >= 4:
+        pytest.skip("a multi-GPU box runs the nccl variants above")
+    small = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-streamed"]
+    line = _bench(["--gpus", "4", "--config", "c5", "--channels", "4096", "--samples", "50000"] + small, "gloo")
+    assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["config"]["channels_per_gpu"] == 1024
+    assert set(line["gather"]) == {"root", "all"} and line["gather"]["root"]["ms"] > 0
+    line = _bench(["--gpus", "4", "--channels", "16", "--samples", "1000000"] + small, "gloo")
+    assert line["n_gpus"] == 4 and line["scaling"] == "weak" and line["roofline"]["achieved"] > 0

@@ -280,3 +280,44 @@ def test_phase_recurrence_shortened_chain_is_exact():
             a, xa = ref_step(a, xa, delta, N)
             b, xb = new_step(b, xb, delta, N, (nphi & (nphi - 1)) == 0)
             assert struct.pack("d", a) == struct.pack("d", b) and xa == xb, (nphi, rate, i)
+
+
+def test_mod_form_of_julia_0_3_quantified(O):
+    """update(::FIRArbitrary) wraps the accumulator with mod(acc - 1, N𝜙) (src/Filters.jl:668).  The oracle takes it as the
+    exact remainder (Julia >= 0.4); older Base versions computed rem(y + rem(x, y), y), which rounds once more when
+    y + rem(x, y) is not representable.  The reference is Julia-0.3 code, so: how far apart are the two?  A one-tap-per-phase
+    filter with h = 0, 1, 2, ... fed with ones outputs acc - 1 exactly (yLower = 𝜙Idx - 1, yUpper = 1, combine in Float64),
+    i.e. the accumulator of every output.
+
+    Result (also DESIGN.md 3): for a power-of-two N𝜙 -- BASELINE config 4 has N𝜙 = 32 -- the two forms are IDENTICAL over
+    1e7 outputs: rem(x, y) is then a multiple of ulp(acc + Δ) >= ulp(N𝜙 + rem), so the extra sum is exact.  For other N𝜙
+    the older form drifts by one rounding of that sum per wrap in which the phase stays in (N𝜙, N𝜙 + 1)."""
+    def accs(rate, Nphi, n_out, julia03):
+        O.set_mod_form(julia03)
+        try:
+            h = np.arange(Nphi, dtype=np.float64)
+            y = O.FIRFilter(h, rate, Nphi, tx=np.float64).filt(np.ones(int(n_out / rate)))
+        finally:
+            O.set_mod_form(False)
+        return y
+
+    rate = float(np.pi / 3)
+    a, b = accs(rate, 32, 10_000_000, False), accs(rate, 32, 10_000_000, True)
+    assert len(a) == len(b) >= 9_999_000
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), "config 4 (N𝜙 = 32): the two mod forms must agree bit for bit"
+    for r, N in ((0.5, 64), (2.9, 8), (1 / 2.123456789, 32)):          # other powers of two, rates on either side of 1
+        a, b = accs(r, N, 1_000_000, False), accs(r, N, 1_000_000, True)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (r, N)
+    report = []
+    for r, N in ((rate, 10), (0.37, 12), (1.7, 7), (2.9, 24)):
+        a, b = accs(r, N, 1_000_000, False), accs(r, N, 1_000_000, True)
+        m = min(len(a), len(b))
+        nd = int(np.count_nonzero(a[:m] != b[:m]))
+        first = int(np.flatnonzero(a[:m] != b[:m])[0]) if nd else -1
+        # (phase distance, folded onto the circle: after the first difference the two streams are different streams)
+        d = np.abs(a[:m] - b[:m])
+        d = np.minimum(d, N - d)
+        report.append((r, N, len(a) - len(b), nd, first, float(d.max() / np.spacing(float(N)))))
+        assert abs(len(a) - len(b)) <= 1
+        assert d.max() <= 1e-6, report[-1]                              # roundings of 1 ulp(2 N𝜙) each: a slow random walk, not a jump
+    print("mod forms, (rate, Nphi, count difference, outputs that differ of 1e6, first, max phase distance in ulp(Nphi)):", report)

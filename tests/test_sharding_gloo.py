@@ -153,20 +153,21 @@ def _time_worker(rank, world, port, case, q):
                 return torch.from_numpy(np.stack(rows))
 
         ts = pkg.TimeShardedFilter(h, ratio, n, filter_factory=OracleStream)
-        y_local = ts.filt(torch.from_numpy(ts.local_slice(x).copy()))
-        full = ts.gather(y_local, dst=0)
+        # the stream continues over successive blocks of n samples (the last rank's tail feeds rank 0's next block); the
+        # reference for a time-sharded run is the caller's chunk loop with the same boundaries, over all blocks
+        nblocks = 3
+        xs = [x] + [np.roll(x, 17 * (b + 1), axis=1) * np.float32(0.5 + b) for b in range(nblocks - 1)]
+        fos = [mk() for _ in range(nch)]
         ok = True
-        if rank == 0:
-            # the reference for a time-sharded run is the caller's chunk loop with the same boundaries
-            ref_rows = []
-            for c in range(nch):
-                fo = mk()
-                ref_rows.append(np.concatenate([fo.filt(x[c, a:a + m]) for a, m in ts.slices]))
-            ref = np.stack(ref_rows)
-            ok = full is not None and full.numpy().dtype == ref.dtype and full.numpy().shape == ref.shape and \
-                np.array_equal(full.numpy().view(np.uint8), ref.view(np.uint8))
-        else:
-            ok = full is None
+        for xb in xs:
+            y_local = ts.filt(torch.from_numpy(ts.local_slice(xb).copy()))
+            full = ts.gather(y_local, dst=0)
+            if rank == 0:
+                ref = np.stack([np.concatenate([fos[c].filt(xb[c, a:a + m]) for a, m in ts.slices]) for c in range(nch)])
+                ok = ok and full is not None and full.numpy().dtype == ref.dtype and full.numpy().shape == ref.shape and \
+                    np.array_equal(full.numpy().view(np.uint8), ref.view(np.uint8))
+            else:
+                ok = ok and full is None
         q.put((rank, bool(ok), ts.start, ts.count))
     finally:
         dist.destroy_process_group()
@@ -189,3 +190,104 @@ def test_time_sharded_filter_world2_gloo(pkg, O, case):
     res.sort()
     assert all(r[1] for r in res), res
     assert res[0][2] == 0 and res[1][2] == res[0][3] and res[0][3] + res[1][3] == case[4]
+
+
+def _short_slice_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class Stub:                      # only what the split check needs: it must raise before anything is sent
+            historyLen = 40
+
+            def filt(self, xl):
+                raise AssertionError("the split is invalid: filt must not be reached")
+
+        ts = pkg.TimeShardedFilter(np.ones(41, dtype=np.float32), Fraction(1, 1), 100, filter_factory=Stub)   # slices of 34, 33, 33 < 40
+        try:
+            ts.filt(torch.zeros(1, ts.count))
+            q.put((rank, "no error"))
+        except ValueError as e:
+            q.put((rank, "ValueError" if "shorter than the filter history" in str(e) else str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_time_sharding_rejects_a_short_slice_on_every_rank_before_any_message(pkg):
+    """a slice shorter than the history used to raise on the SENDING rank only, after its neighbour had
+    posted the receive -- which then waited for ever (RCCL) or for gloo's 30-minute timeout.  The split is known to every
+    rank: all of them raise the same ValueError before anything is posted."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_short_slice_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, "ValueError"), (1, "ValueError"), (2, "ValueError")], res
+
+
+def _c5_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from oracle import oracle as O
+    pkg = ge.load_package()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nch, n, ratio = 4096, 96, Fraction(147, 160)
+        h = np.random.default_rng(1).standard_normal(147 * 2).astype(np.float32)
+        probe = [0, 511, 512, 2047, 2048, 3583, 3584, 4095]                  # the channels either side of the rank boundaries
+
+        def row(c):                                                           # channel c of the global signal, by construction
+            r = np.random.default_rng(10_000 + c)
+            return (r.standard_normal(n) + 1j * r.standard_normal(n)).astype(np.complex64)
+
+        class OracleBatch:
+            def filt(self, xl):
+                return torch.from_numpy(np.stack([O.filt(h, r, ratio) for r in xl.numpy()]))
+
+        sf = pkg.ChannelShardedFilter(h, ratio, nch, filter_factory=OracleBatch)
+        assert (sf.start, sf.count) == (512 * rank, 512)
+        xl = torch.from_numpy(np.stack([row(c) for c in range(sf.start, sf.start + sf.count)]))
+        y_local = sf.filt(xl)
+        full = sf.gather(y_local, dst=0, n_out=y_local.shape[1])
+        allg = sf.all_gather(y_local, n_out=y_local.shape[1])
+        ok = allg.shape[0] == nch and all(np.array_equal(allg[c].numpy(), O.filt(h, row(c), ratio)) for c in probe)
+        if rank == 0:
+            ok = ok and full is not None and torch.equal(full, allg)
+        else:
+            ok = ok and full is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_split_over_eight_ranks_gloo(pkg, O):
+    """BASELINE config 5's real split: 4096 ComplexF32 channels over EIGHT ranks = 512-channel shards, gathered to rank 0
+    and all-gathered; the channels either side of every rank boundary against the oracle.  (Eight processes on ONE GPU
+    exceed the GPU box's process guard -- at most six -- so the eight-rank rehearsal of the collectives runs here, on
+    the CPU over gloo, with the per-rank compute injected; the HIP filter behind the same class on the true 512-channel
+    shards: tests/test_multigpu.py.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c5_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(8)], res
