@@ -322,6 +322,7 @@ const char *mrhip_last_kernel_name(const mrhip_filter *f);
  *   [3] period of the accumulator's cycle, 0 if none was found (a cycle makes the schedule a closed form)
  *   [4] outputs scheduled by the host loop             [5] outputs scheduled by the closed form of a cycle
  *   [6] pieces scheduled and verified on the device    [7] pieces whose verification failed (redone by the host loop)
+ *   [8] calls that reused the schedule of an identical earlier call (same accumulator, inputDeficit and length)
  * (diagnostics and tests; results never depend on the path taken) */
 int mrhip_schedule_info(const mrhip_filter *f, int64_t *info, int n);
 

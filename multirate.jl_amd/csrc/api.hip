@@ -11,7 +11,7 @@
 #include <numeric>
 #include <unordered_map>
 
-#include "mrhip_internal.h"
+#include "mrhip_filter.h"
 
 namespace mrhip {
 
@@ -478,6 +478,7 @@ void mrhip_destroy(mrhip_filter *f)
 // filter's own stream).
 static int push_state(mrhip_filter *f)
 {
+    if (f->s_sched) { f->async_pending = true; return rec_push(f, f->s_sched); }   // FIRArbitrary / FIRFarrow: every write of the record, in program order
     hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
     if (rec_push(f, s) != MRHIP_OK) {
         (void)hipGetLastError();
@@ -691,7 +692,8 @@ int mrhip_reset(mrhip_filter *f)
     // (rate 1.0: the cycle IS that state); otherwise forget the cycle (the prefix finds it again).
     if (f->per_valid && f->per_reset_pos >= 0 && MRHIP_ENV_INT("MRHIP_SCHED_KEEP_DRIFT", 1) != 0) f->per_pos = f->per_reset_pos;
     else if (f->per_valid || MRHIP_ENV_INT("MRHIP_SCHED_KEEP_DRIFT", 1) == 0) sched_forget(f);
-    return rec_push(f, s);            // the device record: constructor state, in stream order behind the zeroing
+    if (f->s_sched) f->async_pending = true;
+    return f->s_sched ? rec_push(f, f->s_sched) : rec_push(f, s);   // the device record: constructor state, in stream order
 }
 
 int mrhip_set_numerics(mrhip_filter *f, int numerics)
@@ -894,6 +896,8 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
     // see each other) and are re-read from the device before they are next used.
     const bool capturing = stream_is_capturing(stream);
     const bool dev_planned = async || capturing;
+    if (capturing && f->async_pending)
+        return fail(MRHIP_ERR_UNSUPPORTED, "asynchronous calls of this filter are outstanding: mrhip_sync_state before capturing (a replay must find the record they leave)");
     if (!dev_planned && !f->mirror_valid)
         if (int rc = rec_pull(f)) return rc;
     if (x_len == 0) {                  // nothing to do: zero outputs, history and state unchanged
@@ -974,30 +978,47 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             if (est >= 0x7fffffffLL) return fail(MRHIP_ERR_INVALID_ARG, "call too long for one launch (internal)");
             int spans[kSchedSpanSizes];
             span_bounds(f->rate, spans);
+            // The schedule runs on the filter's schedule stream, BESIDE the filter kernel of the call before (its inputs are
+            // the record, which moved on with that call's FINISH kernel, and nothing else); schedule buffers and call records
+            // alternate, events order writer and reader of each (mrhip_filter.h: s_sched).  Inside a capture: one stream.
+            hipStream_t ss = capturing || !f->s_sched ? stream : f->s_sched;
             SchedOut so{};
-            if (int rc = sched_enqueue(f, x_len, est, dev_planned ? y_capacity : INT64_MAX, count_dev, !dev_planned, stream, &so)) return rc;   // (a call that is waited for checks the count against the room itself)
-            sched_dn = f->ds_n[so.buf]; sched_dacc = f->ds_acc[so.buf]; sched_spans = spans;
+            so.buf = capturing ? 0 : f->flip;
+            if (!capturing) f->flip ^= 1;
+            if (ss != stream && f->ev_filt_valid[so.buf]) MRHIP_CHECK_HIP(hipStreamWaitEvent(ss, f->ev_filt[so.buf], 0));
+            if (int rc = sched_enqueue(f, x_len, est, dev_planned ? y_capacity : INT64_MAX, count_dev, !dev_planned, ss, &so)) return rc;   // (a call that is waited for checks the count against the room itself)
+            const int b = so.buf;                                         // (a memo hit names the buffer that holds the entries)
+            sched_dn = f->ds_n[b]; sched_dacc = f->ds_acc[b]; sched_spans = spans;
+            auto join = [&]() -> int {                                  // the filter kernel behind its schedule
+                if (ss == stream) return MRHIP_OK;
+                MRHIP_CHECK_HIP(hipEventRecord(f->ev_fin[b], ss));
+                MRHIP_CHECK_HIP(hipStreamWaitEvent(stream, f->ev_fin[b], 0));
+                return MRHIP_OK;
+            };
             const bool room = y && y_capacity >= est && (f->nch == 1 || y_stride >= est);
             bool launched = false;
             if (so.pending && room && est > 0) {
-                if (int rc = launch_range(0, est, nullptr, f->d_call)) return rc;
+                if (int rc = join()) return rc;
+                if (int rc = launch_range(0, est, nullptr, f->d_calls[b])) return rc;
                 launched = true;
             }
             rec_current = so.pending;
             if (dev_planned) {
-                // nobody collects: the host's copy of the state is stale from here on (a capture additionally moves it on
-                // as the shadow of one replay -- not for these kinds: their state is the device's alone)
+                // nobody collects: the host's copy of the state is stale from here on
                 f->mirror_valid = false;
+                if (!capturing) f->async_pending = true;
                 n_out = -1;
                 st = ArbState{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
             } else {
                 for (;;) {
                     bool relaunch = false;
-                    if (int rc = sched_collect(f, x_len, est, INT64_MAX, count_dev, stream, &so, &relaunch)) return rc;
+                    if (int rc = sched_collect(f, x_len, est, INT64_MAX, count_dev, ss, &so, &relaunch)) return rc;
                     if (!relaunch) break;
                     rec_current = so.pending;
-                    if (so.pending && room) { if (int rc = launch_range(0, est, nullptr, f->d_call)) return rc; }
-                    else launched = false;
+                    if (so.pending && room) {
+                        if (int rc = join()) return rc;
+                        if (int rc = launch_range(0, est, nullptr, f->d_calls[b])) return rc;
+                    } else launched = false;
                 }
                 n_out = so.count;
                 st = so.end;
@@ -1005,17 +1026,29 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 if (n_out > y_capacity) {
                     if (rec_current) {      // the record moved on with the schedule: take the stream back to the call's start
                         f->sched_cached = false;
-                        (void)rec_push(f, stream);
+                        (void)rec_push(f, ss);
                     }
                     return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
                 }
                 if (n_out > 0 && !launched) {
                     if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
                     if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
+                    if (int rc = join()) return rc;
                     if (int rc = launch_range(0, n_out, nullptr, nullptr)) return rc;
                 }
                 f->sched_drift = so.drift; f->sched_ksteps = so.ksteps;
                 if (so.periodic || f->per_valid) f->per_pos = so.per_pos_end;
+                // this call becomes the memo entry of buffer b (arb_schedule.hip): its entries stay there until b is rewritten
+                if (!so.memo_hit) {
+                    f->memo_valid = true; f->memo_buf = b;
+                    f->memo_acc0 = so.memo_acc0; f->memo_d0 = so.memo_d0; f->memo_xlen = x_len;
+                    f->memo_count = n_out; f->memo_end = st; f->memo_drift = so.drift; f->memo_ksteps = so.ksteps;
+                    f->memo_per_pos_end = so.per_pos_end;
+                }
+            }
+            if (ss != stream) {                                          // buffer b's next writer waits for this reader
+                MRHIP_CHECK_HIP(hipEventRecord(f->ev_filt[b], stream));
+                f->ev_filt_valid[b] = true;
             }
         } else if (!cached && est > 2 * piece && y && y_capacity >= est && (f->nch == 1 || y_stride >= est) && est < 0x7fffffffLL) {
             if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
@@ -1111,6 +1144,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             n_out = -1;
         }
         f->mirror_valid = false;
+        if (!capturing) f->async_pending = true;
     } else {
         const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len);
         n_out = p.n_out;
@@ -1139,7 +1173,11 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
     }
     // the device record follows every call in stream order: a call whose kernels did not file its end state pushes it
     if (!rec_current && (f->kind != MRHIP_FIR_STANDARD && f->kind != MRHIP_FIR_INTERPOLATOR))
-        if (int rc = rec_push(f, stream, -1, std::max<int64_t>(n_out, 0))) return rc;
+    {
+        const bool on_sched = arb && f->s_sched && !capturing;
+        if (int rc = rec_push(f, on_sched ? f->s_sched : stream, -1, std::max<int64_t>(n_out, 0))) return rc;
+        if (on_sched) f->async_pending = true;       // (nobody waits for that push: a capture must not start before it has run)
+    }
 
     // history <- last H samples of [history ; x]   (shiftin!, support.jl:61-80), ping-pong buffers
     if (f->H > 0 && !did_shiftin) {
@@ -1235,8 +1273,7 @@ int mrhip_sync_state(mrhip_filter *f, int64_t *last_n_written)
     const DevStream r = *f->h_rec;
     if (last_n_written) *last_n_written = r.n_written;
     if (r.error != 0) {
-        hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
-        if (int rc = rec_push(f, s)) return rc;                     // (clears the sticky error; the state stays)
+        if (int rc = push_state(f)) return rc;                      // (clears the sticky error; the state stays)
         return fail(r.error, r.error == MRHIP_ERR_BUFFER_TOO_SMALL ? "buffer is too small (a device-planned call clipped its outputs)"
                                                                    : "a device-planned call failed (the stream was moved off the cycle its schedule relies on, or its schedule overran the bound)");
     }
@@ -1455,9 +1492,9 @@ int mrhip_schedule_info(const mrhip_filter *f, int64_t *info, int n)
 {
     if (!f || !info || n < 0) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
     if (f->kind != MRHIP_FIR_ARBITRARY && f->kind != MRHIP_FIR_FARROW) return fail(MRHIP_ERR_INVALID_ARG, "not a FIRArbitrary / FIRFarrow filter");
-    const int64_t v[8] = {f->splan.ok, f->splan.ncand, f->splan.nwin, f->per_valid ? f->per_Q : 0,
-                          f->stat_host_steps, f->stat_periodic_steps, f->stat_device_pieces, f->stat_fallback_pieces};
-    for (int i = 0; i < n && i < 8; ++i) info[i] = v[i];
+    const int64_t v[9] = {f->splan.ok, f->splan.ncand, f->splan.nwin, f->per_valid ? f->per_Q : 0,
+                          f->stat_host_steps, f->stat_periodic_steps, f->stat_device_pieces, f->stat_fallback_pieces, f->stat_memo_hits};
+    for (int i = 0; i < n && i < 9; ++i) info[i] = v[i];
     return MRHIP_OK;
 }
 

@@ -18,7 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "mrhip_internal.h"
+#include "mrhip_filter.h"
 
 namespace mrhip {
 namespace {
@@ -322,7 +322,10 @@ static int enqueue_tables(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y
             // a piece may be 16x as long as the drift baseline behind it: the slope error then moves the last segments'
             // starts out of the candidate window, where the shift argument takes over (exact all the same; rates whose
             // phase sits ON a threshold -- where it would not hold -- cycle, and take the closed form)
-            const int64_t P = sched_piece_steps(kz, f->sched_pmax);
+            int64_t P = sched_piece_steps(kz, f->sched_pmax);
+            // the piece that reaches the bound of the count is cut to the groups it needs (always the last one; the FINISH
+            // kernel, which re-derives the sizes, only ever sums the pieces in front of it)
+            if (kk + P > est + 1) P = std::max<int64_t>((est + 1 - kk + kSchedGroup - 1) / kSchedGroup, 1) * kSchedGroup;
             out->pk0.push_back(kk); out->psteps.push_back(P);
             kk += P; kz += static_cast<double>(P);
         }
@@ -345,7 +348,7 @@ static int enqueue_tables(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y
         MRHIP_CHECK_HIP(launch_schedule_piece(c, a, s));
     }
     SchedFinishArgs fa{};
-    fa.rec = f->d_rec; fa.mirror = mirror_of(f); fa.call = f->d_call;
+    fa.rec = f->d_rec; fa.mirror = mirror_of(f); fa.call = f->d_calls[b];
     fa.status = f->ds_status; fa.state = f->ds_state; fa.fail_state = fail_state_of(f);
     fa.sched_n = static_cast<int *>(f->ds_n[b]); fa.sched_acc = static_cast<double *>(f->ds_acc[b]);
     fa.count_out = count_out;
@@ -366,8 +369,7 @@ static int enqueue_tables(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y
 int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, bool host_ok, hipStream_t s, SchedOut *out)
 {
     const SchedPlan &c = f->splan;
-    const int b = 0;
-    out->buf = b;
+    const int b = out->buf;              // schedule buffer and call record of this call (the caller alternates them)
     // (allocations wait for the stream: never inside a capture -- the caller warms a filter up before it captures, or the
     //  buffers of an earlier call of the same size are there already)
     if (int rc = ensure_ds(f, b, static_cast<size_t>(est + f->sched_pmax + f->sched_prefix + 2 * kSchedGroup), s)) return rc;
@@ -376,9 +378,10 @@ int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacit
 
     if (!host_ok) {
         // ---- everything from the device record ------------------------------------------------------------------
+        if (f->memo_valid && f->memo_buf == b) f->memo_valid = false;
         if (f->per_valid) {
             PerPlanArgs pa{};
-            pa.rec = f->d_rec; pa.mirror = mirror_of(f); pa.call = f->d_call;
+            pa.rec = f->d_rec; pa.mirror = mirror_of(f); pa.call = f->d_calls[b];
             pa.per_acc = f->d_per_acc; pa.per_xoff = f->d_per_xoff; pa.count_out = count_out;
             pa.Q = f->per_Q; pa.XQ = f->per_XQ; pa.x_len = x_len; pa.est = est; pa.y_capacity = y_capacity;
             hipLaunchKernelGGL(sched_periodic_plan_kernel, dim3(1), dim3(64), 0, s, pa);
@@ -387,7 +390,7 @@ int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacit
             const long long blocks = std::min<long long>((est + kPerThreads) / kPerThreads, 4096);
             hipLaunchKernelGGL(sched_periodic_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kPerThreads), 0, s, f->d_per_acc, f->d_per_xoff,
                                static_cast<long long>(f->per_Q), static_cast<long long>(f->per_XQ), 0LL, 0LL, 0LL,
-                               static_cast<int *>(f->ds_n[b]), static_cast<double *>(f->ds_acc[b]), static_cast<const DevCall *>(f->d_call));
+                               static_cast<int *>(f->ds_n[b]), static_cast<double *>(f->ds_acc[b]), static_cast<const DevCall *>(f->d_calls[b]));
             MRHIP_CHECK_HIP(hipGetLastError());
             MRHIP_CHECK_HIP(hipEventRecord(f->ev_rec, s));
             out->pending = true;
@@ -410,6 +413,20 @@ int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacit
         st.alpha = st.acc - static_cast<double>(st.phiIdx);
         st.inputDeficit = st.xIdx - x_len;
     };
+    // memo: the schedule is a pure function of (accumulator, inputDeficit, x_len) -- a call that repeats the one whose entries
+    // a schedule buffer still holds (reset + the same block again) takes them as they are
+    static const bool memo_on = env_i64("MRHIP_SCHED_MEMO", 1) != 0;
+    if (memo_on && f->memo_valid && f->memo_acc0 == f->phiAcc && f->memo_d0 == f->inputDeficit && f->memo_xlen == x_len && f->sched_corrupt_piece == -1) {
+        out->buf = f->memo_buf;
+        out->host_known = true; out->count = f->memo_count; out->end = f->memo_end;
+        out->drift = f->memo_drift; out->ksteps = f->memo_ksteps; out->per_pos_end = f->memo_per_pos_end;
+        out->periodic = f->per_valid;
+        out->memo_hit = true;
+        ++f->stat_memo_hits;
+        return MRHIP_OK;
+    }
+    if (f->memo_valid && f->memo_buf == b) f->memo_valid = false;     // buffer b is about to be rewritten
+    out->memo_acc0 = f->phiAcc; out->memo_d0 = f->inputDeficit;
     if (x_len < f->inputDeficit) {          // Filters.jl:705-709: not one output
         st.inputDeficit = f->inputDeficit - x_len;
         st.xIdx = f->inputDeficit;

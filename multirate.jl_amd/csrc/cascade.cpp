@@ -8,7 +8,7 @@
 #include <cmath>
 #include <vector>
 
-#include "mrhip_internal.h"
+#include "mrhip_filter.h"
 
 struct mrhip_cascade {
     std::vector<mrhip_filter *> stages;

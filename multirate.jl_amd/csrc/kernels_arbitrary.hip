@@ -340,9 +340,23 @@ __global__ __launch_bounds__(kArbThreads, 3) void farrow_tiled_kernel(FarrowArgs
                 return a.tap_f32 ? static_cast<R>(static_cast<float>(yv)) : static_cast<R>(yv);
             };
             if constexpr (TREG > 0) {
+                // (the degree in the outer loop, the taps unrolled inside: TREG independent Horner chains whose coefficient loads
+                //  go out together -- see kernels_farrow_pipe.hip)
+                double yv[TREG];
+#pragma unroll
+                for (int i = 0; i < TREG; ++i) yv[i] = i < T ? a.pnfb[static_cast<long long>(i) * (P + 1) + P] : 0.0;
+                for (int j = P - 1; j >= 0; --j) {
+#pragma unroll
+                    for (int i = 0; i < TREG; ++i) {
+                        if (i < T) {
+                            const double t = phase * yv[i];
+                            yv[i] = a.pnfb[static_cast<long long>(i) * (P + 1) + j] + t;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < TREG; ++i)
-                    if (i < T) treg[i] = tap_of(i);
+                    if (i < T) treg[i] = a.tap_f32 ? static_cast<R>(static_cast<float>(yv[i])) : static_cast<R>(yv[i]);
             } else {
                 for (int i = 0; i < T; ++i) tl[i * kArbThreads + tid] = tap_of(i);
             }

@@ -236,16 +236,27 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
         }
         R treg[TREG];
         if (have) {
+            // Horner in Float64, separately rounded multiply and add (Polynomials.jl polyval: y = p[end]; y = p[i] + x*y) -- the
+            // degree in the OUTER loop, the taps unrolled inside it: every step then issues the coefficient reads of all taps
+            // together and runs TREG independent multiply-add chains.  (Tap by tap, as rounds 2-3 had it, each of the
+            // tapsPerPhi x polyorder steps waited for its own LDS read: ~5 000 cycles of latency per tile, which a 64-channel
+            // launch hides behind its dot products and a one-channel launch -- the reference's own FIRFarrow benchmark shape,
+            // examples/Arb-Farrow Speed Comparison.jl -- does not: 0.21 ms per 1e7 samples against 0.07 for FIRArbitrary.)
+            double yv[TREG];
 #pragma unroll
-            for (int i = 0; i < TREG; ++i) {
-                treg[i] = static_cast<R>(0);
-                if (EXACT || i < T) {                             // Horner in Float64, separately rounded multiply and add
-                    const double *c = lcoef + i * (P + 1);
-                    double yv = c[P];
-                    for (int j = P - 1; j >= 0; --j) { const double t = phase * yv; yv = c[j] + t; }
-                    treg[i] = a.tap_f32 ? static_cast<R>(static_cast<float>(yv)) : static_cast<R>(yv);
+            for (int i = 0; i < TREG; ++i) yv[i] = (EXACT || i < T) ? lcoef[i * (P + 1) + P] : 0.0;
+            for (int j = P - 1; j >= 0; --j) {
+#pragma unroll
+                for (int i = 0; i < TREG; ++i) {
+                    if (EXACT || i < T) {
+                        const double t = phase * yv[i];
+                        yv[i] = lcoef[i * (P + 1) + j] + t;
+                    }
                 }
             }
+#pragma unroll
+            for (int i = 0; i < TREG; ++i)
+                treg[i] = (EXACT || i < T) ? (a.tap_f32 ? static_cast<R>(static_cast<float>(yv[i])) : static_cast<R>(yv[i])) : static_cast<R>(0);
         }
         const bool seam = n < a.seam_below;                       // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818 (never in a piece that continues a call)
         const R acc0 = seam ? static_cast<R>(0.0) : static_cast<R>(-0.0);

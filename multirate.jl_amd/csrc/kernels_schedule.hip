@@ -348,20 +348,8 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
         ns.ksteps = ps.ksteps + static_cast<double>(static_cast<long long>(a.ngroups) * kGroupSegs * kSeg);
         a.state[a.piece + 1] = ns;
     }
-    // largest input span of the aligned tiles of 64 ... 1024 outputs inside this group (the filter kernels' planners size
-    // their LDS sample tiles with them); entries past the call's end count as x_len
-    {
-        int first_task = 0;
-        for (int z = 0; z < kSchedSpanSizes; ++z) {
-            const int ts = kSchedSpanBase << z, ntile = kGroupSegs * kSeg / ts;
-            for (int t = sl - first_task; t >= 0 && t < ntile; t += kGroupSegs) {      // tasks are dealt round the 64 lanes
-                const int e0 = t * ts, e1 = e0 + ts - 1;
-                const long long n0 = s_n[(e0 / kSeg) * (kSeg + 1) + e0 % kSeg], n1 = s_n[(e1 / kSeg) * (kSeg + 1) + e1 % kSeg];
-                if (n0 <= a.x_len) atomicMax(&a.status->max_span[z], static_cast<int>((n1 < a.x_len ? n1 : a.x_len) - n0));
-            }
-            first_task = (first_task + ntile) % kGroupSegs;
-        }
-    }
+    // (rounds 1-3 reported the largest input span of the aligned tiles here, for the filter kernels' planners; they size their
+    //  tiles from an a-priori bound now -- api.hip: span_bounds -- because the filter kernel is enqueued before this one has run)
     // coalesced copy of the group's 4096 entries
     int *__restrict__ gn = a.sched_n + a.k0 + static_cast<long long>(g) * kGroupSegs * kSeg;
     double *__restrict__ ga = a.sched_acc + a.k0 + static_cast<long long>(g) * kGroupSegs * kSeg;

@@ -164,39 +164,6 @@ __host__ __device__ inline long long sched_piece_steps(double ks, long long pmax
     while (P * 2 <= pmax && static_cast<double>(P * 2) <= 16.0 * ks) P *= 2;
     return P;
 }
-}  // namespace mrhip
-struct mrhip_filter;
-namespace mrhip {
-void sched_configure(mrhip_filter *f);
-void sched_forget(mrhip_filter *f);
-void sched_free(mrhip_filter *f);
-bool sched_wants_device(const mrhip_filter *f, int64_t est);
-// Enqueue the schedule of one call on `s` (see arb_schedule.hip).  host_ok: the host's copy of the stream state is exact
-// and may be used (serial prefix, closed form of a cycle); otherwise everything is taken from the device record.
-struct SchedOut {
-    int buf = 0;                  // schedule buffer that will hold the entries
-    bool host_known = false;      // the host evaluated the whole call itself: count / end are final, nothing to collect
-    bool pending = false;         // a FINISH kernel will deliver the result into the mirror (ev_rec)
-    int64_t count = 0;
-    ArbState end;
-    bool periodic = false;
-    int64_t per_pos_end = 0;
-    double drift = 0.0, ksteps = 0.0;
-    // for a host redo after a failed piece: what was enqueued
-    std::vector<int64_t> pk0, psteps;
-    int64_t k_first = 0;
-};
-int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, bool host_ok, hipStream_t s, SchedOut *out);
-int sched_collect(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, hipStream_t s, SchedOut *io, bool *relaunch);
-// stream_state.hip: the device record
-int rec_alloc(mrhip_filter *f);
-void rec_free(mrhip_filter *f);
-// write the host's state into the device record (and its mirror), in stream order on `s`; call_n_out >= 0 also arms the
-// DevCall with that output count (a call the host evaluated, whose filter kernel reads the DevCall)
-int rec_push(mrhip_filter *f, hipStream_t s, long long call_n_out = -1, long long n_written = -1);
-// wait for everything enqueued on the filter's behalf and take the device record over into the host fields
-int rec_pull(mrhip_filter *f);
-hipError_t launch_poly_plan(mrhip_filter *f, int64_t x_len, long long P, long long y_capacity, long long *count_out, hipStream_t s);
 double sched_anchor_host(const SchedPlan &c, double acc_p, double k);   // un-rounded phase after k steps (host_logic.cpp)
 
 // ---------------------------------------------------------------------------------------
@@ -484,112 +451,3 @@ hipError_t launch_poly_phase_stationary(const TypeKey &tk, bool fused, const Pol
                                         dim3 block, size_t lds, hipStream_t s, const char **kname, int num_cus);
 
 }  // namespace mrhip
-
-// ---------------------------------------------------------------------------------------
-// the filter object
-// ---------------------------------------------------------------------------------------
-struct mrhip_filter {
-    int kind = 0, th = 0, tx = 0, ty = 0;
-    int nc = 1;
-    bool r_f64 = false;
-    int64_t nch = 1;
-    int64_t hLen = 0, L = 1, M = 1, Nphi = 1, T = 1, H = 0;
-    int device = 0;
-    int num_cus = 256;
-    int numerics = MRHIP_NUMERICS_STRICT;
-    int force_generic = 0;   // MRHIP_FORCE_GENERIC=1 in the environment: always use the universal kernels
-
-    // device memory
-    void *d_taps = nullptr, *d_dtaps = nullptr;
-    double *d_pnfb = nullptr;              // FIRFarrow: polynomial filter bank on the device
-    std::vector<double> h_pnfb;            // ... and on the host, [T][polyorder+1]
-    int64_t polyorder = 0;
-    void *d_hist[2] = {nullptr, nullptr};
-    unsigned *d_counters = nullptr;   // pair kernel's dynamic scheduling: 33 counters, 256 bytes apart, zero between launches
-    int hist_cur = 0;
-    // host copies of the taps in tap dtype (for get_taps)
-    std::vector<unsigned char> h_taps, h_dtaps;
-
-    // streaming state (1-based, reference field names in multirate_hip.h)
-    int64_t phiIdx = 1, inputDeficit = 1, xIdx = 1;
-    double rate = 0.0, phiAcc = 1.0, alpha = 0.0, delta = 0.0;
-
-    // the stream state on the device (DevStream above; stream_state.hip).  The host fields above mirror it exactly while
-    // mirror_valid; device-planned calls whose result the host has not yet collected (mrhip_filt_device_async, calls
-    // captured into a HIP graph) clear the flag, mrhip_sync_state / any call that needs the state restores it.
-    mrhip::DevStream *d_rec = nullptr;      // device
-    mrhip::DevCall *d_call = nullptr;       // device: the call record of the filter's current device-planned call
-    mrhip::DevStream *h_rec = nullptr;      // pinned host memory the plan kernels mirror the record into
-    bool mirror_valid = true;
-    bool captured = false;                  // a call went into a HIP graph: replays advance the record behind the host's back
-    hipEvent_t ev_rec = nullptr;            // recorded behind a plan kernel: the mirror holds that call's result once it fires
-
-    // FIRArbitrary schedule staging
-    std::vector<int32_t> sched_n;
-    std::vector<double> sched_acc;
-    // schedule cache: valid when computed from exactly this (state, x_len); lets next_output_count and
-    // the filt call that follows share one evaluation of the serial recurrence
-    bool sched_cached = false;
-    int64_t sched_xlen = -1, sched_count = 0;
-    double sched_acc0 = 0.0;
-    int64_t sched_deficit0 = 0;
-    mrhip::ArbState sched_end;
-    void *pin_n = nullptr, *pin_acc = nullptr;   // pinned host
-    size_t pin_cap = 0;
-    void *d_sched_n = nullptr, *d_sched_acc = nullptr;
-    size_t d_sched_cap = 0;
-    hipEvent_t sched_copied = nullptr;
-    bool sched_in_flight = false;
-
-    // device-evaluated schedule (arb_schedule.hip, kernels_schedule.hip)
-    mrhip::SchedPlan splan{};
-    int64_t sched_prefix = 65536, sched_pmax = 1 << 22, sched_device_min = 1 << 16;   // MRHIP_SCHED_* (read at create)
-    int sched_corrupt_piece = -1;                 // test hook: falsify the tables of this device piece (counted per filter)
-    bool sched_use_cycle = true;
-    double sched_drift = 0.0, sched_ksteps = 0.0; // running drift estimate of the stream: (true - un-rounded phase) over ksteps steps
-    void *ds_n[2] = {nullptr, nullptr}, *ds_acc[2] = {nullptr, nullptr};   // schedule buffers ([0] in use: one stream, in order)
-    size_t ds_cap[2] = {0, 0};
-    double *ds_pathT = nullptr;
-    int *ds_pathW = nullptr;
-    mrhip::SchedGroupEntry *ds_gtab = nullptr;
-    mrhip::SchedGroupStart *ds_gstart = nullptr;
-    int64_t ds_work_groups = 0;
-    mrhip::SchedPieceState *ds_state = nullptr, *ds_pin_state = nullptr;
-    int64_t ds_state_cap = 0;
-    mrhip::SchedStatus *ds_status = nullptr, *ds_pin_status = nullptr;
-    // a detected cycle of the accumulator (PERIODIC mode)
-    bool per_valid = false;
-    int64_t per_Q = 0, per_XQ = 0, per_pos = 0, per_reset_pos = -1;
-    std::vector<double> per_acc;
-    std::vector<int64_t> per_xoff;                // [Q + 1] xIdx advance from cycle position 0
-    int per_span[mrhip::kSchedSpanSizes] = {};
-    double *d_per_acc = nullptr;
-    long long *d_per_xoff = nullptr;
-    int64_t stat_host_steps = 0, stat_periodic_steps = 0, stat_device_pieces = 0, stat_fallback_pieces = 0;
-
-    // host-pointer path staging: two slots each way (H2D of piece i+1 and D2H of piece i-1 overlap the kernel of
-    // piece i: copy streams s_in / s_out beside the kernel stream own_stream, ordered by the events below)
-    void *d_xbuf[2] = {nullptr, nullptr}, *d_ybuf[2] = {nullptr, nullptr};
-    size_t d_xcap[2] = {0, 0}, d_ycap[2] = {0, 0};
-    hipStream_t own_stream = nullptr, s_in = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-
-    // Stream ordering of the per-filter device state (history ping-pong, counters, schedule buffers): every call
-    // enqueues on the caller's stream; when a call arrives on a DIFFERENT stream than the previous one, an event is
-    // recorded on the previous stream and the new stream waits for it (adopt_stream in api.hip).  Nothing is paid while
-    // a filter stays on one stream.
-    hipStream_t last_stream = nullptr;
-    bool last_stream_valid = false;
-    hipEvent_t xs_event = nullptr;
-
-    // measurement
-    bool timing = false;
-    int timing_stride = 1;            // bracket every timing_stride-th compute launch (1 = all)
-    int timing_group = 1;             // > 1: one bracket around every timing_group consecutive compute launches
-    int64_t timing_launch = 0;        // compute launches seen since timing was enabled
-    bool timing_open = false;         // between the two marks of a launch
-    bool ev_skip = false;             // ... of a launch that is not bracketed
-    std::vector<hipEvent_t> ev_pool;   // pairs: [2i] start, [2i+1] stop
-    size_t ev_used = 0;                // events handed out since the last mrhip_timing_read
-    const char *last_kernel = "";
-};

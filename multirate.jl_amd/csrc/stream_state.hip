@@ -13,7 +13,7 @@
 // Nothing here has a CPU fallback.
 #include <cstring>
 
-#include "mrhip_internal.h"
+#include "mrhip_filter.h"
 
 namespace mrhip {
 namespace {
@@ -81,20 +81,28 @@ __global__ __launch_bounds__(64) void poly_plan_kernel(PlanArgs a)
 int rec_alloc(mrhip_filter *f)
 {
     void *d = nullptr;
-    MRHIP_CHECK_HIP(hipMalloc(&d, 256 + sizeof(DevCall)));
+    MRHIP_CHECK_HIP(hipMalloc(&d, 256 + 2 * 256));
     f->d_rec = static_cast<DevStream *>(d);
-    f->d_call = reinterpret_cast<DevCall *>(static_cast<unsigned char *>(d) + 256);
+    static_assert(sizeof(DevStream) <= 256 && sizeof(DevCall) <= 256, "record slots");
+    for (int b = 0; b < 2; ++b) f->d_calls[b] = reinterpret_cast<DevCall *>(static_cast<unsigned char *>(d) + 256 * (b + 1));
+    f->d_call = f->d_calls[0];
     void *h = nullptr;
     MRHIP_CHECK_HIP(hipHostMalloc(&h, 512, hipHostMallocMapped));
     std::memset(h, 0, 512);
     f->h_rec = static_cast<DevStream *>(h);
     MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_rec, hipEventDisableTiming));
+    if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {      // the schedule's own stream (mrhip_filter.h: s_sched)
+        MRHIP_CHECK_HIP(hipStreamCreateWithFlags(&f->s_sched, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_fin[b], hipEventDisableTiming));
+            MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_filt[b], hipEventDisableTiming));
+        }
+    }
     DevStream v{};
     v.phiIdx = 1; v.inputDeficit = 1; v.acc = 1.0;
     v.sched_fail = kSchedNoFail;
-    DevCall c{};
+    MRHIP_CHECK_HIP(hipMemsetAsync(d, 0, 256 + 2 * 256, f->own_stream));
     MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_rec, &v, sizeof v, hipMemcpyHostToDevice, f->own_stream));
-    MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_call, &c, sizeof c, hipMemcpyHostToDevice, f->own_stream));
     MRHIP_CHECK_HIP(hipStreamSynchronize(f->own_stream));
     *f->h_rec = v;
     return MRHIP_OK;
@@ -102,10 +110,13 @@ int rec_alloc(mrhip_filter *f)
 
 void rec_free(mrhip_filter *f)
 {
+    if (f->s_sched) { (void)hipStreamSynchronize(f->s_sched); (void)hipStreamDestroy(f->s_sched); }
+    for (hipEvent_t e : {f->ev_fin[0], f->ev_fin[1], f->ev_filt[0], f->ev_filt[1]})
+        if (e) (void)hipEventDestroy(e);
     if (f->d_rec) (void)hipFree(f->d_rec);
     if (f->h_rec) (void)hipHostFree(f->h_rec);
     if (f->ev_rec) (void)hipEventDestroy(f->ev_rec);
-    f->d_rec = nullptr; f->d_call = nullptr; f->h_rec = nullptr; f->ev_rec = nullptr;
+    f->d_rec = nullptr; f->d_call = nullptr; f->h_rec = nullptr; f->ev_rec = nullptr; f->s_sched = nullptr;
 }
 
 // the pinned mirror as the device sees it
@@ -136,10 +147,14 @@ int rec_pull(mrhip_filter *f)
 {
     // graph replays run on streams the library never saw: after a capture only the whole device is a safe wait
     if (f->captured) MRHIP_CHECK_HIP(hipDeviceSynchronize());
-    else if (f->last_stream_valid && hipStreamSynchronize(f->last_stream) != hipSuccess) {
-        (void)hipGetLastError();
-        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+    else {
+        if (f->last_stream_valid && hipStreamSynchronize(f->last_stream) != hipSuccess) {
+            (void)hipGetLastError();
+            MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        }
+        if (f->s_sched) MRHIP_CHECK_HIP(hipStreamSynchronize(f->s_sched));
     }
+    f->async_pending = false;
     const DevStream r = *f->h_rec;
     f->phiIdx = r.phiIdx; f->inputDeficit = r.inputDeficit;
     if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {

@@ -112,48 +112,48 @@ def rows(which):
     harb = pkg.firdes(32 * 32, 0.45 / 32, beta=7.8562) * 32
     R147 = 147 / 160
 
-    if "c1" in which:
+    def _c1():
         run("C1 rational 147//160 f32 1ch x 1e6 (one call)", h147, Fraction(147, 160), 32, 1, 1_000_000, torch.float32, 7.675, 48 * R147)
-    if "c2" in which:
+    def _c2():
         run("C2 rational 147//160 f32 1ch x 1e8 in 1e6 chunks (resident signal: mrhip_filt_device_chunked)", h147, Fraction(147, 160), 32, 1, 100_000_000, torch.float32, 7.675, 48 * R147, reps=3, chunk=1_000_000)
-    if "c2s" in which:
+    def _c2s():
         run("C2s the same, one launch per arriving 1e6-sample chunk (MRHIP_CHUNKED_PER_CALL=1)", h147, Fraction(147, 160), 32, 1, 100_000_000, torch.float32, 7.675, 48 * R147, reps=2, chunk=1_000_000, per_call=True)
-    if "c3a" in which:
+    def _c3a():
         run("C3a interpolator 4//1 128 taps c64 256ch x 1e6", h128, Fraction(4, 1), 32, 256, 1_000_000, torch.complex64, 40.0, 2 * 2 * 32 * 4)
-    if "c3b" in which:
+    def _c3b():
         run("C3b decimator 1//4 128 taps c64 256ch x 1e6", h128, Fraction(1, 4), 32, 256, 1_000_000, torch.complex64, 10.0, 2 * 2 * 128 / 4)
-    if "c4" in which:
+    def _c4():
         run("C4 arbitrary pi/3 32x32 taps f64 64ch x 1e7", harb, float(math.pi / 3), 32, 64, 10_000_000, torch.float64, 8 + 8 * math.pi / 3, (2 * 64 + 2) * math.pi / 3, reps=2)
-    if "c4f" in which:
+    def _c4f():
         run("C4f farrow pi/3 32x32 taps polyorder 4 f64 64ch x 1e7", harb, float(math.pi / 3), 32, 64, 10_000_000, torch.float64, 8 + 8 * math.pi / 3, (2 * 32 + 2 * 4 * 32 / 64) * math.pi / 3, reps=2, polyorder=4,
             note="flops include the Float64 Horner evaluation of the 32 taps of every output index, done once for all 64 channels")
-    if "c5" in which:
+    def _c5():
         run("C5 rational 147//160 c64 512ch x 1e6 (one GPU's shard of 4096)", h147, Fraction(147, 160), 32, 512, 1_000_000, torch.complex64, 15.35, 2 * 48 * R147)
 
     # shapes outside BASELINE.json (where the non-headline kernels stand)
-    if "x160" in which:
+    def _x160():
         h160 = pkg.firdes(24 * 160, 0.5 / 160, beta=7.8562).astype(np.float32)
         run("X rational 160//147 (44.1k->48k) f32 64ch x 1e6", h160, Fraction(160, 147), 32, 64, 1_000_000, torch.float32, 4 + 4 * 160 / 147, 48 * 160 / 147)
-    if "xf64" in which:
+    def _xf64():
         run("X rational 147//160 f64 64ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 64, 1_000_000, torch.float64, 2 * 7.675, 48 * R147)
-    if "xmix" in which:
+    def _xmix():
         # the reference's own published benchmark (README.md:172-193): firdes returns Float64 taps, x = rand(Float32, 1_000_000)
         # -> Float64 output (Filters.jl:581); 0.0569 s = 17.56 Msamples/s on unnamed 2014 hardware, one channel
         run("X README mixed precision: 147//160 Float64 taps x Float32 samples -> Float64, 64ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 64, 1_000_000,
             torch.float32, 4 + 8 * R147, 48 * R147, note="reference README.md:172-193: 17.56 Msamples/s in (0.0569 s for 1e6 samples, 1 channel, Julia 0.3, unnamed 2014 CPU)")
         run("X README mixed precision, the README's own size: 1ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 1, 1_000_000,
             torch.float32, 4 + 8 * R147, 48 * R147, note="reference README.md:172-193: 0.0569 s per call = 17.56 Msamples/s")
-    if "xstd" in which:
+    def _xstd():
         run("X standard 1//1 128 taps f32 64ch x 4e6", h128, Fraction(1, 1), 32, 64, 4_000_000, torch.float32, 8.0, 2 * 128)
-    if "x32" in which:
+    def _x32():
         h32 = pkg.firdes(24 * 3, 0.5 / 3, beta=7.8562).astype(np.float32)
         run("X rational 3//2 f32 64ch x 1e6", h32, Fraction(3, 2), 32, 64, 1_000_000, torch.float32, 4 + 6, 48 * 1.5)
         run("X rational 2//3 f32 64ch x 1e6", h32, Fraction(2, 3), 32, 64, 1_000_000, torch.float32, 4 + 8 / 3, 72 * 2 / 3)
-    if "xc32" in which:   # the headline's launch size (491 MB) on the ComplexF32 kernel: 32 complex channels x 1e6 per launch
+    def _xc32():   # the headline's launch size (491 MB) on the ComplexF32 kernel: 32 complex channels x 1e6 per launch
         run("X rational 147//160 c64 32ch x 2e7 in 1e6 chunks, per call", h147, Fraction(147, 160), 32, 32, 20_000_000, torch.complex64, 15.35, 2 * 48 * R147, reps=3, chunk=1_000_000, per_call=True)
         run("X rational 147//160 f32 64ch x 2e7 in 1e6 chunks, per call", h147, Fraction(147, 160), 32, 64, 20_000_000, torch.float32, 7.675, 48 * R147, reps=3, chunk=1_000_000, per_call=True)
 
-    if "xarb" in which:   # config 4's shape in the other sample / tap types (which FIRArbitrary / FIRFarrow kernel serves them, and how fast)
+    def _xarb():   # config 4's shape in the other sample / tap types (which FIRArbitrary / FIRFarrow kernel serves them, and how fast)
         for th, dt, sb, nm in ((np.float32, torch.float32, 4, "f32 taps x f32"), (np.float32, torch.complex64, 8, "f32 taps x c64"),
                                (np.float64, torch.float32, 4, "f64 taps x f32"), (np.float64, torch.complex64, 8, "f64 taps x c64"),
                                (np.float64, torch.complex128, 16, "f64 taps x c128")):
@@ -163,10 +163,10 @@ def rows(which):
                 fl = ((2 * 64 + 2) if po is None else (2 * 32 + 2 * 4 * 32 / 64)) * nc * math.pi / 3
                 run(f"X {kind} pi/3 32x32 {nm} 64ch x 4e6", harb.astype(th), float(math.pi / 3), 32, 64, 4_000_000, dt, sb + ob * math.pi / 3, fl, reps=2, polyorder=po)
 
-    if "xmix64" in which:
+    def _xmix64():
         run("X README mixed precision: 147//160 Float64 taps x Float32 samples -> Float64, 64ch x 1e6", h147.astype(np.float64), Fraction(147, 160), 32, 64, 1_000_000,
             torch.float32, 4 + 8 * R147, 48 * R147, note="reference README.md:172-193: 17.56 Msamples/s in (0.0569 s for 1e6 samples, 1 channel, Julia 0.3, unnamed 2014 CPU)")
-    if "af" in which:
+    def _af():
         # examples/Arb-Farrow Speed Comparison.jl:38-54: N𝜙 = 32, 10 taps per phase, polyorder 4, x = rand(Tx, 10_000_000), ONE channel,
         # rates 1.0 and 1/2.123456789, Tx in (Float32, Float64, Complex64, Complex128); h = firdes(...) .* N𝜙 is Float64 there (the
         # script's `Th = Float32` is never applied); the reference prints samples/s and records no result
@@ -179,6 +179,10 @@ def rows(which):
                     fl = (2 * 20 + 2 if po is None else 2 * 10) * nc * rate
                     run(f"AF {kind} rate {rate:.9g} {str(dt).replace('torch.', '')} 1ch x 1e7 (Arb-Farrow Speed Comparison.jl shape)", haf, float(rate), 32, 1,
                         10_000_000, dt, sb + ob * rate, fl, reps=2, polyorder=po)
+
+    table = {"c1": _c1, "c2": _c2, "c2s": _c2s, "c3a": _c3a, "c3b": _c3b, "c4": _c4, "c4f": _c4f, "c5": _c5, "x160": _x160, "xf64": _xf64, "xmix": _xmix, "xstd": _xstd, "x32": _x32, "xc32": _xc32, "xarb": _xarb, "xmix64": _xmix64, "af": _af}
+    for name in which:                # in the order asked for (bench.py wants the BASELINE rows last)
+        table[name]()
 
 
 def run_rows(which, reps_note=None):

@@ -98,7 +98,7 @@ def time_sharded(pkg, O, dist, torch, rank, world, backend, dev_index, dev):
             y_local = ts.filt(xl)
             full = ts.gather(y_local if backend == "nccl" else y_local.cpu(), dst=0)
             if rank == 0:
-                for c in (0, nch - 1):
+                for c in sorted(fos):
                     ref = np.concatenate([fos[c].filt(xb[c, a:a + m]) for a, m in ts.slices])
                     got = full[c].cpu().numpy()
                     assert got.shape == ref.shape and got.dtype == ref.dtype, (ratio, got.shape, ref.shape, got.dtype, ref.dtype)
