@@ -15,6 +15,10 @@
 
 namespace mrhip {
 
+// kernels_farrow_wave.hip: FIRFarrow for fewer than four channels (one lane per output, windows straight from global memory)
+bool plan_farrow_wave(const FarrowArgs &a);
+hipError_t launch_farrow_wave(const TypeKey &tk, bool fused, const FarrowArgs &a, hipStream_t s, const char **kname, int num_cus);
+
 thread_local LaunchEvents g_launch_events;
 static thread_local std::string g_last_error;
 
@@ -375,6 +379,14 @@ static int create_farrow_common(const std::vector<double> &pnfb_in, int64_t hLen
     if (hipMalloc(reinterpret_cast<void **>(&f->d_pnfb), f->h_pnfb.size() * sizeof(double)) != hipSuccess ||
         hipMemcpy(f->d_pnfb, f->h_pnfb.data(), f->h_pnfb.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(MRHIP_ERR_HIP, "uploading the polynomial filter bank failed");
+    if (!rc && f->T <= 32) {        // the same bank degree-major, padded to 32 taps with zeros (kernels_farrow_wave.hip)
+        std::vector<double> t(static_cast<size_t>(polyorder + 1) * 32, 0.0);
+        for (int64_t i = 0; i < f->T; ++i)
+            for (int64_t j = 0; j <= polyorder; ++j) t[static_cast<size_t>(j) * 32 + i] = f->h_pnfb[static_cast<size_t>(i) * (polyorder + 1) + j];
+        if (hipMalloc(reinterpret_cast<void **>(&f->d_pnfb_t), t.size() * sizeof(double)) != hipSuccess ||
+            hipMemcpy(f->d_pnfb_t, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(MRHIP_ERR_HIP, "uploading the polynomial filter bank failed");
+    }
     if (!rc) rc = alloc_common(f);
     if (rc) { mrhip_destroy(f); return rc; }
     sched_configure(f);
@@ -458,7 +470,7 @@ void mrhip_destroy(mrhip_filter *f)
     (void)drain_filter(f);                       // this filter's work only; other streams of the process keep running
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
         if (st) (void)hipStreamSynchronize(st);
-    for (void *p : {f->d_taps, f->d_dtaps, static_cast<void *>(f->d_pnfb), f->d_hist[0], f->d_hist[1], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc,
+    for (void *p : {f->d_taps, f->d_dtaps, static_cast<void *>(f->d_pnfb), static_cast<void *>(f->d_pnfb_t), f->d_hist[0], f->d_hist[1], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc,
                     f->d_xbuf[0], f->d_xbuf[1], f->d_ybuf[0], f->d_ybuf[1]})
         if (p) (void)hipFree(p);
     if (f->pin_n) (void)hipHostFree(f->pin_n);
@@ -941,7 +953,12 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 if (int rc = timing_mark(f, stream)) return rc;
                 ArbTileArgs fta;
                 size_t flds = 0;
-                if (!f->force_generic && plan_farrow_tiled(tk, fa, n_host, sched_spans, f->num_cus, &fta, &flds))
+                if (!f->force_generic && f->d_pnfb_t && plan_farrow_wave(fa)) {
+                    FarrowArgs fw = fa;
+                    fw.pnfb = f->d_pnfb_t;                              // degree-major, padded: [polyorder+1][32]
+                    MRHIP_CHECK_HIP(launch_farrow_wave(tk, fused, fw, stream, &f->last_kernel, f->num_cus));
+                }
+                else if (!f->force_generic && plan_farrow_tiled(tk, fa, n_host, sched_spans, f->num_cus, &fta, &flds))
                     MRHIP_CHECK_HIP(launch_farrow_tiled(tk, fused, fa, fta, flds, stream, &f->last_kernel, f->num_cus));
                 else
                     MRHIP_CHECK_HIP(launch_farrow(tk, fused, fa, stream, &f->last_kernel));

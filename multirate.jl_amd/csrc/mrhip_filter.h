@@ -21,6 +21,7 @@ struct mrhip_filter {
     // device memory
     void *d_taps = nullptr, *d_dtaps = nullptr;
     double *d_pnfb = nullptr;              // FIRFarrow: polynomial filter bank on the device
+    double *d_pnfb_t = nullptr;            // ... degree-major and padded to 32 taps, [polyorder+1][32] (farrow_wave_kernel; tapsPerPhi <= 32)
     std::vector<double> h_pnfb;            // ... and on the host, [T][polyorder+1]
     int64_t polyorder = 0;
     void *d_hist[2] = {nullptr, nullptr};

@@ -548,7 +548,7 @@ def test_farrow_sweep_bit_exact_with_shared_polynomials(pkg, O, torch_cuda):
         f = pkg.FIRFilter(h, rate, Nphi, order, pnfb=pn)
         outs = [o.cpu().numpy() for o in _run_chunks(f, torch.from_numpy(x).cuda(), sizes)]
         y = np.concatenate(outs, axis=1)
-        assert f.last_kernel_name() in ("farrow_kernel", "farrow_tiled_kernel", "farrow_pipe_kernel") and f.kernel_name == "FIRFarrow"
+        assert f.last_kernel_name() in ("farrow_kernel", "farrow_tiled_kernel", "farrow_pipe_kernel", "farrow_wave_kernel") and f.kernel_name == "FIRFarrow"
         assert np.array_equal(f.pnfb(), pn)
         for c in range(nch):
             fo = O.FIRFilter(h, rate, Nphi, tx=tx, polyorder=order, pnfb=pn)
@@ -1165,7 +1165,8 @@ def test_farrow_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
             finally:
                 O.set_fused(False)
             f.close(); g.close()
-    assert "farrow_pipe_kernel" in seen and "farrow_tiled_kernel" in seen, seen
+    # (fewer than four channels: farrow_wave_kernel, one lane per output straight from global memory)
+    assert {"farrow_pipe_kernel", "farrow_tiled_kernel", "farrow_wave_kernel"} <= seen, seen
 
 
 def test_advance_state_equals_filtering(pkg, O, torch_cuda):
@@ -1220,8 +1221,8 @@ def test_pipe_kernels_many_tiles_per_workgroup(pkg, O, torch_cuda, monkeypatch):
                     xd = torch.from_numpy(x).cuda()
                     mk = (lambda: pkg.FIRFilter(h, rate, nphi, 3, pnfb=pn)) if farrow else (lambda: pkg.FIRFilter(h, rate, nphi))
                     outs = {}
-                    for name, env in (("pipe", {}), ("pipe, register staging", {"MRHIP_PIPE_DMA": "0"}),
-                                      ("tiled", {"MRHIP_FARROW_PIPE": "0", "MRHIP_ARB_PIPE": "0"})):
+                    for name, env in (("pipe", {"MRHIP_FARROW_WAVE": "0"}), ("pipe, register staging", {"MRHIP_PIPE_DMA": "0", "MRHIP_FARROW_WAVE": "0"}),
+                                      ("tiled", {"MRHIP_FARROW_PIPE": "0", "MRHIP_ARB_PIPE": "0", "MRHIP_FARROW_WAVE": "0"}), ("default", {})):
                         for k, v in env.items():
                             monkeypatch.setenv(k, v)
                         f = mk()
@@ -1238,6 +1239,9 @@ def test_pipe_kernels_many_tiles_per_workgroup(pkg, O, torch_cuda, monkeypatch):
                         seen.add(kn)
                         assert kn in ("arb_pipe_kernel", "farrow_pipe_kernel"), kn
                         assert_bit_equal(got, want, f"{name} vs {kt}: farrow={farrow} rate={rate} T={T} {np.dtype(tx)} x {np.dtype(th)} taps nch={nch}")
+                    got, kn = outs["default"]                 # what the dispatcher picks: farrow_wave_kernel below four channels
+                    assert kn == ("farrow_wave_kernel" if farrow and nch < 4 else "farrow_pipe_kernel" if farrow else "arb_pipe_kernel"), kn
+                    assert_bit_equal(got, want, f"default ({kn}) vs {kt}: farrow={farrow} rate={rate} T={T} nch={nch}")
     assert seen == {"arb_pipe_kernel", "farrow_pipe_kernel"}
 
 
