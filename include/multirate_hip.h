@@ -252,6 +252,15 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
  * A call longer than one launch (2^30 samples; 2^24 / rate for FIRArbitrary) is MRHIP_ERR_UNSUPPORTED here. */
 int mrhip_filt_device_async(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
                             int64_t y_capacity, int64_t y_stride, int64_t *count_out, void *stream);
+/* filt!(buffer_i, self_i, x_i) for i = 0..n-1 -- n INDEPENDENT FIRFilter objects, each with its own phase, input deficit,
+ * history and call length, the reference's one-FIRFilter-per-signal streaming usage (README.md:87-141) -- issued as ONE
+ * launch when the filters agree in kind (FIRRational / FIRInterpolator), ratio, tapsPerPhi, dtypes, numerics and device:
+ * every workgroup of the launch works for one of the streams.  x[i] / y[i] are device pointers, channel c of filter i at
+ * x[i] + c*x_len[i] and y[i] + c*y_capacity[i]; n_written[i] (optional) receives filter i's per-channel count.  Results,
+ * states and histories are exactly those of n mrhip_filt_device calls, which is also what runs when the filters do not agree
+ * (and inside a HIP-graph capture).  MRHIP_ERR_BUFFER_TOO_SMALL before anything is enqueued. */
+int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *const *x, const int64_t *x_len, void *const *y,
+                            const int64_t *y_capacity, int64_t *n_written, void *stream);
 /* the largest per-channel output count a call of `inputlength` samples can have whatever the stream state: outputlength
  * (src/Filters.jl:352-385) evaluated for 𝜙Idx = inputDeficit = 1 (+ 2 for FIRArbitrary / FIRFarrow, whose outputlength is
  * an estimate, :375-381) */

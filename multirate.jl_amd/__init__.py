@@ -18,11 +18,13 @@ from __future__ import annotations
 from .host import (  # noqa: F401
     FIRFilter,
     FilterCascade,
+    MultiStream,
     MultirateHIPError,
     NUMERICS_FUSED,
     NUMERICS_STRICT,
     filt,
     filt_,
+    filt_multi,
     inputlength,
     library_path,
     load_library,
@@ -39,7 +41,7 @@ from .design import (BANDPASS, BANDSTOP, HIGHPASS, LOWPASS, firdes, firprototype
 from .sharding import ChannelShardedFilter, TimeShardedFilter, shard_channels, shard_time  # noqa: F401
 
 __all__ = [
-    "FIRFilter", "FilterCascade", "filt", "filt_", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
+    "FIRFilter", "FilterCascade", "MultiStream", "filt", "filt_", "filt_multi", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
     "setphase", "tapsforphase", "polyfit", "firdes", "firprototype", "kaiserlength", "kaiser", "LOWPASS", "BANDPASS", "HIGHPASS", "BANDSTOP", "ChannelShardedFilter", "TimeShardedFilter", "shard_channels", "shard_time", "load_library",
     "library_path", "MultirateHIPError", "NUMERICS_STRICT", "NUMERICS_FUSED",
 ]

@@ -475,6 +475,9 @@ void mrhip_destroy(mrhip_filter *f)
         if (p) (void)hipFree(p);
     if (f->pin_n) (void)hipHostFree(f->pin_n);
     if (f->pin_acc) (void)hipHostFree(f->pin_acc);
+    if (f->multi_pin) (void)hipHostFree(f->multi_pin);
+    if (f->multi_dev) (void)hipFree(f->multi_dev);
+    if (f->multi_ev) (void)hipEventDestroy(f->multi_ev);
     sched_free(f);
     rec_free(f);
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
@@ -1274,6 +1277,121 @@ int mrhip_filt_device_async(mrhip_filter *f, const void *x, int64_t x_len, int64
 {
     static_assert(sizeof(long long) == sizeof(int64_t), "the count is written by the device as a long long");
     return filt_device_any(f, x, x_len, x_stride, y, y_capacity, y_stride, nullptr, stream, true, reinterpret_cast<long long *>(count_out));
+}
+
+// SEVERAL INDEPENDENT STREAMS, ONE LAUNCH.  The reference's streaming usage is one FIRFilter per signal (README.md:87-141): N
+// signals are N objects with N phases and N call lengths, and a filter object's channels cannot serve them (channels share
+// the call length and therefore the state).  One launch per stream cannot fill 256 CUs (a 1e6-sample chunk of one channel
+// is all launch ramp: 6-7 % of the HBM roofline); here the streams of one launch are the scheduling groups of the pair
+// kernel: every workgroup works for one stream and takes that stream's signal, history, taps, record, lengths and
+// call-start state from a descriptor (MultiDesc, pair_loader.h: pair_take_dyn).  FIRRational / FIRInterpolator on the
+// output-pair kernel; anything else is the plain loop of single calls (same results).
+int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *const *x, const int64_t *x_len, void *const *y,
+                            const int64_t *y_capacity, int64_t *n_written, void *stream_)
+{
+    if (!filters || n < 1 || !x || !x_len || !y || !y_capacity) return fail(MRHIP_ERR_INVALID_ARG, "NULL argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    mrhip_filter *f0 = filters[0];
+    if (!f0) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    auto single_calls = [&]() -> int {
+        for (int i = 0; i < n; ++i) {
+            int64_t got = 0;
+            const int64_t xs = x_len[i], ys = y_capacity[i];
+            if (int rc = mrhip_filt_device(filters[i], x[i], xs, xs, y[i], ys, ys, &got, stream_)) return rc;
+            if (n_written) n_written[i] = got;
+        }
+        return MRHIP_OK;
+    };
+    bool same = (f0->kind == MRHIP_FIR_RATIONAL || f0->kind == MRHIP_FIR_INTERPOLATOR) && !f0->force_generic && n > 1 && n <= 4096;
+    for (int i = 0; i < n && same; ++i) {
+        const mrhip_filter *f = filters[i];
+        if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+        for (int j = 0; j < i; ++j)
+            if (filters[j] == f) return fail(MRHIP_ERR_INVALID_ARG, "the same filter twice in one multi-stream call");
+        same = f->kind == f0->kind && f->L == f0->L && f->M == f0->M && f->T == f0->T && f->tx == f0->tx && f->th == f0->th &&
+               f->numerics == f0->numerics && f->device == f0->device && x_len[i] > 0 && x_len[i] < 0x7fffffffLL && x[i] && y[i];
+    }
+    if (!same || stream_is_capturing(stream)) return single_calls();
+    DeviceGuard guard(f0->device);
+    if (!guard.ok) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
+    const TypeKey tk = type_key(f0);
+    const bool fused = f0->numerics == MRHIP_NUMERICS_FUSED;
+    // what every stream's call will do (closed form), and the geometry of the launch: planned for the longest stream
+    std::vector<CallPlan> plans(static_cast<size_t>(n));
+    int64_t n_out_max = 0, nch_total = 0, x_len_max = 0;
+    for (int i = 0; i < n; ++i) {
+        mrhip_filter *f = filters[i];
+        if (!f->mirror_valid)
+            if (int rc = rec_pull(f)) return rc;
+        plans[i] = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len[i]);
+        if (plans[i].n_out > y_capacity[i]) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
+        n_out_max = std::max(n_out_max, plans[i].n_out);
+        x_len_max = std::max(x_len_max, x_len[i]);
+        nch_total += f->nch;
+    }
+    if (n_out_max < 1) return single_calls();                        // (short inputs only: history shifts, no kernel worth sharing)
+    PolyArgs a{};
+    a.x = x[0]; a.y = y[0]; a.hist = f0->d_hist[f0->hist_cur]; a.hist_new = f0->d_hist[f0->hist_cur ^ 1]; a.taps = f0->d_taps;
+    a.x_stride = x_len_max; a.y_stride = n_out_max; a.x_len = x_len_max; a.n_out = n_out_max;
+    a.u0 = 0; a.d0 = 1; a.zero_start_below = 0;
+    a.L = static_cast<int>(f0->L); a.M = static_cast<int>(f0->M); a.T = static_cast<int>(f0->T); a.H = static_cast<int>(f0->H);
+    a.nch = static_cast<int>(std::min<int64_t>(nch_total, 0x7fffffff));
+    PairArgs pa;
+    dim3 block;
+    size_t lds = 0;
+    if (!plan_rational_opair(tk, a, f0->num_cus, &pa, &block, &lds)) return single_calls();
+    // descriptors: pinned staging -> device, owned by the first filter of the call
+    const size_t bytes = static_cast<size_t>(n) * sizeof(MultiDesc);
+    if (bytes > f0->multi_cap) {
+        if (f0->multi_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f0->multi_ev)); f0->multi_in_flight = false; }
+        if (int rc = drain_filter(f0)) return rc;
+        if (f0->multi_pin) (void)hipHostFree(f0->multi_pin);
+        if (f0->multi_dev) (void)hipFree(f0->multi_dev);
+        f0->multi_pin = f0->multi_dev = nullptr; f0->multi_cap = 0;
+        MRHIP_CHECK_HIP(hipHostMalloc(&f0->multi_pin, bytes * 2, hipHostMallocDefault));
+        MRHIP_CHECK_HIP(hipMalloc(&f0->multi_dev, bytes * 2));
+        f0->multi_cap = bytes * 2;
+        if (!f0->multi_ev) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f0->multi_ev, hipEventDisableTiming));
+    }
+    if (f0->multi_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f0->multi_ev)); f0->multi_in_flight = false; }
+    MultiDesc *d = static_cast<MultiDesc *>(f0->multi_pin);
+    unsigned steps_max = 0;
+    for (int i = 0; i < n; ++i) {
+        mrhip_filter *f = filters[i];
+        if (int rc = adopt_stream(f, stream)) return rc;
+        const CallPlan &p = plans[i];
+        const int64_t spc = (p.n_out + pa.P - 1) / pa.P;
+        if (spc * f->nch >= (1LL << 31)) return fail(MRHIP_ERR_INVALID_ARG, "stream too long for one launch");
+        MultiDesc &m = d[i];
+        m.x = x[i]; m.y = y[i]; m.hist = f->d_hist[f->hist_cur]; m.hist_new = f->d_hist[f->hist_cur ^ 1]; m.taps = f->d_taps; m.rec = f->d_rec;
+        m.x_stride = x_len[i]; m.y_stride = y_capacity[i]; m.x_len = x_len[i]; m.n_out = p.n_out;
+        m.u0 = p.phi0 - 1; m.d0 = p.d0; m.phi_end = p.phi_end; m.d_end = p.d_end;
+        m.steps_per_channel = static_cast<unsigned>(spc);
+        m.total_steps = static_cast<unsigned>(spc * f->nch);
+        m.spc_magic = spc <= 1 ? 0xffffffffu : static_cast<unsigned>((1ULL << 32) / static_cast<unsigned long long>(spc));
+        m.nch = static_cast<int>(f->nch);
+        steps_max = std::max(steps_max, m.total_steps);
+    }
+    MRHIP_CHECK_HIP(hipMemcpyAsync(f0->multi_dev, f0->multi_pin, bytes, hipMemcpyHostToDevice, stream));
+    MRHIP_CHECK_HIP(hipEventRecord(f0->multi_ev, stream));
+    f0->multi_in_flight = true;
+    a.rec = f0->d_rec; a.dyn = nullptr;
+    a.multi = static_cast<const MultiDesc *>(f0->multi_dev); a.multi_n = n;
+    pa.total_steps = steps_max;                                     // (sizes the grid: workgroups per stream <= tiles of the longest)
+    if (int rc = timing_mark(f0, stream)) return rc;
+    MRHIP_CHECK_HIP(launch_rational_opair(fused, a, pa, block, lds, stream, &f0->last_kernel, f0->num_cus, f0->d_counters));
+    if (int rc = timing_mark(f0, stream)) return rc;
+    for (int i = 0; i < n; ++i) {                                    // the kernel filed every stream's end state and history
+        mrhip_filter *f = filters[i];
+        f->phiIdx = plans[i].phi_end; f->inputDeficit = plans[i].d_end;
+        if (plans[i].n_out == 0) {
+            // (a stream without outputs in this call has no tiles: its workgroups still shift its history and file its state)
+        }
+        if (f->H > 0) f->hist_cur ^= 1;
+        f->last_kernel = f0->last_kernel;
+        if (n_written) n_written[i] = plans[i].n_out;
+    }
+    return MRHIP_OK;
 }
 
 int64_t mrhip_outputlength_bound(const mrhip_filter *f, int64_t inputlength)

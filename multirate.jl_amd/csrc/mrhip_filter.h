@@ -123,6 +123,12 @@ struct mrhip_filter {
     bool last_stream_valid = false;
     hipEvent_t xs_event = nullptr;
 
+    // mrhip_filt_device_multi: descriptor staging of the launches this filter leads (pinned host + device, one event)
+    void *multi_pin = nullptr, *multi_dev = nullptr;
+    size_t multi_cap = 0;
+    hipEvent_t multi_ev = nullptr;
+    bool multi_in_flight = false;
+
     // measurement
     bool timing = false;
     int timing_stride = 1;            // bracket every timing_stride-th compute launch (1 = all)

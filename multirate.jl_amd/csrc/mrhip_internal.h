@@ -238,6 +238,24 @@ struct PolyArgs {            // rational family: STANDARD / DECIMATOR / INTERPOL
     DevStream *rec;
     const DevCall *dyn;
     long long phi_end, d_end;
+    // SEVERAL INDEPENDENT STREAMS in one launch (mrhip_filt_device_multi; pair kernels only): multi != NULL: workgroup b works
+    // for stream b % multi_n alone and takes everything above that differs from stream to stream -- signal, history, taps,
+    // record, lengths, call-start state, step walk -- from multi[b % multi_n]; the values above are those of the launch's
+    // planning (the longest stream).
+    const struct MultiDesc *multi;
+    int multi_n;
+};
+
+struct MultiDesc {           // one independent stream (one FIRFilter of the reference: README.md:87-141) of a multi-stream launch
+    const void *x;
+    void *y;
+    const void *hist;
+    void *hist_new;
+    const void *taps;
+    DevStream *rec;
+    long long x_stride, y_stride, x_len, n_out, u0, d0, phi_end, d_end;
+    unsigned steps_per_channel, total_steps, spc_magic;
+    int nch;
 };
 
 struct ArbArgs {             // FIRArbitrary

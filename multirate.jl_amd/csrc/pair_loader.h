@@ -28,6 +28,19 @@ __device__ __forceinline__ TileAt pair_tile_at(const PairArgs &pa, unsigned g, u
 // walk come from the record the call's plan kernel filled; the kernel arguments hold upper bounds the launch was sized with.
 __device__ __forceinline__ void pair_take_dyn(PolyArgs &a, PairArgs &pa)
 {
+    if (a.multi) {
+        // several independent streams in one launch: this workgroup belongs to stream blockIdx.x % multi_n (= its scheduling
+        // group: pa.ngroups == multi_n, grabs dealt round-robin among the stream's workgroups) and to nobody else
+        const MultiDesc *__restrict__ d = a.multi + (blockIdx.x % static_cast<unsigned>(a.multi_n));
+        a.x = d->x; a.y = d->y; a.hist = d->hist; a.hist_new = d->hist_new; a.taps = d->taps; a.rec = d->rec;
+        a.x_stride = d->x_stride; a.y_stride = d->y_stride; a.x_len = d->x_len; a.n_out = d->n_out;
+        a.u0 = d->u0; a.d0 = d->d0; a.phi_end = d->phi_end; a.d_end = d->d_end; a.nch = d->nch;
+        pa.o0 = d->d0 - a.T;
+        pa.steps_per_channel = d->steps_per_channel;
+        pa.total_steps = d->total_steps;
+        pa.spc_magic = d->spc_magic;
+        pa.steps_per_group = d->total_steps;                  // the group IS the stream: steps [0, total_steps)
+    }
     if (a.dyn) {
         const DevCall *__restrict__ d = a.dyn;
         a.n_out = d->n_out; a.u0 = d->u0; a.d0 = d->d0;
@@ -104,7 +117,7 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
     // newest in the low bits): tile i+1 has landed once no more operations are outstanding than the ns-2
     // newest tiles own.
     const unsigned grp = blockIdx.x % static_cast<unsigned>(pa.ngroups);
-    const unsigned grp_lo = umin(grp * pa.steps_per_group, pa.total_steps);
+    const unsigned grp_lo = a.multi ? 0u : umin(grp * pa.steps_per_group, pa.total_steps);     // (multi: the stream's own step numbers)
     const unsigned grp_hi = umin(grp_lo + pa.steps_per_group, pa.total_steps);
     unsigned *const ctr = pa.counters + grp * 64u;            // one counter per 256 bytes
     unsigned pend = 0;                                        // lane 0: the grab number drawn ahead of need
@@ -194,7 +207,8 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
     }
     // the stream state on the device (mrhip_internal.h: DevStream): a call the host planned carries its end state
     // (Filters.jl:571-572, 627-628) in the arguments and one lane files it; a device-planned call's plan kernel already has
-    if (blockIdx.x == 0 && lane == 0 && a.rec && !a.dyn) {
+    const unsigned wg_in_grp = blockIdx.x / static_cast<unsigned>(pa.ngroups);                // (multi: this workgroup's number within its stream)
+    if ((a.multi ? wg_in_grp == 0u : blockIdx.x == 0) && lane == 0 && a.rec && !a.dyn) {
         a.rec->phiIdx = a.phi_end;
         a.rec->inputDeficit = a.d_end;
         a.rec->n_written = a.n_out;
@@ -207,7 +221,9 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
         const float *__restrict__ xin = static_cast<const float *>(a.x);
         const float *__restrict__ hold = static_cast<const float *>(a.hist);
         float *__restrict__ hnew = static_cast<float *>(a.hist_new);
-        for (int c2 = blockIdx.x; c2 < a.nch; c2 += gridDim.x)
+        const int c_first = a.multi ? static_cast<int>(wg_in_grp) : static_cast<int>(blockIdx.x);
+        const int c_step = a.multi ? static_cast<int>(static_stride) : static_cast<int>(gridDim.x);   // (multi: the workgroups of this stream)
+        for (int c2 = c_first; c2 < a.nch; c2 += c_step)
             for (int i = lane; i < a.H; i += 64) {
                 const long long e = static_cast<long long>(i) + a.x_len;          // index into [hist ; x]
 #pragma unroll

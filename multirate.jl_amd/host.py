@@ -96,6 +96,7 @@ ABI = [
     ("mrhip_get_taps", _i, [_vp, _i, _vp]),
     ("mrhip_filt_device", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
     ("mrhip_filt_device_async", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
+    ("mrhip_filt_device_multi", _i, [C.POINTER(_vp), _i, C.POINTER(_vp), _pi64, C.POINTER(_vp), _pi64, _pi64, _vp]),
     ("mrhip_outputlength_bound", _i64, [_vp, _i64]),
     ("mrhip_sync_state", _i, [_vp, _pi64]),
     ("mrhip_set_history_device", _i, [_vp, _vp, _vp]),
@@ -618,6 +619,64 @@ class FIRFilter:
         if est_mode:
             y = np.ascontiguousarray(y[:, :got])
         return y[0] if one else y
+
+
+def filt_multi(filters, xs):
+    """``[filt(f, x) for f, x in zip(filters, xs)]`` for INDEPENDENT FIRFilter objects (each its own phase, deficit, history
+    and call length: the reference's one-FIRFilter-per-signal streaming usage, README.md:87-141) issued as ONE launch
+    (``mrhip_filt_device_multi``).  ``xs`` are torch CUDA tensors, ``(n_i,)`` or ``(nchannels_i, n_i)``, contiguous."""
+    if not filters or len(filters) != len(xs):
+        raise MultirateHIPError(1, "filt_multi takes as many signals as filters")
+    lib = load_library()
+    n = len(filters)
+    ys, shapes = [], []
+    for f, x in zip(filters, xs):
+        if not _is_torch(x) or not x.is_cuda or not x.is_contiguous():
+            raise MultirateHIPError(1, "filt_multi takes contiguous torch CUDA tensors")
+        nch, m, one = f._shape(x)
+        f._ensure(_torch_np_dtype(x.dtype), nch)
+        cnt = max(f.next_output_count(m), 0)
+        ys.append(torch.empty((nch, cnt), dtype=_np_torch_dtype(f.output_dtype), device=x.device))
+        shapes.append((m, cnt, one))
+    hs = (C.c_void_p * n)(*[f._handle.value for f in filters])
+    xp = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    yp = (C.c_void_p * n)(*[y.data_ptr() for y in ys])
+    xl = (C.c_int64 * n)(*[s[0] for s in shapes])
+    yc = (C.c_int64 * n)(*[s[1] for s in shapes])
+    nw = (C.c_int64 * n)()
+    stream = torch.cuda.current_stream(xs[0].device).cuda_stream
+    _check(lib.mrhip_filt_device_multi(hs, n, xp, xl, yp, yc, nw, C.c_void_p(stream)))
+    out = []
+    for y, (m, cnt, one), got in zip(ys, shapes, nw):
+        assert got == cnt
+        out.append(y[0] if one else y)
+    return out
+
+
+class MultiStream:
+    """A fixed set of independent FIRFilter streams and their (fixed) device buffers, prepared once so that every
+    ``run()`` is ONE library call = one launch (``mrhip_filt_device_multi``): the per-round form of ``filt_multi`` for a
+    loop over arriving chunks that land in the same buffers.  ``ys[i]`` must hold ``filters[i].next_output_count`` of every
+    round (e.g. ``outputlength_bound``)."""
+
+    def __init__(self, filters, ys, xs):
+        self._lib = load_library()
+        self.filters, self.ys, self.xs = list(filters), list(ys), list(xs)
+        n = self.n = len(self.filters)
+        for f, x in zip(self.filters, self.xs):
+            nch, m, _ = f._shape(x)
+            f._ensure(_torch_np_dtype(x.dtype), nch)
+        self._hs = (C.c_void_p * n)(*[f._handle.value for f in self.filters])
+        self._xp = (C.c_void_p * n)(*[x.data_ptr() for x in self.xs])
+        self._yp = (C.c_void_p * n)(*[y.data_ptr() for y in self.ys])
+        self._xl = (C.c_int64 * n)(*[x.shape[-1] for x in self.xs])
+        self._yc = (C.c_int64 * n)(*[y.shape[-1] for y in self.ys])
+        self.counts = (C.c_int64 * n)()
+
+    def run(self):
+        stream = torch.cuda.current_stream(self.xs[0].device).cuda_stream
+        _check(self._lib.mrhip_filt_device_multi(self._hs, self.n, self._xp, self._xl, self._yp, self._yc, self.counts, C.c_void_p(stream)))
+        return self.counts
 
 
 # ---- free functions with the reference's names -------------------------------------------------

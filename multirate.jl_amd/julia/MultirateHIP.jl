@@ -383,6 +383,19 @@ end
 sethistorydevice!(f::FIRFilter, histptr::Ptr{Cvoid}; stream::Ptr{Cvoid} = C_NULL) =
     check(ccall((:mrhip_set_history_device, libmr), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), f.handle, histptr, stream))
 
+# n INDEPENDENT FIRFilter objects (each its own phase, deficit, history and call length: README.md:87-141) in ONE launch
+# (mrhip_filt_device_multi).  xptrs[i] / yptrs[i]: device pointers, one channel per column, column stride = xlens[i] / ycaps[i].
+function filt_device_multi!(fs::Vector{<:FIRFilter}, yptrs::Vector{Ptr{Cvoid}}, ycaps::Vector{Int64}, xptrs::Vector{Ptr{Cvoid}},
+                            xlens::Vector{Int64}; stream::Ptr{Cvoid} = C_NULL)
+    n = length(fs)
+    hs = Ptr{Cvoid}[f.handle for f in fs]
+    nw = zeros(Int64, n)
+    check(ccall((:mrhip_filt_device_multi, libmr), Cint,
+                (Ptr{Ptr{Cvoid}}, Cint, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}),
+                hs, n, xptrs, xlens, yptrs, ycaps, nw, stream))
+    nw
+end
+
 # The streaming loop `for each chunk: filt!(view(y, k+1:...), f, view(x, a+1:a+chunk))` over a device-resident signal,
 # issued by the library in one call (mrhip_filt_device_chunked): same outputs, same end state.
 function filt_device_chunked!(f::FIRFilter, yptr::Ptr{Cvoid}, ycap::Integer, ystride::Integer, xptr::Ptr{Cvoid}, xlen::Integer,

@@ -103,7 +103,7 @@ DEFAULT_ROWS = ["c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5", "x160", "xf6
 # what bench.py reports next to the headline: every BASELINE config on one GPU, the README's mixed precision, the reference's
 # own FIRArbitrary / FIRFarrow benchmark shape
 # (the BASELINE rows LAST: the driver's record keeps the END of the line)
-BENCH_ROWS = ["xarb", "af", "xmix64", "c2", "c3a", "c3b", "c4", "c4f", "c5"]
+BENCH_ROWS = ["xarb", "af", "ms", "xmix64", "c2", "c3a", "c3b", "c4", "c4f", "c5"]
 
 
 def rows(which):
@@ -180,7 +180,56 @@ def rows(which):
                     run(f"AF {kind} rate {rate:.9g} {str(dt).replace('torch.', '')} 1ch x 1e7 (Arb-Farrow Speed Comparison.jl shape)", haf, float(rate), 32, 1,
                         10_000_000, dt, sb + ob * rate, fl, reps=2, polyorder=po)
 
-    table = {"c1": _c1, "c2": _c2, "c2s": _c2s, "c3a": _c3a, "c3b": _c3b, "c4": _c4, "c4f": _c4f, "c5": _c5, "x160": _x160, "xf64": _xf64, "xmix": _xmix, "xstd": _xstd, "x32": _x32, "xc32": _xc32, "xarb": _xarb, "xmix64": _xmix64, "af": _af}
+    def _ms():
+        # the north star's "one-channel-per-stream": 64 INDEPENDENT single-channel FIRFilters (README.md:87-141: one object per
+        # signal), chunks of about 1e6 samples of UNEQUAL lengths arriving round after round, one launch per round
+        # (mrhip_filt_device_multi) -- against one launch per stream and round (the plain loop)
+        ns, rounds = 64, 5
+        rng = np.random.default_rng(1)
+        lens = [int(v) for v in rng.integers(900_000, 1_100_000, size=ns)]
+        fs = [pkg.FIRFilter(h147, Fraction(147, 160), device=dev.index or 0, numerics=pkg.NUMERICS_FUSED if FUSED else pkg.NUMERICS_STRICT).bind(np.float32, 1) for _ in range(ns)]
+        xs = [torch.rand((1, n_), device=dev, dtype=torch.float32) for n_ in lens]
+        for i, f in enumerate(fs):                       # every stream somewhere else in its phase cycle
+            f.filt(xs[i][:, :1000 + 13 * i])
+        ys = [torch.empty((1, f.outputlength_bound(n_)), device=dev, dtype=torch.float32) for f, n_ in zip(fs, lens)]
+        total = float(sum(lens))
+        for label, multi in (("one launch per round (mrhip_filt_device_multi)", True), ("one launch per stream and round (plain loop)", False)):
+            ms = pkg.MultiStream(fs, ys, xs)
+            def go():
+                if multi:
+                    ms.run()
+                else:
+                    for f, y, x in zip(fs, ys, xs):
+                        f.filt_into(y, x)
+            go(); go()
+            for f in fs:
+                f.set_timing(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(rounds):
+                go()
+            torch.cuda.synchronize()
+            wall_ms = (time.perf_counter() - t0) * 1e3 / rounds
+            ms_k, nl = 0.0, 0
+            for f in fs:
+                a, b = f.timing_read()
+                nl += a; ms_k += b
+                f.set_timing(False)
+            per = ms_k / rounds
+            gb = total * 7.675 / 1e9
+            EMIT(json.dumps({"config": f"MS 64 independent 147//160 f32 streams x ~1e6-sample chunks of unequal lengths, {label}", "kernel": fs[0].last_kernel_name(),
+                             "numerics": "fused" if FUSED else "strict", "channels": ns, "samples_per_channel": int(total / ns),
+                             "kernel_ms_per_pass": round(per, 4), "wall_ms_per_pass_incl_host": round(wall_ms, 3), "launches_per_pass": nl // rounds,
+                             "Msamples_per_s_in": round(total / (per * 1e-3) / 1e6, 1), "Msamples_per_s_in_wall": round(total / (wall_ms * 1e-3) / 1e6, 1),
+                             "algorithmic_GBps": round(gb / (per * 1e-3), 1), "frac_of_8TBps": round(gb / (per * 1e-3) / HBM_GBPS, 4),
+                             "frac_of_8TBps_wall": round(gb / (wall_ms * 1e-3) / HBM_GBPS, 4), "flops_per_input_sample": round(48 * R147, 2),
+                             "TFLOPs": round(total * 48 * R147 / (per * 1e-3) / 1e12, 2), "arith": "f32",
+                             "frac_of_strict_valu": round(total * 48 * R147 / (per * 1e-3) / 1e12 / (FMA_TF[False] / 2), 4),
+                             "frac_of_fma_valu": round(total * 48 * R147 / (per * 1e-3) / 1e12 / FMA_TF[False], 4)}))
+        for f in fs:
+            f.close()
+
+    table = {"ms": _ms, "c1": _c1, "c2": _c2, "c2s": _c2s, "c3a": _c3a, "c3b": _c3b, "c4": _c4, "c4f": _c4f, "c5": _c5, "x160": _x160, "xf64": _xf64, "xmix": _xmix, "xstd": _xstd, "x32": _x32, "xc32": _xc32, "xarb": _xarb, "xmix64": _xmix64, "af": _af}
     for name in which:                # in the order asked for (bench.py wants the BASELINE rows last)
         table[name]()
 

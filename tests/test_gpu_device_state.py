@@ -217,3 +217,45 @@ def test_async_call_needs_room_for_the_bound(pkg, torch_cuda):
     f.filt_into_async(torch.empty(600, dtype=torch.float32, device="cuda"), x)
     assert f.sync_state() == 600
     f.close()
+
+
+def test_independent_streams_in_one_launch(pkg, O, torch_cuda):
+    """mrhip_filt_device_multi: 64 INDEPENDENT single-channel FIRFilter objects (the reference's one-FIRFilter-per-signal
+    streaming usage, README.md:87-141) with different phases, deficits, histories and chunk lengths, filtered by ONE
+    launch per round of chunks; every stream bit-equal to its own oracle, round after round, state and history included.
+    Streams with two channels, a stream too short for an output and the mixed-shape fallback ride along."""
+    torch = torch_cuda
+    L, M, ns = 147, 160, 64
+    h = pkg.firdes(24 * L, 0.5 / L, beta=7.8562).astype(np.float32)
+    rng = np.random.default_rng(64)
+    nchs = [2 if i % 9 == 4 else 1 for i in range(ns)]
+    fs = [pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nchs[i]) for i in range(ns)]
+    fos = [[O.FIRFilter(h, Fraction(L, M), tx=np.float32) for _ in range(nchs[i])] for i in range(ns)]
+    # every stream starts somewhere else: a first plain call of its own length
+    for i, f in enumerate(fs):
+        x0 = rng.standard_normal((nchs[i], 1000 + 37 * i)).astype(np.float32)
+        y0 = f.filt(torch.from_numpy(x0).cuda()).cpu().numpy()
+        for c in range(nchs[i]):
+            assert_bit_equal(y0[c], fos[i][c].filt(x0[c]), f"first call, stream {i}")
+    for rnd in range(3):
+        lens = [int(rng.integers(20_000, 60_000)) for _ in range(ns)]
+        lens[7] = 3 if rnd == 1 else lens[7]                   # a chunk of three samples: sometimes no output at all
+        xs_h = [rng.standard_normal((nchs[i], lens[i])).astype(np.float32) for i in range(ns)]
+        xs = [torch.from_numpy(x).cuda() for x in xs_h]
+        ys = pkg.filt_multi(fs, xs)
+        assert fs[0].last_kernel_name() == "rational_opair_kernel"
+        for i in range(ns):
+            for c in range(nchs[i]):
+                assert_bit_equal(ys[i].cpu().numpy()[c], fos[i][c].filt(xs_h[i][c]), f"round {rnd} stream {i} channel {c}")
+            st, so = fs[i].state, fos[i][0].state
+            assert (st.phiIdx, st.inputDeficit) == (so.phiIdx, so.inputDeficit), (rnd, i)
+            assert_bit_equal(fs[i].history.reshape(nchs[i], -1)[0], fos[i][0].history, f"history of stream {i}")
+    # filters that do not agree (another ratio): the plain loop of single calls behind the same entry
+    g = pkg.FIRFilter(h[:96], Fraction(3, 2)).bind(np.float32, 1)
+    go = O.FIRFilter(h[:96], Fraction(3, 2), tx=np.float32)
+    xa, xb = rng.standard_normal(5000).astype(np.float32), rng.standard_normal(4000).astype(np.float32)
+    ya, yb = pkg.filt_multi([fs[0], g], [torch.from_numpy(xa[None, :]).cuda(), torch.from_numpy(xb).cuda()])
+    assert_bit_equal(ya.cpu().numpy()[0], fos[0][0].filt(xa), "fallback, stream 0")
+    assert_bit_equal(yb.cpu().numpy(), go.filt(xb), "fallback, other ratio")
+    for f in fs + [g]:
+        f.close()

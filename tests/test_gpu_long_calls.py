@@ -96,3 +96,39 @@ def test_call_longer_than_2_31_samples(pkg, O, torch_cuda):
     f.close()
     del x, y
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("nch", [1, 5])
+def test_farrow_pieces_of_a_split_call_do_not_restart_the_seam(pkg, O, torch_cuda, monkeypatch, nch):
+    """FIRFarrow's dot is the Vector seam variant (support.jl:46: starts from zero) for the first tapsPerPhi-1
+    inputs of a CALL; the pieces mrhip_filt_device cuts a long call into continue that call, so their first outputs must not
+    start from zero again -- visible only as the sign of an all-(-0.0) sum: positive taps (a constant polynomial bank), -0.0
+    samples across every piece seam.  One channel: farrow_wave_kernel; five: farrow_pipe_kernel."""
+    torch = torch_cuda
+    monkeypatch.setenv("MRHIP_LAUNCH_MAX", "4099")
+    Nphi, T = 8, 6
+    h = np.ones(Nphi * T, dtype=np.float64)
+    n = 20_011
+    x = np.full((nch, n), -0.0, dtype=np.float64)
+    x[:, 15_000:] = np.random.default_rng(4).standard_normal((nch, n - 15_000))
+    f = pkg.FIRFilter(h, 0.9, Nphi, 2).bind(np.float64, nch)
+    fo = O.FIRFilter(h, 0.9, Nphi, tx=np.float64, polyorder=2, pnfb=f.pnfb())
+    y = f.filt(torch.from_numpy(x).cuda()).cpu().numpy()
+    yo = fo.filt(x[nch - 1])                                # ONE reference call
+    assert_bit_equal(y[nch - 1], yo, "split FIRFarrow call")
+    assert np.signbit(yo[T + 5:5000]).all() and not np.signbit(yo[:T - 1]).any()       # -0 past the call's own seam, +0 on it
+    assert f.last_kernel_name() == ("farrow_wave_kernel" if nch < 4 else "farrow_pipe_kernel")
+    f.close()
+
+
+def test_launch_pieces_keep_inputs_and_outputs_below_2_31(pkg, torch_cuda):
+    """a FIRRational with L > M writes more than it reads: the per-launch step of a split call must bound the
+    OUTPUTS too (5//2 with 2^30 inputs per launch would have indexed 2.7e9 outputs in 31 bits).  Plan-level: the bound of a
+    one-launch call (mrhip_outputlength_bound of the largest x_len a single launch takes) stays below 2^31 for every kind."""
+    h = np.ones(20, dtype=np.float32)
+    for ratio in (Fraction(5, 2), Fraction(441, 160), Fraction(7, 1), Fraction(2, 5), Fraction(1, 1)):
+        f = pkg.FIRFilter(h, ratio).bind(np.float32, 1)
+        L, M = ratio.numerator, ratio.denominator
+        step = (1 << 30) * M // L if L > M else 1 << 30
+        assert f.outputlength_bound(step) < 2 ** 31, (ratio, f.outputlength_bound(step))
+        f.close()
