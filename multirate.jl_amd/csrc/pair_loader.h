@@ -64,6 +64,7 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
     // across tiles (their barrier carries no memory wait).
     // Stages one tile; returns the number of LDS-DMA operations it left in flight (0 for the
     // checked register path, which drains everything before returning).
+    const unsigned pad_magic = pa.pad_every > 0 ? 0xffffffffu / static_cast<unsigned>(pa.pad_every + 1) + 1u : 0u;   // ceil(2^32 / (cd + 1)) (cd + 1 is no power of two's divisor issue: cd + 1 >= 3 odd)
     auto stage_tile = [&](const TileAt &ta, int stage) -> int {
         const int sch = ta.ch;
         constexpr int EPC = 4 / NC;                                 // samples per 16-byte DMA chunk
@@ -83,7 +84,10 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
             for (int slot = 0; slot < nslots; ++slot) {
                 const int ci = slot * 64 + lane;
                 int d = ci;
-                if (cd > 0) { const int g = ci / (cd + 1), r = ci - g * (cd + 1); d = r == cd ? 0 : g * cd + r; }
+                // (the pad period is a run-time value: a multiply-high by ceil(2^32 / (cd + 1)), exact for ci < 2^16, instead of
+                //  an integer division per lane and slot -- ~40 VALU instructions each, on the SIMD the loader shares with a
+                //  compute wave: a third of C3b's VALU instructions were this, profiles/r04/item7/)
+                if (cd > 0) { const int g = static_cast<int>(__umulhi(static_cast<unsigned>(ci), pad_magic)), r = ci - g * (cd + 1); d = r == cd ? 0 : g * cd + r; }
                 const int cis = d < nchunks ? d : 0;                     // pad chunks and padding lanes re-read chunk 0
                 dma16(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
             }

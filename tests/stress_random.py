@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--arb", type=float, default=None, help="fraction of FIRArbitrary / FIRFarrow cases (default 0.15)")
+    ap.add_argument("--async-mix", type=float, default=0.0, help="fraction of the tuned filter's calls issued through filt_into_async "
+                    "(planned on the device from the device-resident stream state; counts collected once per case)")
     ap.add_argument("--big", action="store_true", help="long launches: 32-96 channels x 0.5-4e6 samples, ratios the pair kernels take "
                     "(dynamic scheduling, two-stage tiles)")
     args = ap.parse_args()
@@ -114,8 +116,32 @@ def main():
             os.environ.pop("MRHIP_FORCE_GENERIC", None)
             f = mk()
             outs, pos = [], 0
-            for s_ in sizes:
-                outs.append(f.filt(xd[:, pos:pos + s_])); pos += s_
+            if args.async_mix > 0.0 and n > 0:
+                # a mix of plain calls and calls nobody waits for: the latter leave their counts in a device array; the
+                # host-side view of the state is stale in between and must be re-read by the next plain call
+                f.bind(np.dtype(tx), nch)
+                cnt = torch.full((len(sizes),), -1, dtype=torch.int64, device="cuda")
+                pend = []
+                tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+                       np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}[np.dtype(f.output_dtype)]
+                for i_, s_ in enumerate(sizes):
+                    if rng.random() < args.async_mix:
+                        yb = torch.empty((nch, f.outputlength_bound(s_)), dtype=tdt, device="cuda")
+                        f.filt_into_async(yb, xd[:, pos:pos + s_], cnt[i_:i_ + 1])
+                        pend.append((len(outs), i_, yb))
+                        outs.append(None)
+                    else:
+                        outs.append(f.filt(xd[:, pos:pos + s_]))
+                    pos += s_
+                f.sync_state()
+                c_ = cnt.cpu().tolist()
+                for slot, i_, yb in pend:
+                    outs[slot] = yb[:, :max(c_[i_], 0)] if s_ >= 0 else yb[:, :0]
+                    if sizes[i_] == 0:
+                        outs[slot] = yb[:, :0]
+            else:
+                for s_ in sizes:
+                    outs.append(f.filt(xd[:, pos:pos + s_])); pos += s_
             y = torch.cat(outs, dim=-1).cpu().numpy()
             kname = f.last_kernel_name()
             os.environ["MRHIP_FORCE_GENERIC"] = "1"
