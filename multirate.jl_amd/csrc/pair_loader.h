@@ -28,6 +28,9 @@ __device__ __forceinline__ TileAt pair_tile_at(const PairArgs &pa, unsigned g, u
 // walk come from the record the call's plan kernel filled; the kernel arguments hold upper bounds the launch was sized with.
 __device__ __forceinline__ void pair_take_dyn(PolyArgs &a, PairArgs &pa)
 {
+#ifdef MRHIP_NO_TAKE_DYN        // (A/B builds only: profiles/r04/experiments.md A)
+    return;
+#endif
     if (a.multi) {
         // several independent streams in one launch: this workgroup belongs to stream blockIdx.x % multi_n (= its scheduling
         // group: pa.ngroups == multi_n, grabs dealt round-robin among the stream's workgroups) and to nobody else
