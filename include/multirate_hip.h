@@ -254,7 +254,8 @@ int mrhip_filt_device_async(mrhip_filter *f, const void *x, int64_t x_len, int64
                             int64_t y_capacity, int64_t y_stride, int64_t *count_out, void *stream);
 /* filt!(buffer_i, self_i, x_i) for i = 0..n-1 -- n INDEPENDENT FIRFilter objects, each with its own phase, input deficit,
  * history and call length, the reference's one-FIRFilter-per-signal streaming usage (README.md:87-141) -- issued as ONE
- * launch when the filters agree in kind (FIRRational / FIRInterpolator), ratio, tapsPerPhi, dtypes, numerics and device:
+ * launch when the filters agree in kind (the rational family: FIRStandard, FIRDecimator, FIRInterpolator, FIRRational), ratio,
+ * tapsPerPhi, dtypes, numerics and device:
  * every workgroup of the launch works for one of the streams.  x[i] / y[i] are device pointers, channel c of filter i at
  * x[i] + c*x_len[i] and y[i] + c*y_capacity[i]; n_written[i] (optional) receives filter i's per-channel count.  Results,
  * states and histories are exactly those of n mrhip_filt_device calls, which is also what runs when the filters do not agree

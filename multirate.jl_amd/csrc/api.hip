@@ -561,12 +561,42 @@ int64_t mrhip_advance_state(mrhip_filter *f, int64_t n)
     if (stream_is_capturing(s)) { (void)fail(MRHIP_ERR_UNSUPPORTED, "advance_state while the filter's stream is being captured"); return -1; }
     int64_t total;
     if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {
-        ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
-        total = run_arbitrary_schedule(st, f->delta, f->Nphi, n, nullptr, nullptr);    // (count only: no entries kept)
-        f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;   // Filters.jl:731-735
-        f->inputDeficit = st.inputDeficit;
+        // The recurrence of update() (Filters.jl:663-673) over n samples, count and end state only.  Long stretches go through
+        // the device-evaluated schedule (the same kernels a filt! call runs, without the filter kernel), launch-sized piece
+        // by piece: 1e8 outputs in a few ms instead of 0.13 s of the host's serial loop (time sharding enters a stream at
+        // its first sample this way, sharding.py); short ones, and rates the device evaluation does not cover, keep the loop.
+        total = 0;
+        int64_t left = n;
+        const int64_t step = std::max<int64_t>(4096, static_cast<int64_t>(static_cast<double>(1LL << 24) / f->rate));
+        while (left > 0) {
+            const int64_t len = std::min(left, step);
+            const int64_t est = len >= f->inputDeficit ? static_cast<int64_t>(std::ceil(static_cast<double>(len - f->inputDeficit + 1) * f->rate)) + 2 : 0;
+            ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
+            int64_t got = 0;
+            if (sched_wants_device(f, est) && f->s_sched) {
+                SchedOut so{};
+                so.buf = f->flip; f->flip ^= 1;
+                if (f->ev_filt_valid[so.buf] && hipStreamWaitEvent(f->s_sched, f->ev_filt[so.buf], 0) != hipSuccess) return -1;
+                if (sched_enqueue(f, len, est, INT64_MAX, nullptr, true, f->s_sched, &so)) return -1;
+                for (;;) {
+                    bool relaunch = false;
+                    if (sched_collect(f, len, est, INT64_MAX, nullptr, f->s_sched, &so, &relaunch)) return -1;
+                    if (!relaunch) break;
+                }
+                got = so.count; st = so.end;
+                f->sched_drift = so.drift; f->sched_ksteps = so.ksteps;
+                if (so.periodic || f->per_valid) f->per_pos = so.per_pos_end;
+                f->memo_valid = false;                      // (the entries in the buffer belong to a call that was never made)
+            } else {
+                got = run_arbitrary_schedule(st, f->delta, f->Nphi, len, nullptr, nullptr);    // (count only: no entries kept)
+                sched_forget(f);
+            }
+            f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;   // Filters.jl:731-735
+            f->inputDeficit = st.inputDeficit;
+            total += got;
+            left -= len;
+        }
         f->sched_cached = false;
-        sched_forget(f);
     } else {
         const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, n);
         f->phiIdx = p.phi_end;                                              // Filters.jl:515-516, 571-572, 647-648
@@ -1284,8 +1314,9 @@ int mrhip_filt_device_async(mrhip_filter *f, const void *x, int64_t x_len, int64
 // the call length and therefore the state).  One launch per stream cannot fill 256 CUs (a 1e6-sample chunk of one channel
 // is all launch ramp: 6-7 % of the HBM roofline); here the streams of one launch are the scheduling groups of the pair
 // kernel: every workgroup works for one stream and takes that stream's signal, history, taps, record, lengths and
-// call-start state from a descriptor (MultiDesc, pair_loader.h: pair_take_dyn).  FIRRational / FIRInterpolator on the
-// output-pair kernel; anything else is the plain loop of single calls (same results).
+// call-start state from a descriptor (MultiDesc, pair_loader.h: pair_take_dyn).  The rational family on its two pair kernels
+// (FIRRational / FIRInterpolator: rational_opair_kernel, FIRStandard / FIRDecimator: fir_stream_kernel); anything else is the
+// plain loop of single calls (same results).
 int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *const *x, const int64_t *x_len, void *const *y,
                             const int64_t *y_capacity, int64_t *n_written, void *stream_)
 {
@@ -1302,7 +1333,7 @@ int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *con
         }
         return MRHIP_OK;
     };
-    bool same = (f0->kind == MRHIP_FIR_RATIONAL || f0->kind == MRHIP_FIR_INTERPOLATOR) && !f0->force_generic && n > 1 && n <= 4096;
+    bool same = !(f0->kind == MRHIP_FIR_ARBITRARY || f0->kind == MRHIP_FIR_FARROW) && !f0->force_generic && n > 1 && n <= 4096;
     for (int i = 0; i < n && same; ++i) {
         const mrhip_filter *f = filters[i];
         if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
@@ -1333,13 +1364,15 @@ int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *con
     PolyArgs a{};
     a.x = x[0]; a.y = y[0]; a.hist = f0->d_hist[f0->hist_cur]; a.hist_new = f0->d_hist[f0->hist_cur ^ 1]; a.taps = f0->d_taps;
     a.x_stride = x_len_max; a.y_stride = n_out_max; a.x_len = x_len_max; a.n_out = n_out_max;
-    a.u0 = 0; a.d0 = 1; a.zero_start_below = 0;
+    a.u0 = 0; a.d0 = 1;
+    a.zero_start_below = f0->kind == MRHIP_FIR_STANDARD ? f0->hLen + 1 : f0->kind == MRHIP_FIR_DECIMATOR ? f0->hLen : 0;   // support.jl:46 (per call: every stream's call starts here)
     a.L = static_cast<int>(f0->L); a.M = static_cast<int>(f0->M); a.T = static_cast<int>(f0->T); a.H = static_cast<int>(f0->H);
     a.nch = static_cast<int>(std::min<int64_t>(nch_total, 0x7fffffff));
     PairArgs pa;
     dim3 block;
     size_t lds = 0;
-    if (!plan_rational_opair(tk, a, f0->num_cus, &pa, &block, &lds)) return single_calls();
+    const bool column = f0->L == 1;                                  // FIRStandard / FIRDecimator: the streaming single-column kernel
+    if (!(column ? plan_fir_stream(tk, a, f0->num_cus, &pa, &block, &lds) : plan_rational_opair(tk, a, f0->num_cus, &pa, &block, &lds))) return single_calls();
     // descriptors: pinned staging -> device, owned by the first filter of the call
     const size_t bytes = static_cast<size_t>(n) * sizeof(MultiDesc);
     if (bytes > f0->multi_cap) {
@@ -1379,7 +1412,8 @@ int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *con
     a.multi = static_cast<const MultiDesc *>(f0->multi_dev); a.multi_n = n;
     pa.total_steps = steps_max;                                     // (sizes the grid: workgroups per stream <= tiles of the longest)
     if (int rc = timing_mark(f0, stream)) return rc;
-    MRHIP_CHECK_HIP(launch_rational_opair(fused, a, pa, block, lds, stream, &f0->last_kernel, f0->num_cus, f0->d_counters));
+    if (column) MRHIP_CHECK_HIP(launch_fir_stream(fused, a, pa, block, lds, stream, &f0->last_kernel, f0->num_cus, f0->d_counters));
+    else MRHIP_CHECK_HIP(launch_rational_opair(fused, a, pa, block, lds, stream, &f0->last_kernel, f0->num_cus, f0->d_counters));
     if (int rc = timing_mark(f0, stream)) return rc;
     for (int i = 0; i < n; ++i) {                                    // the kernel filed every stream's end state and history
         mrhip_filter *f = filters[i];

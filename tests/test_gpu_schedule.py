@@ -198,3 +198,27 @@ def test_late_group_of_the_last_piece_still_writes_its_entries(pkg, torch_cuda, 
         assert info["device_pieces"] > 0 and info["fallback_pieces"] == 0, info
         assert torch.equal(yd.view(torch.int32), yh.view(torch.int32))
     fd.close(); fh.close()
+
+
+@pytest.mark.parametrize("rate", [math.pi / 3, 0.26, 3.0])
+def test_advance_state_over_long_stretches_uses_the_device_schedule(pkg, torch_cuda, monkeypatch, rate):
+    """mrhip_advance_state for FIRArbitrary: 6e7 samples through the device-evaluated schedule (launch-sized pieces, no filter
+    kernel) == the host's serial loop (MRHIP_SCHED_DEVICE=0), count and end state; and a filter entered there produces what
+    the one that filtered its way there produces."""
+    torch = torch_cuda
+    h = np.random.default_rng(5).standard_normal(96).astype(np.float32)
+    n = 60_000_000
+    monkeypatch.setenv("MRHIP_SCHED_DEVICE", "0")
+    fh = pkg.FIRFilter(h, rate, 32).bind(np.float32, 1)
+    ch = fh.advance_state(n)
+    monkeypatch.delenv("MRHIP_SCHED_DEVICE")
+    fd = pkg.FIRFilter(h, rate, 32).bind(np.float32, 1)
+    cd = fd.advance_state(n)
+    assert cd == ch
+    sd, sh = fd.state, fh.state
+    assert (sd.phiAccumulator, sd.inputDeficit, sd.phiIdx) == (sh.phiAccumulator, sh.inputDeficit, sh.phiIdx)
+    info = fd.schedule_info()
+    assert info["device_pieces"] > 0 or info["periodic_steps"] > 0, info
+    x = torch.rand(100_000, device="cuda", dtype=torch.float32) - 0.5
+    assert torch.equal(fd.filt(x).view(torch.int32), fh.filt(x).view(torch.int32))
+    fd.close(); fh.close()
