@@ -93,11 +93,16 @@ size_t y_elt(const mrhip_filter *f) { return dtype_size(f->ty); }
 
 // upload taps (tap dtype on the host) as R-typed device array; f32 -> f64 widening is exact and is
 // what Julia's promotion does on every multiply (Real*Real / Real*Complex methods).
-int upload_taps(mrhip_filter *f, const std::vector<unsigned char> &src, void **dptr)
+// The vector sits between two runs of kTapPad zero elements: fir_stream_rt_kernel reads whole blocks of taps around the
+// ends of a window (it discards what the out-of-window ones produce) without a clamp per tap.
+int upload_taps(mrhip_filter *f, const std::vector<unsigned char> &src, void **dptr, void **alloc)
 {
     const size_t n = src.size() / dtype_scalar_size(f->th);
-    const size_t bytes = std::max<size_t>(n * r_size(f), 16);
-    MRHIP_CHECK_HIP(hipMalloc(dptr, bytes));
+    const size_t pad = static_cast<size_t>(mrhip::kTapPad) * r_size(f);
+    const size_t bytes = std::max<size_t>(n * r_size(f), 16) + 2 * pad;
+    MRHIP_CHECK_HIP(hipMalloc(alloc, bytes));
+    MRHIP_CHECK_HIP(hipMemset(*alloc, 0, bytes));
+    *dptr = static_cast<unsigned char *>(*alloc) + pad;
     if (f->r_f64 && f->th == MRHIP_F32) {
         std::vector<double> w(n);
         const float *s = reinterpret_cast<const float *>(src.data());
@@ -205,10 +210,6 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
                 *did_shiftin = a.H > 0;          // its loader waves write the call-end history themselves
                 return launch_fir_stream(fused, a, spa, sblock, slds, s, kname, f->num_cus, counters);
             }
-            DirectArgs da;
-            size_t lds = 0;
-            if (plan_fir_direct(tk, a, f->num_cus, &da, &lds))
-                return launch_fir_direct(tk, fused, a, da, lds, s, kname, f->num_cus);
         }
         {
             PairArgs pa;
@@ -303,7 +304,7 @@ int mrhip_create_rational(const void *h, int64_t hLen, int th, int64_t num, int6
         f->h_taps.resize(static_cast<size_t>(f->T) * L * es);
         taps2pfb(h, hLen, th, L, f->h_taps.data());
     }
-    int rc = upload_taps(f, f->h_taps, &f->d_taps);
+    int rc = upload_taps(f, f->h_taps, &f->d_taps, &f->d_taps_alloc);
     if (!rc) rc = alloc_common(f);
     if (rc) { mrhip_destroy(f); return rc; }
     *out = f;
@@ -347,8 +348,8 @@ int mrhip_create_arbitrary(const void *h, int64_t hLen, int th, double rate, int
     taps2pfb(h, hLen, th, Nphi, f->h_taps.data());
     taps2pfb(dh.data(), hLen, th, Nphi, f->h_dtaps.data());
 
-    int rc = upload_taps(f, f->h_taps, &f->d_taps);
-    if (!rc) rc = upload_taps(f, f->h_dtaps, &f->d_dtaps);
+    int rc = upload_taps(f, f->h_taps, &f->d_taps, &f->d_taps_alloc);
+    if (!rc) rc = upload_taps(f, f->h_dtaps, &f->d_dtaps, &f->d_dtaps_alloc);
     if (!rc) rc = alloc_common(f);
     if (rc) { mrhip_destroy(f); return rc; }
     sched_configure(f);
@@ -470,7 +471,7 @@ void mrhip_destroy(mrhip_filter *f)
     (void)drain_filter(f);                       // this filter's work only; other streams of the process keep running
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
         if (st) (void)hipStreamSynchronize(st);
-    for (void *p : {f->d_taps, f->d_dtaps, static_cast<void *>(f->d_pnfb), static_cast<void *>(f->d_pnfb_t), f->d_hist[0], f->d_hist[1], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc,
+    for (void *p : {f->d_taps_alloc, f->d_dtaps_alloc, static_cast<void *>(f->d_pnfb), static_cast<void *>(f->d_pnfb_t), f->d_hist[0], f->d_hist[1], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc,
                     f->d_xbuf[0], f->d_xbuf[1], f->d_ybuf[0], f->d_ybuf[1]})
         if (p) (void)hipFree(p);
     if (f->pin_n) (void)hipHostFree(f->pin_n);

@@ -1,13 +1,15 @@
-// kernels_fir_stream.hip -- FIRStandard (M = 1) and FIRDecimator (L = 1, M = 2..32, 40, 48, 50, 64; real Float32: every M up to 64 but 36 and 38), 2 to 16384 taps (as long as a tile fits the LDS),
-// with Float32 arithmetic (Float32 or ComplexF32 samples, Float32 taps) and Float64 arithmetic (Float64 or ComplexF64 samples,
-// or Float32 / ComplexF32 samples with Float64 taps): the streaming form of kernels_fir_direct.hip (BASELINE config 3b).  This file holds
-// the planning and the dispatch; the kernel is fir_stream_kernel.inc, instantiated by kernels_fir_stream_{f32,f64,mix}.hip.
+// kernels_fir_stream.hip -- FIRStandard (M = 1) and FIRDecimator (L = 1), 2 to 16384 taps (as long as a tile fits the LDS), with
+// Float32 arithmetic (Float32 or ComplexF32 samples, Float32 taps) and Float64 arithmetic (Float64 or ComplexF64 samples, or
+// Float32 / ComplexF32 samples with Float64 taps): BASELINE config 3b.  This file holds the planning and the dispatch.  Two
+// kernels share the mapping below: fir_stream_kernel.inc, instantiated per decimation M = 1..15 by
+// kernels_fir_stream_{f32,f64,mix}.hip, and fir_stream_rt_kernel (kernels_fir_stream_rt.hip), which takes M at run time
+// and serves every other decimation whose step fits the LDS.
 //
 // reference: src/Filters.jl:450-473 (Standard), :598-631 (Decimator); dot: src/support.jl:33-55.
 //
-// What was wrong with the direct kernel: it stages a tile synchronously (all threads load, barrier, compute, barrier)
-// through a transposed LDS layout and reads ONE sample per LDS instruction; it sat at 30-44 % of the multiply+add
-// rate.  Here the machinery of the rational kernel is reused (pair_loader.h): a loader wave streams tiles HBM -> LDS
+// (Rounds 1-3 also had fir_direct_kernel: a tile staged synchronously -- all threads load, barrier, compute, barrier --
+// through a transposed LDS layout, ONE sample per LDS instruction, 30-44 % of the multiply+add rate.  Retired in round 4:
+// nothing reaches it any more.)  Here the machinery of the rational kernel is reused (pair_loader.h): a loader wave streams tiles HBM -> LDS
 // with LDS-DMA one tile ahead, steps are handed out dynamically, shiftin! is fused.
 //
 // Mapping.  A lane owns two adjacent outputs 2l and 2l+1 of a step; their windows start 2lM and 2lM + M samples into
@@ -29,6 +31,7 @@
 // product initialises the accumulator, the start-from-zero quirk of the Vector seam variant, support.jl:46; FUSED:
 // explicit fma) => bit-identical results.
 #include "fir_stream_kernel.inc"
+#include "mrhip_filter.h"   // kTapPad
 
 namespace mrhip {
 
@@ -36,9 +39,10 @@ namespace mrhip {
 hipError_t launch_fir_stream_f32(int nc, bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_fir_stream_f64(int nc, bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_fir_stream_mix(int nc, bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
+hipError_t launch_fir_stream_rt(bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);   // kernels_fir_stream_rt.hip
 
-// Covers L == 1, M <= 32 or in {40, 48, 50, 64} (real Float32 samples and taps: every M <= 64 but 36 and 38), 2 <= T <= 16384, every sample type.  Returns false
-// otherwise (the caller falls back to kernels_fir_direct.hip).
+// Covers L == 1, 1 <= T <= 16384, every sample type, every M whose step of 128 outputs fits a stage (2 * M * bytes per sample
+// <= ~900; 8- and 16-byte samples: <= ~590, see below).  Returns false otherwise (the caller goes on to poly_tiled_kernel).
 bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {
     if (!stream_env_int("MRHIP_STREAM", 1)) return false;   // read per call: tests switch kernels at run time
@@ -47,10 +51,21 @@ bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs
     const int nc = tk.complex_x ? 2 : 1;
     const long long es = (tk.x_f64 ? 8 : 4) * nc;
     int pad_every = 0, min_taps = 0;   // (min_taps: one block of reads; shorter filters take the kernel's per-sample loop)
-    const bool f32a = !tk.r_f64 && !tk.complex_x;          // (real Float32 samples x Float32 taps: more decimations are instantiated)
-    if (a.M > 64 || !(es == 16 ? stream_geometry<16>(static_cast<int>(a.M), f32a, &pad_every, &min_taps)
-                      : es == 8 ? stream_geometry<8>(static_cast<int>(a.M), f32a, &pad_every, &min_taps) : stream_geometry<4>(static_cast<int>(a.M), f32a, &pad_every, &min_taps))) return false;
-    if (a.T < 2 || a.T > 16384) return false;   // (a tile must hold T samples: checked below)
+    const bool have_ct = a.M <= 64 && (es == 16 ? stream_geometry<16>(static_cast<int>(a.M), &pad_every, &min_taps)
+                                       : es == 8 ? stream_geometry<8>(static_cast<int>(a.M), &pad_every, &min_taps) : stream_geometry<4>(static_cast<int>(a.M), &pad_every, &min_taps));
+    // MRHIP_STREAM_RT: 0 = only the per-M instantiations, 1 = the run-time-M kernel where M is not instantiated, 2 = always
+    const int rt_mode = stream_env_int("MRHIP_STREAM_RT", 1);
+    const bool rt = rt_mode == 2 || (rt_mode == 1 && !have_ct);
+    if (!rt && !have_ct) return false;
+    int rt_rd = 16;
+    if (rt) {                                               // the geometry of StreamGeo, at run time
+        if (a.M < 1 || a.M + 16 > kTapPad) return false;    // (its blocks of tap reads stay inside the pads of the tap vector)
+        const long long S = 2 * a.M * es;
+        rt_rd = S % 16 ? 8 : 16;
+        const long long cd = rt_rd == 16 ? S / 16 : 0;
+        pad_every = cd >= 2 && cd % 2 == 0 ? static_cast<int>(cd) : 0;
+    }
+    if (a.T < 1 || a.T > 16384) return false;   // (a tile must hold T samples: checked below)
     // compute waves: 3 (+ loader = a 256-thread workgroup) unless overridden; a step is 2 outputs per lane
     int ncw = stream_env_int("MRHIP_STREAM_WAVES", 3);
     if (ncw < 1) ncw = 1;
@@ -76,6 +91,9 @@ bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs
     }
     const long long nslots = (lds_chunks(J) + 63) / 64;
     if (nslots > 60 || nslots * 1024 * ns > 150 * 1024) return false;
+    // One workgroup (= one compute wave at these sizes) per CU: 8- and 16-byte samples are then faster on poly_tiled_kernel
+    // (measured, profiles/r04/stream_rt_vs_per_m.txt: 1//38 ComplexF32 0.31 vs 0.25 ms); Float32 samples are not (1//80: 0.22 vs 0.46)
+    if (rt && es >= 8 && nslots * 1024 * ns + 64 > 78 * 1024 && stream_env_int("MRHIP_STREAM_RT_ONE_WG", 0) == 0) return false;
     const size_t stage_bytes = static_cast<size_t>(nslots) * 1024;
     PairArgs pa{};
     pa.c = ncw; pa.P = static_cast<int>(P); pa.cM = static_cast<int>(cM);
@@ -88,6 +106,7 @@ bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs
     pa.nc = nc;
     pa.x_f64 = tk.x_f64 ? 1 : 0; pa.r_f64 = tk.r_f64 ? 1 : 0;
     pa.pad_every = pad_every;
+    pa.rt = rt ? 1 : 0; pa.rt_rd = rt_rd;
     pa.bank_off = -1;
     pa.o0 = a.d0 - a.T;                      // x index of LDS sample 0 of a channel's first tile (negative => history)
     pa.tile_in = J * cM;
@@ -114,6 +133,10 @@ hipError_t launch_fir_stream(bool fused, const PolyArgs &a, const PairArgs &pa_i
     if (!counters) return hipErrorInvalidValue;
     PairArgs pa = pa_in;
     pa.counters = counters;
+    if (pa.rt) {
+        *kname = "fir_stream_rt_kernel";
+        return launch_fir_stream_rt(fused, block, lds, s, a, pa, num_cus);
+    }
     *kname = "fir_stream_kernel";
     if (pa.r_f64)
         return pa.x_f64 ? launch_fir_stream_f64(pa.nc, fused, block, lds, s, a, pa, num_cus) : launch_fir_stream_mix(pa.nc, fused, block, lds, s, a, pa, num_cus);

@@ -383,6 +383,7 @@ bool plan_phase_stationary(const TypeKey &tk, const PolyArgs &a, int num_cus, Ti
 #ifdef MRHIP_PS_FAST_BUILD
     if (a.T != 24) return false;
 #endif
+    if (MRHIP_ENV_INT("MRHIP_PS", 1) == 0) return false;   // (tests and A/B runs: take this kernel out of the dispatcher)
     if (a.T < 1 || a.T > 32) return false;
     if (a.L > kMaxThreads) return false;
     const int sw = (tk.x_f64 ? 2 : 1) * (tk.complex_x ? 2 : 1);

@@ -7,6 +7,11 @@
 // ---------------------------------------------------------------------------------------
 // the filter object
 // ---------------------------------------------------------------------------------------
+namespace mrhip {
+// zero elements either side of a device tap vector (api.hip upload_taps; kernels_fir_stream.hip plans against it)
+constexpr int kTapPad = 256;
+}
+
 struct mrhip_filter {
     int kind = 0, th = 0, tx = 0, ty = 0;
     int nc = 1;
@@ -19,7 +24,8 @@ struct mrhip_filter {
     int force_generic = 0;   // MRHIP_FORCE_GENERIC=1 in the environment: always use the universal kernels
 
     // device memory
-    void *d_taps = nullptr, *d_dtaps = nullptr;
+    void *d_taps = nullptr, *d_dtaps = nullptr;            // (inside d_taps_alloc / d_dtaps_alloc: kTapPad zero elements either side)
+    void *d_taps_alloc = nullptr, *d_dtaps_alloc = nullptr;
     double *d_pnfb = nullptr;              // FIRFarrow: polynomial filter bank on the device
     double *d_pnfb_t = nullptr;            // ... degree-major and padded to 32 taps, [polyorder+1][32] (farrow_wave_kernel; tapsPerPhi <= 32)
     std::vector<double> h_pnfb;            // ... and on the host, [T][polyorder+1]

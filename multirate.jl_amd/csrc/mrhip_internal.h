@@ -339,6 +339,8 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     int bank_off;                 // LDS byte offset of the tap bank staged by the compute waves before the first tile (-1: none;
                                   // the loader wave then joins one extra barrier before its first tile barrier)
     int static_grabs;             // 1: grabs are dealt round-robin without atomics (small launches)
+    int rt;                       // fir_stream: 1 = the run-time-decimation kernel (kernels_fir_stream_rt.hip), rt_rd = bytes per LDS read
+    int rt_rd;
     unsigned *counters;           // device: [g*64] next grab of group g, [ngroups*64] workgroups finished (re-arms all)
     unsigned spc_magic;           // floor(2^32 / steps_per_channel) (0xffffffff for 1): step number -> channel by multiply-high
     long long o0;            // d0 - T: x index of LDS sample 0 of tile 0 (negative => history)
@@ -351,14 +353,6 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
 
 // scheduling counters of the pair kernels: [g*64] for group g < 32 (256 bytes apart), [32*64] workgroups finished
 constexpr size_t kCounterBytes = 33 * 256;
-
-struct DirectArgs {          // tiling of the single-column kernel (kernels_fir_direct.hip)
-    int J;                   // steps of 256 outputs per tile
-    int tile_len;            // samples staged per tile
-    int row_pitch;           // samples per residue row of the transposed LDS tile
-    long long tiles_per_channel;
-    long long total_tiles;
-};
 
 struct ArbTileArgs {         // tiling of the FIRArbitrary kernel (kernels_arbitrary.hip)
     int cpl;                 // channels per lane (1, 2 or 4): a tile covers cpl channels
@@ -451,9 +445,6 @@ hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &
 bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_fir_stream(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                              const char **kname, int num_cus, unsigned *counters);   // FIRStandard / FIRDecimator, streaming form; also performs shiftin!
-bool plan_fir_direct(const TypeKey &tk, const PolyArgs &a, int num_cus, DirectArgs *out, size_t *lds);
-hipError_t launch_fir_direct(const TypeKey &tk, bool fused, const PolyArgs &a, const DirectArgs &da, size_t lds, hipStream_t s,
-                             const char **kname, int num_cus);
 bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_host, const int *spans, int num_cus, ArbTileArgs *out, size_t *lds);
 bool plan_arb_pipe(const TypeKey &tk, const ArbArgs &a, long long span256, ArbTileArgs *out, size_t *lds);
 hipError_t launch_arb_pipe(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,

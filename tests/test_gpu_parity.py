@@ -325,7 +325,8 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
              (9, 10, 200, np.float32, np.float32), (31, 32, 31 * 7, np.float32, np.float32), (5, 7, 33, np.float32, np.float32),
              (146, 147, 146 * 32, np.float32, np.float32), (147, 160, 147 * 24, np.float32, np.complex64),
              (9, 10, 200, np.float32, np.complex64), (5, 7, 33, np.float32, np.complex64), (1, 4, 128, np.float32, np.complex64), (1, 1, 300, np.float64, np.float64),
-             (1, 7, 129, np.float64, np.complex128), (1, 32, 1, np.float32, np.float32), (1, 5, 64, np.float64, np.float32),
+             (1, 7, 129, np.float64, np.complex128), (1, 32, 1, np.float32, np.float32), (1, 5, 64, np.float64, np.float32), (1, 1, 1, np.float32, np.complex64), (1, 3, 1, np.float64, np.float64),
+             (1, 24, 100, np.float32, np.complex64), (1, 100, 333, np.float32, np.float32),
              (1, 4, 128, np.float32, np.float32), (1, 1, 64, np.float32, np.complex64), (1, 2, 200, np.float32, np.float32),
              (1, 8, 131, np.float32, np.complex64), (1, 1, 300, np.float32, np.float32), (1, 4, 509, np.float32, np.complex64),
              (5, 1, 160, np.float32, np.float32), (3, 1, 17, np.float32, np.complex64), (7, 1, 50, np.float32, np.float32),
@@ -340,7 +341,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         f = pkg.FIRFilter(h, Fraction(L, M))
         y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_opair_kernel", "fir_direct_kernel", "fir_stream_kernel"), (L, M, hl)
+        assert f.last_kernel_name() in ("poly_phase_stationary_kernel", "rational_opair_kernel", "fir_stream_rt_kernel", "fir_stream_kernel"), (L, M, hl, f.last_kernel_name())
         tuned_seen.add(f.last_kernel_name())
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, Fraction(L, M))
@@ -349,7 +350,7 @@ def test_tuned_and_generic_kernels_agree(pkg, torch_cuda, monkeypatch):
         monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
         assert_bit_equal(y_t, y_g, f"tuned vs generic L={L} M={M} hLen={hl} {th} {tx}")
         assert_bit_equal(f.history, g.history, "history")
-    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_opair_kernel", "fir_direct_kernel", "fir_stream_kernel"}, tuned_seen
+    assert tuned_seen == {"poly_phase_stationary_kernel", "rational_opair_kernel", "fir_stream_rt_kernel", "fir_stream_kernel"}, tuned_seen
 
 
 def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
@@ -415,10 +416,11 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
 
 def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
     """fir_stream_kernel (FIRStandard / FIRDecimator, Float32 and Float64 arithmetic, loader-wave staging, padded LDS tile,
-    scalar taps): M = 1..32, 40, 48, 50, 64, tap counts 32..512 (whole blocks and ragged), Float32 and ComplexF32, STRICT and FUSED,
-    multi-channel, chunked with 1-sample pieces and pieces shorter than the history (the start-from-zero quirk of the
-    Vector seam variant, support.jl:46, applies to the first hLen outputs of EVERY call); inputs contain -0.0, +-Inf,
-    NaN.  Bit-exact against the universal kernel, the direct kernel it replaces, and the oracle."""
+    scalar taps; M = 1..15: one instantiation per decimation) and fir_stream_rt_kernel (the decimation at run time: the dispatcher's
+    choice from M = 16, forced with MRHIP_STREAM_RT=2 below it): M = 1..32, 40, 48, 50, 64, tap counts 2..512 (whole blocks and ragged),
+    Float32 and ComplexF32, STRICT and FUSED, multi-channel, chunked with 1-sample pieces and pieces shorter than the history (the
+    start-from-zero quirk of the Vector seam variant, support.jl:46, applies to the first hLen outputs of EVERY call); inputs contain
+    -0.0, +-Inf, NaN.  Bit-exact against each other, the universal kernel and the oracle."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     for M in list(range(1, 17)) + [17, 19, 20, 22, 24, 25, 27, 30, 31, 32, 40, 48, 50, 64]:
@@ -448,18 +450,18 @@ def test_stream_kernel_standard_and_decimator(pkg, O, torch_cuda, monkeypatch):
                     xd = torch.from_numpy(x).cuda()
                     sizes = [10_007, 1, 13, T // 2, 19_990, 40_009 - 10_007 - 1 - 13 - T // 2 - 19_990]
                     ys = {}
-                    for mode in ("stream", "direct", "generic"):
-                        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False); monkeypatch.delenv("MRHIP_STREAM", raising=False)
-                        if mode == "direct":
-                            monkeypatch.setenv("MRHIP_STREAM", "0")
+                    for mode in ("stream", "rt", "generic"):
+                        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False); monkeypatch.delenv("MRHIP_STREAM_RT", raising=False)
+                        if mode == "rt":
+                            monkeypatch.setenv("MRHIP_STREAM_RT", "2")
                         if mode == "generic":
                             monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
                         f = pkg.FIRFilter(h, Fraction(1, M), numerics=numerics)
                         y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
                         ys[mode] = (y, f.history.copy(), f.last_kernel_name(), (f.state.phiIdx, f.state.inputDeficit))
-                    monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False); monkeypatch.delenv("MRHIP_STREAM", raising=False)
-                    assert ys["stream"][2] == "fir_stream_kernel" and ys["direct"][2].startswith(("fir_direct", "poly_tiled")) and ys["generic"][2] == "poly_generic_kernel", (M, T, th, tx, ys["stream"][2], ys["direct"][2])
-                    for other in ("direct", "generic"):
+                    monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False); monkeypatch.delenv("MRHIP_STREAM_RT", raising=False)
+                    assert ys["stream"][2] == ("fir_stream_kernel" if M <= 15 else "fir_stream_rt_kernel") and ys["rt"][2] == "fir_stream_rt_kernel" and ys["generic"][2] == "poly_generic_kernel", (M, T, th, tx, ys["stream"][2], ys["rt"][2])
+                    for other in ("rt", "generic"):
                         assert_bit_equal(ys["stream"][0], ys[other][0], f"stream vs {other} M={M} T={T} {th} {tx} numerics={numerics}")
                         assert_bit_equal(ys["stream"][1], ys[other][1], "history")
                         assert ys["stream"][3] == ys[other][3]
@@ -489,6 +491,12 @@ def test_stream_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
         f = pkg.FIRFilter(h, Fraction(1, M))
         y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
         assert f.last_kernel_name() == "fir_stream_kernel", (M, T, f.last_kernel_name())
+        monkeypatch.setenv("MRHIP_STREAM_RT", "2")
+        r = pkg.FIRFilter(h, Fraction(1, M))
+        yr = torch.cat(_run_chunks(r, xd, sizes), dim=-1).cpu().numpy()
+        assert r.last_kernel_name() == "fir_stream_rt_kernel", (M, T, r.last_kernel_name())
+        monkeypatch.delenv("MRHIP_STREAM_RT", raising=False)
+        assert_bit_equal(y, yr, f"per-M vs run-time-M kernel M={M} T={T} {th} {tx}")
         monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
         g = pkg.FIRFilter(h, Fraction(1, M))
         yg = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
@@ -802,13 +810,13 @@ def test_chunked_streaming_entry_matches_caller_loop(pkg, torch_cuda):
 
 
 def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
-    """Filters the register-resident kernels do not take (tapsPerPhi > 64, > 48 for Float64 arithmetic, > 32 for complex samples with Float64 arithmetic, L > 512 phases, hLen > 512 with a decimation that is not instantiated) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
+    """Filters the register-resident kernels do not take (tapsPerPhi > 64, > 48 for Float64 arithmetic, > 32 for complex samples with Float64 arithmetic, L > 512 phases, a decimation whose step does not fit the streaming kernels' LDS stage) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
     across chunk seams, for every dtype combination, 1..35 channels (all channels-per-lane variants + ragged group)."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     cases = [(2, 3, 140, np.float32, np.float32, 35), (3, 2, 200, np.float32, np.complex64, 9), (147, 160, 147 * 70, np.float32, np.float32, 33),
              (2, 3, 100, np.float64, np.float64, 4),
-             (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 36, 700, np.float32, np.float32, 5),
+             (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 150, 700, np.float32, np.float32, 5),
              (1, 33, 600, np.float64, np.complex128, 2), (5, 64, 5 * 40, np.float64, np.float32, 32), (4, 7, 4 * 49, np.float32, np.float64, 1)]
     for (L, M, hl, th, tx, nch) in cases:
         h = rng.standard_normal(hl).astype(th)
@@ -1244,8 +1252,8 @@ def test_pipe_kernels_many_tiles_per_workgroup(pkg, O, torch_cuda, monkeypatch):
 
 
 def test_stream_kernel_decimations_33_to_63_real_float32(pkg, O, torch_cuda, monkeypatch):
-    """fir_stream_kernel's extra instantiations for real Float32 samples and taps (every decimation up to 64 except 36 and 38,
-    which stay on fir_direct_kernel like the ComplexF32 ones): against the oracle and the universal kernel, chunked."""
+    """Decimations 33..63 of real Float32 samples (rounds 2-3: extra instantiations of fir_stream_kernel, 36 and 38 on the retired
+    fir_direct_kernel; now all on fir_stream_rt_kernel): against the oracle and the universal kernel, chunked."""
     torch = torch_cuda
     rng = np.random.default_rng(3363)
     for M in (33, 35, 37, 44, 49, 52, 57, 63, 36, 38):
@@ -1258,7 +1266,7 @@ def test_stream_kernel_decimations_33_to_63_real_float32(pkg, O, torch_cuda, mon
             monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
             f = pkg.FIRFilter(h, Fraction(1, M))
             y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
-            assert f.last_kernel_name() == ("fir_direct_kernel" if M in (36, 38) else "fir_stream_kernel"), (M, f.last_kernel_name())
+            assert f.last_kernel_name() == "fir_stream_rt_kernel", (M, f.last_kernel_name())
             monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
             g = pkg.FIRFilter(h, Fraction(1, M))
             yg = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
