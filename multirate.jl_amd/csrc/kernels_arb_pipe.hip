@@ -89,6 +89,11 @@ __device__ __forceinline__ R sample_of_pair(v2u_t v, int which)   // two Float32
 // DMA: the sample rows go HBM -> LDS by LDS-DMA (global_load_lds, 16 bytes per lane: no staging registers, no ds_write); the
 // rows then have a pitch of whole 16-byte chunks.  First / last tiles and partial channel groups are staged synchronously
 // through registers.
+// (experiment, profiles/r04/experiments.md: C4 4.97 ms with the 16-byte tap reads vs 4.83-4.9 without -- the LDS cost follows the
+//  bytes, not the instruction count)
+#ifndef MRHIP_AP_TD128
+#define MRHIP_AP_TD128 0
+#endif
 template <typename TX, typename R, int NC, bool FUSED, int CPL, bool DMA>
 __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, ArbTileArgs ta)
 {
@@ -98,7 +103,10 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                                                                       // kept twice, one sample apart (copy B: odd window starts)
     static_assert(SB == 8 || (SB == 4 && NC == 1), "8-byte samples, or Float32");
     using StageT = std::conditional_t<SB == 8, unsigned long long, unsigned>;
-    constexpr int NR = 4 + (PAIR ? 1 : 2) * CPL;                      // LDS reads per tap pair
+    // TD: Float64 taps -- tap i of a phase and its difference-bank partner sit side by side in LDS (16 bytes) and come with ONE
+    // ds_read_b128: two tap reads per tap pair instead of four
+    constexpr bool TD = sizeof(R) == 8 && MRHIP_AP_TD128 != 0;
+    constexpr int NR = (TD ? 2 : 4) + (PAIR ? 1 : 2) * CPL;           // LDS reads per tap pair
     static_assert(NR <= 15, "lgkmcnt is a 4-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
@@ -114,8 +122,8 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
         const int total = a.Nphi * T;
         for (int e = tid; e < total; e += kPipeThreads) {
             const int phi = e / T, i = e - phi * T;
-            lpfb[phi * TP + i] = g0[e];
-            ldpfb[phi * TP + i] = g1[e];
+            if constexpr (TD) { lpfb[(phi * TP + i) * 2] = g0[e]; lpfb[(phi * TP + i) * 2 + 1] = g1[e]; }
+            else { lpfb[phi * TP + i] = g0[e]; ldpfb[phi * TP + i] = g1[e]; }
         }
     }
     const int RP = DMA ? ta.row_pitch : MS;                          // row pitch in samples (DMA: whole 16-byte chunks)
@@ -287,8 +295,8 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             const double alpha = acc_mine - phif;                 // src/Filters.jl:671-672
             const int phi = static_cast<int>(phif) - 1;           // 0-based column
             const int w = n_mine - cur.n_lo;                      // oldest sample of this output's window, within the tile
-            unsigned tpa = lds0 + static_cast<unsigned>(phi * TP) * RS;                  // taps of this phase
-            unsigned dpa = tpa + static_cast<unsigned>(ta.bank_elems) * RS;              // ... of the difference bank
+            unsigned tpa = lds0 + static_cast<unsigned>(phi * TP) * (TD ? 2u * RS : RS);  // taps of this phase
+            unsigned dpa = tpa + static_cast<unsigned>(ta.bank_elems) * RS;              // ... of the difference bank (TD: unused)
             unsigned sa[CPL];
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) {
@@ -303,13 +311,17 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) dev::pin(sa[cc]);
 
-            struct Blk { TapReg t0, t1, d0, d1; v2u_t s0[CPL], s1[PAIR ? 1 : CPL]; };
+            struct Blk { TapReg t0, t1, d0, d1; dev::v4u_t td0, td1; v2u_t s0[CPL], s1[PAIR ? 1 : CPL]; };
             auto issue = [&](Blk &b, auto off_c) {              // taps i, i + 1 at byte offset OFF from the running bases
                 constexpr int OFF = decltype(off_c)::value;
                 constexpr int TOFF = OFF / 8 * static_cast<int>(RS);           // the same tap pair in the tap banks
                 constexpr int SOFF = OFF / 8 * static_cast<int>(SB);           // ... in the sample tile
-                b.t0 = lds_read_tap<R, TOFF>(tpa); b.t1 = lds_read_tap<R, TOFF + static_cast<int>(RS)>(tpa);
-                b.d0 = lds_read_tap<R, TOFF>(dpa); b.d1 = lds_read_tap<R, TOFF + static_cast<int>(RS)>(dpa);
+                if constexpr (TD) {
+                    b.td0 = dev::lds_read_b128<2 * TOFF>(tpa); b.td1 = dev::lds_read_b128<2 * TOFF + 16>(tpa);
+                } else {
+                    b.t0 = lds_read_tap<R, TOFF>(tpa); b.t1 = lds_read_tap<R, TOFF + static_cast<int>(RS)>(tpa);
+                    b.d0 = lds_read_tap<R, TOFF>(dpa); b.d1 = lds_read_tap<R, TOFF + static_cast<int>(RS)>(dpa);
+                }
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
                     b.s0[cc] = dev::lds_read_b64<SOFF>(sa[cc]);
@@ -319,7 +331,8 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             auto landed = [&](Blk &b, auto n_c) {               // at most N later reads still in flight => b has landed
                 constexpr int N = decltype(n_c)::value;
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
-                dev::pin(b.t0); dev::pin(b.t1); dev::pin(b.d0); dev::pin(b.d1);
+                if constexpr (TD) { dev::pin(b.td0); dev::pin(b.td1); }
+                else { dev::pin(b.t0); dev::pin(b.t1); dev::pin(b.d0); dev::pin(b.d1); }
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) { dev::pin(b.s0[cc]); if constexpr (!PAIR) dev::pin(b.s1[cc]); }
             };
@@ -331,8 +344,14 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 for (int c = 0; c < NC; ++c) { lo[cc][c] = static_cast<R>(-0.0); up[cc][c] = static_cast<R>(-0.0); }
             }
             auto compute = [&](const Blk &b) {
-                const R t0 = __builtin_bit_cast(R, b.t0), t1 = __builtin_bit_cast(R, b.t1);
-                const R d0 = __builtin_bit_cast(R, b.d0), d1 = __builtin_bit_cast(R, b.d1);
+                R t0, t1, d0, d1;
+                if constexpr (TD) {
+                    t0 = __builtin_bit_cast(R, v2u_t{b.td0.x, b.td0.y}); d0 = __builtin_bit_cast(R, v2u_t{b.td0.z, b.td0.w});
+                    t1 = __builtin_bit_cast(R, v2u_t{b.td1.x, b.td1.y}); d1 = __builtin_bit_cast(R, v2u_t{b.td1.z, b.td1.w});
+                } else {
+                    t0 = __builtin_bit_cast(R, b.t0); t1 = __builtin_bit_cast(R, b.t1);
+                    d0 = __builtin_bit_cast(R, b.d0); d1 = __builtin_bit_cast(R, b.d1);
+                }
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
 #pragma unroll
@@ -348,7 +367,7 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 }
             };
             auto advance = [&](unsigned bytes) {                  // `bytes` of samples = bytes / 8 taps
-                tpa += bytes / 8u * RS; dpa += bytes / 8u * RS;
+                tpa += bytes / 8u * (TD ? 2u * RS : RS); dpa += bytes / 8u * RS;
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) sa[cc] += bytes / 8u * SB;
             };
@@ -373,12 +392,12 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                     if (p + 1 < nblk) compute(B);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)");            // the unused last reads
-                dev::pin(A.t0);
+                if constexpr (TD) dev::pin(A.td0); else dev::pin(A.t0);
             }
             if (T & 1) {                                         // odd tapsPerPhi: the last tap alone
                 const int i = T - 1;
-                const unsigned tl = lds0 + static_cast<unsigned>(phi * TP + i) * RS;
-                TapReg t = lds_read_tap<R, 0>(tl), d = lds_read_tap<R, 0>(tl + static_cast<unsigned>(ta.bank_elems) * RS);
+                const unsigned tl = lds0 + static_cast<unsigned>(phi * TP + i) * (TD ? 2u * RS : RS);
+                TapReg t = lds_read_tap<R, 0>(tl), d = lds_read_tap<R, 0>(tl + (TD ? RS : static_cast<unsigned>(ta.bank_elems) * RS));
                 std::conditional_t<PAIR, unsigned, v2u_t> s[CPL];     // (copy A holds every sample at its own index)
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
@@ -460,6 +479,8 @@ hipError_t launch_pipe_t(bool fused, const ArbArgs &a, const ArbTileArgs &ta, si
         hipError_t eo = occupancy_cached(reinterpret_cast<const void *>(kfn), kPipeThreads, lds, &per_cu);
         if (eo != hipSuccess) return eo;
         if (per_cu < 1) per_cu = 1;
+        const int bpc = MRHIP_ENV_INT("MRHIP_PIPE_BPC", 0);           // experiments: fewer workgroups per CU than fit
+        if (bpc > 0 && bpc < per_cu) per_cu = bpc;
         long long g = static_cast<long long>(num_cus) * per_cu;
         if (g > ta.total_tiles) g = ta.total_tiles;
         if (g < 1) g = 1;

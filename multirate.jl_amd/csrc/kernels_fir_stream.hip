@@ -1,7 +1,7 @@
 // kernels_fir_stream.hip -- FIRStandard (M = 1) and FIRDecimator (L = 1), 2 to 16384 taps (as long as a tile fits the LDS), with
 // Float32 arithmetic (Float32 or ComplexF32 samples, Float32 taps) and Float64 arithmetic (Float64 or ComplexF64 samples, or
 // Float32 / ComplexF32 samples with Float64 taps): BASELINE config 3b.  This file holds the planning and the dispatch.  Two
-// kernels share the mapping below: fir_stream_kernel.inc, instantiated per decimation M = 1..15 by
+// kernels share the mapping below: fir_stream_kernel.inc, instantiated per decimation M = 1..11, 13, 15 by
 // kernels_fir_stream_{f32,f64,mix}.hip, and fir_stream_rt_kernel (kernels_fir_stream_rt.hip), which takes M at run time
 // and serves every other decimation whose step fits the LDS.
 //

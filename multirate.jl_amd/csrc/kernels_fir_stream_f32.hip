@@ -1,4 +1,4 @@
-// kernels_fir_stream_f32.hip -- instantiations of fir_stream_kernel.inc: Float32 arithmetic (Float32 and ComplexF32 samples), M = 1..15, STRICT and FUSED.
+// kernels_fir_stream_f32.hip -- instantiations of fir_stream_kernel.inc: Float32 arithmetic (Float32 and ComplexF32 samples), M = 1..11, 13, 15, STRICT and FUSED.
 #include "fir_stream_kernel.inc"
 
 namespace mrhip {

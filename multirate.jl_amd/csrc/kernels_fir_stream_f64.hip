@@ -1,4 +1,4 @@
-// kernels_fir_stream_f64.hip -- instantiations of fir_stream_kernel.inc: Float64 and ComplexF64 samples, Float64 arithmetic, M = 1..15, STRICT and FUSED.
+// kernels_fir_stream_f64.hip -- instantiations of fir_stream_kernel.inc: Float64 and ComplexF64 samples, Float64 arithmetic, M = 1..11, 13, 15, STRICT and FUSED.
 #include "fir_stream_kernel.inc"
 
 namespace mrhip {

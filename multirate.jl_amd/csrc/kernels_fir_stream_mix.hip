@@ -1,4 +1,4 @@
-// kernels_fir_stream_mix.hip -- instantiations of fir_stream_kernel.inc: Float32 / ComplexF32 samples with Float64 taps (samples widened exactly on load), M = 1..15, STRICT and FUSED.
+// kernels_fir_stream_mix.hip -- instantiations of fir_stream_kernel.inc: Float32 / ComplexF32 samples with Float64 taps (samples widened exactly on load), M = 1..11, 13, 15, STRICT and FUSED.
 #include "fir_stream_kernel.inc"
 
 namespace mrhip {

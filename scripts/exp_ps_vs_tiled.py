@@ -17,7 +17,7 @@ pkg = ge.load_package()
 
 
 def run(h, ratio, x, env, reps=5):
-    for k in ("MRHIP_PS", "MRHIP_FORCE_GENERIC"):
+    for k in ("MRHIP_PS", "MRHIP_OPAIR", "MRHIP_FORCE_GENERIC"):
         os.environ.pop(k, None)
     os.environ.update(env)
     f = pkg.FIRFilter(h, ratio)
@@ -38,7 +38,26 @@ def run(h, ratio, x, env, reps=5):
     return best, name, nbytes
 
 
+def opair_vs_ps():
+    """M / L in [2, 6): the output-pair kernel's SMIN = 2..5 instantiations (11 MB of code objects) against the phase-stationary kernel"""
+    rng = np.random.default_rng(1)
+    for L, M in ((2, 5), (3, 7), (3, 10), (2, 9), (3, 14), (2, 11), (5, 28)):
+        for tx in (np.float32, np.complex64):
+            for T in (8, 24, 32):
+                h = rng.standard_normal(T * L).astype(np.float32)
+                x = torch.from_numpy(rng.standard_normal((16, 4_000_000)).astype(np.float32)).cuda()
+                if tx == np.complex64:
+                    x = torch.view_as_complex(torch.stack([x, x.flip(1)], dim=-1).contiguous())
+                out = []
+                for label, env in (("default", {}), ("no-opair", {"MRHIP_OPAIR": "0"})):
+                    ms, name, nbytes = run(h, Fraction(L, M), x, env)
+                    out.append(f"{label}: {ms:7.3f} ms {nbytes / ms / 1e6:6.0f} GB/s {name[:28]:28s}")
+                print(f"{L:4d}//{M:<4d} T={T:2d} float32 x {np.dtype(tx).name:9s} " + " | ".join(out), flush=True)
+
+
 def main():
+    if "--opair" in sys.argv:
+        return opair_vs_ps()
     rng = np.random.default_rng(0)
     cases = [(2, 13, np.float32, np.float32), (3, 20, np.float32, np.float32), (5, 64, np.float32, np.complex64), (625, 512, np.float32, np.float32),
              (1000, 999, np.float32, np.float32), (640, 441, np.float32, np.complex64), (3, 7, np.float64, np.float64), (2, 5, np.float64, np.complex64),

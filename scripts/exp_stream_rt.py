@@ -41,8 +41,9 @@ def main():
     rng = np.random.default_rng(0)
     rows = []
     cases = []
+    small = "--small-m" in sys.argv
     for tx in (np.float32, np.complex64, np.float64):
-        for M in ((1, 2, 3, 4, 5, 8, 10, 16, 20, 32, 33, 36, 38, 48, 64, 65, 80, 100) if not quick else (1, 3, 10, 16, 36, 80)):
+        for M in (tuple(range(1, 16)) if small else (1, 2, 3, 4, 5, 8, 10, 16, 20, 32, 33, 36, 38, 48, 64, 65, 80, 100) if not quick else (1, 3, 10, 16, 36, 80)):
             for T in ((24, 128) if not quick else (128,)):
                 cases.append((tx, M, T))
     for tx, M, T in cases:
