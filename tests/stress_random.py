@@ -87,7 +87,7 @@ def main():
             elif kind == "interp":
                 L, M = int(rng.integers(2, 40)), 1
             elif kind == "decim":
-                L, M = 1, int(rng.integers(2, 70))
+                L, M = 1, int(rng.integers(2, 120))
             elif kind == "decim16":
                 L, M = 1, int(rng.integers(1, 17))
             elif kind == "wide":                 # ratios beyond (1/2, 2): L >= 2M and 2 <= M/L < 6

@@ -92,9 +92,10 @@ def test_graph_capture_rational_chunk_that_advances_the_state(pkg, O, torch_cuda
 
 
 @pytest.mark.parametrize("L,M,tx,chunk,ncalls", [(1, 4, np.complex64, 10_007, 3), (3, 17, np.float64, 4_099, 2), (1, 1, np.float32, 5_001, 2),
-                                                 (4, 1, np.float32, 3_001, 2), (2, 13, np.float32, 7_919, 1)])
+                                                 (4, 1, np.float32, 3_001, 2), (2, 13, np.float32, 7_919, 1),
+                                                 (1, 20, np.float32, 10_007, 3), (1, 37, np.complex64, 9_001, 2)])
 def test_graph_capture_other_rational_kinds(pkg, O, torch_cuda, L, M, tx, chunk, ncalls):
-    """FIRDecimator (inputDeficit moves), FIRRational on other kernels (2//13 has no device-planned tuned kernel: the
+    """FIRDecimator (inputDeficit moves; 1//20 and 1//37: fir_stream_rt_kernel, the decimation a run-time value), FIRRational on other kernels (2//13 has no device-planned tuned kernel: the
     universal kernel serves it), FIRStandard / FIRInterpolator (no state), several calls per graph."""
     torch = torch_cuda
     nrep, nch = 12, 2
@@ -105,6 +106,8 @@ def test_graph_capture_other_rational_kinds(pkg, O, torch_cuda, L, M, tx, chunk,
     x = torch.from_numpy(xh).cuda()
     f = pkg.FIRFilter(h, Fraction(L, M)).bind(tx, nch)
     outs, counts = _graph_stream(torch, f, x, chunk, nrep, ncalls)
+    if L == 1 and M >= 16:
+        assert f.last_kernel_name() == "fir_stream_rt_kernel", f.last_kernel_name()
     fo = O.FIRFilter(h, Fraction(L, M), tx=tx)
     yo = _oracle_chunks(fo, xh[1], chunk, ncalls * nrep)
     assert counts == [len(v) for v in yo]
@@ -261,7 +264,7 @@ def test_independent_streams_in_one_launch(pkg, O, torch_cuda):
         f.close()
 
 
-@pytest.mark.parametrize("ratio,tx", [(Fraction(1, 5), np.complex64), (Fraction(1, 1), np.float32), (Fraction(4, 1), np.float32)])
+@pytest.mark.parametrize("ratio,tx", [(Fraction(1, 5), np.complex64), (Fraction(1, 1), np.float32), (Fraction(4, 1), np.float32), (Fraction(1, 24), np.float32)])
 def test_independent_streams_other_kinds(pkg, O, torch_cuda, ratio, tx):
     """mrhip_filt_device_multi for FIRDecimator / FIRStandard (fir_stream_kernel: the Vector seam's start from zero applies to
     every stream's own call) and FIRInterpolator: 24 streams of unequal lengths, three rounds, each against its own oracle."""
@@ -281,7 +284,7 @@ def test_independent_streams_other_kinds(pkg, O, torch_cuda, ratio, tx):
             x[:40] = -0.0                                   # the seam's start from zero is visible only on signed zeros
             xs_h.append(x.astype(tx))
         ys = pkg.filt_multi(fs, [torch.from_numpy(x).cuda() for x in xs_h])
-        assert fs[0].last_kernel_name() == ("fir_stream_kernel" if ratio.numerator == 1 else "rational_opair_kernel")
+        assert fs[0].last_kernel_name() == ("rational_opair_kernel" if ratio.numerator != 1 else "fir_stream_rt_kernel" if ratio.denominator == 24 else "fir_stream_kernel")
         for i in range(ns):
             assert_bit_equal(ys[i].cpu().numpy(), fos[i].filt(xs_h[i]), f"{ratio} round {rnd} stream {i}")
             assert (fs[i].state.phiIdx, fs[i].state.inputDeficit) == (fos[i].state.phiIdx, fos[i].state.inputDeficit)
