@@ -103,7 +103,7 @@ DEFAULT_ROWS = ["c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5", "x160", "xf6
 # what bench.py reports next to the headline: every BASELINE config on one GPU, the README's mixed precision, the reference's
 # own FIRArbitrary / FIRFarrow benchmark shape
 # (the BASELINE rows LAST: the driver's record keeps the END of the line)
-BENCH_ROWS = ["xarb", "af", "ms", "xmix64", "c2", "c3a", "c3b", "c4", "c4f", "c5"]
+BENCH_ROWS = ["xarb", "af", "xdec", "ms", "xmix64", "c2", "c3a", "c3b", "c4", "c4f", "c5"]
 
 
 def rows(which):
@@ -129,6 +129,13 @@ def rows(which):
             note="flops include the Float64 Horner evaluation of the 32 taps of every output index, done once for all 64 channels")
     def _c5():
         run("C5 rational 147//160 c64 512ch x 1e6 (one GPU's shard of 4096)", h147, Fraction(147, 160), 32, 512, 1_000_000, torch.complex64, 15.35, 2 * 48 * R147)
+
+    def _xdec():
+        # decimations the run-time-M streaming kernel serves (fir_stream_rt_kernel): bytes per input sample sizeof(Tx) + sizeof(Tb)/M
+        for M, dt, nm, es in ((32, torch.float32, "f32", 4), (36, torch.float32, "f32", 4), (100, torch.float32, "f32", 4), (24, torch.complex64, "c64", 8)):
+            hd = pkg.firdes(128, 0.5 / M, beta=7.8562).astype(np.float32)
+            nc = 2 if dt == torch.complex64 else 1
+            run(f"X decimator 1//{M} 128 taps {nm} 64ch x 4e6", hd, Fraction(1, M), 32, 64, 4_000_000, dt, es + es / M, nc * 2 * 128 / M)
 
     # shapes outside BASELINE.json (where the non-headline kernels stand)
     def _x160():
@@ -229,7 +236,7 @@ def rows(which):
         for f in fs:
             f.close()
 
-    table = {"ms": _ms, "c1": _c1, "c2": _c2, "c2s": _c2s, "c3a": _c3a, "c3b": _c3b, "c4": _c4, "c4f": _c4f, "c5": _c5, "x160": _x160, "xf64": _xf64, "xmix": _xmix, "xstd": _xstd, "x32": _x32, "xc32": _xc32, "xarb": _xarb, "xmix64": _xmix64, "af": _af}
+    table = {"ms": _ms, "c1": _c1, "c2": _c2, "c2s": _c2s, "c3a": _c3a, "c3b": _c3b, "c4": _c4, "c4f": _c4f, "c5": _c5, "x160": _x160, "xf64": _xf64, "xmix": _xmix, "xstd": _xstd, "x32": _x32, "xc32": _xc32, "xarb": _xarb, "xmix64": _xmix64, "af": _af, "xdec": _xdec}
     for name in which:                # in the order asked for (bench.py wants the BASELINE rows last)
         table[name]()
 

@@ -21,7 +21,7 @@ if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
   rm -rf "$OUT/prof_cfg" "$OUT/prof_c2"
   rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_full" -o full -- python3 "$R/bench.py" --no-streamed --no-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/prof_full.log"
   rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_chunk" -o chunk -- python3 "$R/bench.py" --chunk 1000000 --no-cpu-baseline > "$OUT/bench_chunked_under_rocprof.json" 2> "$OUT/prof_chunk.log"
-  rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_cfg" -o cfg -- python3 "$R/scripts/bench_configs.py" c3a c3b c4 c4f c5 xmix64 af ms > "$OUT/configs_under_rocprof.jsonl" 2> "$OUT/prof_cfg.log"
+  rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_cfg" -o cfg -- python3 "$R/scripts/bench_configs.py" c3a c3b c4 c4f c5 xmix64 af ms xdec > "$OUT/configs_under_rocprof.jsonl" 2> "$OUT/prof_cfg.log"
   rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_c2" -o c2 -- python3 "$R/scripts/bench_configs.py" c2 > "$OUT/c2_under_rocprof.jsonl" 2> "$OUT/prof_c2.log"
 fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
