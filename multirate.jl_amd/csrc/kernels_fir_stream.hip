@@ -58,20 +58,34 @@ bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs
     const bool rt = rt_mode == 2 || (rt_mode == 1 && !have_ct);
     if (!rt && !have_ct) return false;
     int rt_rd = 16;
+    bool single = false;                                    // one output per lane (kernels_fir_stream_rt.hip)
     if (rt) {                                               // the geometry of StreamGeo, at run time
         if (a.M < 1 || a.M + 16 > kTapPad) return false;    // (its blocks of tap reads stay inside the pads of the tap vector)
-        const long long S = 2 * a.M * es;
+        // Two outputs per lane share most of a run, but a lane then owns 2 * M samples of LDS and a CU holds half the waves; one
+        // output per lane reads T instead of (T + M) / 2 samples per output from LDS and has no mixed block in the middle of a
+        // run.  Measured over M = 8..120, 24 and 128 taps, every sample type (profiles/r04/stream_rt_single_vs_pair.txt): one
+        // output per lane wins (up to 1.8x) except where M is a whole number of blocks AND the pair still fills its waves
+        // (128 <= M * es <= 192: 1//32 and 1//48 Float32, 1//16 ComplexF32 / Float64).  Its lane stride M * es must keep the
+        // reads 8-byte aligned (Float32 with an odd M: pairs).  MRHIP_STREAM_RT_SINGLE=0|1 forces either.
+        const int sm = stream_env_int("MRHIP_STREAM_RT_SINGLE", -1);
+        const long long bs = es == 16 ? 8 : 16;             // the kernel's block of samples
+        const bool pair_pref = a.M % bs == 0 && a.M * es >= 128 && a.M * es <= 192;
+        single = (a.M * es) % 8 == 0 && (sm == 1 || (sm < 0 && !pair_pref));
+        // ComplexF64 beyond 1//32: poly_tiled_kernel is ahead (1//36, 128 taps: 0.32 vs 0.68 ms)
+        if (es == 16 && a.M > 32 && stream_env_int("MRHIP_STREAM_RT_ONE_WG", 0) == 0) return false;
+        const long long S = (single ? 1 : 2) * a.M * es;
         rt_rd = S % 16 ? 8 : 16;
         const long long cd = rt_rd == 16 ? S / 16 : 0;
         pad_every = cd >= 2 && cd % 2 == 0 ? static_cast<int>(cd) : 0;
     }
+    const long long opw = single ? 64 : 128;                // outputs per compute wave and step
     if (a.T < 1 || a.T > 16384) return false;   // (a tile must hold T samples: checked below)
     // compute waves: 3 (+ loader = a 256-thread workgroup) unless overridden; a step is 2 outputs per lane
     int ncw = stream_env_int("MRHIP_STREAM_WAVES", 3);
     if (ncw < 1) ncw = 1;
     if (ncw > 7) ncw = 7;
-    while (ncw > 1 && 128LL * ncw * a.M * es > 24 * 1024) --ncw;   // a step of wide samples at a large decimation must leave room for two stages
-    const long long P = 128LL * ncw, cM = P * a.M;
+    while (ncw > 1 && opw * ncw * a.M * es > 24 * 1024) --ncw;   // a step of wide samples at a large decimation must leave room for two stages
+    const long long P = opw * ncw, cM = P * a.M;
     const long long tail = a.T + 16;                            // run overhang T - M beyond the step, + the rounding of the last read
     // (the head block reads a whole block: BS <= T samples, inside the run)
     const int wg_per_cu = std::max(1, std::min(6, 32 / (ncw + 1)));
@@ -91,9 +105,9 @@ bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs
     }
     const long long nslots = (lds_chunks(J) + 63) / 64;
     if (nslots > 60 || nslots * 1024 * ns > 150 * 1024) return false;
-    // One workgroup (= one compute wave at these sizes) per CU: 8- and 16-byte samples are then faster on poly_tiled_kernel
+    // Pairs with one workgroup (= one compute wave at these sizes) per CU: 8- and 16-byte samples are then faster on poly_tiled_kernel
     // (measured, profiles/r04/stream_rt_vs_per_m.txt: 1//38 ComplexF32 0.31 vs 0.25 ms); Float32 samples are not (1//80: 0.22 vs 0.46)
-    if (rt && es >= 8 && nslots * 1024 * ns + 64 > 78 * 1024 && stream_env_int("MRHIP_STREAM_RT_ONE_WG", 0) == 0) return false;
+    if (rt && !single && es >= 8 && nslots * 1024 * ns + 64 > 78 * 1024 && stream_env_int("MRHIP_STREAM_RT_ONE_WG", 0) == 0) return false;
     const size_t stage_bytes = static_cast<size_t>(nslots) * 1024;
     PairArgs pa{};
     pa.c = ncw; pa.P = static_cast<int>(P); pa.cM = static_cast<int>(cM);
@@ -106,7 +120,7 @@ bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs
     pa.nc = nc;
     pa.x_f64 = tk.x_f64 ? 1 : 0; pa.r_f64 = tk.r_f64 ? 1 : 0;
     pa.pad_every = pad_every;
-    pa.rt = rt ? 1 : 0; pa.rt_rd = rt_rd;
+    pa.rt = rt ? (single ? 2 : 1) : 0; pa.rt_rd = rt_rd;
     pa.bank_off = -1;
     pa.o0 = a.d0 - a.T;                      // x index of LDS sample 0 of a channel's first tile (negative => history)
     pa.tile_in = J * cM;

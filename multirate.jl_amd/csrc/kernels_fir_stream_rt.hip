@@ -1,6 +1,7 @@
 // kernels_fir_stream_rt.hip -- fir_stream_kernel with the decimation M as a RUN-TIME value: FIRStandard / FIRDecimator
 // (src/Filters.jl:450-473, :598-631; dot: src/support.jl:33-55) at ANY decimation whose step of 128 outputs fits the LDS
-// (2 * M * bytes-per-sample <= ~900), one kernel per (sample type, arithmetic type, components, bytes per LDS read).
+// (2 * M * bytes-per-sample <= ~900; twice that with one output per lane), one kernel per (sample type, arithmetic type,
+// components, bytes per LDS read).
 //
 // fir_stream_kernel.inc is instantiated per M (the position of the second output's first sample inside the first block of
 // reads, the pad period of the staged tile and every LDS offset are compile-time constants there): 40 decimations x 3
@@ -67,16 +68,20 @@ void fir_stream_rt_kernel(PolyArgs a, PairArgs pa)
     const int T = a.T;
     const int M = static_cast<int>(a.M);
     const int n_out = static_cast<int>(a.n_out);
-    const int lanes = pa.P >> 1;                // lanes that own an output pair
+    // pa.rt == 2: ONE output per lane (large decimations: a lane's run is M samples shorter and the lanes lie M instead of 2M
+    // samples apart -- half the LDS per lane, twice the waves per CU; every block is then of the first class or mixed)
+    const bool single = pa.rt == 2;
+    const int opl = single ? 1 : 2;             // outputs per lane
+    const int lanes = single ? pa.P : pa.P >> 1;
     // the staged tile: CD data chunks of 16 bytes, then one pad chunk (pad_every = 0: linear)
     const int CD = pa.pad_every > 0 ? pa.pad_every : 0x7fffffff;
-    const int lane_bytes = pa.pad_every > 0 ? 16 * (pa.pad_every + 1) : 2 * M * ES;
+    const int lane_bytes = pa.pad_every > 0 ? 16 * (pa.pad_every + 1) : opl * M * ES;
     // the block walk of a lane's run (wave-uniform; see the header)
-    const int NBLK = (T + M + BS - 1) / BS;
-    const int fB1 = std::min(M / BS, T / BS);                                     // B: [0, fB1)
-    const int fA0 = std::max(fB1, (M + BS - 1) / BS), fA1 = std::max(fA0, T / BS);   // A: [fA0, fA1)
-    const int fD0 = std::max(fA1, std::max((T + BS - 1) / BS, (M + BS - 1) / BS));
-    const int fD1 = std::max(fD0, (T + M) / BS);                                  // D: [fD0, fD1)
+    const int NBLK = (T + (single ? 0 : M) + BS - 1) / BS;
+    const int fB1 = single ? T / BS : std::min(M / BS, T / BS);                   // B: [0, fB1)
+    const int fA0 = single ? fB1 : std::max(fB1, (M + BS - 1) / BS), fA1 = single ? fB1 : std::max(fA0, T / BS);   // A: [fA0, fA1)
+    const int fD0 = single ? fB1 : std::max(fA1, std::max((T + BS - 1) / BS, (M + BS - 1) / BS));
+    const int fD1 = single ? fB1 : std::max(fD0, (T + M) / BS);                   // D: [fD0, fD1)
 
     for (int s = 0;; s = (s + 1 == pa.ns ? 0 : s + 1)) {
         __builtin_amdgcn_s_barrier();             // one barrier per tile, no memory wait (opair_kernel.inc)
@@ -100,7 +105,7 @@ void fir_stream_rt_kernel(PolyArgs a, PairArgs pa)
         if (tid < lanes) {
 #pragma unroll 1
             for (int j = 0; j < J; ++j) {
-                const int k0 = j * pa.P + 2 * tid;                        // tile-relative index of this lane's first output
+                const int k0 = j * pa.P + opl * tid;                      // tile-relative index of this lane's first output
                 if (k0 >= remaining) break;
                 const unsigned char *const run = stage + (static_cast<size_t>(j) * lanes + tid) * lane_bytes;
                 // the accumulators start at -0.0 (the first product then initialises them exactly), at +0.0 where the
@@ -172,7 +177,7 @@ void fir_stream_rt_kernel(PolyArgs a, PairArgs pa)
                     // bit e: sample j0 + e is inside [0, T) / [M, T + M)
                     auto below = [](int n) -> unsigned { return n <= 0 ? 0u : (n >= BS ? (1u << BS) - 1u : (1u << n) - 1u); };
                     const unsigned m0 = below(T - j0);
-                    const unsigned m1 = below(T + M - j0) & ~below(M - j0);
+                    const unsigned m1 = single ? 0u : below(T + M - j0) & ~below(M - j0);
 #pragma unroll
                     for (int e = 0; e < BS; ++e) {
                         const R t0 = tc[j0 + e], t1 = tc[j0 + e - M];
@@ -229,7 +234,7 @@ void fir_stream_rt_kernel(PolyArgs a, PairArgs pa)
                 blocks_c(b, NBLK);
 
                 R *const dst = yc + static_cast<long long>(k0) * NC;
-                if (k0 + 1 < remaining) {
+                if (!single && k0 + 1 < remaining) {
                     R o2[2 * NC];
 #pragma unroll
                     for (int cc = 0; cc < NC; ++cc) { o2[cc] = acc0[cc]; o2[NC + cc] = acc1[cc]; }
@@ -286,16 +291,16 @@ hipError_t launch_rt_t(bool fused, dim3 block, size_t lds, hipStream_t s, const 
 
 hipError_t launch_fir_stream_rt(bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus)
 {
-    const bool rd8 = pa.rt_rd == 8;
+    const bool rd8 = pa.rt_rd == 8;             // (lane strides that are an odd multiple of 8 bytes)
     if (!pa.r_f64) {
-        if (pa.nc == 2) return launch_rt_t<float, float, 2, 16>(fused, block, lds, s, a, pa, num_cus);
+        if (pa.nc == 2) return rd8 ? launch_rt_t<float, float, 2, 8>(fused, block, lds, s, a, pa, num_cus) : launch_rt_t<float, float, 2, 16>(fused, block, lds, s, a, pa, num_cus);
         return rd8 ? launch_rt_t<float, float, 1, 8>(fused, block, lds, s, a, pa, num_cus) : launch_rt_t<float, float, 1, 16>(fused, block, lds, s, a, pa, num_cus);
     }
     if (pa.x_f64) {
         if (pa.nc == 2) return launch_rt_t<double, double, 2, 16>(fused, block, lds, s, a, pa, num_cus);
-        return launch_rt_t<double, double, 1, 16>(fused, block, lds, s, a, pa, num_cus);
+        return rd8 ? launch_rt_t<double, double, 1, 8>(fused, block, lds, s, a, pa, num_cus) : launch_rt_t<double, double, 1, 16>(fused, block, lds, s, a, pa, num_cus);
     }
-    if (pa.nc == 2) return launch_rt_t<float, double, 2, 16>(fused, block, lds, s, a, pa, num_cus);
+    if (pa.nc == 2) return rd8 ? launch_rt_t<float, double, 2, 8>(fused, block, lds, s, a, pa, num_cus) : launch_rt_t<float, double, 2, 16>(fused, block, lds, s, a, pa, num_cus);
     return rd8 ? launch_rt_t<float, double, 1, 8>(fused, block, lds, s, a, pa, num_cus) : launch_rt_t<float, double, 1, 16>(fused, block, lds, s, a, pa, num_cus);
 }
 

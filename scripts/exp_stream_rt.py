@@ -36,7 +36,41 @@ def run(h, M, x, env, reps=5):
     return best, name, x.numel() * x.element_size() + y.numel() * y.element_size()
 
 
+def single_vs_pair():
+    """one output per lane against two (MRHIP_STREAM_RT_SINGLE), run-time-M kernel forced; the outputs are compared bit for bit"""
+    rng = np.random.default_rng(0)
+    for tx in (np.float32, np.complex64, np.float64, np.complex128):
+        for M in (8, 12, 16, 20, 24, 32, 36, 48, 64, 80, 100, 120):
+            for T in (24, 128):
+                es = np.dtype(tx).itemsize
+                if (M * es) % 8:
+                    continue
+                n = 8_000_000 if es <= 8 else 4_000_000
+                th = np.float64 if tx in (np.float64, np.complex128) else np.float32
+                h = rng.standard_normal(T).astype(th)
+                x = torch.from_numpy(rng.standard_normal((16, n)).astype(np.float32)).cuda()
+                if tx == np.complex64:
+                    x = torch.view_as_complex(torch.stack([x, x.flip(1)], dim=-1).contiguous())
+                elif tx == np.float64:
+                    x = x.double()
+                elif tx == np.complex128:
+                    x = torch.view_as_complex(torch.stack([x.double(), x.flip(1).double()], dim=-1).contiguous())
+                out, ys = {}, {}
+                for label, env in (("pair", {"MRHIP_STREAM_RT": "2", "MRHIP_STREAM_RT_SINGLE": "0", "MRHIP_STREAM_RT_ONE_WG": "1"}),
+                                   ("single", {"MRHIP_STREAM_RT": "2", "MRHIP_STREAM_RT_SINGLE": "1", "MRHIP_STREAM_RT_ONE_WG": "1"}),
+                                   ("tiled", {"MRHIP_STREAM": "0"})):
+                    for k in ("MRHIP_STREAM_RT_SINGLE", "MRHIP_STREAM_RT_ONE_WG"):
+                        os.environ.pop(k, None)
+                    ms, name, nbytes = run(h, M, x, env)
+                    out[label] = (ms, name, nbytes / ms / 1e6)
+                    f = pkg.FIRFilter(h, Fraction(1, M)); ys[label] = f.filt(x[:, :200_000]); f.close()
+                same = all(torch.equal(torch.view_as_real(ys["pair"]) if ys["pair"].is_complex() else ys["pair"], torch.view_as_real(v) if v.is_complex() else v) for v in ys.values())
+                print(f"{np.dtype(tx).name:10s} M={M:3d} T={T:3d} " + " | ".join(f"{k}: {v[0]:7.3f} ms {v[2]:6.0f} GB/s {v[1][:14]:14s}" for k, v in out.items()) + f" | same bits: {same}", flush=True)
+
+
 def main():
+    if "--single" in sys.argv:
+        return single_vs_pair()
     quick = "--quick" in sys.argv
     rng = np.random.default_rng(0)
     rows = []

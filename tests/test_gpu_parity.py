@@ -816,7 +816,7 @@ def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
     rng = np.random.default_rng(77)
     cases = [(2, 3, 140, np.float32, np.float32, 35), (3, 2, 200, np.float32, np.complex64, 9), (147, 160, 147 * 70, np.float32, np.float32, 33),
              (2, 3, 100, np.float64, np.float64, 4),
-             (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 150, 700, np.float32, np.float32, 5),
+             (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 250, 700, np.float32, np.float32, 5),
              (1, 33, 600, np.float64, np.complex128, 2), (5, 64, 5 * 40, np.float64, np.float32, 32), (4, 7, 4 * 49, np.float32, np.float64, 1)]
     for (L, M, hl, th, tx, nch) in cases:
         h = rng.standard_normal(hl).astype(th)

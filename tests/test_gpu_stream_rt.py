@@ -33,22 +33,30 @@ def _run_chunks(f, x, sizes):
     return outs
 
 
-def _rt_plans(M, T, es):
-    """kernels_fir_stream.hip plan_fir_stream, the run-time-M branch: does a step of 128 outputs fit two LDS stages (8- and
-    16-byte samples: with room for two workgroups per CU)?"""
-    S = 2 * M * es
+def _rt_plans(M, T, es, single=None):
+    """kernels_fir_stream.hip plan_fir_stream, the run-time-M branch: one or two outputs per lane, and does a step fit two LDS
+    stages (pairs of 8- and 16-byte samples: with room for two workgroups per CU)?  `single`: None = the plan's own choice."""
+    bs = 8 if es == 16 else 16
+    if single is None:
+        single = (M * es) % 8 == 0 and not (M % bs == 0 and 128 <= M * es <= 192)
+    if single and (M * es) % 8:
+        single = False
+    if es == 16 and M > 32:
+        return False
+    S = (1 if single else 2) * M * es
     cd = S // 16 if S % 16 == 0 else 0
     pad = cd if cd >= 2 and cd % 2 == 0 else 0
+    opw = 64 if single else 128
     ncw = 3
-    while ncw > 1 and 128 * ncw * M * es > 24 * 1024:
+    while ncw > 1 and opw * ncw * M * es > 24 * 1024:
         ncw -= 1
-    nchunks = ((128 * ncw * M + T + 16) * es + 15) // 16
+    nchunks = ((opw * ncw * M + T + 16) * es + 15) // 16
     if pad:
         nchunks = (nchunks + pad - 1) // pad * (pad + 1)
     nslots = (nchunks + 63) // 64
     if nslots > 60 or nslots * 2048 > 150 * 1024 or M + 16 > 256:
         return False
-    return not (es >= 8 and nslots * 2048 + 64 > 78 * 1024)
+    return not (not single and es >= 8 and nslots * 2048 + 64 > 78 * 1024)
 
 
 TYPES = ((np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float64), (np.float64, np.float32),
@@ -69,19 +77,28 @@ def _case(pkg, O, torch, monkeypatch, rng, M, T, th, tx, numerics, want_rt=True)
     sizes = [10_007, 1, 13, max(T // 2, 1), 9_990]
     sizes.append(n - sum(sizes))
     ys = {}
-    for mode in ("rt", "generic"):
+    es = np.dtype(tx).itemsize
+    for mode in ("rt", "pair", "single", "generic"):
         monkeypatch.setenv("MRHIP_STREAM_RT", "2")
-        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False); monkeypatch.delenv("MRHIP_STREAM_RT_SINGLE", raising=False)
         if mode == "generic":
             monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+        elif mode != "rt":
+            monkeypatch.setenv("MRHIP_STREAM_RT_SINGLE", "1" if mode == "single" else "0")
         f = pkg.FIRFilter(h, Fraction(1, M), numerics=numerics)
         y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
         ys[mode] = (y, f.history.copy(), f.last_kernel_name(), (f.state.phiIdx, f.state.inputDeficit))
         f.close()
-    monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+    monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False); monkeypatch.delenv("MRHIP_STREAM_RT_SINGLE", raising=False)
     what = f"M={M} T={T} {th.__name__} x {tx.__name__} numerics={numerics}"
     if want_rt:
         assert ys["rt"][2] == "fir_stream_rt_kernel", (what, ys["rt"][2])
+    for mode, single in (("pair", False), ("single", True)):       # the two lane maps, forced
+        if _rt_plans(M, T, es, single) and not (single and (M * es) % 8):
+            assert ys[mode][2] == "fir_stream_rt_kernel", (what, mode, ys[mode][2])
+        assert_bit_equal(ys[mode][0], ys["generic"][0], f"{mode} vs generic {what}")
+        assert_bit_equal(ys[mode][1], ys["generic"][1], f"history {mode} {what}")
+        assert ys[mode][3] == ys["generic"][3]
     assert ys["generic"][2] == "poly_generic_kernel"
     assert_bit_equal(ys["rt"][0], ys["generic"][0], f"rt vs generic {what}")
     assert_bit_equal(ys["rt"][1], ys["generic"][1], f"history {what}")
@@ -101,8 +118,9 @@ def _case(pkg, O, torch, monkeypatch, rng, M, T, th, tx, numerics, want_rt=True)
 
 
 def test_runtime_decimation_kernel_matrix(pkg, O, torch_cuda, monkeypatch):
-    """Every block class of the kernel (B / A / D / the sample-by-sample one): decimations below, at and above the block size,
-    windows shorter than the decimation, tap counts that are and are not whole blocks; every sample / tap type pairing."""
+    """Every block class of the kernel (B / A / D / the sample-by-sample one) under both lane maps (two outputs per lane, one output
+    per lane -- each forced, and the plan's own choice): decimations below, at and above the block size, windows shorter than the
+    decimation, tap counts that are and are not whole blocks; every sample / tap type pairing."""
     rng = np.random.default_rng(4101)
     n_rt = 0
     for M in (1, 2, 3, 5, 8, 10, 15, 16, 17, 31, 32, 33, 36, 38, 47, 48, 55):
