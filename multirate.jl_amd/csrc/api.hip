@@ -215,7 +215,7 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
             PairArgs pa;
             dim3 block;
             size_t lds = 0;
-            if (plan_rational_opair(tk, a, f->num_cus, &pa, &block, &lds)) {
+            if (plan_rational_opair(tk, fused, a, f->num_cus, &pa, &block, &lds)) {
                 *rec_written = true;
                 *did_shiftin = a.H > 0;
                 return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, counters);
@@ -898,7 +898,7 @@ static hipError_t launch_poly_dyn(mrhip_filter *f, const TypeKey &tk, bool fused
             *did_shiftin = a.H > 0;
             return launch_fir_stream(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
         }
-        if (a.L > 1 && plan_rational_opair(tk, a, f->num_cus, &pa, &block, &lds)) {
+        if (a.L > 1 && plan_rational_opair(tk, fused, a, f->num_cus, &pa, &block, &lds)) {
             hipError_t e = launch_poly_plan(f, x_len, pa.P, y_capacity, count_dev, s);
             if (e != hipSuccess) return e;
             *did_shiftin = a.H > 0;
@@ -1373,7 +1373,7 @@ int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *con
     dim3 block;
     size_t lds = 0;
     const bool column = f0->L == 1;                                  // FIRStandard / FIRDecimator: the streaming single-column kernel
-    if (!(column ? plan_fir_stream(tk, a, f0->num_cus, &pa, &block, &lds) : plan_rational_opair(tk, a, f0->num_cus, &pa, &block, &lds))) return single_calls();
+    if (!(column ? plan_fir_stream(tk, a, f0->num_cus, &pa, &block, &lds) : plan_rational_opair(tk, fused, a, f0->num_cus, &pa, &block, &lds))) return single_calls();
     // descriptors: pinned staging -> device, owned by the first filter of the call
     const size_t bytes = static_cast<size_t>(n) * sizeof(MultiDesc);
     if (bytes > f0->multi_cap) {

@@ -68,7 +68,7 @@ constexpr int kOMaxThreads = 512;
 // SMIN >= 2: Float32 arithmetic and tapsPerPhi <= 32) for Float32 arithmetic (Float32 or ComplexF32 samples, Float32 taps)
 // and Float64 arithmetic (Float64 or ComplexF64 samples; Float64 taps x Float32 or ComplexF32 samples).  Returns false otherwise
 // (the caller tries the next kernel).
-bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
+bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {
     if (!opair_env_int("MRHIP_OPAIR", 1)) return false;   // read per call: tests switch kernels at run time
     if (tk.x_f64 && !tk.r_f64) return false;
@@ -81,6 +81,7 @@ bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, Pair
     if (a.L < 2 || a.M < 1 || a.zero_start_below > 0) return false;   // (L == 1: the single-column kernels; M == 1: FIRInterpolator)
     const int smin = static_cast<int>(a.M / a.L);        // the two windows of a lane start SMIN or SMIN + 1 samples apart
     if (smin > 5) return false;
+    if (!opair_instantiated(fused, smin, a.T)) return false;   // (FUSED: M/L < 2 and tapsPerPhi a multiple of 4)
     if (smin >= 2 && (tk.r_f64 || a.T > 32)) return false;   // instantiated for Float32 arithmetic, tapsPerPhi <= 32
     const int env_c = opair_env_int("MRHIP_OPAIR_C", 0), env_j = opair_env_int("MRHIP_OPAIR_J", 0), env_ns = opair_env_int("MRHIP_OPAIR_NS", 0);
     // c: lanes = c*L/2 <= 512; c*L and c*M even (a lane owns two outputs; the run base keeps its parity from step to

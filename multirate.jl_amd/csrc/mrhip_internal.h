@@ -439,9 +439,13 @@ hipError_t launch_farrow_tiled(const TypeKey &tk, bool fused, const FarrowArgs &
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
 // least-squares polynomial fit of y[0..n) at x = 1..n (support.jl:85-88); coef receives polyorder+1 ascending powers
 bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef);
-bool plan_rational_opair(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
+bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                                  const char **kname, int num_cus, unsigned *counters);   // FIRRational and FIRInterpolator, two outputs per lane; also performs shiftin!
+// rational_opair_kernel: STRICT (the product: bit-identical to the reference) is instantiated for every tapsPerPhi of every M/L class;
+// the opt-in FUSED numerics for M/L < 2 and tapsPerPhi a multiple of 4 only (other FUSED shapes run on poly_phase_stationary_kernel /
+// poly_tiled_kernel): the FUSED half of the matrix was 18 MB of code objects.
+constexpr bool opair_instantiated(bool fused, int smin, int T) { return !fused || (smin <= 1 && T % 4 == 0); }
 bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
 hipError_t launch_fir_stream(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                              const char **kname, int num_cus, unsigned *counters);   // FIRStandard / FIRDecimator, streaming form; also performs shiftin!

@@ -398,7 +398,13 @@ def test_output_pair_kernel_both_directions(pkg, O, torch_cuda, monkeypatch):
                 g = pkg.FIRFilter(h, Fraction(L, M), numerics=numerics)
                 y_g = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
                 monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
-                assert kn == "rational_opair_kernel", (L, M, hl, th, tx, kn)
+                # STRICT: every shape here is the output-pair kernel's; FUSED (opt-in) is instantiated for M/L < 2 and tapsPerPhi a
+                # multiple of 4, the other FUSED shapes run on the phase-stationary / tiled kernels -- same results either way
+                tpp = -(-hl // L)
+                if numerics == pkg.NUMERICS_STRICT or (M < 2 * L and tpp % 4 == 0):
+                    assert kn == "rational_opair_kernel", (L, M, hl, th, tx, numerics, kn)
+                else:
+                    assert kn in ("poly_phase_stationary_kernel", "poly_tiled_kernel"), (L, M, hl, th, tx, numerics, kn)
                 assert_bit_equal(y_t, y_g, f"opair vs generic L={L} M={M} hLen={hl} {th} {tx} numerics={numerics}")
                 assert_bit_equal(f.history, g.history, "history")
                 assert (f.state.phiIdx, f.state.inputDeficit) == (g.state.phiIdx, g.state.inputDeficit)
