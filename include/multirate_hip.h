@@ -299,7 +299,12 @@ void mrhip_cascade_destroy(mrhip_cascade *c);
 int64_t mrhip_cascade_outputlength(const mrhip_cascade *c, int64_t inputlength);
 /* exact per-channel output count of the next mrhip_cascade_filt_device call with `inputlength` samples */
 int64_t mrhip_cascade_next_output_count(const mrhip_cascade *c, int64_t inputlength);
-/* same contract as mrhip_filt_device for the whole chain; MRHIP_ERR_BUFFER_TOO_SMALL leaves every stage untouched */
+/* same contract as mrhip_filt_device for the whole chain; MRHIP_ERR_BUFFER_TOO_SMALL leaves every stage untouched.
+ * Under HIP-graph capture the lengths planned at capture time are what every replay runs with (a stage's input length is part
+ * of the next stage's launch), so every stage must map its input length to the same count on every replay: rational-family
+ * stages with inputlength * L a multiple of M; anything else (and FIRArbitrary / FIRFarrow stages) is MRHIP_ERR_UNSUPPORTED
+ * before anything is launched.  y needs room for mrhip_outputlength_bound of the last stage, and one plain call of the same
+ * size must have run before the capture (it allocates the buffers between the stages). */
 int mrhip_cascade_filt_device(mrhip_cascade *c, const void *x, int64_t x_len, int64_t x_stride, void *y, int64_t y_capacity,
                               int64_t y_stride, int64_t *n_written, void *stream);
 int mrhip_cascade_reset(mrhip_cascade *c);

@@ -90,29 +90,55 @@ int mrhip_cascade_filt_device(mrhip_cascade *c, const void *x, int64_t x_len, in
     if (n_written) *n_written = 0;
     if (x_len < 0 || y_capacity < 0) return fail(MRHIP_ERR_INVALID_ARG, "negative length");
     const size_t ns = c->stages.size();
+    // Under HIP-graph capture every replay runs the stages with the lengths planned NOW (a stage's input length is baked into
+    // the next stage's launch): each stage must therefore turn the same number of samples into the same number of outputs on
+    // every replay -- rational family with inputlength * L a multiple of M (the state then returns to itself; FIRStandard and
+    // FIRInterpolator always do).  Anything else is refused instead of replaying stale lengths.  A captured stage is planned
+    // on the device and wants room for mrhip_outputlength_bound outputs: the buffers between the stages get that.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    if (capturing) {
+        int64_t m = x_len;
+        for (size_t i = 0; i < ns; ++i) {
+            const mrhip_filter *f = c->stages[i];
+            if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW)
+                return fail(MRHIP_ERR_UNSUPPORTED, "cascade under graph capture: a FIRArbitrary / FIRFarrow stage produces a count that differs from replay to replay; capture its calls on their own (mrhip_filt_device_async)");
+            if (static_cast<__int128>(m) * f->L % f->M != 0)
+                return fail(MRHIP_ERR_UNSUPPORTED, "cascade under graph capture: a stage's inputlength * L is not a multiple of M, so its output count differs from replay to replay");
+            m = static_cast<int64_t>(static_cast<__int128>(m) * f->L / f->M);
+        }
+    }
     // counts of every stage first (pure functions of state and length): the error check precedes any work
-    std::vector<int64_t> cnt(ns);
+    std::vector<int64_t> cnt(ns), room(ns);
     int64_t n = x_len;
     for (size_t i = 0; i < ns; ++i) {
-        n = n > 0 ? std::max<int64_t>(mrhip_next_output_count(c->stages[i], n), 0) : 0;
+        const int64_t in_n = n;
+        if (capturing) n = static_cast<int64_t>(static_cast<__int128>(n) * c->stages[i]->L / c->stages[i]->M);   // (exact whatever the state: checked above; the host's view of the state may not be read during a capture)
+        else n = n > 0 ? std::max<int64_t>(mrhip_next_output_count(c->stages[i], n), 0) : 0;
         cnt[i] = n;
+        room[i] = std::max<int64_t>(mrhip_outputlength_bound(c->stages[i], in_n), n);   // (what a device-planned call of this length wants: a plain call of the size warms the buffers up for a capture)
     }
-    if (n > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
+    if ((capturing ? room[ns - 1] : n) > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, capturing ? "buffer is too small: a captured call needs room for mrhip_outputlength_bound outputs of the last stage" : "buffer is too small");
     if (n > 0 && !y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
     if (c->nch > 1 && n > 0 && y_stride < n) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (prev != c->device && hipSetDevice(c->device) != hipSuccess) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
     int rc = MRHIP_OK;
+    for (size_t i = 0; i + 1 < ns && !rc; ++i) {
+        const size_t want = std::max<size_t>(static_cast<size_t>(room[i]) * dtype_size(c->stages[i]->ty) * static_cast<size_t>(c->nch), 16);
+        if (capturing && want > c->cap_bytes[i & 1])
+            rc = fail(MRHIP_ERR_UNSUPPORTED, "cascade under graph capture: the buffers between the stages are allocated by the first call of a size; run one plain call of this size before capturing");
+    }
     for (size_t i = 0; i + 1 < ns && !rc; ++i)
-        rc = grow(c, static_cast<int>(i & 1), std::max<size_t>(static_cast<size_t>(cnt[i]) * dtype_size(c->stages[i]->ty) * static_cast<size_t>(c->nch), 16));
+        rc = grow(c, static_cast<int>(i & 1), std::max<size_t>(static_cast<size_t>(room[i]) * dtype_size(c->stages[i]->ty) * static_cast<size_t>(c->nch), 16));
     const void *in = x;
     int64_t in_len = x_len, in_stride = x_stride;
     for (size_t i = 0; i < ns && !rc && in_len > 0; ++i) {
         const bool last = i + 1 == ns;
         void *outp = last ? y : c->buf[i & 1];
-        const int64_t cap = last ? y_capacity : cnt[i];
-        const int64_t stride = last ? y_stride : std::max<int64_t>(cnt[i], 1);
+        const int64_t cap = last ? y_capacity : room[i];
+        const int64_t stride = last ? y_stride : std::max<int64_t>(room[i], 1);
         int64_t got = 0;
         rc = mrhip_filt_device(c->stages[i], in, in_len, in_stride, outp, cap, stride, &got, stream);
         if (!rc && got != cnt[i]) rc = fail(MRHIP_ERR_INVALID_ARG, "cascade: a stage produced a different count than planned");

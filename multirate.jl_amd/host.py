@@ -749,6 +749,31 @@ class FilterCascade:
         assert nw.value == cnt
         return y[0] if one else y
 
+    def filt_into(self, buffer, x) -> int:
+        """The chain into a caller-owned device buffer (one row per channel); returns the per-channel output count.  This is
+        the form a HIP graph can capture: every stage must then map its input length to the same count on every replay
+        (inputlength * L a multiple of M), the buffer needs room for the last stage's ``outputlength_bound`` and one plain
+        call of the same size must have run before (it allocates the buffers between the stages)."""
+        if not (_is_torch(x) and x.is_cuda and _is_torch(buffer) and buffer.is_cuda):
+            raise MultirateHIPError(1, "FilterCascade.filt_into takes device tensors")
+        one = x.ndim == 1
+        nch, n = (1, x.shape[0]) if one else (x.shape[0], x.shape[1])
+        self._ensure(_torch_np_dtype(x.dtype), nch)
+        if x.stride(-1) != 1 or buffer.stride(-1) != 1:
+            raise MultirateHIPError(1, "x and buffer must be contiguous along time (planar channels)")
+        if _torch_np_dtype(buffer.dtype) != self.output_dtype:
+            raise MultirateHIPError(1, f"buffer dtype must be {self.output_dtype}")
+        if buffer.ndim != x.ndim or (not one and buffer.shape[0] != nch):
+            raise MultirateHIPError(1, "buffer must have one row per channel")
+        cap = buffer.shape[-1]
+        xs = x.stride(0) if (not one and nch > 1) else n
+        ys = buffer.stride(0) if (not one and nch > 1) else cap
+        nw = C.c_int64(0)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(self._lib.mrhip_cascade_filt_device(self._handle, C.c_void_p(x.data_ptr()), n, xs, C.c_void_p(buffer.data_ptr()),
+                                                   cap, ys, C.byref(nw), C.c_void_p(stream)))
+        return nw.value
+
     def outputlength(self, inputlength: int) -> int:
         n = int(inputlength)
         for f in self.stages:

@@ -290,3 +290,58 @@ def test_independent_streams_other_kinds(pkg, O, torch_cuda, ratio, tx):
             assert (fs[i].state.phiIdx, fs[i].state.inputDeficit) == (fos[i].state.phiIdx, fos[i].state.inputDeficit)
     for f in fs:
         f.close()
+
+
+def test_cascade_under_graph_capture(pkg, O, torch_cuda):
+    """FilterCascade (decimate 1//4, then 3//2) captured into a HIP graph: every stage maps its input length to the same count
+    on every replay (8 000 -> 2 000 -> 3 000), so the lengths baked into the launches hold; 20 replays == the oracle's chunk
+    loop.  A chunk that does not (8 001) is refused before anything is launched, the capture stays valid; so is a capture
+    before the buffers between the stages exist."""
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    h1 = rng.standard_normal(64).astype(np.float32)
+    h2 = rng.standard_normal(3 * 24).astype(np.float32)
+    nch, chunk, nrep = 3, 8_000, 20
+    xh = rng.standard_normal((nch, chunk * (nrep + 1))).astype(np.float32)
+    x = torch.from_numpy(xh).cuda()
+    cas = pkg.FilterCascade(pkg.FIRFilter(h1, Fraction(1, 4)), pkg.FIRFilter(h2, Fraction(3, 2)))
+    o1, o2 = O.FIRFilter(h1, Fraction(1, 4), tx=np.float32), O.FIRFilter(h2, Fraction(3, 2), tx=np.float32)
+    xs = torch.zeros((nch, chunk), dtype=torch.float32, device="cuda")
+    # room for the last stage's bound of a device-planned call
+    bound = cas.stages[1].bind(np.float32, nch).outputlength_bound(cas.stages[0].bind(np.float32, nch).outputlength_bound(chunk))
+    ys = torch.zeros((nch, bound), dtype=torch.float32, device="cuda")
+
+    s = torch.cuda.Stream()
+    g0 = torch.cuda.CUDAGraph()                                 # cold: the buffers between the stages do not exist yet
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g0, stream=s):
+        with pytest.raises(pkg.MultirateHIPError) as ei:
+            cas.filt_into(ys, xs)
+        assert ei.value.code == 5                               # MRHIP_ERR_UNSUPPORTED
+        xs.add_(0)                                              # (the capture is intact: it records this)
+    # one plain call of the size: allocates the buffers, and is the stream's first chunk
+    xs.copy_(x[:, :chunk])
+    n0 = cas.filt_into(ys, xs)
+    ref0 = o2.filt(o1.filt(xh[1, :chunk]))
+    assert n0 == len(ref0) == 3_000
+    assert_bit_equal(ys[1, :n0].cpu().numpy(), ref0, "plain call")
+    for f in cas.stages:
+        f.sync_state()
+    xlong = torch.zeros((nch, chunk + 1), dtype=torch.float32, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=s):
+        n1 = cas.filt_into(ys, xs)
+        with pytest.raises(pkg.MultirateHIPError):              # 8 001 samples: the decimator's count would differ between replays
+            cas.filt_into(ys, xlong)
+    assert n1 == 3_000
+    for rep in range(1, nrep + 1):
+        xs.copy_(x[:, rep * chunk:(rep + 1) * chunk])
+        g.replay()
+        torch.cuda.synchronize()
+        ref = o2.filt(o1.filt(xh[1, rep * chunk:(rep + 1) * chunk]))
+        assert_bit_equal(ys[1, :3_000].cpu().numpy(), ref, f"replay {rep}")
+    for f, fo in zip(cas.stages, (o1, o2)):
+        f.sync_state()
+        assert (f.state.phiIdx, f.state.inputDeficit) == (fo.state.phiIdx, fo.state.inputDeficit)
+    cas.close()
