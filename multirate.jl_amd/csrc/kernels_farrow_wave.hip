@@ -57,21 +57,26 @@ __global__ __launch_bounds__(kFwThreads) void farrow_wave_kernel(FarrowArgs a)
     long long kw = static_cast<long long>(blockIdx.x) * kFwThreads + (threadIdx.x & ~63);   // this wave's first output
     if (kw >= n_out) return;
     constexpr bool EARLY = TREG <= 16;                                   // channel 0's samples are requested before the Horner steps
-    auto entry = [&](long long kw_, long long *n_, double *ph_) {        // schedule entry of this lane's output (idle lanes of the
+    constexpr int DEAD = TREG <= 16 ? 3 : 7;                             // slot classes 4, 8, 12, 16 | 24, 32 (launch_fw_t)
+    // (the entry's index stays the 32-bit value the load delivers until the top of the iteration that uses it: widened right
+    //  behind the prefetch it made the wave wait there -- vmcnt is in order -- for the twelve sample loads issued before it,
+    //  i.e. BEFORE the Horner steps those loads are meant to hide behind)
+    auto entry = [&](long long kw_, int *n_, double *ph_) {              // schedule entry of this lane's output (idle lanes of the
         long long kk = kw_ + lane;                                       // last wave repeat its last output)
         if (kk >= n_out) kk = n_out - 1;
         *n_ = a.n_idx[kk];
         *ph_ = a.acc[kk];
     };
-    long long n;
+    int n32;
     double phase;
-    entry(kw, &n, &phase);
+    entry(kw, &n32, &phase);
     for (;;) {                                                           // (wave-uniform trip count)
+        const long long n = n32;
         const long long k = kw + lane;
         const bool have = k < n_out;
         const long long kw_next = kw + step;
         const bool more = kw_next < n_out;
-        long long n_next = n;
+        int n_next = n32;
         double phase_next = phase;
         const bool seam = n < a.seam_below;                              // kernel.xIdx < kernel.tapsPer𝜙, Filters.jl:818
         const long long base = n - T;                                    // 0-based index of the oldest sample (negative: history)
@@ -98,6 +103,9 @@ __global__ __launch_bounds__(kFwThreads) void farrow_wave_kernel(FarrowArgs a)
 #pragma unroll
                     for (int c = 0; c < NC; ++c) v[i][c] = p[c];
                 }
+                // (keeps the two paths' loads apart: merged at the join, the common path computed a 64-bit address per load for
+                //  them instead of one base with immediate offsets)
+                asm volatile("; window at the signal's ends");
             }
         };
         if constexpr (EARLY) load_samples(0);                            // in flight during the Horner steps
@@ -119,14 +127,20 @@ __global__ __launch_bounds__(kFwThreads) void farrow_wave_kernel(FarrowArgs a)
             }
         }
         R treg[TREG];
+        if (a.tap_f32) {                                                 // (a wave-uniform BRANCH: as a select per tap it was two conversions
+#pragma unroll                                                           //  and two selects per tap for every filter)
+            for (int i = 0; i < TREG; ++i) treg[i] = static_cast<R>(static_cast<float>(yv[i]));
+        } else {
 #pragma unroll
-        for (int i = 0; i < TREG; ++i) treg[i] = a.tap_f32 ? static_cast<R>(static_cast<float>(yv[i])) : static_cast<R>(yv[i]);
+            for (int i = 0; i < TREG; ++i) treg[i] = static_cast<R>(yv[i]);
+        }
         for (int ch = 0; ch < a.nch; ++ch) {
             if (!EARLY || ch > 0) load_samples(ch);
             R acc[NC];
 #pragma unroll
             for (int i = 0; i < TREG; ++i) {
-                const bool live = i < T;                                 // (wave-uniform)
+                // (wave-uniform; tapsPerPhi lies in the slot class: only its last DEAD slots can be past the window)
+                const bool live = i < TREG - DEAD ? true : i < T;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     const R x = static_cast<R>(v[i][c]);
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(kFwThreads) void farrow_wave_kernel(FarrowArgs a)
             }
         }
         if (!more) break;
-        kw = kw_next; n = n_next; phase = phase_next;
+        kw = kw_next; n32 = n_next; phase = phase_next;
     }
 }
 
@@ -184,11 +198,17 @@ hipError_t launch_fw_t(bool fused, const FarrowArgs &a, hipStream_t s, int num_c
 
 }  // namespace
 
-// Eligible: fewer than four channels and at most 32 taps (T = 0 cannot happen: tapsPerPhi >= 1).  MRHIP_FARROW_WAVE=0: off.
+// Eligible: at most 16 taps per phase and at most 8 channels (measured, profiles/r04/farrow_wave_vs_pipe.txt, 1e7 samples in all:
+// 10 taps, 1 / 4 / 8 channels 0.072 / 0.047 / 0.039 ms against farrow_pipe_kernel's 0.210 / 0.069 / 0.055; at 16 channels level, at 64
+// the LDS tiles win 0.22 vs 0.34; with 32 taps -- samples requested after the Horner steps, 64 registers of taps -- the pipe kernel is
+// ahead from one channel on: 0.283 vs 0.316).  MRHIP_FARROW_WAVE=0: off; MRHIP_FARROW_WAVE_MAXCH=n: at most n channels, any tap count
+// up to 32 (tests run every slot class with it).
 bool plan_farrow_wave(const FarrowArgs &a)
 {
     if (MRHIP_ENV_INT("MRHIP_FARROW_WAVE", 1) == 0) return false;
-    return a.nch >= 1 && a.nch < 4 && a.T >= 1 && a.T <= 32 && (a.n_out >= 1 || a.dyn);
+    const int forced = MRHIP_ENV_INT("MRHIP_FARROW_WAVE_MAXCH", -1);
+    const int maxch = forced >= 0 ? forced : (a.T <= 16 ? 8 : 0);
+    return a.nch >= 1 && a.nch <= maxch && a.T >= 1 && a.T <= 32 && (a.n_out >= 1 || a.dyn);
 }
 
 hipError_t launch_farrow_wave(const TypeKey &tk, bool fused, const FarrowArgs &a, hipStream_t s, const char **kname, int num_cus)

@@ -98,12 +98,12 @@ def test_call_longer_than_2_31_samples(pkg, O, torch_cuda):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("nch", [1, 5])
+@pytest.mark.parametrize("nch", [1, 5, 12])
 def test_farrow_pieces_of_a_split_call_do_not_restart_the_seam(pkg, O, torch_cuda, monkeypatch, nch):
     """FIRFarrow's dot is the Vector seam variant (support.jl:46: starts from zero) for the first tapsPerPhi-1
     inputs of a CALL; the pieces mrhip_filt_device cuts a long call into continue that call, so their first outputs must not
     start from zero again -- visible only as the sign of an all-(-0.0) sum: positive taps (a constant polynomial bank), -0.0
-    samples across every piece seam.  One channel: farrow_wave_kernel; five: farrow_pipe_kernel."""
+    samples across every piece seam.  One and five channels: farrow_wave_kernel; twelve: farrow_pipe_kernel."""
     torch = torch_cuda
     monkeypatch.setenv("MRHIP_LAUNCH_MAX", "4099")
     Nphi, T = 8, 6
@@ -117,7 +117,7 @@ def test_farrow_pieces_of_a_split_call_do_not_restart_the_seam(pkg, O, torch_cud
     yo = fo.filt(x[nch - 1])                                # ONE reference call
     assert_bit_equal(y[nch - 1], yo, "split FIRFarrow call")
     assert np.signbit(yo[T + 5:5000]).all() and not np.signbit(yo[:T - 1]).any()       # -0 past the call's own seam, +0 on it
-    assert f.last_kernel_name() == ("farrow_wave_kernel" if nch < 4 else "farrow_pipe_kernel")
+    assert f.last_kernel_name() == ("farrow_wave_kernel" if nch <= 8 else "farrow_pipe_kernel")
     f.close()
 
 

@@ -1177,7 +1177,7 @@ def test_farrow_pipe_kernel_sweep(pkg, O, torch_cuda, monkeypatch):
             finally:
                 O.set_fused(False)
             f.close(); g.close()
-    # (fewer than four channels: farrow_wave_kernel, one lane per output straight from global memory)
+    # (at most 16 taps per phase and 8 channels: farrow_wave_kernel, one lane per output straight from global memory)
     assert {"farrow_pipe_kernel", "farrow_tiled_kernel", "farrow_wave_kernel"} <= seen, seen
 
 
@@ -1234,7 +1234,8 @@ def test_pipe_kernels_many_tiles_per_workgroup(pkg, O, torch_cuda, monkeypatch):
                     mk = (lambda: pkg.FIRFilter(h, rate, nphi, 3, pnfb=pn)) if farrow else (lambda: pkg.FIRFilter(h, rate, nphi))
                     outs = {}
                     for name, env in (("pipe", {"MRHIP_FARROW_WAVE": "0"}), ("pipe, register staging", {"MRHIP_PIPE_DMA": "0", "MRHIP_FARROW_WAVE": "0"}),
-                                      ("tiled", {"MRHIP_FARROW_PIPE": "0", "MRHIP_ARB_PIPE": "0", "MRHIP_FARROW_WAVE": "0"}), ("default", {})):
+                                      ("tiled", {"MRHIP_FARROW_PIPE": "0", "MRHIP_ARB_PIPE": "0", "MRHIP_FARROW_WAVE": "0"}), ("default", {}),
+                                      ("wave", {"MRHIP_FARROW_WAVE_MAXCH": "64"})):
                         for k, v in env.items():
                             monkeypatch.setenv(k, v)
                         f = mk()
@@ -1251,9 +1252,12 @@ def test_pipe_kernels_many_tiles_per_workgroup(pkg, O, torch_cuda, monkeypatch):
                         seen.add(kn)
                         assert kn in ("arb_pipe_kernel", "farrow_pipe_kernel"), kn
                         assert_bit_equal(got, want, f"{name} vs {kt}: farrow={farrow} rate={rate} T={T} {np.dtype(tx)} x {np.dtype(th)} taps nch={nch}")
-                    got, kn = outs["default"]                 # what the dispatcher picks: farrow_wave_kernel below four channels
-                    assert kn == ("farrow_wave_kernel" if farrow and nch < 4 else "farrow_pipe_kernel" if farrow else "arb_pipe_kernel"), kn
+                    got, kn = outs["default"]                 # what the dispatcher picks (more than 16 taps per phase: the pipe kernels)
+                    assert kn == ("farrow_pipe_kernel" if farrow else "arb_pipe_kernel"), kn
                     assert_bit_equal(got, want, f"default ({kn}) vs {kt}: farrow={farrow} rate={rate} T={T} nch={nch}")
+                    got, kn = outs["wave"]                    # farrow_wave_kernel's 24- and 32-slot classes, forced
+                    assert kn == ("farrow_wave_kernel" if farrow else "arb_pipe_kernel"), kn
+                    assert_bit_equal(got, want, f"wave ({kn}) vs {kt}: farrow={farrow} rate={rate} T={T} nch={nch}")
     assert seen == {"arb_pipe_kernel", "farrow_pipe_kernel"}
 
 
