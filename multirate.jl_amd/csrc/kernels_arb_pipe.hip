@@ -94,7 +94,9 @@ __device__ __forceinline__ R sample_of_pair(v2u_t v, int which)   // two Float32
 #ifndef MRHIP_AP_TD128
 #define MRHIP_AP_TD128 0
 #endif
-template <typename TX, typename R, int NC, bool FUSED, int CPL, bool DMA>
+// TEX > 0: tapsPerPhi == TEX exactly (a multiple of 4): the tap-pair pipeline is unrolled whole with immediate LDS offsets -- no
+// running bases to advance (6 vector adds per two pairs), no loop counter.
+template <typename TX, typename R, int NC, bool FUSED, int CPL, bool DMA, int TEX = 0>
 __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, ArbTileArgs ta)
 {
     constexpr int ROWS = kPipeElems / CPL;
@@ -376,7 +378,27 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             using I32 = std::integral_constant<int, 32>;
             using INR = std::integral_constant<int, NR>;
             const int nblk = T >> 1;                             // tap pairs (uniform)
-            if (nblk > 0) {
+            if constexpr (TEX > 0) {
+                static_assert(TEX % 4 == 0 && TEX <= 64, "whole double pairs, offsets within the tile's pad");
+                Blk A, B;
+                issue(A, I0{});
+                // (no read past the last pair here: the loop below reads one pair too many and retires it with a wait before its
+                //  registers are touched again; unrolled, the compiler sees those results are never used, gives all of them ONE
+                //  scratch register and reuses it at once -- the reads, still in flight, then land on top of an accumulator)
+                dev::static_for<0, TEX / 4>([&](auto K) {
+                    constexpr int o = decltype(K)::value * 32;
+                    issue(B, std::integral_constant<int, o + 16>{});
+                    landed(A, INR{});
+                    compute(A);
+                    if constexpr (decltype(K)::value + 1 < TEX / 4) {
+                        issue(A, std::integral_constant<int, o + 32>{});
+                        landed(B, INR{});
+                    } else {
+                        landed(B, I0{});
+                    }
+                    compute(B);
+                });
+            } else if (nblk > 0) {
                 // Straight-line pipeline, no conditional issue (a conditional read makes the two register sets merge through
                 // copies): the pair after the last one is read too -- it lies inside LDS (the next column, the pad behind the
                 // sample buffers) and is never used.
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 asm volatile("s_waitcnt lgkmcnt(0)");            // the unused last reads
                 if constexpr (TD) dev::pin(A.td0); else dev::pin(A.t0);
             }
-            if (T & 1) {                                         // odd tapsPerPhi: the last tap alone
+            if (TEX == 0 && (T & 1)) {                           // odd tapsPerPhi: the last tap alone
                 const int i = T - 1;
                 const unsigned tl = lds0 + static_cast<unsigned>(phi * TP + i) * (TD ? 2u * RS : RS);
                 TapReg t = lds_read_tap<R, 0>(tl), d = lds_read_tap<R, 0>(tl + (TD ? RS : static_cast<unsigned>(ta.bank_elems) * RS));
@@ -497,7 +519,13 @@ hipError_t launch_pipe_t(bool fused, const ArbArgs &a, const ArbTileArgs &ta, si
     case 4:
         // (four ComplexF32 channels per lane with Float64 arithmetic and register staging would spill: never planned, not built)
         if constexpr (!DMA && NC == 2 && sizeof(R) == 8) return hipErrorInvalidValue;
-        else return fused ? go(arb_pipe_kernel<TX, R, NC, true, 4, DMA>) : go(arb_pipe_kernel<TX, R, NC, false, 4, DMA>);
+        else {
+            if constexpr (DMA) {                                // BASELINE config 4's shape: 32 taps per phase, unrolled whole
+                if (a.T == 32 && MRHIP_ENV_INT("MRHIP_ARB_EXACT", 1) != 0)
+                    return fused ? go(arb_pipe_kernel<TX, R, NC, true, 4, DMA, 32>) : go(arb_pipe_kernel<TX, R, NC, false, 4, DMA, 32>);
+            }
+            return fused ? go(arb_pipe_kernel<TX, R, NC, true, 4, DMA>) : go(arb_pipe_kernel<TX, R, NC, false, 4, DMA>);
+        }
     case 2: return fused ? go(arb_pipe_kernel<TX, R, NC, true, 2, DMA>) : go(arb_pipe_kernel<TX, R, NC, false, 2, DMA>);
     default: return fused ? go(arb_pipe_kernel<TX, R, NC, true, 1, DMA>) : go(arb_pipe_kernel<TX, R, NC, false, 1, DMA>);
     }

@@ -1287,3 +1287,36 @@ def test_stream_kernel_decimations_33_to_63_real_float32(pkg, O, torch_cuda, mon
             assert_bit_equal(y[nch - 1], yo, f"1//{M} hLen={hl} vs oracle")
             assert_bit_equal(f.history, g.history, "history")
             f.close(); g.close()
+
+
+def test_arb_pipe_exact_32_taps(pkg, O, torch_cuda, monkeypatch):
+    """arb_pipe_kernel's whole-pipeline unrolling for 32 taps per phase (BASELINE config 4's shape; taken with >= 32 channels and
+    LDS-DMA staging): bit-identical to the looped form (MRHIP_ARB_EXACT=0), to the universal kernel and to the oracle, for every
+    sample / tap type the kernel serves, STRICT and FUSED, chunked (first / last tiles are staged through registers)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(3232)
+    Nphi, T, nch, n = 32, 32, 37, 70_001
+    for th, tx in ((np.float64, np.float64), (np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float32), (np.float64, np.complex64)):
+        h = rng.standard_normal(Nphi * T).astype(th)
+        x = _rand(rng, (nch, n), tx) - 0.5
+        xd = torch.from_numpy(x).cuda()
+        sizes = [30_000, 1, n - 30_001]
+        for rate in (math.pi / 3, 0.71):
+            for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
+                ys = {}
+                for mode, env in (("exact", {}), ("loop", {"MRHIP_ARB_EXACT": "0"}), ("generic", {"MRHIP_FORCE_GENERIC": "1"})):
+                    for k, v in env.items():
+                        monkeypatch.setenv(k, v)
+                    f = pkg.FIRFilter(h, float(rate), Nphi, numerics=numerics)
+                    ys[mode] = (torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy(), f.last_kernel_name())
+                    f.close()
+                    for k in env:
+                        monkeypatch.delenv(k)
+                tag = f"{np.dtype(th)} taps x {np.dtype(tx)} rate={rate:.3f} numerics={numerics}"
+                assert ys["exact"][1] == "arb_pipe_kernel" and ys["loop"][1] == "arb_pipe_kernel" and ys["generic"][1] == "arb_generic_kernel", (tag, ys["exact"][1], ys["generic"][1])
+                assert_bit_equal(ys["exact"][0], ys["loop"][0], "unrolled vs looped " + tag)
+                assert_bit_equal(ys["exact"][0], ys["generic"][0], "unrolled vs universal " + tag)
+                if numerics == pkg.NUMERICS_STRICT:
+                    fo = O.FIRFilter(h, float(rate), Nphi, tx=tx)
+                    yo = np.concatenate(_run_chunks(fo, x[nch - 1], sizes))
+                    assert_bit_equal(ys["exact"][0][nch - 1], yo, "unrolled vs oracle " + tag)
