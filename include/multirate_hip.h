@@ -252,6 +252,15 @@ int mrhip_filt_device(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_s
  * A call longer than one launch (2^30 samples; 2^24 / rate for FIRArbitrary) is MRHIP_ERR_UNSUPPORTED here. */
 int mrhip_filt_device_async(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
                             int64_t y_capacity, int64_t y_stride, int64_t *count_out, void *stream);
+/* The second stage of a device-resident chain (filt(f2, filt(f1, x)) in the reference's terms: the caller passes one filter's
+ * output Vector to the next, src/Filters.jl:744-751): `f`'s input is what `prev`'s latest asynchronous or captured call --
+ * earlier on the same stream -- wrote, and its LENGTH is that call's count, which only the device knows.  x_len_bound =
+ * mrhip_outputlength_bound(prev, prev's input length): the launch is sized for it, and y_capacity / y_stride must cover
+ * mrhip_outputlength_bound(f, x_len_bound).  Rational-family filters that the pair kernels serve (else
+ * MRHIP_ERR_UNSUPPORTED, nothing enqueued); same count_out / state rules as mrhip_filt_device_async.  With it a chain
+ * of filters runs, and replays from a HIP graph, at any chunk size without the host learning a single count. */
+int mrhip_filt_device_chained(mrhip_filter *f, const mrhip_filter *prev, const void *x, int64_t x_len_bound, int64_t x_stride,
+                              void *y, int64_t y_capacity, int64_t y_stride, int64_t *count_out, void *stream);
 /* filt!(buffer_i, self_i, x_i) for i = 0..n-1 -- n INDEPENDENT FIRFilter objects, each with its own phase, input deficit,
  * history and call length, the reference's one-FIRFilter-per-signal streaming usage (README.md:87-141) -- issued as ONE
  * launch when the filters agree in kind (the rational family: FIRStandard, FIRDecimator, FIRInterpolator, FIRRational), ratio,
@@ -307,6 +316,13 @@ int64_t mrhip_cascade_next_output_count(const mrhip_cascade *c, int64_t inputlen
  * size must have run before the capture (it allocates the buffers between the stages). */
 int mrhip_cascade_filt_device(mrhip_cascade *c, const void *x, int64_t x_len, int64_t x_stride, void *y, int64_t y_capacity,
                               int64_t y_stride, int64_t *n_written, void *stream);
+/* The chain with nothing returned to the host (asynchronous, or under HIP-graph capture at ANY chunk size): the first stage is
+ * mrhip_filt_device_async, every later one mrhip_filt_device_chained on the previous stage's count.  y needs room for the
+ * last stage's bound of the bounds; *count_out (device-accessible, may be NULL) receives the chain's per-channel output
+ * count.  One plain call of the same size must have run before a capture (it allocates the buffers between the stages);
+ * rational-family stages on the pair kernels, else MRHIP_ERR_UNSUPPORTED. */
+int mrhip_cascade_filt_device_async(mrhip_cascade *c, const void *x, int64_t x_len, int64_t x_stride, void *y, int64_t y_capacity,
+                                    int64_t y_stride, int64_t *count_out, void *stream);
 int mrhip_cascade_reset(mrhip_cascade *c);
 
 /* replaces the stateless filt(h, x, ratio), src/Filters.jl:858-861, and

@@ -885,7 +885,7 @@ static int64_t output_bound(const mrhip_filter *f, int64_t x_len)
 // kernels and the universal one); `a` holds the upper bounds the launch is sized with.  *P receives the outputs per step
 // the plan kernel needs for the pair kernels' step walk.
 static hipError_t launch_poly_dyn(mrhip_filter *f, const TypeKey &tk, bool fused, const PolyArgs &a, int64_t x_len, long long y_capacity,
-                                  long long *count_dev, hipStream_t s, const char **kname, bool *did_shiftin)
+                                  long long *count_dev, hipStream_t s, const char **kname, bool *did_shiftin, const DevCall *x_from = nullptr)
 {
     *did_shiftin = false;
     if (!f->force_generic) {
@@ -893,18 +893,21 @@ static hipError_t launch_poly_dyn(mrhip_filter *f, const TypeKey &tk, bool fused
         dim3 block;
         size_t lds = 0;
         if (a.L == 1 && plan_fir_stream(tk, a, f->num_cus, &pa, &block, &lds)) {
-            hipError_t e = launch_poly_plan(f, x_len, pa.P, y_capacity, count_dev, s);
+            hipError_t e = launch_poly_plan(f, x_len, pa.P, y_capacity, count_dev, s, x_from);
             if (e != hipSuccess) return e;
             *did_shiftin = a.H > 0;
             return launch_fir_stream(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
         }
         if (a.L > 1 && plan_rational_opair(tk, fused, a, f->num_cus, &pa, &block, &lds)) {
-            hipError_t e = launch_poly_plan(f, x_len, pa.P, y_capacity, count_dev, s);
+            hipError_t e = launch_poly_plan(f, x_len, pa.P, y_capacity, count_dev, s, x_from);
             if (e != hipSuccess) return e;
             *did_shiftin = a.H > 0;
             return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
         }
     }
+    // (a chained call -- its input length is the previous stage's count, on the device -- is served by the pair kernels only:
+    //  the universal kernel's history update is a launch of its own that takes the length from the host)
+    if (x_from) return hipErrorNotSupported;
     hipError_t e = launch_poly_plan(f, x_len, 1, y_capacity, count_dev, s);
     if (e != hipSuccess) return e;
     return launch_poly_generic(tk, fused, a, s, kname);
@@ -918,7 +921,7 @@ static hipError_t launch_poly_dyn(mrhip_filter *f, const TypeKey &tk, bool fused
 // stream state, like every call that is being captured into a HIP graph.
 static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_t x_stride, void *y,
                            int64_t y_capacity, int64_t y_stride, int64_t *n_written, void *stream_, bool continuation,
-                           bool async = false, long long *count_dev = nullptr)
+                           bool async = false, long long *count_dev = nullptr, const DevCall *x_from = nullptr)
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
     if (n_written) *n_written = 0;
@@ -946,6 +949,8 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         return fail(MRHIP_ERR_UNSUPPORTED, "asynchronous calls of this filter are outstanding: mrhip_sync_state before capturing (a replay must find the record they leave)");
     if (!dev_planned && !f->mirror_valid)
         if (int rc = rec_pull(f)) return rc;
+    if (x_from && (!dev_planned || f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW))
+        return fail(MRHIP_ERR_UNSUPPORTED, "a chained call is an asynchronous or captured call of a rational-family filter");
     if (x_len == 0) {                  // nothing to do: zero outputs, history and state unchanged
         if (count_dev) MRHIP_CHECK_HIP(hipMemsetAsync(count_dev, 0, sizeof(long long), stream));
         return MRHIP_OK;
@@ -1181,10 +1186,17 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         a.nch = static_cast<int>(f->nch);
         a.rec = f->d_rec; a.dyn = f->d_call;
         if (int rc = timing_mark(f, stream)) return rc;
-        MRHIP_CHECK_HIP(launch_poly_dyn(f, tk, fused, a, x_len, y_capacity, count_dev, stream, &f->last_kernel, &did_shiftin));
+        {
+            const hipError_t e = launch_poly_dyn(f, tk, fused, a, x_len, y_capacity, count_dev, stream, &f->last_kernel, &did_shiftin, x_from);
+            if (e == hipErrorNotSupported && x_from)
+                return fail(MRHIP_ERR_UNSUPPORTED, "a chained call (input length = the previous stage's count, on the device) needs a filter the pair kernels serve (rational_opair_kernel / fir_stream_kernel)");
+            MRHIP_CHECK_HIP(e);
+        }
         if (int rc = timing_mark(f, stream)) return rc;
         rec_current = true;
-        if (f->mirror_valid || capturing) {
+        if (x_from) {
+            n_out = -1;                 // (the host never learns a chained call's length: its view of the state is re-read from the device)
+        } else if (f->mirror_valid || capturing) {
             // the shadow of ONE execution: exact while the host knew the state when the capture (or the run of
             // asynchronous calls) began; re-read from the device before it is next used either way
             const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len);
@@ -1308,6 +1320,21 @@ int mrhip_filt_device_async(mrhip_filter *f, const void *x, int64_t x_len, int64
 {
     static_assert(sizeof(long long) == sizeof(int64_t), "the count is written by the device as a long long");
     return filt_device_any(f, x, x_len, x_stride, y, y_capacity, y_stride, nullptr, stream, true, reinterpret_cast<long long *>(count_out));
+}
+
+// A CHAINED asynchronous call: this filter's input is what `prev`'s latest device-planned call (asynchronous or captured, earlier
+// on the same stream) wrote -- `prev`'s count, known on the device only, is this call's input length; x_len_bound is its upper
+// bound (mrhip_outputlength_bound of `prev`'s input), for which the launch is sized and y must have room.
+int mrhip_filt_device_chained(mrhip_filter *f, const mrhip_filter *prev, const void *x, int64_t x_len_bound, int64_t x_stride, void *y,
+                              int64_t y_capacity, int64_t y_stride, int64_t *count_out, void *stream)
+{
+    if (!f || !prev) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    if (prev->kind == MRHIP_FIR_ARBITRARY || prev->kind == MRHIP_FIR_FARROW)
+        return fail(MRHIP_ERR_UNSUPPORTED, "chained calls follow a rational-family filter (FIRArbitrary / FIRFarrow alternate their call records)");
+    if (f->device != prev->device) return fail(MRHIP_ERR_INVALID_ARG, "the two filters live on different devices");
+    if (x_len_bound >= (1LL << 30)) return fail(MRHIP_ERR_UNSUPPORTED, "a chained call is one launch");
+    return filt_device_one(f, x, x_len_bound, x_stride, y, y_capacity, y_stride, nullptr, stream, false, true,
+                           reinterpret_cast<long long *>(count_out), prev->d_call);
 }
 
 // SEVERAL INDEPENDENT STREAMS, ONE LAUNCH.  The reference's streaming usage is one FIRFilter per signal (README.md:87-141): N

@@ -149,6 +149,57 @@ int mrhip_cascade_filt_device(mrhip_cascade *c, const void *x, int64_t x_len, in
     return rc;
 }
 
+int mrhip_cascade_filt_device_async(mrhip_cascade *c, const void *x, int64_t x_len, int64_t x_stride, void *y, int64_t y_capacity,
+                                    int64_t y_stride, int64_t *count_out, void *stream)
+{
+    if (!c) return fail(MRHIP_ERR_INVALID_ARG, "NULL cascade");
+    if (x_len < 0 || y_capacity < 0) return fail(MRHIP_ERR_INVALID_ARG, "negative length");
+    const size_t ns = c->stages.size();
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    if (x_len == 0) {                  // nothing to do: no stage runs, every state stays (and no stage's call record goes stale)
+        if (count_out) MRHIP_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int64_t), static_cast<hipStream_t>(stream)));
+        return MRHIP_OK;
+    }
+    // every stage is sized for the BOUND of what the stage before it can produce
+    std::vector<int64_t> room(ns);
+    int64_t n = x_len;
+    for (size_t i = 0; i < ns; ++i) {
+        const mrhip_filter *f = c->stages[i];
+        if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW)
+            return fail(MRHIP_ERR_UNSUPPORTED, "asynchronous cascade: rational-family stages only (a FIRArbitrary / FIRFarrow stage cannot be chained on a device-side count)");
+        n = std::max<int64_t>(mrhip_outputlength_bound(f, n), 0);
+        room[i] = n;
+    }
+    if (room[ns - 1] > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small: an asynchronous cascade needs room for the bound of the last stage's output");
+    if (room[ns - 1] > 0 && !y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
+    if (c->nch > 1 && y_stride < room[ns - 1]) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output bound");
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != c->device && hipSetDevice(c->device) != hipSuccess) return fail(MRHIP_ERR_HIP, "hipSetDevice failed");
+    int rc = MRHIP_OK;
+    for (size_t i = 0; i + 1 < ns && !rc; ++i) {
+        const size_t want = std::max<size_t>(static_cast<size_t>(room[i]) * dtype_size(c->stages[i]->ty) * static_cast<size_t>(c->nch), 16);
+        if (capturing && want > c->cap_bytes[i & 1])
+            rc = fail(MRHIP_ERR_UNSUPPORTED, "cascade under graph capture: the buffers between the stages are allocated by the first call of a size; run one plain call of this size before capturing");
+        if (!rc) rc = grow(c, static_cast<int>(i & 1), want);
+    }
+    const void *in = x;
+    int64_t in_len = x_len, in_stride = x_stride;
+    for (size_t i = 0; i < ns && !rc; ++i) {
+        const bool last = i + 1 == ns;
+        void *outp = last ? y : c->buf[i & 1];
+        const int64_t cap = last ? y_capacity : room[i];
+        const int64_t stride = last ? y_stride : std::max<int64_t>(room[i], 1);
+        int64_t *cnt = last ? count_out : nullptr;
+        rc = i == 0 ? mrhip_filt_device_async(c->stages[0], in, in_len, in_stride, outp, cap, stride, cnt, stream)
+                    : mrhip_filt_device_chained(c->stages[i], c->stages[i - 1], in, in_len, in_stride, outp, cap, stride, cnt, stream);
+        in = outp; in_len = room[i]; in_stride = stride;
+    }
+    if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
+    return rc;
+}
+
 int mrhip_cascade_reset(mrhip_cascade *c)
 {
     if (!c) return fail(MRHIP_ERR_INVALID_ARG, "NULL cascade");

@@ -183,5 +183,5 @@ void rec_free(mrhip_filter *f);
 int rec_push(mrhip_filter *f, hipStream_t s, long long call_n_out = -1, long long n_written = -1);
 // wait for everything enqueued on the filter's behalf and take the device record over into the host fields
 int rec_pull(mrhip_filter *f);
-hipError_t launch_poly_plan(mrhip_filter *f, int64_t x_len, long long P, long long y_capacity, long long *count_out, hipStream_t s);
+hipError_t launch_poly_plan(mrhip_filter *f, int64_t x_len, long long P, long long y_capacity, long long *count_out, hipStream_t s, const DevCall *x_from = nullptr);
 }  // namespace mrhip

@@ -194,6 +194,7 @@ struct DevCall {                      // what the kernels of ONE device-planned 
     unsigned steps_per_channel, total_steps, spc_magic, pad0;   // pair kernels: the step walk for this n_out
     long long per_pos, per_xbase;     // PERIODIC schedule: cycle position / x offset at the call's first entry
     long long k_done;                 // schedule entries valid so far (a call whose schedule is continued after a host redo)
+    long long x_len;                  // rational family: the call's input length (a chained call takes it from the previous stage's count)
 };
 // Closed form of the rational loop (host_logic.cpp: plan_rational), usable on both sides
 struct CallPlanPOD { long long n_out, phi0, d0, phi_end, d_end; int short_input; };

@@ -47,6 +47,7 @@ __device__ __forceinline__ void pair_take_dyn(PolyArgs &a, PairArgs &pa)
     if (a.dyn) {
         const DevCall *__restrict__ d = a.dyn;
         a.n_out = d->n_out; a.u0 = d->u0; a.d0 = d->d0;
+        a.x_len = d->x_len;                                   // (a chained call: the previous stage's count; else the launch's own value)
         pa.o0 = d->d0 - a.T;
         pa.steps_per_channel = d->steps_per_channel;
         pa.total_steps = d->total_steps;

@@ -43,6 +43,7 @@ struct PlanArgs {
     long long *count_out;
     long long L, M, x_len, P, y_capacity;
     int kind, nch;
+    const DevCall *x_from;        // a chained call: the input length is the count this record holds (x_len above: its upper bound)
 };
 
 // filt! of the rational family planned where the state lives (Filters.jl:543-547 short input, :558-571 the loop in closed
@@ -51,8 +52,15 @@ __global__ __launch_bounds__(64) void poly_plan_kernel(PlanArgs a)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     DevStream r = *a.rec;
-    const CallPlanPOD p = plan_rational_pod(a.kind, a.L, a.M, r.phiIdx, r.inputDeficit, a.x_len);
+    long long x_len = a.x_len;
+    if (a.x_from) {
+        x_len = a.x_from->n_out;
+        if (x_len > a.x_len) { x_len = a.x_len; r.error = MRHIP_ERR_BUFFER_TOO_SMALL; }   // cannot happen: the bound is the previous stage's own
+        if (x_len < 0) x_len = 0;
+    }
+    const CallPlanPOD p = plan_rational_pod(a.kind, a.L, a.M, r.phiIdx, r.inputDeficit, x_len);
     DevCall c{};
+    c.x_len = x_len;
     c.n_out = p.n_out;
     if (c.n_out > a.y_capacity) {           // cannot happen: the host checked the capacity against the largest count of any state
         c.n_out = a.y_capacity;
@@ -169,9 +177,10 @@ int rec_pull(mrhip_filter *f)
     return MRHIP_OK;
 }
 
-hipError_t launch_poly_plan(mrhip_filter *f, int64_t x_len, long long P, long long y_capacity, long long *count_out, hipStream_t s)
+hipError_t launch_poly_plan(mrhip_filter *f, int64_t x_len, long long P, long long y_capacity, long long *count_out, hipStream_t s, const DevCall *x_from)
 {
     PlanArgs a{};
+    a.x_from = x_from;
     a.rec = f->d_rec; a.mirror = mirror_dev(f); a.call = f->d_call; a.count_out = count_out;
     a.L = f->L; a.M = f->M; a.x_len = x_len; a.P = P > 0 ? P : 1; a.y_capacity = y_capacity;
     a.kind = f->kind; a.nch = static_cast<int>(f->nch);

@@ -96,6 +96,7 @@ ABI = [
     ("mrhip_get_taps", _i, [_vp, _i, _vp]),
     ("mrhip_filt_device", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
     ("mrhip_filt_device_async", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
+    ("mrhip_filt_device_chained", _i, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     ("mrhip_filt_device_multi", _i, [C.POINTER(_vp), _i, C.POINTER(_vp), _pi64, C.POINTER(_vp), _pi64, _pi64, _vp]),
     ("mrhip_outputlength_bound", _i64, [_vp, _i64]),
     ("mrhip_sync_state", _i, [_vp, _pi64]),
@@ -108,6 +109,7 @@ ABI = [
     ("mrhip_cascade_outputlength", _i64, [_vp, _i64]),
     ("mrhip_cascade_next_output_count", _i64, [_vp, _i64]),
     ("mrhip_cascade_filt_device", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
+    ("mrhip_cascade_filt_device_async", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     ("mrhip_cascade_reset", _i, [_vp]),
     ("mrhip_filt_once", _i, [_vp, _i64, _i, _i64, _i64, _d, _i64, _vp, _i64, _i, _vp, _i64, _pi64, _i]),
     ("mrhip_set_timing", _i, [_vp, _i]),
@@ -522,12 +524,15 @@ class FIRFilter:
             raise MultirateHIPError(1, "outputlength_bound needs a bound filter (call filt once, or bind())")
         return self._lib.mrhip_outputlength_bound(self._handle, int(inputlength))
 
-    def filt_into_async(self, buffer, x, count=None) -> None:
+    def filt_into_async(self, buffer, x, count=None, after: "FIRFilter" = None) -> None:
         """filt!(buffer, self, x) planned ON THE DEVICE from the device-resident stream state (``mrhip_filt_device_async``):
         nothing is returned and the host never waits, so a loop of such calls only enqueues -- and captures into a HIP
         graph at any fixed chunk size, for every kind.  ``buffer`` must hold ``outputlength_bound(n)`` samples per channel;
         ``count`` (optional) is a one-element int64 CUDA tensor that receives the per-channel output count in stream order.
-        ``sync_state()`` returns the last call's count and brings the host-side view of the state up to date."""
+        ``sync_state()`` returns the last call's count and brings the host-side view of the state up to date.
+        ``after=prev`` makes this a CHAINED call (``mrhip_filt_device_chained``): ``x`` is the buffer ``prev``'s latest
+        asynchronous or captured call wrote, its length is that call's count (known on the device only) and ``x.shape[-1]`` is the
+        bound the launch is sized for (``prev.outputlength_bound(...)``)."""
         if not _is_torch(x) or not x.is_cuda:
             raise MultirateHIPError(1, "filt_into_async takes torch device tensors")
         if x.stride(-1) != 1 or buffer.stride(-1) != 1:
@@ -547,6 +552,12 @@ class FIRFilter:
                 raise MultirateHIPError(1, "count must be an int64 CUDA tensor")
             cptr = C.c_void_p(count.data_ptr())
         stream = torch.cuda.current_stream(x.device).cuda_stream
+        if after is not None:
+            if after._handle is None:
+                raise MultirateHIPError(1, "after= needs a bound filter")
+            _check(self._lib.mrhip_filt_device_chained(self._handle, after._handle, C.c_void_p(x.data_ptr()), n, xs, C.c_void_p(buffer.data_ptr()),
+                                                       cap, ys, cptr, C.c_void_p(stream)))
+            return
         _check(self._lib.mrhip_filt_device_async(self._handle, C.c_void_p(x.data_ptr()), n, xs, C.c_void_p(buffer.data_ptr()),
                                                  cap, ys, cptr, C.c_void_p(stream)))
 
@@ -773,6 +784,41 @@ class FilterCascade:
         _check(self._lib.mrhip_cascade_filt_device(self._handle, C.c_void_p(x.data_ptr()), n, xs, C.c_void_p(buffer.data_ptr()),
                                                    cap, ys, C.byref(nw), C.c_void_p(stream)))
         return nw.value
+
+    def outputlength_bound(self, inputlength: int) -> int:
+        """Room per channel an asynchronous (or captured) call of ``inputlength`` samples needs: the stages' bounds in turn."""
+        n = int(inputlength)
+        for f in self.stages:
+            n = f.outputlength_bound(n)
+        return n
+
+    def filt_into_async(self, buffer, x, count=None) -> None:
+        """The chain with nothing returned to the host (``mrhip_cascade_filt_device_async``): the first stage is planned on the
+        device, every later one takes its input length from the previous stage's count ON THE DEVICE -- so the chain captures into a
+        HIP graph at any chunk size.  ``buffer`` holds ``outputlength_bound(n)`` samples per channel; ``count``: one-element int64 CUDA
+        tensor for the chain's per-channel output count.  Before a capture run one plain call of the same size (buffers)."""
+        if not (_is_torch(x) and x.is_cuda and _is_torch(buffer) and buffer.is_cuda):
+            raise MultirateHIPError(1, "FilterCascade.filt_into_async takes device tensors")
+        one = x.ndim == 1
+        nch, n = (1, x.shape[0]) if one else (x.shape[0], x.shape[1])
+        self._ensure(_torch_np_dtype(x.dtype), nch)
+        if x.stride(-1) != 1 or buffer.stride(-1) != 1:
+            raise MultirateHIPError(1, "x and buffer must be contiguous along time (planar channels)")
+        if _torch_np_dtype(buffer.dtype) != self.output_dtype:
+            raise MultirateHIPError(1, f"buffer dtype must be {self.output_dtype}")
+        if buffer.ndim != x.ndim or (not one and buffer.shape[0] != nch):
+            raise MultirateHIPError(1, "buffer must have one row per channel")
+        cap = buffer.shape[-1]
+        xs = x.stride(0) if (not one and nch > 1) else n
+        ys = buffer.stride(0) if (not one and nch > 1) else cap
+        cptr = None
+        if count is not None:
+            if not (_is_torch(count) and count.is_cuda and count.dtype == torch.int64 and count.numel() >= 1):
+                raise MultirateHIPError(1, "count must be an int64 CUDA tensor")
+            cptr = C.c_void_p(count.data_ptr())
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(self._lib.mrhip_cascade_filt_device_async(self._handle, C.c_void_p(x.data_ptr()), n, xs, C.c_void_p(buffer.data_ptr()),
+                                                         cap, ys, cptr, C.c_void_p(stream)))
 
     def outputlength(self, inputlength: int) -> int:
         n = int(inputlength)

@@ -372,6 +372,16 @@ function filt_device_async!(f::FIRFilter, yptr::Ptr{Cvoid}, ycap::Integer, ystri
                 f.handle, xptr, xlen, xstride, yptr, ycap, ystride, countptr, stream))
     nothing
 end
+# the second stage of a device-resident chain: x is what `prev`'s latest asynchronous / captured call wrote, its length that call's
+# count (on the device only); xlenbound = outputlengthbound(prev, ...) sizes the launch (mrhip_filt_device_chained)
+function filt_device_chained!(f::FIRFilter, prev::FIRFilter, yptr::Ptr{Cvoid}, ycap::Integer, ystride::Integer, xptr::Ptr{Cvoid}, xlenbound::Integer,
+                              xstride::Integer, ::Type{Tx}, nch::Integer; countptr::Ptr{Int64} = Ptr{Int64}(C_NULL), stream::Ptr{Cvoid} = C_NULL) where {Tx}
+    bind!(f, Tx, nch)
+    check(ccall((:mrhip_filt_device_chained, libmr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Cvoid}),
+                f.handle, prev.handle, xptr, xlenbound, xstride, yptr, ycap, ystride, countptr, stream))
+    nothing
+end
 outputlengthbound(f::FIRFilter, n::Integer) = Int(ccall((:mrhip_outputlength_bound, libmr), Int64, (Ptr{Cvoid}, Int64), f.handle, n))
 # wait for the filter's enqueued calls, bring the host-side view of the state up to date; returns the last call's count
 function syncstate!(f::FIRFilter)
@@ -450,6 +460,15 @@ end
 outputlength(c::FilterCascade, n::Integer) = Int(ccall((:mrhip_cascade_outputlength, libmr), Int64, (Ptr{Cvoid}, Int64), c.handle, n))
 nextoutputcount(c::FilterCascade, n::Integer) = Int(ccall((:mrhip_cascade_next_output_count, libmr), Int64, (Ptr{Cvoid}, Int64), c.handle, n))
 reset(c::FilterCascade) = (c.handle == C_NULL || check(ccall((:mrhip_cascade_reset, libmr), Cint, (Ptr{Cvoid},), c.handle)); c)
+# the chain with nothing returned to the host (asynchronous / capturable at any chunk size): the first stage is planned on the device,
+# every later one takes its input length from the previous stage's count on the device (mrhip_cascade_filt_device_async)
+function filt_device_async!(buffer, c::FilterCascade, x; countptr::Ptr{Int64} = Ptr{Int64}(C_NULL), stream::Ptr{Cvoid} = C_NULL)
+    bind!(c, eltype(x), size(x, 2))
+    check(ccall((:mrhip_cascade_filt_device_async, libmr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Cvoid}),
+                c.handle, devptr(x), size(x, 1), colstride(x), devptr(buffer), size(buffer, 1), colstride(buffer), countptr, stream))
+    nothing
+end
 # filt!(buffer, cascade, x) on device arrays: returns the per-channel output count
 function filt_device!(buffer, c::FilterCascade, x; stream::Ptr{Cvoid} = C_NULL)
     bind!(c, eltype(x), size(x, 2))

@@ -345,3 +345,92 @@ def test_cascade_under_graph_capture(pkg, O, torch_cuda):
         f.sync_state()
         assert (f.state.phiIdx, f.state.inputDeficit) == (fo.state.phiIdx, fo.state.inputDeficit)
     cas.close()
+
+
+def test_chained_asynchronous_calls(pkg, O, torch_cuda):
+    """mrhip_filt_device_chained: decimate 1//4, then 147//160, both asynchronous -- the second filter's input length is the
+    first one's count, which only the device knows (ragged chunks: it changes from call to call).  Outputs, counts and end
+    states == the oracle's loop of filt(f2, filt(f1, x))."""
+    torch = torch_cuda
+    rng = np.random.default_rng(123)
+    h1 = rng.standard_normal(64).astype(np.float32)
+    h2 = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    nch = 2
+    f1 = pkg.FIRFilter(h1, Fraction(1, 4)).bind(np.float32, nch)
+    f2 = pkg.FIRFilter(h2, Fraction(147, 160)).bind(np.float32, nch)
+    o1, o2 = O.FIRFilter(h1, Fraction(1, 4), tx=np.float32), O.FIRFilter(h2, Fraction(147, 160), tx=np.float32)
+    sizes = [40_001, 17, 3, 99_999, 1, 64_000, 2, 77_777]
+    xh = rng.standard_normal((nch, sum(sizes))).astype(np.float32)
+    x = torch.from_numpy(xh).cuda()
+    big = max(sizes)
+    mid = torch.zeros((nch, f1.outputlength_bound(big)), dtype=torch.float32, device="cuda")
+    outs = [torch.zeros((nch, f2.outputlength_bound(f1.outputlength_bound(s))), dtype=torch.float32, device="cuda") for s in sizes]
+    cnt = torch.zeros(len(sizes), dtype=torch.int64, device="cuda")
+    pos = 0
+    for i, s in enumerate(sizes):                               # only enqueues: no count ever reaches the host
+        b1 = f1.outputlength_bound(s)
+        f1.filt_into_async(mid[:, :b1], x[:, pos:pos + s])
+        f2.filt_into_async(outs[i], mid[:, :b1], cnt[i:i + 1], after=f1)
+        pos += s
+    torch.cuda.synchronize()
+    assert f2.last_kernel_name() == "rational_opair_kernel" and f1.last_kernel_name() == "fir_stream_kernel"
+    c = cnt.cpu().tolist()
+    pos = 0
+    for i, s in enumerate(sizes):
+        ref = o2.filt(o1.filt(xh[1, pos:pos + s]))
+        assert c[i] == len(ref), (i, s, c[i], len(ref))
+        assert_bit_equal(outs[i][1, :c[i]].cpu().numpy(), ref, f"call {i} ({s} samples)")
+        pos += s
+    for f, fo in ((f1, o1), (f2, o2)):
+        f.sync_state()
+        assert (f.state.phiIdx, f.state.inputDeficit) == (fo.state.phiIdx, fo.state.inputDeficit)
+    # a filter the pair kernels do not serve cannot be chained: refused, nothing enqueued
+    g = pkg.FIRFilter(rng.standard_normal(2 * 24).astype(np.float32), Fraction(2, 13)).bind(np.float32, nch)
+    with pytest.raises(pkg.MultirateHIPError) as ei:
+        g.filt_into_async(torch.zeros((nch, g.outputlength_bound(mid.shape[1])), dtype=torch.float32, device="cuda"), mid, after=f1)
+    assert ei.value.code == 5
+    for f in (f1, f2, g):
+        f.close()
+
+
+def test_cascade_captured_at_a_chunk_size_that_changes_the_counts(pkg, O, torch_cuda):
+    """FilterCascade.filt_into_async (mrhip_cascade_filt_device_async) under HIP-graph capture with a PRIME chunk: decimate 1//4,
+    then 3//2 -- the decimator's count alternates between replays, the rational stage takes it from the device.  30 replays ==
+    the oracle's chunk loop (outputs, counts, end states)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(321)
+    h1 = rng.standard_normal(48).astype(np.float32)
+    h2 = rng.standard_normal(3 * 24).astype(np.float32)
+    nch, chunk, nrep = 2, 10_007, 30
+    xh = rng.standard_normal((nch, chunk * (nrep + 1))).astype(np.float32)
+    x = torch.from_numpy(xh).cuda()
+    cas = pkg.FilterCascade(pkg.FIRFilter(h1, Fraction(1, 4)), pkg.FIRFilter(h2, Fraction(3, 2)))
+    o1, o2 = O.FIRFilter(h1, Fraction(1, 4), tx=np.float32), O.FIRFilter(h2, Fraction(3, 2), tx=np.float32)
+    xs = torch.zeros((nch, chunk), dtype=torch.float32, device="cuda")
+    xs.copy_(x[:, :chunk])
+    y0 = cas.filt(xs)                                            # a plain call of the size: allocates the buffers; the stream's first chunk
+    assert_bit_equal(y0[1].cpu().numpy(), o2.filt(o1.filt(xh[1, :chunk])), "plain call")
+    ys = torch.zeros((nch, cas.outputlength_bound(chunk)), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for f in cas.stages:
+        f.sync_state()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=s):
+        cas.filt_into_async(ys, xs, cnt)
+    counts = set()
+    for rep in range(1, nrep + 1):
+        xs.copy_(x[:, rep * chunk:(rep + 1) * chunk])
+        g.replay()
+        torch.cuda.synchronize()
+        ref = o2.filt(o1.filt(xh[1, rep * chunk:(rep + 1) * chunk]))
+        c = int(cnt.item())
+        counts.add(c)
+        assert c == len(ref), (rep, c, len(ref))
+        assert_bit_equal(ys[1, :c].cpu().numpy(), ref, f"replay {rep}")
+    assert len(counts) >= 2                                      # the counts did change between replays
+    for f, fo in zip(cas.stages, (o1, o2)):
+        f.sync_state()
+        assert (f.state.phiIdx, f.state.inputDeficit) == (fo.state.phiIdx, fo.state.inputDeficit)
+    cas.close()
