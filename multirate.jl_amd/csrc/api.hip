@@ -952,6 +952,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
     if (x_from && (!dev_planned || f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW))
         return fail(MRHIP_ERR_UNSUPPORTED, "a chained call is an asynchronous or captured call of a rational-family filter");
     if (x_len == 0) {                  // nothing to do: zero outputs, history and state unchanged
+        f->last_call_dev_planned = false;                      // (no plan kernel ran: the call record still holds an older call's count)
         if (count_dev) MRHIP_CHECK_HIP(hipMemsetAsync(count_dev, 0, sizeof(long long), stream));
         return MRHIP_OK;
     }
@@ -1207,8 +1208,10 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             n_out = -1;
         }
         f->mirror_valid = false;
+        f->last_call_dev_planned = true;
         if (!capturing) f->async_pending = true;
     } else {
+        f->last_call_dev_planned = false;
         const CallPlan p = plan_rational(f->kind, f->L, f->M, f->phiIdx, f->inputDeficit, x_len);
         n_out = p.n_out;
         // reference: error() before any work, Filters.jl:460 (Standard), :503 (Interpolator), :550 (Rational)
@@ -1332,6 +1335,8 @@ int mrhip_filt_device_chained(mrhip_filter *f, const mrhip_filter *prev, const v
     if (prev->kind == MRHIP_FIR_ARBITRARY || prev->kind == MRHIP_FIR_FARROW)
         return fail(MRHIP_ERR_UNSUPPORTED, "chained calls follow a rational-family filter (FIRArbitrary / FIRFarrow alternate their call records)");
     if (f->device != prev->device) return fail(MRHIP_ERR_INVALID_ARG, "the two filters live on different devices");
+    if (!prev->last_call_dev_planned)
+        return fail(MRHIP_ERR_INVALID_ARG, "the previous filter's latest call was not planned on the device (mrhip_filt_device_async, or a call under capture): its count is not in its call record");
     if (x_len_bound >= (1LL << 30)) return fail(MRHIP_ERR_UNSUPPORTED, "a chained call is one launch");
     return filt_device_one(f, x, x_len_bound, x_stride, y, y_capacity, y_stride, nullptr, stream, false, true,
                            reinterpret_cast<long long *>(count_out), prev->d_call);

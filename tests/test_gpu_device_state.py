@@ -384,7 +384,12 @@ def test_chained_asynchronous_calls(pkg, O, torch_cuda):
     for f, fo in ((f1, o1), (f2, o2)):
         f.sync_state()
         assert (f.state.phiIdx, f.state.inputDeficit) == (fo.state.phiIdx, fo.state.inputDeficit)
+    # a chained call behind a HOST-planned call of its predecessor: that call's count is not in the call record -- refused
+    y1 = f1.filt(x[:, :4_000])
+    with pytest.raises(pkg.MultirateHIPError):
+        f2.filt_into_async(outs[0], mid[:, :f1.outputlength_bound(4_000)], after=f1)
     # a filter the pair kernels do not serve cannot be chained: refused, nothing enqueued
+    f1.filt_into_async(mid[:, :f1.outputlength_bound(4_000)], x[:, :4_000])
     g = pkg.FIRFilter(rng.standard_normal(2 * 24).astype(np.float32), Fraction(2, 13)).bind(np.float32, nch)
     with pytest.raises(pkg.MultirateHIPError) as ei:
         g.filt_into_async(torch.zeros((nch, g.outputlength_bound(mid.shape[1])), dtype=torch.float32, device="cuda"), mid, after=f1)
