@@ -1063,10 +1063,13 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             if (dev_planned) {
                 // nobody collects: the host's copy of the state is stale from here on
                 f->mirror_valid = false;
+                f->last_call_dev_planned = so.pending && launched;        // (a chained call may follow: its input length is this call's count)
+                f->last_call_rec = f->d_calls[b];
                 if (!capturing) f->async_pending = true;
                 n_out = -1;
                 st = ArbState{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
             } else {
+                f->last_call_dev_planned = false;
                 for (;;) {
                     bool relaunch = false;
                     if (int rc = sched_collect(f, x_len, est, INT64_MAX, count_dev, ss, &so, &relaunch)) return rc;
@@ -1209,6 +1212,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         }
         f->mirror_valid = false;
         f->last_call_dev_planned = true;
+        f->last_call_rec = f->d_call;
         if (!capturing) f->async_pending = true;
     } else {
         f->last_call_dev_planned = false;
@@ -1332,14 +1336,12 @@ int mrhip_filt_device_chained(mrhip_filter *f, const mrhip_filter *prev, const v
                               int64_t y_capacity, int64_t y_stride, int64_t *count_out, void *stream)
 {
     if (!f || !prev) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
-    if (prev->kind == MRHIP_FIR_ARBITRARY || prev->kind == MRHIP_FIR_FARROW)
-        return fail(MRHIP_ERR_UNSUPPORTED, "chained calls follow a rational-family filter (FIRArbitrary / FIRFarrow alternate their call records)");
     if (f->device != prev->device) return fail(MRHIP_ERR_INVALID_ARG, "the two filters live on different devices");
-    if (!prev->last_call_dev_planned)
+    if (!prev->last_call_dev_planned || !prev->last_call_rec)
         return fail(MRHIP_ERR_INVALID_ARG, "the previous filter's latest call was not planned on the device (mrhip_filt_device_async, or a call under capture): its count is not in its call record");
     if (x_len_bound >= (1LL << 30)) return fail(MRHIP_ERR_UNSUPPORTED, "a chained call is one launch");
     return filt_device_one(f, x, x_len_bound, x_stride, y, y_capacity, y_stride, nullptr, stream, false, true,
-                           reinterpret_cast<long long *>(count_out), prev->d_call);
+                           reinterpret_cast<long long *>(count_out), prev->last_call_rec);
 }
 
 // SEVERAL INDEPENDENT STREAMS, ONE LAUNCH.  The reference's streaming usage is one FIRFilter per signal (README.md:87-141): N

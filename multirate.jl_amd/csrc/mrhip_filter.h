@@ -48,6 +48,7 @@ struct mrhip_filter {
     mrhip::DevCall *d_calls[2] = {nullptr, nullptr};   // ... FIRArbitrary / FIRFarrow alternate between two (see s_sched)
     bool async_pending = false;             // asynchronous calls are outstanding (nobody collected their result yet)
     bool last_call_dev_planned = false;   // the latest filt! was planned on the device: its DevCall holds that call's count (what a chained call reads)
+    const mrhip::DevCall *last_call_rec = nullptr;   // ... and this is that DevCall (FIRArbitrary / FIRFarrow alternate between two)
     mrhip::DevStream *h_rec = nullptr;      // pinned host memory the plan kernels mirror the record into
     bool mirror_valid = true;
     bool captured = false;                  // a call went into a HIP graph: replays advance the record behind the host's back

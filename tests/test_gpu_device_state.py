@@ -439,3 +439,55 @@ def test_cascade_captured_at_a_chunk_size_that_changes_the_counts(pkg, O, torch_
         f.sync_state()
         assert (f.state.phiIdx, f.state.inputDeficit) == (fo.state.phiIdx, fo.state.inputDeficit)
     cas.close()
+
+
+@pytest.mark.parametrize("kind", ["arbitrary", "farrow"])
+def test_cascade_with_an_arbitrary_rate_first_stage_under_capture(pkg, O, torch_cuda, kind):
+    """FIRArbitrary / FIRFarrow (rate 0.37: the count differs from call to call and only the device knows it), then a decimator 1//3
+    chained on that count: FilterCascade.filt_into_async captured once, 25 replays == the oracle's chunk loop."""
+    torch = torch_cuda
+    rng = np.random.default_rng(777)
+    Nphi, chunk, nrep, nch = 32, 50_021, 25, 2
+    h1 = (pkg.firdes(Nphi * 8, 0.45 / Nphi, beta=7.8562) * Nphi)
+    h2 = rng.standard_normal(45).astype(np.float64)
+    po = 3 if kind == "farrow" else None
+    f1 = pkg.FIRFilter(h1, 0.37, Nphi, po)
+    cas = pkg.FilterCascade(f1, pkg.FIRFilter(h2, Fraction(1, 3)))
+    xh = rng.random((nch, chunk * (nrep + 2)))
+    x = torch.from_numpy(xh).cuda()
+    xs = torch.zeros((nch, chunk), dtype=torch.float64, device="cuda")
+    xs.copy_(x[:, :chunk])
+    y0 = cas.filt(xs)                                            # plain call: buffers, schedule work space, the stream's first chunk
+    o1 = O.FIRFilter(h1, 0.37, Nphi, tx=np.float64, polyorder=po, pnfb=f1.pnfb()) if po else O.FIRFilter(h1, 0.37, Nphi, tx=np.float64)
+    o2 = O.FIRFilter(h2, Fraction(1, 3), tx=np.float64)
+    assert_bit_equal(y0[1].cpu().numpy(), o2.filt(o1.filt(xh[1, :chunk])), "plain call")
+    ys = torch.zeros((nch, cas.outputlength_bound(chunk)), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    xs.copy_(x[:, chunk:2 * chunk])
+    cas.filt_into_async(ys, xs, cnt)                             # an asynchronous call of the size: the device schedule's buffers exist before the capture
+    torch.cuda.synchronize()
+    ref = o2.filt(o1.filt(xh[1, chunk:2 * chunk]))
+    assert int(cnt.item()) == len(ref)
+    assert_bit_equal(ys[1, :len(ref)].cpu().numpy(), ref, "asynchronous call")
+    for f in cas.stages:
+        f.sync_state()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=s):
+        cas.filt_into_async(ys, xs, cnt)
+    counts = set()
+    for rep in range(2, nrep + 2):
+        xs.copy_(x[:, rep * chunk:(rep + 1) * chunk])
+        g.replay()
+        torch.cuda.synchronize()
+        ref = o2.filt(o1.filt(xh[1, rep * chunk:(rep + 1) * chunk]))
+        c = int(cnt.item())
+        counts.add(c)
+        assert c == len(ref), (rep, c, len(ref))
+        assert_bit_equal(ys[1, :c].cpu().numpy(), ref, f"replay {rep}")
+    assert len(counts) >= 2
+    for f, fo in zip(cas.stages, (o1, o2)):
+        f.sync_state()
+    assert (cas.stages[1].state.phiIdx, cas.stages[1].state.inputDeficit) == (o2.state.phiIdx, o2.state.inputDeficit)
+    cas.close()
