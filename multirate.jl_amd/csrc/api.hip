@@ -905,10 +905,8 @@ static hipError_t launch_poly_dyn(mrhip_filter *f, const TypeKey &tk, bool fused
             return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, f->d_counters);
         }
     }
-    // (a chained call -- its input length is the previous stage's count, on the device -- is served by the pair kernels only:
-    //  the universal kernel's history update is a launch of its own that takes the length from the host)
-    if (x_from) return hipErrorNotSupported;
-    hipError_t e = launch_poly_plan(f, x_len, 1, y_capacity, count_dev, s);
+    // (a chained call on the universal kernel: its history update is a launch of its own, which takes the length from the call record too)
+    hipError_t e = launch_poly_plan(f, x_len, 1, y_capacity, count_dev, s, x_from);
     if (e != hipSuccess) return e;
     return launch_poly_generic(tk, fused, a, s, kname);
 }
@@ -1254,6 +1252,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         HistArgs ha{};
         ha.x = x; ha.hist_old = f->d_hist[f->hist_cur]; ha.hist_new = f->d_hist[hist_next];
         ha.x_stride = x_stride; ha.x_len = x_len; ha.H = static_cast<int>(f->H); ha.nch = static_cast<int>(f->nch);
+        ha.dyn = x_from ? f->d_call : nullptr;                 // (a chained call: the length its plan kernel took from the previous stage)
         MRHIP_CHECK_HIP(launch_shiftin(tk, ha, stream));
     }
     if (f->H > 0) {

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void shiftin_kernel(HistArgs a)
     if (t >= total) return;
     const int ch = static_cast<int>(t / a.H);
     const int i = static_cast<int>(t - static_cast<long long>(ch) * a.H);
-    const long long e = static_cast<long long>(i) + a.x_len;   // index into [hist_old ; x]
+    const long long x_len = a.dyn ? a.dyn->x_len : a.x_len;
+    const long long e = static_cast<long long>(i) + x_len;     // index into [hist_old ; x]
     const TX *src = e < a.H
         ? static_cast<const TX *>(a.hist_old) + (static_cast<long long>(ch) * a.H + e) * NC
         : static_cast<const TX *>(a.x) + (static_cast<long long>(ch) * a.x_stride + (e - a.H)) * NC;

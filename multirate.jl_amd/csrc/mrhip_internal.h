@@ -301,6 +301,7 @@ struct HistArgs {            // shiftin! (src/support.jl:61-80) for every channe
     long long x_len;
     int H;
     int nch;
+    const DevCall *dyn;      // a chained device-planned call: the input length is dyn->x_len (x_len above: its upper bound)
 };
 
 struct TileArgs {            // tiling of the phase-stationary kernel (kernels_phase_stationary.hip)

@@ -388,12 +388,27 @@ def test_chained_asynchronous_calls(pkg, O, torch_cuda):
     y1 = f1.filt(x[:, :4_000])
     with pytest.raises(pkg.MultirateHIPError):
         f2.filt_into_async(outs[0], mid[:, :f1.outputlength_bound(4_000)], after=f1)
-    # a filter the pair kernels do not serve cannot be chained: refused, nothing enqueued
-    f1.filt_into_async(mid[:, :f1.outputlength_bound(4_000)], x[:, :4_000])
-    g = pkg.FIRFilter(rng.standard_normal(2 * 24).astype(np.float32), Fraction(2, 13)).bind(np.float32, nch)
-    with pytest.raises(pkg.MultirateHIPError) as ei:
-        g.filt_into_async(torch.zeros((nch, g.outputlength_bound(mid.shape[1])), dtype=torch.float32, device="cuda"), mid, after=f1)
-    assert ei.value.code == 5
+    # a filter the pair kernels do not serve (2//13: the universal kernel plans on the device too) chains as well
+    hg = rng.standard_normal(2 * 24).astype(np.float32)
+    g = pkg.FIRFilter(hg, Fraction(2, 13)).bind(np.float32, nch)
+    og = O.FIRFilter(hg, Fraction(2, 13), tx=np.float32)
+    o1b = O.FIRFilter(h1, Fraction(1, 4), tx=np.float32)
+    f1.reset()
+    yg = torch.zeros((nch, g.outputlength_bound(f1.outputlength_bound(50_003))), dtype=torch.float32, device="cuda")
+    cg = torch.zeros(2, dtype=torch.int64, device="cuda")
+    pos = 0
+    for i, sz in enumerate((50_003, 7_919)):
+        b1 = f1.outputlength_bound(sz)
+        f1.filt_into_async(mid[:, :b1], x[:, pos:pos + sz])
+        g.filt_into_async(yg, mid[:, :b1], cg[i:i + 1], after=f1)
+        torch.cuda.synchronize()
+        ref = og.filt(o1b.filt(xh[1, pos:pos + sz]))
+        assert int(cg[i].item()) == len(ref), (i, int(cg[i].item()), len(ref))
+        assert_bit_equal(yg[1, :len(ref)].cpu().numpy(), ref, f"2//13 chained, call {i}")
+        pos += sz
+    assert g.last_kernel_name() == "poly_generic_kernel"
+    g.sync_state()
+    assert (g.state.phiIdx, g.state.inputDeficit) == (og.state.phiIdx, og.state.inputDeficit)
     for f in (f1, f2, g):
         f.close()
 
