@@ -256,8 +256,8 @@ int mrhip_filt_device_async(mrhip_filter *f, const void *x, int64_t x_len, int64
  * output Vector to the next, src/Filters.jl:744-751): `f`'s input is what `prev`'s latest asynchronous or captured call --
  * earlier on the same stream -- wrote, and its LENGTH is that call's count, which only the device knows.  x_len_bound =
  * mrhip_outputlength_bound(prev, prev's input length): the launch is sized for it, and y_capacity / y_stride must cover
- * mrhip_outputlength_bound(f, x_len_bound).  `f`: a rational-family filter (FIRArbitrary / FIRFarrow:
- * MRHIP_ERR_UNSUPPORTED, nothing enqueued); `prev`: any kind, FIRArbitrary / FIRFarrow included; same count_out / state rules
+ * mrhip_outputlength_bound(f, x_len_bound).  `f` and `prev`: any kind (FIRArbitrary / FIRFarrow lay their phase
+ * schedule out for the device-side length in the kernels that evaluate it); same count_out / state rules
  * as mrhip_filt_device_async.  With it a chain of filters runs, and replays from a HIP graph, at any chunk size without
  * the host learning a single count. */
 int mrhip_filt_device_chained(mrhip_filter *f, const mrhip_filter *prev, const void *x, int64_t x_len_bound, int64_t x_stride,
@@ -321,7 +321,7 @@ int mrhip_cascade_filt_device(mrhip_cascade *c, const void *x, int64_t x_len, in
  * mrhip_filt_device_async, every later one mrhip_filt_device_chained on the previous stage's count.  y needs room for the
  * last stage's bound of the bounds; *count_out (device-accessible, may be NULL) receives the chain's per-channel output
  * count.  One plain call of the same size must have run before a capture (it allocates the buffers between the stages);
- * the stages after the first are rational-family filters (the first may be any kind), else MRHIP_ERR_UNSUPPORTED. */
+ * every kind of stage in every position. */
 int mrhip_cascade_filt_device_async(mrhip_cascade *c, const void *x, int64_t x_len, int64_t x_stride, void *y, int64_t y_capacity,
                                     int64_t y_stride, int64_t *count_out, void *stream);
 int mrhip_cascade_reset(mrhip_cascade *c);

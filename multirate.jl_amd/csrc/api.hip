@@ -947,8 +947,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         return fail(MRHIP_ERR_UNSUPPORTED, "asynchronous calls of this filter are outstanding: mrhip_sync_state before capturing (a replay must find the record they leave)");
     if (!dev_planned && !f->mirror_valid)
         if (int rc = rec_pull(f)) return rc;
-    if (x_from && (!dev_planned || f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW))
-        return fail(MRHIP_ERR_UNSUPPORTED, "a chained call is an asynchronous or captured call of a rational-family filter");
+    if (x_from && !dev_planned) return fail(MRHIP_ERR_UNSUPPORTED, "a chained call is an asynchronous or captured call");
     if (x_len == 0) {                  // nothing to do: zero outputs, history and state unchanged
         f->last_call_dev_planned = false;                      // (no plan kernel ran: the call record still holds an older call's count)
         if (count_dev) MRHIP_CHECK_HIP(hipMemsetAsync(count_dev, 0, sizeof(long long), stream));
@@ -1036,12 +1035,13 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             // The schedule runs on the filter's schedule stream, BESIDE the filter kernel of the call before (its inputs are
             // the record, which moved on with that call's FINISH kernel, and nothing else); schedule buffers and call records
             // alternate, events order writer and reader of each (mrhip_filter.h: s_sched).  Inside a capture: one stream.
-            hipStream_t ss = capturing || !f->s_sched ? stream : f->s_sched;
+            // (a chained call's schedule reads the previous stage's call record, which is written on the caller's stream: it runs there)
+            hipStream_t ss = capturing || !f->s_sched || x_from ? stream : f->s_sched;
             SchedOut so{};
             so.buf = capturing ? 0 : f->flip;
             if (!capturing) f->flip ^= 1;
             if (ss != stream && f->ev_filt_valid[so.buf]) MRHIP_CHECK_HIP(hipStreamWaitEvent(ss, f->ev_filt[so.buf], 0));
-            if (int rc = sched_enqueue(f, x_len, est, dev_planned ? y_capacity : INT64_MAX, count_dev, !dev_planned, ss, &so)) return rc;   // (a call that is waited for checks the count against the room itself)
+            if (int rc = sched_enqueue(f, x_len, est, dev_planned ? y_capacity : INT64_MAX, count_dev, !dev_planned, ss, &so, x_from)) return rc;   // (a call that is waited for checks the count against the room itself)
             const int b = so.buf;                                         // (a memo hit names the buffer that holds the entries)
             sched_dn = f->ds_n[b]; sched_dacc = f->ds_acc[b]; sched_spans = spans;
             auto join = [&]() -> int {                                  // the filter kernel behind its schedule
@@ -1252,7 +1252,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         HistArgs ha{};
         ha.x = x; ha.hist_old = f->d_hist[f->hist_cur]; ha.hist_new = f->d_hist[hist_next];
         ha.x_stride = x_stride; ha.x_len = x_len; ha.H = static_cast<int>(f->H); ha.nch = static_cast<int>(f->nch);
-        ha.dyn = x_from ? f->d_call : nullptr;                 // (a chained call: the length its plan kernel took from the previous stage)
+        ha.dyn = x_from ? f->last_call_rec : nullptr;          // (a chained call: the length its plan / FINISH kernel took from the previous stage)
         MRHIP_CHECK_HIP(launch_shiftin(tk, ha, stream));
     }
     if (f->H > 0) {
@@ -1339,6 +1339,8 @@ int mrhip_filt_device_chained(mrhip_filter *f, const mrhip_filter *prev, const v
     if (!prev->last_call_dev_planned || !prev->last_call_rec)
         return fail(MRHIP_ERR_INVALID_ARG, "the previous filter's latest call was not planned on the device (mrhip_filt_device_async, or a call under capture): its count is not in its call record");
     if (x_len_bound >= (1LL << 30)) return fail(MRHIP_ERR_UNSUPPORTED, "a chained call is one launch");
+    if ((f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) && static_cast<double>(x_len_bound) * f->rate >= static_cast<double>(1LL << 24))
+        return fail(MRHIP_ERR_UNSUPPORTED, "a chained call is one launch (2^24 schedule entries for FIRArbitrary / FIRFarrow)");
     return filt_device_one(f, x, x_len_bound, x_stride, y, y_capacity, y_stride, nullptr, stream, false, true,
                            reinterpret_cast<long long *>(count_out), prev->last_call_rec);
 }

@@ -50,12 +50,18 @@ struct PerPlanArgs {
     const long long *per_xoff;
     long long *count_out;
     long long Q, XQ, x_len, est, y_capacity;
+    const DevCall *x_from;        // a chained call: the input length is this record's count (x_len: its upper bound)
 };
 __global__ __launch_bounds__(64) void sched_periodic_plan_kernel(PerPlanArgs a)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (a.x_from) {
+        const long long n = a.x_from->n_out;
+        a.x_len = n < 0 ? 0 : (n < a.x_len ? n : a.x_len);
+    }
     DevStream r = *a.rec;
     DevCall c{};
+    c.x_len = a.x_len;
     r.sched_fail = kSchedNoFail;
     const long long pos = r.per_pos;
     if (!(pos >= 0 && pos < a.Q) || !(a.per_acc[pos] == r.acc)) {
@@ -309,7 +315,7 @@ static const SchedPieceState *fail_state_host(const mrhip_filter *f)
 // TABLES from schedule entry k with the piece list sized by the drift baseline `ks`: begin, pieces, finish, event.
 // host state != NULL: the call-start state of the first piece is the host's (behind a prefix or a redone piece).
 static int enqueue_tables(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, int64_t k, double ks,
-                          const SchedPieceState *host_state, bool serial_fallback, hipStream_t s, SchedOut *out)
+                          const SchedPieceState *host_state, bool serial_fallback, hipStream_t s, SchedOut *out, const DevCall *x_from = nullptr)
 {
     const SchedPlan &c = f->splan;
     const int b = out->buf;
@@ -335,6 +341,7 @@ static int enqueue_tables(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y
     SchedBeginArgs ba{};
     ba.rec = f->d_rec; ba.status = f->ds_status; ba.state = f->ds_state;
     if (host_state) { ba.use_host = 1; ba.acc = host_state->acc; ba.xIdx = host_state->xIdx; ba.drift = host_state->drift; ba.ksteps = host_state->ksteps; }
+    ba.x_from = x_from;
     MRHIP_CHECK_HIP(launch_sched_begin(ba, x_len, k, s));
     for (int64_t p = 0; p < np; ++p) {
         SchedPieceArgs a{};
@@ -366,7 +373,8 @@ static int enqueue_tables(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y
 // ends, profiles/r03/experiments.md B.)  The count and the end state either are final on return (out->host_known: the host
 // evaluated the call itself -- a serial prefix that reached the end, the closed form of a cycle) or arrive in the pinned
 // mirror behind f->ev_rec (out->pending); either way the device record and the DevCall are current in stream order.
-int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, bool host_ok, hipStream_t s, SchedOut *out)
+int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, bool host_ok, hipStream_t s, SchedOut *out,
+                  const DevCall *x_from)
 {
     const SchedPlan &c = f->splan;
     const int b = out->buf;              // schedule buffer and call record of this call (the caller alternates them)
@@ -384,6 +392,7 @@ int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacit
             pa.rec = f->d_rec; pa.mirror = mirror_of(f); pa.call = f->d_calls[b];
             pa.per_acc = f->d_per_acc; pa.per_xoff = f->d_per_xoff; pa.count_out = count_out;
             pa.Q = f->per_Q; pa.XQ = f->per_XQ; pa.x_len = x_len; pa.est = est; pa.y_capacity = y_capacity;
+            pa.x_from = x_from;
             hipLaunchKernelGGL(sched_periodic_plan_kernel, dim3(1), dim3(64), 0, s, pa);
             MRHIP_CHECK_HIP(hipGetLastError());
             if (est + 2 > static_cast<int64_t>(f->ds_cap[b])) return fail(MRHIP_ERR_INVALID_ARG, "schedule buffer too small for the periodic schedule (internal)");
@@ -398,8 +407,9 @@ int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacit
             return MRHIP_OK;
         }
         // the host's lower bound of the drift baseline sizes the pieces (every piece is verified whatever its size)
-        return enqueue_tables(f, x_len, est, y_capacity, count_out, 0, f->sched_ksteps, nullptr, true, s, out);
+        return enqueue_tables(f, x_len, est, y_capacity, count_out, 0, f->sched_ksteps, nullptr, true, s, out, x_from);
     }
+    if (x_from) return fail(MRHIP_ERR_INVALID_ARG, "a chained call is planned on the device (internal)");
 
     static const bool prof = env_i64("MRHIP_DEBUG", 0) == 2;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

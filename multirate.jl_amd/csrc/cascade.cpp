@@ -166,8 +166,6 @@ int mrhip_cascade_filt_device_async(mrhip_cascade *c, const void *x, int64_t x_l
     int64_t n = x_len;
     for (size_t i = 0; i < ns; ++i) {
         const mrhip_filter *f = c->stages[i];
-        if (i > 0 && (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW))
-            return fail(MRHIP_ERR_UNSUPPORTED, "asynchronous cascade: a FIRArbitrary / FIRFarrow stage can only come first (its phase schedule is laid out for an input length the host knows)");
         n = std::max<int64_t>(mrhip_outputlength_bound(f, n), 0);
         room[i] = n;
     }

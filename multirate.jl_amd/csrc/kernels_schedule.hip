@@ -286,6 +286,7 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
     const int g = blockIdx.x, sl = threadIdx.x, nwin = c.nwin;
     const SchedPieceState ps = a.state[a.piece];
     const SchedGroupStart gs = a.gstart[g];
+    const long long x_len = a.status->x_len;               // (written by the call's BEGIN kernel, which ran before every piece)
     const long long seg = static_cast<long long>(g) * kGroupSegs + sl;
     bool bad = gs.cand < 0;
     double T = ps.acc;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
     for (int i = 0; i < kSeg; ++i) {
         s_n[sl * (kSeg + 1) + i] = static_cast<int>(x);
         s_acc[sl * (kSeg + 1) + i] = acc;
-        if (i > 0 && x > a.x_len && prev_x <= a.x_len) { end_k = kbase + i; end_acc = acc; end_x = x; }
+        if (i > 0 && x > x_len && prev_x <= x_len) { end_k = kbase + i; end_acc = acc; end_x = x; }
         prev_x = x;
         sched_step(acc, x, c);
     }
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
     }
     __syncthreads();
     if (!bad && !(acc == s_T[sl + 1] && x == s_X[sl + 1])) bad = true;
-    if (prev_x <= a.x_len && x > a.x_len) { end_k = kbase + kSeg; end_acc = acc; end_x = x; }   // the call ends between two segments
+    if (prev_x <= x_len && x > x_len) { end_k = kbase + kSeg; end_acc = acc; end_x = x; }   // the call ends between two segments
     if (bad) atomicMin(&a.status->fail_piece, a.piece);
     if (end_k >= 0) {                                     // unique: xIdx never decreases
         a.status->end_k = end_k;
@@ -364,6 +365,10 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
 __global__ __launch_bounds__(64) void sched_begin_kernel(SchedBeginArgs a, long long x_len, long long k_first)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (a.x_from) {                   // a chained call: what the stage before it wrote (never more than the bound the launch was sized for)
+        const long long n = a.x_from->n_out;
+        x_len = n < 0 ? 0 : (n < x_len ? n : x_len);
+    }
     SchedPieceState ps;
     if (a.use_host) { ps.acc = a.acc; ps.xIdx = a.xIdx; ps.drift = a.drift; ps.ksteps = a.ksteps; }
     else { const DevStream r = *a.rec; ps.acc = r.acc; ps.xIdx = r.inputDeficit; ps.drift = r.drift; ps.ksteps = r.ksteps; }   // xIdx starts at inputDeficit, Filters.jl:715
@@ -375,6 +380,7 @@ __global__ __launch_bounds__(64) void sched_begin_kernel(SchedBeginArgs a, long 
         st.end_acc = ps.acc;
         st.end_xIdx = ps.xIdx;
     }
+    st.x_len = x_len;                 // the pieces and the FINISH kernel read it from here
     *a.status = st;
     a.state[0] = ps;
 }
@@ -384,8 +390,10 @@ __global__ __launch_bounds__(64) void sched_finish_kernel(SchedPlan c, SchedFini
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     DevStream r = *a.rec;
     const SchedStatus st = *a.status;
+    a.x_len = st.x_len;               // (as the BEGIN kernel resolved it: a chained call's comes from the stage before)
     const int fail = st.fail_piece;
     DevCall call{};
+    call.x_len = st.x_len;
     r.sched_fail = kSchedNoFail;
     if (fail != kSchedNoFail && !a.serial_fallback) {
         // the host waits for this call anyway: it redoes the piece with its own serial loop and continues from there

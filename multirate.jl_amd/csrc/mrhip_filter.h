@@ -175,7 +175,8 @@ struct SchedOut {
     double memo_acc0 = 0.0;       // the call-start state, for the memo entry this call becomes
     int64_t memo_d0 = 0;
 };
-int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, bool host_ok, hipStream_t s, SchedOut *out);
+int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, bool host_ok, hipStream_t s, SchedOut *out,
+                  const mrhip::DevCall *x_from = nullptr);
 int sched_collect(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacity, long long *count_out, hipStream_t s, SchedOut *io, bool *relaunch);
 // stream_state.hip: the device record
 int rec_alloc(mrhip_filter *f);

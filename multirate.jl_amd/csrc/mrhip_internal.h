@@ -106,6 +106,7 @@ struct SchedStatus {
     long long end_xIdx;
     int max_span[kSchedSpanSizes];   // largest n[last] - n[first] over aligned tiles of kSchedSpanBase << i outputs
     int pad[3];
+    long long x_len;         // the call's input length as the BEGIN kernel resolved it (a chained call: the previous stage's count)
 };
 struct SchedGroupEntry { double shift; int advance; int next; };        // map of one group: candidate -> (next, +shift, +xIdx)
 struct SchedGroupStart { double shift; long long advance; int cand; int pad; };   // true start of a group, as candidate + shift
@@ -139,6 +140,7 @@ struct SchedBeginArgs {
     SchedPieceState *state;
     int use_host;                 // 1: (acc, xIdx, drift, ksteps) below are the state at schedule entry k_first
     double acc; long long xIdx; double drift, ksteps;
+    const DevCall *x_from;        // a chained call: the input length is this record's count (the x_len argument: its upper bound)
 };
 struct SchedFinishArgs {
     DevStream *rec, *mirror;

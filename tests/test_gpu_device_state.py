@@ -506,3 +506,57 @@ def test_cascade_with_an_arbitrary_rate_first_stage_under_capture(pkg, O, torch_
         f.sync_state()
     assert (cas.stages[1].state.phiIdx, cas.stages[1].state.inputDeficit) == (o2.state.phiIdx, o2.state.inputDeficit)
     cas.close()
+
+
+@pytest.mark.parametrize("kind,rate", [("arbitrary", math.pi / 3), ("farrow", 0.83), ("arbitrary", 3.0)])
+def test_cascade_with_an_arbitrary_rate_later_stage_under_capture(pkg, O, torch_cuda, kind, rate):
+    """Decimate 1//4 (prime chunk: its count alternates), THEN FIRArbitrary / FIRFarrow: the phase schedule of the second stage is
+    laid out on the device for an input length only the device knows (the BEGIN kernel takes it from the decimator's call record).
+    Captured once, 25 replays == the oracle's chunk loop; rate 3.0 cycles (closed form on the device)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(888)
+    Nphi, chunk, nrep, nch = 32, 40_009, 25, 2
+    h1 = rng.standard_normal(40).astype(np.float64)
+    h2 = (pkg.firdes(Nphi * 8, 0.45 / Nphi, beta=7.8562) * Nphi)
+    po = 3 if kind == "farrow" else None
+    f2 = pkg.FIRFilter(h2, rate, Nphi, po).bind(np.float64, nch)
+    cas = pkg.FilterCascade(pkg.FIRFilter(h1, Fraction(1, 4)), f2)
+    xh = rng.random((nch, chunk * (nrep + 3)))
+    x = torch.from_numpy(xh).cuda()
+    xs = torch.zeros((nch, chunk), dtype=torch.float64, device="cuda")
+    o1 = O.FIRFilter(h1, Fraction(1, 4), tx=np.float64)
+    o2 = O.FIRFilter(h2, rate, Nphi, tx=np.float64, polyorder=po, pnfb=f2.pnfb()) if po else O.FIRFilter(h2, rate, Nphi, tx=np.float64)
+    ys = None
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for rep in range(3):                                         # a plain call, then two asynchronous ones of the size (buffers, schedule work space)
+        xs.copy_(x[:, rep * chunk:(rep + 1) * chunk])
+        ref = o2.filt(o1.filt(xh[1, rep * chunk:(rep + 1) * chunk]))
+        if rep == 0:
+            y0 = cas.filt(xs)
+            assert_bit_equal(y0[1].cpu().numpy(), ref, "plain call")
+            ys = torch.zeros((nch, cas.outputlength_bound(chunk)), dtype=torch.float64, device="cuda")
+        else:
+            cas.filt_into_async(ys, xs, cnt)
+            torch.cuda.synchronize()
+            assert int(cnt.item()) == len(ref), (rep, int(cnt.item()), len(ref))
+            assert_bit_equal(ys[1, :len(ref)].cpu().numpy(), ref, f"asynchronous call {rep}")
+    for f in cas.stages:
+        f.sync_state()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=s):
+        cas.filt_into_async(ys, xs, cnt)
+    for rep in range(3, nrep + 3):
+        xs.copy_(x[:, rep * chunk:(rep + 1) * chunk])
+        g.replay()
+        torch.cuda.synchronize()
+        ref = o2.filt(o1.filt(xh[1, rep * chunk:(rep + 1) * chunk]))
+        c = int(cnt.item())
+        assert c == len(ref), (rep, c, len(ref))
+        assert_bit_equal(ys[1, :c].cpu().numpy(), ref, f"replay {rep}")
+    cas.stages[0].sync_state()
+    assert (cas.stages[0].state.phiIdx, cas.stages[0].state.inputDeficit) == (o1.state.phiIdx, o1.state.inputDeficit)
+    cas.stages[1].sync_state()
+    assert cas.stages[1].state.inputDeficit == o2.state.inputDeficit
+    cas.close()
