@@ -1,23 +1,29 @@
 // kernels_fir_stream_rt.hip -- fir_stream_kernel with the decimation M as a RUN-TIME value: FIRStandard / FIRDecimator
-// (src/Filters.jl:450-473, :598-631; dot: src/support.jl:33-55) at ANY decimation whose step of 128 outputs fits the LDS
-// (2 * M * bytes-per-sample <= ~900; twice that with one output per lane), one kernel per (sample type, arithmetic type,
-// components, bytes per LDS read).
+// (src/Filters.jl:450-473, :598-631; dot: src/support.jl:33-55) at ANY decimation whose step fits the LDS (M * bytes-per-sample
+// <= ~900 with one output per lane, half that with two), one kernel per (sample type, arithmetic type, components, bytes per
+// LDS read).
 //
 // fir_stream_kernel.inc is instantiated per M (the position of the second output's first sample inside the first block of
-// reads, the pad period of the staged tile and every LDS offset are compile-time constants there): 40 decimations x 3
-// arithmetic families x 2 numerics modes, 12.6 MB of code objects, and any M outside the list fell to fir_direct_kernel
-// at a third of the rate.  Here the same mapping (a lane owns two adjacent outputs; ONE run of T + M samples feeds both
-// dots; taps by scalar loads; tiles staged by the loader wave of pair_loader.h with the pad chunks of the bank rule of
-// kernels_fir_stream.hip) walks the run in blocks of BS samples and sorts the blocks, wave-uniformly, into
-//   B  the first output alone   (blocks wholly below sample M),
-//   A  both outputs             (blocks wholly inside [M, T)),
-//   D  the second output alone  (blocks wholly inside [T, T + M)),
-//   C  anything else, sample by sample under wave-uniform masks (the block that holds sample M, the ends of the two
-//      windows when T or M is not a whole number of blocks; in FUSED mode every block of a tile that touches the
-//      start-from-zero seam of support.jl:46).
-// All four are branch-free: the accumulators start at -0.0 (at +0.0 on the seam) and EVERY tap is one multiply and one add -- x + (-0.0) == x
-// for every x (signed zeros, NaN and infinities included), so the first product "initialises" the accumulator exactly as
-// the reference's `dotprod = h[1] * x[..]` does, without a special first step at a run-time position.
+// reads, the pad period of the staged tile and every LDS offset are compile-time constants there): rounds 2-3 had 40
+// decimations x 3 arithmetic families x 2 numerics modes, 12.6 MB of code objects, and any M outside the list fell to
+// fir_direct_kernel at a third of the rate.  Here the same machinery (taps by scalar loads; tiles staged by the loader wave of
+// pair_loader.h with the pad chunks of the bank rule of kernels_fir_stream.hip) takes M, the lane stride and the pad period as
+// values, in one of two lane maps (pa.rt; kernels_fir_stream.hip plans which, from the measured table):
+//   * TWO adjacent outputs per lane: ONE run of T + M samples feeds both dots; the run is walked in blocks of BS samples that
+//     are sorted, wave-uniformly, into
+//       B  the first output alone   (blocks wholly below sample M),
+//       A  both outputs             (blocks wholly inside [M, T)),
+//       D  the second output alone  (blocks wholly inside [T, T + M)),
+//       C  anything else, sample by sample under wave-uniform masks (the block that holds sample M, the ends of the two
+//          windows when T or M is not a whole number of blocks; in FUSED mode every block of a tile that touches the
+//          start-from-zero seam of support.jl:46);
+//   * ONE output per lane (large decimations: half the LDS per lane, twice the waves per CU): a run of T samples, every block
+//     of class B but the last, which is of class C when T is not a whole number of blocks.
+// All of it is branch-free: the accumulators start at -0.0 (at +0.0 on the seam) and EVERY tap is one multiply and one add --
+// x + (-0.0) == x for every x (signed zeros, NaN and infinities included), so the first product "initialises" the accumulator
+// exactly as the reference's `dotprod = h[1] * x[..]` does, without a special first step at a run-time position.  The mixed
+// block reads both tap runs whole (they may reach into the zero pads either side of the device tap vector, api.hip
+// upload_taps) and keeps, per tap, the old accumulator where a bit mask says the sample is outside that window.
 //
 // Arithmetic: exactly fir_stream_kernel's (STRICT: separately rounded multiply and add, oldest sample first; FUSED: fma) =>
 // bit-identical results.
