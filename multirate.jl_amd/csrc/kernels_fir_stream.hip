@@ -41,8 +41,9 @@ hipError_t launch_fir_stream_f64(int nc, bool fused, dim3 block, size_t lds, hip
 hipError_t launch_fir_stream_mix(int nc, bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);
 hipError_t launch_fir_stream_rt(bool fused, dim3 block, size_t lds, hipStream_t s, const PolyArgs &a, const PairArgs &pa, int num_cus);   // kernels_fir_stream_rt.hip
 
-// Covers L == 1, 1 <= T <= 16384, every sample type, every M whose step of 128 outputs fits a stage (2 * M * bytes per sample
-// <= ~900; 8- and 16-byte samples: <= ~590, see below).  Returns false otherwise (the caller goes on to poly_tiled_kernel).
+// Covers L == 1, 1 <= T <= 16384, every sample type, every M whose step fits a stage: M * bytes per sample <= ~900 with one
+// output per lane (the run-time kernel's second lane map; ComplexF64: M <= 32), half that with two.  Returns false otherwise
+// (the caller goes on to poly_tiled_kernel).
 bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
 {
     if (!stream_env_int("MRHIP_STREAM", 1)) return false;   // read per call: tests switch kernels at run time
