@@ -30,7 +30,7 @@ namespace {
 
 constexpr int kSeg = kSchedSeg;          // steps per segment
 constexpr int kGroupSegs = 64;           // segments per group (= per workgroup of K1 / K3)
-constexpr int kTabThreads = 1024;        // 64 segments x 16 candidates in one round: four waves per SIMD hide the dependent Float64 chain
+constexpr int kTabThreads = 1024;        // at most: the tables kernel runs 64 segments x nwin candidates, one thread each (nwin <= 16: one round)
 
 // One update() of the reference, in a form whose every operation is exact except the one the reference rounds too
 // (the sum): mod(a1-1, N) == (a1-1) - k*N with k = floor(fl((a1-1)/N)), minus one more N when the rounded quotient
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, 
     const int g = blockIdx.x;
     const long long seg0 = static_cast<long long>(g) * kGroupSegs;
     const int tasks = kGroupSegs * nwin;
-    for (int t = threadIdx.x; t < tasks; t += kTabThreads) {
+    for (int t = threadIdx.x; t < tasks; t += static_cast<int>(blockDim.x)) {
         const int sl = t / nwin, ci = t - sl * nwin;
         const double k0 = static_cast<double>((seg0 + sl) * kSeg);
         const double base = sched_base(sched_anchor(ps.acc, k0, slope, c), c);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, 
     }
     __syncthreads();
     // compose: candidate c0 of the group's first segment walked through the 64 maps; the path is kept for K3
-    for (int c0 = threadIdx.x; c0 < nwin; c0 += kTabThreads) {
+    for (int c0 = threadIdx.x; c0 < nwin; c0 += static_cast<int>(blockDim.x)) {
         int ci = c0;
         double S = 0.0;
         long long W = 0;
@@ -482,14 +482,15 @@ hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hi
         hipError_t e = occupancy_cached(reinterpret_cast<const void *>(sched_tables_kernel), kTabThreads, lds, &per_cu);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(sched_tables_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(kTabThreads), lds, s, c, a);
+    const int tab_threads = std::min(kTabThreads, kGroupSegs * c.nwin);      // (64 * nwin: whole waves)
+    hipLaunchKernelGGL(sched_tables_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(static_cast<unsigned>(tab_threads)), lds, s, c, a);
     hipLaunchKernelGGL(sched_chain_kernel, dim3(1), dim3(kChainWaves * 64), 0, s, c, a);
     hipLaunchKernelGGL(sched_emit_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(kGroupSegs), 0, s, c, a);
     return hipGetLastError();
 }
 
 // Constants of the parallel evaluation for one (delta, Nphi); plan.ok == 0: the host loop evaluates the schedule.
-SchedPlan make_sched_plan(double delta, int64_t Nphi)
+SchedPlan make_sched_plan(double delta, int64_t Nphi, int win_mult, int win_min)
 {
     SchedPlan c{};
     c.delta = delta;
@@ -505,7 +506,11 @@ SchedPlan make_sched_plan(double delta, int64_t Nphi)
     c.inv_umin = 1.0 / c.umin;
     c.inv_G = 1.0 / c.G;
     c.ncand = static_cast<int>(c.G / c.umin);
-    c.nwin = std::max(4 * c.ncand, 16);
+    // One residue system modulo G is all the chain needs: a start outside the window is the candidate congruent to it plus a
+    // shift, and every segment is verified (K3).  (Rounds 3-4 ran max(4 * ncand, 16) candidates -- the tables kernel, four to
+    // eight times the work, was 0.8 ms of BASELINE config 4's 5.4 ms per call on a stream that does not repeat:
+    // profiles/r04/experiments.md P; scripts/sched_model.py: as many pieces verify with the small window.)
+    c.nwin = std::max(std::max(win_mult, 1) * c.ncand, std::max(win_min, 2));      // (MRHIP_SCHED_WIN_MULT, MRHIP_SCHED_WIN_MIN)
     c.halfwin = static_cast<double>(c.nwin / 2) * c.umin;
     c.ok = c.nwin <= kSchedMaxWin && c.umin <= 0x1p-20;
     return c;

@@ -124,7 +124,7 @@ struct SchedPieceArgs {
     int piece, ngroups;
     int corrupt_group;       // test hook: -1, or the group whose table is falsified (MRHIP_SCHED_CORRUPT)
 };
-SchedPlan make_sched_plan(double delta, int64_t Nphi);
+SchedPlan make_sched_plan(double delta, int64_t Nphi, int win_mult = 1, int win_min = 4);
 hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hipStream_t s);
 // The two one-lane kernels round the pieces of a call (kernels_schedule.hip).  BEGIN arms the status word and writes the
 // call-start state of piece 0 -- from the device record, or from the host's values when it just evaluated a prefix itself.

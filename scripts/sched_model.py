@@ -19,7 +19,9 @@ whose roundings the outputs depend on, so there is no closed form.  It can still
 2. Equivariance, for starts outside the window.  Every rounding is to a multiple of ulp(a1) <= Utop = ulp(fl(N+1+delta)),
    ties to even, so for a shift d that is a multiple of G = 2*Utop:  step(acc + d) == step(acc) + d  as long as both
    sums fall in the same binade and on the same side of the wrap thresholds.  A start T outside the window is therefore
-   looked up as the window's candidate congruent to T modulo G (NWIN >= G/Umin) plus the shift.
+   looked up as the window's candidate congruent to T modulo G (NWIN >= G/Umin) plus the shift.  NWIN = G/Umin (at least
+   4) is therefore enough -- one residue system; rounds 3-4 ran four of them (at least 16 values) so that most starts
+   needed no shift, which quadrupled the tables' work for no fewer failed pieces.
 3. Chain.  The end value of candidate c of segment s is itself (candidate c', shift) of segment s+1, so a segment is a
    map  c -> (c', shift, advance)  on a finite set with additive shift/advance: maps compose, and the true start of
    every segment follows from the piece's true start by composing tables (hierarchically on the device).
@@ -93,14 +95,14 @@ def wrapd(d, N):
 class Plan:
     """Constants of the parallel evaluation for one (delta, Nphi)."""
 
-    def __init__(self, delta: float, Nphi: int, max_win: int = 256, win_mult: int = 4):
+    def __init__(self, delta: float, Nphi: int, max_win: int = 64, win_mult: int = 1):
         self.delta = float(delta)
         self.N = float(Nphi)
         self.umin = math.ulp(1.0 + delta)
         self.utop = math.ulp(self.N + 1.0 + delta)
         self.G = 2.0 * self.utop
         self.ncand = int(round(self.G / self.umin))
-        self.nwin = max(win_mult * self.ncand, 16)
+        self.nwin = max(win_mult * self.ncand, 4)     # one residue system modulo G (rounds 3-4: four, at least 16 values)
         self.ok = self.nwin <= max_win and delta < 2.0 ** 40 and self.umin <= 2.0 ** -20
 
     def anchor(self, acc_p: float, k, slope: float = 0.0):

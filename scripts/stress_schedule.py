@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--cases", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--show-fallbacks", action="store_true", help="one line per case in which a piece did not verify (redone serially: exact, slow)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     gen = torch.Generator(device="cuda").manual_seed(args.seed)
@@ -94,6 +95,8 @@ def main():
             if not ok:
                 bad += 1
                 print(f"MISMATCH case {case}: rate={rate!r} nphi={nphi} farrow={farrow} {tx} n_in={n_in} cuts={cuts} knobs={knobs} info={info}", flush=True)
+            if args.show_fallbacks and info["fallback_pieces"]:
+                print(f"fallback case {case}: rate={rate!r} nphi={nphi} knobs={knobs} info={info}", flush=True)
             for k in ("device_pieces", "periodic_steps", "host_steps", "fallback_pieces"):
                 tally[k] += info[k]
             tally["cases"] += 1
