@@ -1064,6 +1064,14 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 f->last_call_dev_planned = so.pending && launched;        // (a chained call may follow: its input length is this call's count)
                 f->last_call_rec = f->d_calls[b];
                 if (!capturing) f->async_pending = true;
+                if (!capturing && so.pending && !so.periodic && !x_from) {
+                    // The host's LOWER BOUND of the drift baseline (it sizes the next calls' pieces: at most 16 x the baseline) moves on
+                    // by the fewest outputs this call can have -- xIdx starts at most 1/rate + 1 in and advances at most 1/rate + 1 a
+                    // step -- so that a stream of asynchronous calls is not cut into pieces of 4096 forever; mrhip_sync_state brings
+                    // the exact value.
+                    const double lb = std::floor((static_cast<double>(x_len) - 1.0 / f->rate - 3.0) * f->rate) - 2.0;
+                    if (lb > 0.0) f->sched_ksteps += lb;
+                }
                 n_out = -1;
                 st = ArbState{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
             } else {

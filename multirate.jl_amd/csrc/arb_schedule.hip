@@ -265,7 +265,9 @@ void sched_configure(mrhip_filter *f)
     f->splan = make_sched_plan(f->delta, f->Nphi, static_cast<int>(env_i64("MRHIP_SCHED_WIN_MULT", 1)), static_cast<int>(env_i64("MRHIP_SCHED_WIN_MIN", 4)));
     f->sched_prefix = std::max<int64_t>(env_i64("MRHIP_SCHED_PREFIX", 65536), 0) / kSchedGroup * kSchedGroup;
     f->sched_pmax = std::max<int64_t>(env_i64("MRHIP_SCHED_PMAX", 1 << 22) / kSchedGroup * kSchedGroup, kSchedGroup);
-    f->sched_device_min = env_i64("MRHIP_SCHED_DEVICE_MIN", 1 << 16);   // (below it a call that is waited for takes the host loop: 1.3 ns per output)
+    // below it a call that is waited for takes the host loop: 60 us + 1.3 ns per output against 75 us for the kernels of one piece
+    // and the wait (profiles/r04/experiments.md Q; 2^16 until the baseline of short calls was kept)
+    f->sched_device_min = env_i64("MRHIP_SCHED_DEVICE_MIN", 1 << 14);
     f->sched_corrupt_piece = static_cast<int>(env_i64("MRHIP_SCHED_CORRUPT", -1));
     if (env_i64("MRHIP_SCHED_DEVICE", 1) == 0) f->splan.ok = 0;
     f->sched_use_cycle = env_i64("MRHIP_SCHED_CYCLE", 1) != 0;
@@ -457,10 +459,10 @@ int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacit
         if (!done && f->sched_use_cycle)
             if (int rc = try_find_cycle(f, cnt, st, s)) return rc;
         if (int rc = upload_entries(f, b, 0, cnt, s)) return rc;
-        if (!done) {
-            drift += wrap_half(st.acc - sched_anchor_host(c, acc_start, static_cast<double>(cnt)), c.N);
-            ksteps += static_cast<double>(cnt);
-        }
+        // (also when the prefix reached the call's end: `cnt` updates ran either way.  Round 3 kept the baseline only for a
+        //  prefix the call outlived, so a stream of calls shorter than the prefix never left the host's loop.)
+        drift += wrap_half(st.acc - sched_anchor_host(c, acc_start, static_cast<double>(cnt)), c.N);
+        ksteps += static_cast<double>(cnt);
         k = cnt;
         f->stat_host_steps += cnt;
     }

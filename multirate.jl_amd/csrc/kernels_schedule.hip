@@ -336,6 +336,13 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
         a.status->end_k = end_k;
         a.status->end_acc = end_acc;
         a.status->end_xIdx = end_x;
+        // the drift baseline at the call's end (the next call starts there): this piece's, plus what its first end_k - k0 steps show
+        const double steps = static_cast<double>(end_k - a.k0);
+        double de = end_acc - sched_anchor(ps.acc, steps, 0.0, c);
+        if (de > 0.5 * c.N) de -= c.N;
+        else if (de < -0.5 * c.N) de += c.N;
+        a.status->end_drift = ps.drift + de;
+        a.status->end_ksteps = ps.ksteps + steps;
         __hip_atomic_store(&a.status->done, a.piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (sl == kGroupSegs - 1 && g + 1 == a.ngroups) {     // state of the next piece (used only if this piece verified)
@@ -379,6 +386,8 @@ __global__ __launch_bounds__(64) void sched_begin_kernel(SchedBeginArgs a, long 
         st.end_k = k_first;
         st.end_acc = ps.acc;
         st.end_xIdx = ps.xIdx;
+        st.end_drift = ps.drift;
+        st.end_ksteps = ps.ksteps;
     }
     st.x_len = x_len;                 // the pieces and the FINISH kernel read it from here
     *a.status = st;
@@ -411,16 +420,10 @@ __global__ __launch_bounds__(64) void sched_finish_kernel(SchedPlan c, SchedFini
     double end_acc, drift, ksteps;
     if (fail == kSchedNoFail && st.done) {
         n_out = st.end_k; end_acc = st.end_acc; end_x = st.end_xIdx;
-        // the drift baseline: the state behind the last piece that lies wholly before the call's end
-        long long kk = a.k_first;
-        double ks = a.ks_first;
-        int pl = 0;
-        for (; pl < a.np; ++pl) {
-            const long long P = sched_piece_steps(ks, a.pmax);
-            if (kk + P > n_out) break;
-            kk += P; ks += static_cast<double>(P);
-        }
-        drift = a.state[pl].drift; ksteps = a.state[pl].ksteps;
+        // the drift baseline at the call's end, as the lane that found the end measured it.  (Rounds 3-4 took the state behind
+        // the last piece that lay wholly before the end: a stream of calls of one piece each never got a baseline, and its
+        // pieces stayed at 16 x nothing.)
+        drift = st.end_drift; ksteps = st.end_ksteps;
     } else {
         // the serial recurrence, from the verified start of the piece that failed (or from behind the last piece when the
         // pieces did not reach the call's end) to the end of the call: exact, and slow -- one lane

@@ -107,6 +107,8 @@ struct SchedStatus {
     int max_span[kSchedSpanSizes];   // largest n[last] - n[first] over aligned tiles of kSchedSpanBase << i outputs
     int pad[3];
     long long x_len;         // the call's input length as the BEGIN kernel resolved it (a chained call: the previous stage's count)
+    double end_drift;        // drift baseline at the call's end: the piece's start baseline + the deviation measured up to end_k
+    double end_ksteps;       //   (the next call continues from there: a stream of one-piece calls builds its baseline too)
 };
 struct SchedGroupEntry { double shift; int advance; int next; };        // map of one group: candidate -> (next, +shift, +xIdx)
 struct SchedGroupStart { double shift; long long advance; int cand; int pad; };   // true start of a group, as candidate + shift

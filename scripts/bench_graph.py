@@ -83,6 +83,11 @@ def stream_row(name, make, nch, chunk, ncalls, dtype, reps=5):
 
 
 def main():
+    global stream_row
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    if only:                       # rows whose name contains any of the words given
+        all_rows = stream_row
+        stream_row = lambda name, *a, **k: all_rows(name, *a, **k) if any(w in name for w in only) else None
     h147 = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
     h128 = pkg.firdes(128, 0.5 / 4, beta=7.8562).astype(np.float32)
     haf = pkg.firdes(320, 0.45 / 32, beta=7.8562) * 32
@@ -94,6 +99,9 @@ def main():
     stream_row("decimator 1//4 128 taps f32, 1 channel", lambda: F(h128, Fraction(1, 4)), 1, 99_991, 50, torch.float32)
     stream_row("FIRArbitrary rate 1/2.123456789, 10 taps per phase, f32, 1 channel", lambda: F(haf, 1 / 2.123456789, 32), 1, 99_991, 50, torch.float32)
     stream_row("FIRFarrow rate 1/2.123456789, 10 taps per phase, polyorder 4, f32, 1 channel", lambda: F(haf, 1 / 2.123456789, 32, 4), 1, 99_991, 50, torch.float32)
+    stream_row("FIRArbitrary rate 1/2.123456789, 10 taps per phase, f32, 1 channel", lambda: F(haf, 1 / 2.123456789, 32), 1, 19_997, 50, torch.float32)
+    stream_row("FIRArbitrary rate 1/2.123456789, 10 taps per phase, f32, 1 channel", lambda: F(haf, 1 / 2.123456789, 32), 1, 49_999, 50, torch.float32)
+    stream_row("FIRArbitrary rate 1/2.123456789, 10 taps per phase, f32, 1 channel", lambda: F(haf, 1 / 2.123456789, 32), 1, 299_993, 30, torch.float32)
     stream_row("FIRArbitrary rate pi/3, 32 taps per phase, f64, 64 channels", lambda: F(pkg.firdes(1024, 0.45 / 32, beta=7.8562) * 32, float(np.pi / 3), 32), 64, 99_991, 20, torch.float64)
     stream_row("cascade: decimator 1//4, then 147//160, f32, 1 channel", lambda: pkg.FilterCascade(F(h128, Fraction(1, 4)), F(h147, Fraction(147, 160))), 1, 99_991, 50, torch.float32)
     stream_row("cascade: decimator 1//4, then 147//160, f32, 16 channels", lambda: pkg.FilterCascade(F(h128, Fraction(1, 4)), F(h147, Fraction(147, 160))), 16, 99_991, 50, torch.float32)
