@@ -344,7 +344,17 @@ static int enqueue_tables(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y
     ba.rec = f->d_rec; ba.status = f->ds_status; ba.state = f->ds_state;
     if (host_state) { ba.use_host = 1; ba.acc = host_state->acc; ba.xIdx = host_state->xIdx; ba.drift = host_state->drift; ba.ksteps = host_state->ksteps; }
     ba.x_from = x_from;
-    MRHIP_CHECK_HIP(launch_sched_begin(ba, x_len, k, s));
+    SchedFinishArgs fa{};
+    fa.rec = f->d_rec; fa.mirror = mirror_of(f); fa.call = f->d_calls[b];
+    fa.status = f->ds_status; fa.state = f->ds_state; fa.fail_state = fail_state_of(f);
+    fa.sched_n = static_cast<int *>(f->ds_n[b]); fa.sched_acc = static_cast<double *>(f->ds_acc[b]);
+    fa.count_out = count_out;
+    fa.k_first = k; fa.ks_first = ks; fa.pmax = f->sched_pmax; fa.est = est + 1; fa.x_len = x_len; fa.y_capacity = y_capacity;
+    fa.np = static_cast<int>(np); fa.serial_fallback = serial_fallback ? 1 : 0;
+    // BEGIN in the first piece's tables kernel, FINISH in the last piece's emit kernel (MRHIP_SCHED_FUSE=0: launches of their own)
+    static const bool fuse_on = env_i64("MRHIP_SCHED_FUSE", 1) != 0;
+    const bool fuse = fuse_on && np > 0;
+    if (!fuse) MRHIP_CHECK_HIP(launch_sched_begin(ba, x_len, k, s));
     for (int64_t p = 0; p < np; ++p) {
         SchedPieceArgs a{};
         a.state = f->ds_state; a.status = f->ds_status;
@@ -354,16 +364,15 @@ static int enqueue_tables(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y
         a.piece = static_cast<int>(p); a.ngroups = static_cast<int>(out->psteps[static_cast<size_t>(p)] / kSchedGroup);
         a.corrupt_group = f->sched_corrupt_piece == f->stat_device_pieces + p ? 0 : -1;
         if (f->sched_corrupt_piece <= -2) a.corrupt_group = f->sched_corrupt_piece;   // test hook: group -v-2 of every piece starts late
-        MRHIP_CHECK_HIP(launch_schedule_piece(c, a, s));
+        SchedFuseArgs fu{};
+        if (fuse) {
+            fu.begin = p == 0; fu.finish = p + 1 == np;
+            fu.b = ba; fu.b_x_len = x_len; fu.b_k_first = k;
+            fu.f = fa;
+        }
+        MRHIP_CHECK_HIP(launch_schedule_piece(c, a, s, fuse ? &fu : nullptr));
     }
-    SchedFinishArgs fa{};
-    fa.rec = f->d_rec; fa.mirror = mirror_of(f); fa.call = f->d_calls[b];
-    fa.status = f->ds_status; fa.state = f->ds_state; fa.fail_state = fail_state_of(f);
-    fa.sched_n = static_cast<int *>(f->ds_n[b]); fa.sched_acc = static_cast<double *>(f->ds_acc[b]);
-    fa.count_out = count_out;
-    fa.k_first = k; fa.ks_first = ks; fa.pmax = f->sched_pmax; fa.est = est + 1; fa.x_len = x_len; fa.y_capacity = y_capacity;
-    fa.np = static_cast<int>(np); fa.serial_fallback = serial_fallback ? 1 : 0;
-    MRHIP_CHECK_HIP(launch_sched_finish(c, fa, s));
+    if (!fuse) MRHIP_CHECK_HIP(launch_sched_finish(c, fa, s));
     MRHIP_CHECK_HIP(hipEventRecord(f->ev_rec, s));
     out->pending = true;
     return MRHIP_OK;

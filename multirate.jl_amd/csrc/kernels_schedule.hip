@@ -114,10 +114,15 @@ __device__ __forceinline__ bool sched_stop(const SchedStatus *st, int piece)
     return fp != kSchedNoFail || (dn != 0 && dn - 1 < piece);
 }
 
+__device__ __forceinline__ SchedPieceState sched_begin_body(const SchedBeginArgs &a, long long x_len, long long k_first, bool file);
+__device__ __noinline__ void sched_finish_body(const SchedPlan &c, SchedFinishArgs a);
+
 // ---- K1: candidate tables of one group (64 segments) per workgroup, composed --------------------------------
-__global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, SchedPieceArgs a)
+// fu.begin (piece 0 of a call): the call's BEGIN rides here -- every thread derives the call-start state from the record
+// itself (the status word is still the previous call's: nothing here reads it), one thread files it for the kernels behind.
+__global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, SchedPieceArgs a, SchedFuseArgs fu)
 {
-    if (sched_stop(a.status, a.piece)) return;
+    if (!fu.begin && sched_stop(a.status, a.piece)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nwin = c.nwin;
     double *const eC = reinterpret_cast<double *>(smem);                 // [64][nwin] candidate start value
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, 
     int *const eW = reinterpret_cast<int *>(eSh + kGroupSegs * nwin);    // xIdx advance over the segment
     int *const eCn = eW + kGroupSegs * nwin;                             // candidate of the next segment (-1: none)
 
-    const SchedPieceState ps = a.state[a.piece];
+    const SchedPieceState ps = fu.begin ? sched_begin_body(fu.b, fu.b_x_len, fu.b_k_first, blockIdx.x == 0 && threadIdx.x == 0) : a.state[a.piece];
     const double slope = ps.ksteps > 0.0 ? ps.drift / ps.ksteps : 0.0;
     const int g = blockIdx.x;
     const long long seg0 = static_cast<long long>(g) * kGroupSegs;
@@ -271,7 +276,24 @@ __global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan
 }
 
 // ---- K3: run every segment from its true start, emit, verify -------------------------------------------------
-__global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, SchedPieceArgs a)
+// fu.finish (the last piece of a call): the workgroups count themselves off when they are through -- the ones that had
+// nothing to do too -- and the last one is the call's FINISH.
+__device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedPieceArgs &a);
+__global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, SchedPieceArgs a, SchedFuseArgs fu)
+{
+    sched_emit_body(c, a);
+    if (!fu.finish) return;
+    static_assert(kGroupSegs == 64, "one wave per workgroup: the count below is a wave's");
+    __threadfence();                                          // this workgroup's entries, end and state: out before it counts
+    int last = 0;
+    if (threadIdx.x == 0) last = atomicAdd(&a.status->groups_done, 1) == a.ngroups - 1 ? 1 : 0;
+    last = __shfl(last, 0);
+    if (!last) return;
+    __threadfence();                                          // ... and everyone else's in before the FINISH reads them
+    if (threadIdx.x == 0) sched_finish_body(c, fu.f);
+}
+
+__device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedPieceArgs &a)
 {
     // test hook (MRHIP_SCHED_CORRUPT = -2 - g): group g starts ~0.5 ms late, i.e. after the group that holds the call's end
     // has set `done` -- it must still write its entries (sched_stop)
@@ -368,10 +390,10 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
     }
 }
 
-// ---- BEGIN / FINISH: the one-lane kernels round the pieces of a call (mrhip_internal.h: SchedBeginArgs) ----------------
-__global__ __launch_bounds__(64) void sched_begin_kernel(SchedBeginArgs a, long long x_len, long long k_first)
+// ---- BEGIN / FINISH: one lane each, round the pieces of a call (mrhip_internal.h: SchedBeginArgs) ---------------------
+// The call-start state of piece 0 and the armed status word; `file`: this lane writes them for the kernels behind it.
+__device__ __forceinline__ SchedPieceState sched_begin_body(const SchedBeginArgs &a, long long x_len, long long k_first, bool file)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (a.x_from) {                   // a chained call: what the stage before it wrote (never more than the bound the launch was sized for)
         const long long n = a.x_from->n_out;
         x_len = n < 0 ? 0 : (n < x_len ? n : x_len);
@@ -379,6 +401,7 @@ __global__ __launch_bounds__(64) void sched_begin_kernel(SchedBeginArgs a, long 
     SchedPieceState ps;
     if (a.use_host) { ps.acc = a.acc; ps.xIdx = a.xIdx; ps.drift = a.drift; ps.ksteps = a.ksteps; }
     else { const DevStream r = *a.rec; ps.acc = r.acc; ps.xIdx = r.inputDeficit; ps.drift = r.drift; ps.ksteps = r.ksteps; }   // xIdx starts at inputDeficit, Filters.jl:715
+    if (!file) return ps;
     SchedStatus st{};
     st.fail_piece = kSchedNoFail;
     if (ps.xIdx > x_len) {            // not one output (Filters.jl:705-709): the call ends before its first entry
@@ -392,11 +415,17 @@ __global__ __launch_bounds__(64) void sched_begin_kernel(SchedBeginArgs a, long 
     st.x_len = x_len;                 // the pieces and the FINISH kernel read it from here
     *a.status = st;
     a.state[0] = ps;
+    return ps;
 }
 
-__global__ __launch_bounds__(64) void sched_finish_kernel(SchedPlan c, SchedFinishArgs a)
+__global__ __launch_bounds__(64) void sched_begin_kernel(SchedBeginArgs a, long long x_len, long long k_first)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    (void)sched_begin_body(a, x_len, k_first, true);
+}
+
+__device__ __noinline__ void sched_finish_body(const SchedPlan &c, SchedFinishArgs a)
+{
     DevStream r = *a.rec;
     const SchedStatus st = *a.status;
     a.x_len = st.x_len;               // (as the BEGIN kernel resolved it: a chained call's comes from the stage before)
@@ -460,6 +489,12 @@ __global__ __launch_bounds__(64) void sched_finish_kernel(SchedPlan c, SchedFini
     if (a.count_out) *a.count_out = call.n_out;
 }
 
+__global__ __launch_bounds__(64) void sched_finish_kernel(SchedPlan c, SchedFinishArgs a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    sched_finish_body(c, a);
+}
+
 }  // namespace
 
 hipError_t launch_sched_begin(const SchedBeginArgs &a, long long x_len, long long k_first, hipStream_t s)
@@ -477,8 +512,10 @@ hipError_t launch_sched_finish(const SchedPlan &c, const SchedFinishArgs &a, hip
 size_t sched_tables_lds(const SchedPlan &c) { return static_cast<size_t>(kGroupSegs) * c.nwin * 24; }
 
 // Enqueue the three kernels of one piece (ngroups * 4096 steps from step a.k0 of the call) on `s`.
-hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hipStream_t s)
+hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hipStream_t s, const SchedFuseArgs *fu_)
 {
+    SchedFuseArgs fu{};
+    if (fu_) fu = *fu_;
     const size_t lds = sched_tables_lds(c);
     {   // the dynamic-LDS attribute is per device: remembered per (kernel, device) like every other launch's
         int per_cu = 0;
@@ -486,9 +523,9 @@ hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hi
         if (e != hipSuccess) return e;
     }
     const int tab_threads = std::min(kTabThreads, kGroupSegs * c.nwin);      // (64 * nwin: whole waves)
-    hipLaunchKernelGGL(sched_tables_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(static_cast<unsigned>(tab_threads)), lds, s, c, a);
+    hipLaunchKernelGGL(sched_tables_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(static_cast<unsigned>(tab_threads)), lds, s, c, a, fu);
     hipLaunchKernelGGL(sched_chain_kernel, dim3(1), dim3(kChainWaves * 64), 0, s, c, a);
-    hipLaunchKernelGGL(sched_emit_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(kGroupSegs), 0, s, c, a);
+    hipLaunchKernelGGL(sched_emit_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(kGroupSegs), 0, s, c, a, fu);
     return hipGetLastError();
 }
 

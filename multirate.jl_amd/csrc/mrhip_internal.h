@@ -105,7 +105,8 @@ struct SchedStatus {
     double end_acc;          // state after the last output's update()
     long long end_xIdx;
     int max_span[kSchedSpanSizes];   // largest n[last] - n[first] over aligned tiles of kSchedSpanBase << i outputs
-    int pad[3];
+    int groups_done;         // workgroups of the LAST piece's emit kernel that are through: the last one is the call's FINISH
+    int pad[2];
     long long x_len;         // the call's input length as the BEGIN kernel resolved it (a chained call: the previous stage's count)
     double end_drift;        // drift baseline at the call's end: the piece's start baseline + the deviation measured up to end_k
     double end_ksteps;       //   (the next call continues from there: a stream of one-piece calls builds its baseline too)
@@ -127,7 +128,9 @@ struct SchedPieceArgs {
     int corrupt_group;       // test hook: -1, or the group whose table is falsified (MRHIP_SCHED_CORRUPT)
 };
 SchedPlan make_sched_plan(double delta, int64_t Nphi, int win_mult = 1, int win_min = 4);
-hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hipStream_t s);
+struct SchedFuseArgs;
+// fu != NULL: the call's BEGIN rides in the tables kernel of piece 0 and / or its FINISH in the emit kernel of the last piece
+hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hipStream_t s, const SchedFuseArgs *fu = nullptr);
 // The two one-lane kernels round the pieces of a call (kernels_schedule.hip).  BEGIN arms the status word and writes the
 // call-start state of piece 0 -- from the device record, or from the host's values when it just evaluated a prefix itself.
 // FINISH turns the pieces' verdict into the call's result: output count into the DevCall the filter kernel reads (clamped
@@ -157,6 +160,16 @@ struct SchedFinishArgs {
     long long pmax, est, x_len, y_capacity;
     int np;                       // pieces enqueued
     int serial_fallback;          // redo a failed piece (and everything behind it) here instead of reporting it
+};
+// BEGIN and FINISH without launches of their own (a call of one piece: four dependent launches instead of six before the filter
+// kernel).  begin: every workgroup of piece 0's tables kernel derives the call-start state itself, workgroup 0 files status
+// and state[0] for the kernels behind it.  finish: the workgroups of the last piece's emit kernel count themselves off
+// (SchedStatus::groups_done, release / acquire at device scope); the last one through is the FINISH kernel.
+struct SchedFuseArgs {
+    int begin, finish;
+    SchedBeginArgs b;
+    long long b_x_len, b_k_first;
+    SchedFinishArgs f;
 };
 hipError_t launch_sched_begin(const SchedBeginArgs &a, long long x_len, long long k_first, hipStream_t s);
 hipError_t launch_sched_finish(const SchedPlan &c, const SchedFinishArgs &a, hipStream_t s);
