@@ -352,7 +352,7 @@ static int enqueue_tables(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y
     fa.k_first = k; fa.ks_first = ks; fa.pmax = f->sched_pmax; fa.est = est + 1; fa.x_len = x_len; fa.y_capacity = y_capacity;
     fa.np = static_cast<int>(np); fa.serial_fallback = serial_fallback ? 1 : 0;
     // BEGIN in the first piece's tables kernel, FINISH in the last piece's emit kernel (MRHIP_SCHED_FUSE=0: launches of their own)
-    static const bool fuse_on = env_i64("MRHIP_SCHED_FUSE", 1) != 0;
+    const bool fuse_on = env_i64("MRHIP_SCHED_FUSE", 1) != 0;
     const bool fuse = fuse_on && np > 0;
     if (!fuse) MRHIP_CHECK_HIP(launch_sched_begin(ba, x_len, k, s));
     for (int64_t p = 0; p < np; ++p) {

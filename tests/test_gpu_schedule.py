@@ -222,3 +222,61 @@ def test_advance_state_over_long_stretches_uses_the_device_schedule(pkg, torch_c
     x = torch.rand(100_000, device="cuda", dtype=torch.float32) - 0.5
     assert torch.equal(fd.filt(x).view(torch.int32), fh.filt(x).view(torch.int32))
     fd.close(); fh.close()
+
+
+def test_stream_of_short_calls_leaves_the_host_loop(pkg, O, torch_cuda):
+    """Calls of about 21 000 outputs each -- shorter than the serial prefix that measures the drift baseline (65 536 steps): the
+    prefix's measurement is kept when it reaches a call's end, so after the first few calls the stream runs on the device
+    (round 4 found such streams re-running the prefix on the host for ever); outputs and end state == the oracle's loop."""
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    Nphi, T, rate, chunk, ncalls = 32, 5, 1 / 2.123456789, 44_987, 30
+    h = rng.standard_normal(T * Nphi).astype(np.float32)
+    x = rng.standard_normal(chunk * ncalls).astype(np.float32)
+    f = pkg.FIRFilter(h, rate, Nphi)
+    fo = O.FIRFilter(h, rate, Nphi, tx=np.float32)
+    xd = torch.from_numpy(x).cuda()
+    for i in range(ncalls):
+        y = f.filt(xd[i * chunk:(i + 1) * chunk]).cpu().numpy()
+        assert_bit_equal(y, fo.filt(x[i * chunk:(i + 1) * chunk]), f"call {i}")
+    assert f.state.phiAccumulator == fo.state.phiAccumulator and f.state.inputDeficit == fo.state.inputDeficit
+    info = f.schedule_info()
+    total = int(chunk * ncalls * rate)
+    assert info["host_steps"] < 4 * 65_536 < total // 2, info          # the prefix, not the stream
+    assert info["device_pieces"] >= ncalls - 6, info
+    f.close()
+
+
+@pytest.mark.parametrize("fuse,win", [("0", ("4", "16")), ("1", ("4", "16")), ("0", ("1", "4")), ("1", ("2", "8"))])
+def test_schedule_switches_change_nothing(pkg, O, torch_cuda, monkeypatch, fuse, win):
+    """BEGIN / FINISH as launches of their own or inside the pieces' kernels (MRHIP_SCHED_FUSE), one, two or four residue
+    systems of candidates per segment (MRHIP_SCHED_WIN_MULT / _MIN: rounds 3-4 ran 4 / 16): synchronous and asynchronous
+    calls, several pieces per call -- outputs, counts and end state == the oracle."""
+    torch = torch_cuda
+    _small_pieces(monkeypatch)
+    monkeypatch.setenv("MRHIP_SCHED_FUSE", fuse)
+    monkeypatch.setenv("MRHIP_SCHED_WIN_MULT", win[0])
+    monkeypatch.setenv("MRHIP_SCHED_WIN_MIN", win[1])
+    rng = np.random.default_rng(17)
+    for rate, Nphi in ((math.pi / 3, 32), (1 / 2.123456789, 32), (0.37, 10), (7.77, 7), (2.5, 32)):
+        T = 4
+        h = rng.standard_normal(T * Nphi).astype(np.float32)
+        n = max(int(60_000 / rate), 500)
+        x = rng.standard_normal(3 * n).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        f = pkg.FIRFilter(h, rate, Nphi)
+        fo = O.FIRFilter(h, rate, Nphi, tx=np.float32)
+        assert f.bind(np.float32, 1).schedule_info()["nwin"] == max(int(win[0]) * f.schedule_info()["ncand"], int(win[1]))
+        y0 = f.filt(xd[:n]).cpu().numpy()                                  # waited for
+        assert_bit_equal(y0, fo.filt(x[:n]), f"rate={rate} synchronous")
+        cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+        ys = torch.zeros((2, f.outputlength_bound(n)), dtype=torch.float32, device="cuda")
+        f.filt_into_async(ys[0], xd[n:2 * n], cnt[0:1])                    # nobody waits
+        f.filt_into_async(ys[1], xd[2 * n:], cnt[1:2])
+        f.sync_state()
+        for i in range(2):
+            ref = fo.filt(x[(i + 1) * n:(i + 2) * n])
+            assert int(cnt[i]) == len(ref), (rate, i)
+            assert_bit_equal(ys[i, :len(ref)].cpu().numpy(), ref, f"rate={rate} asynchronous {i}")
+        assert f.state.phiAccumulator == fo.state.phiAccumulator and f.state.inputDeficit == fo.state.inputDeficit, rate
+        f.close()
