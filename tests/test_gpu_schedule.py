@@ -280,3 +280,34 @@ def test_schedule_switches_change_nothing(pkg, O, torch_cuda, monkeypatch, fuse,
             assert_bit_equal(ys[i, :len(ref)].cpu().numpy(), ref, f"rate={rate} asynchronous {i}")
         assert f.state.phiAccumulator == fo.state.phiAccumulator and f.state.inputDeficit == fo.state.inputDeficit, rate
         f.close()
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_falsified_table_in_an_asynchronous_call_is_redone_on_the_device(pkg, O, torch_cuda, monkeypatch, fuse):
+    """Nobody waits for an asynchronous call, so a piece that does not verify cannot be handed to the host: the FINISH (inside
+    the last piece's emit kernel, or a launch of its own) redoes the schedule serially from that piece's verified start to the
+    end of the call.  MRHIP_SCHED_CORRUPT=1 falsifies piece 1 of the call: outputs, count and end state == the oracle."""
+    torch = torch_cuda
+    _small_pieces(monkeypatch)
+    monkeypatch.setenv("MRHIP_SCHED_CORRUPT", "1")
+    monkeypatch.setenv("MRHIP_SCHED_FUSE", fuse)
+    rng = np.random.default_rng(4)
+    h = rng.standard_normal(3 * 32).astype(np.float32)
+    x = rng.standard_normal(60_000).astype(np.float32)
+    rate = math.pi / 3
+    f = pkg.FIRFilter(h, rate, 32).bind(np.float32, 1)
+    fo = O.FIRFilter(h, rate, 32, tx=np.float32)
+    xd = torch.from_numpy(x).cuda()
+    y = torch.zeros(f.outputlength_bound(len(x)), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    f.filt_into_async(y, xd, cnt)
+    n = f.sync_state()
+    yo = fo.filt(x)
+    assert n == len(yo) == int(cnt[0])
+    assert_bit_equal(y[:n].cpu().numpy(), yo, "after a forced fallback on the device")
+    assert f.state.phiAccumulator == fo.state.phiAccumulator and f.state.inputDeficit == fo.state.inputDeficit
+    # the stream goes on from there
+    x2 = rng.standard_normal(5_000).astype(np.float32)
+    monkeypatch.delenv("MRHIP_SCHED_CORRUPT")
+    assert_bit_equal(f.filt(torch.from_numpy(x2).cuda()).cpu().numpy(), fo.filt(x2), "the next call")
+    f.close()
