@@ -995,8 +995,10 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                     fw.pnfb = f->d_pnfb_t;                              // degree-major, padded: [polyorder+1][32]
                     MRHIP_CHECK_HIP(launch_farrow_wave(tk, fused, fw, stream, &f->last_kernel, f->num_cus));
                 }
-                else if (!f->force_generic && plan_farrow_tiled(tk, fa, n_host, sched_spans, f->num_cus, &fta, &flds))
+                else if (!f->force_generic && plan_farrow_tiled(tk, fa, n_host, sched_spans, f->num_cus, &fta, &flds)) {
+                    fta.counters = MRHIP_ENV_INT("MRHIP_PIPE_DYNAMIC", 1) != 0 ? f->d_counters : nullptr;   // (as for FIRArbitrary below)
                     MRHIP_CHECK_HIP(launch_farrow_tiled(tk, fused, fa, fta, flds, stream, &f->last_kernel, f->num_cus));
+                }
                 else
                     MRHIP_CHECK_HIP(launch_farrow(tk, fused, fa, stream, &f->last_kernel));
                 return timing_mark(f, stream);
@@ -1011,13 +1013,18 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             if (int rc = timing_mark(f, stream)) return rc;
             ArbTileArgs ta;
             size_t lds = 0;
-            if (!f->force_generic && plan_arb_tiled(tk, a, n_host, sched_spans, f->num_cus, &ta, &lds))
+            if (!f->force_generic && plan_arb_tiled(tk, a, n_host, sched_spans, f->num_cus, &ta, &lds)) {
+                // the pipe kernel's tiles are handed out from a counter of the filter (its launches are stream-ordered: one at a
+                // time); MRHIP_PIPE_DYNAMIC=0: every workgroup takes every gridDim-th tile
+                ta.counters = MRHIP_ENV_INT("MRHIP_PIPE_DYNAMIC", 1) != 0 ? f->d_counters : nullptr;
                 MRHIP_CHECK_HIP(launch_arb_tiled(tk, fused, a, ta, lds, stream, &f->last_kernel, f->num_cus));
+            }
             else
                 MRHIP_CHECK_HIP(launch_arb_generic(tk, fused, a, stream, &f->last_kernel));
             return timing_mark(f, stream);
         };
         ArbState st;
+        bool host_loop = false;            // this call's schedule came from the host's serial loop (not from sched_enqueue)
         // Upper bound of the output count (the reference's outputlength estimate, Filters.jl:375-381, + 2 for the
         // rounding of its Float64 recurrence); without the host's copy of the state: for inputDeficit = 1.
         const int64_t est = dev_planned ? bound
@@ -1117,6 +1124,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 f->ev_filt_valid[b] = true;
             }
         } else if (!cached && est > 2 * piece && y && y_capacity >= est && (f->nch == 1 || y_stride >= est) && est < 0x7fffffffLL) {
+            host_loop = true;
             if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
             if (int rc = ensure_sched_capacity(f, static_cast<size_t>(est))) return rc;
             sched_dn = f->d_sched_n; sched_dacc = f->d_sched_acc;      // (the buffers may just have been (re)allocated)
@@ -1159,6 +1167,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             f->sched_in_flight = true;
             n_out = k0;
         } else {
+        host_loop = true;
         n_out = arb_schedule(f, x_len, &st);   // update(::FIRFarrow), Filters.jl:780-788, is the same recurrence
         if (f->sched_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->sched_copied)); f->sched_in_flight = false; }
         if (n_out > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
@@ -1178,6 +1187,13 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         }
         // commit the post-call state (Filters.jl:731-735)
         if (!dev_planned) {
+            if (host_loop && f->per_valid) {
+                // the host's loop evaluated this call (a short one): a cycle found earlier moves on by its outputs -- left where it
+                // was, the next ASYNCHRONOUS call would plan from a stale cycle position and be refused by its plan kernel
+                // (tests/stress_random.py --async-mix, seed 111: rate 2.5, N𝜙 = 10)
+                if (f->per_acc[static_cast<size_t>(f->per_pos)] == f->phiAcc) f->per_pos = (f->per_pos + n_out) % f->per_Q;
+                else f->per_valid = false;
+            }
             f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;
             f->inputDeficit = st.inputDeficit;
         }

@@ -18,6 +18,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
+#include <algorithm>
 
 #include "mrhip_internal.h"
 #include "pair_device.h"
@@ -29,6 +31,11 @@ namespace {
 
 using dev::v2u_t;
 
+#ifdef MRHIP_AP_TRACE
+// debug builds (-DMRHIP_AP_TRACE): start / end time of every workgroup of the last 64 launches, dumped at process exit
+__device__ unsigned long long g_ap_trace[64][2048][2];
+__device__ unsigned g_ap_slot;
+#endif
 constexpr int kPipeThreads = 256;
 constexpr int kPipeElems = 8;        // 8-byte samples a thread stages per tile: CPL channels x ROWS rows of 256 samples
 
@@ -139,11 +146,50 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
     tiles_take_dyn(a.n_out, ta, ngroups_ll, a.dyn);                 // (a device-planned call: the count from the call record)
     const int ngroups = static_cast<int>(ngroups_ll);
     long long tile = blockIdx.x;
-    if (tile >= ta.total_tiles) return;
+#ifdef MRHIP_AP_TRACE
+    if (tid == 0 && blockIdx.x < 2048) g_ap_trace[g_ap_slot & 63][blockIdx.x][0] = wall_clock64();
+#endif
+    // Tiles are HANDED OUT in runs of ta.run_tiles consecutive tiles (ta.counters): a workgroup's first run is its index, every
+    // further one the next the whole grid has not taken -- time-major like the static order, so the workgroups that run together
+    // still share a stretch of the schedule.  With tile += gridDim every workgroup owns 1/grid of the tiles whatever happens to
+    // it: the four workgroups of a CU do not advance evenly (the kernel's last third ran on CUs with three, two, one of them
+    // left), and a workgroup that is placed late -- the next call's schedule runs beside this kernel -- ends late by as much
+    // (profiles/r04/experiments.md S).  Runs, not tiles: a device-scope atomic on one address takes ~13 ns, 650 000 of them are
+    // the kernel.  A run's index is needed before the run in front of it ends (the tile after next is prefetched): lane 0 asks
+    // at the top of a tile, publishes behind the tile's staging wait, the barrier at the tile's end makes it everyone's; two
+    // runs are always in hand (q0, q1).
+    unsigned *const ctr = ta.counters;
+    __shared__ unsigned s_grab[2];
+    const long long G = gridDim.x;
+    const int RUN = ctr ? ta.run_tiles : 1;
+    auto leave = [&]() {                                        // every workgroup, the ones without a tile too
+        if (ctr && tid == 0) {
+            __threadfence();                                      // (this workgroup's requests are in before it counts itself off)
+            if (atomicAdd(ctr + 64, 1u) == static_cast<unsigned>(G) - 1u) {
+                __threadfence();
+                ctr[0] = 0u; ctr[64] = 0u;                        // re-armed for the next launch (stream order makes it visible)
+            }
+        }
+    };
+    if (ctr) tile *= RUN;
+    if (tile >= ta.total_tiles) { leave(); return; }
     long long tau = tile / ngroups;
     int cg = static_cast<int>(tile - tau * ngroups);
-    const long long dtau = gridDim.x / ngroups;
-    const int dcg = static_cast<int>(gridDim.x - dtau * ngroups);
+    constexpr long long kNoRun = -1;
+    long long q0 = kNoRun, q1 = kNoRun;                         // first tiles of the next two runs of this workgroup
+    if (ctr) {
+        if (tid == 0) { const unsigned b = atomicAdd(ctr, 2u); s_grab[0] = b; s_grab[1] = b + 1u; }
+        __syncthreads();
+        q0 = (G + s_grab[0]) * RUN; q1 = (G + s_grab[1]) * RUN;
+    }
+    auto after = [&](long long t_) -> long long {               // the tile this workgroup takes after t_
+        if (!ctr) return t_ + G;
+        if (((t_ + 1) & (RUN - 1)) != 0) return t_ + 1;        // (RUN is a power of two)
+        const long long r_ = q0;
+        q0 = q1; q1 = kNoRun;
+        return r_;
+    };
+    long long t1 = after(tile), t2 = after(t1);                 // this workgroup's next tile and the one after it
 
     // n_idx[first output of a tile].  In the tile loop it is loaded TWO tiles ahead by an ordinary load and taken over into a scalar
     // behind the staging wait at the end of a tile, where nothing is in flight any more: left to a load at the top of the tile the
@@ -256,19 +302,20 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
     int n_pre = 0;
     double acc_pre = 0.0;
     if (tid < cur.nout) { n_pre = a.n_idx[cur.k0 + tid]; acc_pre = a.acc[cur.k0 + tid]; }
-    auto step = [&](long long &t_, int &c_) {                    // the tile this workgroup takes after (t_, c_)
-        t_ += dtau; c_ += dcg;
-        if (c_ >= ngroups) { c_ -= ngroups; ++t_; }
-        return t_ * ngroups + c_ < ta.total_tiles;
+    auto split = [&](long long t_, long long &tau_, int &c_) {   // tile index -> (stretch of outputs, channel group)
+        tau_ = t_ / ngroups; c_ = static_cast<int>(t_ - tau_ * ngroups);
+        return t_ < ta.total_tiles;
     };
     long long ntau = tau;
     int ncg = cg;
-    bool have_next = step(ntau, ncg);
+    bool have_next = t1 < ta.total_tiles;
+    if (have_next) (void)split(t1, ntau, ncg);
     int n_lo_next = 0;
     if (have_next) n_lo_next = first_index_sync(ntau);
     store_tile(0);
     __syncthreads();       // the tap banks and the first tile are in LDS
     int buf = 0;
+    unsigned it = 0;
 
     for (;;) {
         // the next tile's loads go out now and land while this tile is computed
@@ -285,9 +332,13 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
             }
             if (tid < nxt.nout) { n_pre = a.n_idx[nxt.k0 + tid]; acc_pre = a.acc[nxt.k0 + tid]; }
         }
+        const bool refill = ctr && q1 == kNoRun;                 // (uniform) a run was taken into use: ask for another, publish it below
+        unsigned grabbed = 0u;
+        if (refill && tid == 0) grabbed = atomicAdd(ctr, 1u);
         long long n2tau = ntau;
         int n2cg = ncg;
-        const bool have_next2 = have_next && step(n2tau, n2cg);
+        const bool have_next2 = have_next && t2 < ta.total_tiles;
+        if (have_next2) (void)split(t2, n2tau, n2cg);
         int first2 = 0;                                         // n_idx[first output] of the tile after the next: taken over below
         if (have_next2) first2 = a.n_idx[n2tau * kPipeThreads];
 
@@ -470,6 +521,7 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
                 store_tile(buf);
             }
         }
+        if (refill && tid == 0) s_grab[it & 1] = grabbed;       // (its return has landed with the staging loads above)
         const int n_lo_next2 = __builtin_amdgcn_readfirstlane(first2);   // (its load has landed with the staging loads above)
         if (tid < cur.nout) {
 #pragma unroll
@@ -490,7 +542,15 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
         __syncthreads();       // one barrier per tile: the next tile is in LDS, and everyone is done with the buffer written after it
         tau = ntau; cg = ncg; cur = nxt;
         ntau = n2tau; ncg = n2cg; have_next = have_next2; n_lo_next = n_lo_next2;
+        if (refill) q1 = (G + s_grab[it & 1]) * RUN;
+        t1 = t2;
+        t2 = after(t2);
+        ++it;
     }
+    leave();
+#ifdef MRHIP_AP_TRACE
+    if (tid == 0 && blockIdx.x < 2048) g_ap_trace[g_ap_slot & 63][blockIdx.x][1] = wall_clock64();
+#endif
 }
 
 template <typename TX, typename R, int NC, bool DMA>
@@ -512,7 +572,49 @@ hipError_t launch_pipe_t(bool fused, const ArbArgs &a, const ArbTileArgs &ta, si
             std::fprintf(stderr, "[mrhip] arb_pipe T=%d Nphi=%d cpl=%d grid=%lld lds=%zu occ/CU=%d regs=%d max_span=%d tiles=%lld\n",
                          a.T, a.Nphi, ta.cpl, g, lds, per_cu, fa.numRegs, ta.max_span, ta.total_tiles);
         }
-        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kPipeThreads), lds, s, a, ta);
+#ifdef MRHIP_AP_TRACE
+        {
+            static unsigned slot = 0;
+            static bool armed = false;
+            static std::vector<long long> grids(64, 0);
+            grids[slot & 63] = g;
+            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ap_slot), &slot, sizeof(slot), 0, hipMemcpyHostToDevice, s);
+            ++slot;
+            if (!armed) {
+                armed = true;
+                std::atexit([] {
+                    (void)hipDeviceSynchronize();
+                    static unsigned long long h[64][2048][2];
+                    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ap_trace), sizeof(h)) != hipSuccess) return;
+                    for (unsigned l = 0; l < 64 && l < slot; ++l) {
+                        const unsigned sl = (slot - 1 - l) & 63;
+                        const long long gg = std::min<long long>(grids[sl], 2048);
+                        if (gg < 2) continue;
+                        unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
+                        int late = 0;
+                        for (long long b = 0; b < gg; ++b) { s0 = std::min(s0, h[sl][b][0]); s1 = std::max(s1, h[sl][b][0]); e0 = std::min(e0, h[sl][b][1]); e1 = std::max(e1, h[sl][b][1]); }
+                        for (long long b = 0; b < gg; ++b) late += h[sl][b][0] - s0 > 5000;     // 100 MHz clock: 50 us
+                        std::fprintf(stderr, "[ap_trace] launch -%u grid=%lld: starts spread %.1f us (%d workgroups more than 50 us late), ends spread %.1f us, kernel %.1f us\n",
+                                     l, gg, (s1 - s0) / 100.0, late, (e1 - e0) / 100.0, (e1 - s0) / 100.0);
+                    }
+                });
+            }
+        }
+#endif
+        // Hand-outs of tiles (ta.counters): for launches long enough to have a tail worth balancing and few enough requests for the
+        // one address they all go to -- at least 64 tiles a workgroup, about 40 runs each (a power of two, 2 ... 32 tiles)
+        ArbTileArgs tq = ta;
+        const long long per_wg = ta.total_tiles / g;
+        if (tq.counters && per_wg >= MRHIP_ENV_INT("MRHIP_PIPE_DYN_MIN", 64)) {
+            int r = 2;
+            while (r < 32 && per_wg / (2 * r) >= 40) r *= 2;
+            const int env_r = MRHIP_ENV_INT("MRHIP_PIPE_RUN", 0);
+            if (env_r >= 2 && (env_r & (env_r - 1)) == 0) r = env_r;
+            tq.run_tiles = r;
+        } else {
+            tq.counters = nullptr;
+        }
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kPipeThreads), lds, s, a, tq);
         return hipGetLastError();
     };
     switch (ta.cpl) {

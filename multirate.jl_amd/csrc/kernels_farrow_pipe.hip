@@ -108,8 +108,31 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
     const long long ntiles = ta.total_tiles;
     const int ngroups = (a.nch + CPL - 1) / CPL;
 
+    // Tiles (a stretch of 256 outputs, every channel group of it) are HANDED OUT when ta.counters is set, as in arb_pipe_kernel: the
+    // first is the workgroup's index, every further one the next the grid has not taken; lane 0 asks for the tile after the
+    // tile after next at the top of a tile and publishes it behind the first staging wait, the tile's barriers make it everyone's.
+    // (One tile per request: a tile is all channel groups here -- tens of microseconds -- so the requests are few.)
+    unsigned *const ctr = DMA ? ta.counters : nullptr;          // (register staging: at the register limit as it is, stays static)
+    __shared__ unsigned s_grab[2];
+    const long long G = gridDim.x;
+    auto leave = [&]() {                                        // every workgroup, the ones without a tile too
+        if (ctr && tid == 0) {
+            __threadfence();
+            if (atomicAdd(ctr + 64, 1u) == static_cast<unsigned>(G) - 1u) {
+                __threadfence();
+                ctr[0] = 0u; ctr[64] = 0u;                        // re-armed for the next launch
+            }
+        }
+    };
     long long tau = blockIdx.x;
-    if (tau >= ntiles) return;
+    if (tau >= ntiles) { leave(); return; }
+    long long t1 = 0, t2 = 0;                                   // handed out: this workgroup's next tile and the one after it
+    if (ctr) {
+        if (tid == 0) { const unsigned b = atomicAdd(ctr, 2u); s_grab[0] = b; s_grab[1] = b + 1u; }
+        __syncthreads();
+        t1 = G + s_grab[0]; t2 = G + s_grab[1];
+    }
+    unsigned it = 0;
     // the polynomial coefficients -> LDS once (read from global memory in the Horner loops they are ~160 dependent
     // vector loads per tile, each waited for: as long as all the dot products of the tile)
     double *const lcoef = reinterpret_cast<double *>(smem + ta.x_offset_bytes);
@@ -204,7 +227,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
     };
 
     int n_lo = first_index_sync(tau);
-    int n_lo_next = tau + gridDim.x < ntiles ? first_index_sync(tau + gridDim.x) : 0;
+    int n_lo_next = (ctr ? t1 : tau + G) < ntiles ? first_index_sync(ctr ? t1 : tau + G) : 0;
     int n_pre = 0;
     double ph_pre = 0.0;
     {
@@ -221,9 +244,9 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
         const long long rem = a.n_out - k0;
         const int nout = rem < kFpThreads ? static_cast<int>(rem) : kFpThreads;
         const long long o = static_cast<long long>(n_lo) - T;    // x[n_lo - T ...] (0-based); n = 1-based newest sample
-        const long long ntau = tau + gridDim.x;
+        const long long ntau = ctr ? t1 : tau + G;
         const bool have_next_tile = ntau < ntiles;
-        const long long n2tau = ntau + gridDim.x;
+        const long long n2tau = ctr ? t2 : ntau + G;
         int first2 = 0;                                           // n_idx[first output] of the tile after the next: taken over below
         if (n2tau < ntiles) first2 = a.n_idx[n2tau * kFpThreads];
         int n_lo_next2 = 0;
@@ -357,6 +380,10 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
             // The prefetched samples go to the other buffer BEFORE the outputs are stored: their wait (vmcnt) would otherwise
             // include the stores.  (The waves still computing this group do not read that buffer.)
             asm volatile("" ::: "memory");   // (the LDS writes below stay below the hand-issued reads above)
+            // the tile after t2: asked for behind the first channel group's arithmetic (a register that lived through it would push
+            // the widest instantiations into scratch), answered with that group's staging wait
+            unsigned grabbed = 0u;
+            if (cg == 0 && ctr && tid == 0) grabbed = atomicAdd(ctr, 1u);
             if (have_next) {
                 buf ^= 1;
                 if constexpr (DMA) {
@@ -370,7 +397,10 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
                     store_group(buf);
                 }
             }
-            if (cg == 0) n_lo_next2 = __builtin_amdgcn_readfirstlane(first2);   // (its load has landed with the staging above)
+            if (cg == 0) {
+                n_lo_next2 = __builtin_amdgcn_readfirstlane(first2);   // (its load has landed with the staging above)
+                if (ctr && tid == 0) s_grab[it & 1] = grabbed;        // (and so has the request's answer)
+            }
             if (have) {
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) {
@@ -392,7 +422,13 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
         tau = ntau;
         n_lo = n_lo_next;
         n_lo_next = n_lo_next2;
+        if (ctr) {
+            t1 = t2;
+            t2 = G + s_grab[it & 1];
+            ++it;
+        }
     }
+    leave();
 }
 
 template <typename TX, typename R, int NC>
@@ -412,7 +448,9 @@ hipError_t launch_fpipe_t(bool fused, const FarrowArgs &a, const ArbTileArgs &ta
             std::fprintf(stderr, "[mrhip] farrow_pipe T=%d P=%d cpl=%d grid=%lld lds=%zu occ/CU=%d regs=%d max_span=%d tiles=%lld\n",
                          a.T, a.polyorder, ta.cpl, g, lds, per_cu, fa.numRegs, ta.max_span, ta.total_tiles);
         }
-        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kFpThreads), lds, s, a, ta);
+        ArbTileArgs tq = ta;                                       // hand-outs only where a workgroup has a few tiles to balance
+        if (tq.counters && ta.total_tiles / g < MRHIP_ENV_INT("MRHIP_PIPE_DYN_MIN_F", 8)) tq.counters = nullptr;
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kFpThreads), lds, s, a, tq);
         return hipGetLastError();
     };
 #define MRHIP_FP_GO(C, D)                                                                                         \

@@ -300,8 +300,13 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
     if (a.corrupt_group <= -2 && static_cast<int>(blockIdx.x) == -a.corrupt_group - 2)
         for (int i = 0; i < 128; ++i) __builtin_amdgcn_s_sleep(127);
     if (sched_stop(a.status, a.piece)) return;
-    __shared__ int s_n[kGroupSegs * (kSeg + 1)];
-    __shared__ double s_acc[kGroupSegs * (kSeg + 1)];
+    // The group's 4096 entries leave through LDS (a lane computes a segment, i.e. 64 CONSECUTIVE entries) in chunks of kEmitChunk
+    // steps: 14 KB a workgroup instead of the 50 KB of the whole group at once -- what is left beside the filter kernel's
+    // workgroups, next to which this kernel runs (profiles/r04/experiments.md S).
+    constexpr int kEmitChunk = 16;
+    static_assert(kSeg % kEmitChunk == 0 && kGroupSegs == 64, "whole chunks; one wave per workgroup");
+    __shared__ int s_n[kGroupSegs * (kEmitChunk + 1)];
+    __shared__ double s_acc[kGroupSegs * (kEmitChunk + 1)];
     __shared__ double s_T[kGroupSegs + 1];
     __shared__ long long s_X[kGroupSegs + 1];
 
@@ -328,12 +333,26 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
     long long end_x = 0;
     const long long kbase = a.k0 + seg * kSeg;            // step number of this segment's first output within the call
     long long prev_x = X;
-    for (int i = 0; i < kSeg; ++i) {
-        s_n[sl * (kSeg + 1) + i] = static_cast<int>(x);
-        s_acc[sl * (kSeg + 1) + i] = acc;
-        if (i > 0 && x > x_len && prev_x <= x_len) { end_k = kbase + i; end_acc = acc; end_x = x; }
-        prev_x = x;
-        sched_step(acc, x, c);
+    int *__restrict__ gn = a.sched_n + a.k0 + static_cast<long long>(g) * kGroupSegs * kSeg;
+    double *__restrict__ ga = a.sched_acc + a.k0 + static_cast<long long>(g) * kGroupSegs * kSeg;
+    for (int i0 = 0; i0 < kSeg; i0 += kEmitChunk) {
+#pragma unroll 4
+        for (int ii = 0; ii < kEmitChunk; ++ii) {
+            const int i = i0 + ii;
+            s_n[sl * (kEmitChunk + 1) + ii] = static_cast<int>(x);
+            s_acc[sl * (kEmitChunk + 1) + ii] = acc;
+            if (i > 0 && x > x_len && prev_x <= x_len) { end_k = kbase + i; end_acc = acc; end_x = x; }
+            prev_x = x;
+            sched_step(acc, x, c);
+        }
+        __syncthreads();
+        // 16 lanes write 16 consecutive entries of one segment: runs of 64 / 128 bytes
+        for (int e = sl; e < kGroupSegs * kEmitChunk; e += kGroupSegs) {
+            const int r = e / kEmitChunk, ii = e - r * kEmitChunk;
+            gn[r * kSeg + i0 + ii] = s_n[r * (kEmitChunk + 1) + ii];
+            ga[r * kSeg + i0 + ii] = s_acc[r * (kEmitChunk + 1) + ii];
+        }
+        __syncthreads();
     }
     // the next segment's start: the next lane's, or the next group's first segment
     if (sl == kGroupSegs - 1) {
@@ -380,14 +399,6 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
     }
     // (rounds 1-3 reported the largest input span of the aligned tiles here, for the filter kernels' planners; they size their
     //  tiles from an a-priori bound now -- api.hip: span_bounds -- because the filter kernel is enqueued before this one has run)
-    // coalesced copy of the group's 4096 entries
-    int *__restrict__ gn = a.sched_n + a.k0 + static_cast<long long>(g) * kGroupSegs * kSeg;
-    double *__restrict__ ga = a.sched_acc + a.k0 + static_cast<long long>(g) * kGroupSegs * kSeg;
-    for (int e = sl; e < kGroupSegs * kSeg; e += kGroupSegs) {
-        const int r = e / kSeg, i = e - r * kSeg;
-        gn[e] = s_n[r * (kSeg + 1) + i];
-        ga[e] = s_acc[r * (kSeg + 1) + i];
-    }
 }
 
 // ---- BEGIN / FINISH: one lane each, round the pieces of a call (mrhip_internal.h: SchedBeginArgs) ---------------------

@@ -387,6 +387,9 @@ struct ArbTileArgs {         // tiling of the FIRArbitrary kernel (kernels_arbit
     long long tile_out;      // outputs per tile
     long long tiles_per_channel;
     long long total_tiles;
+    unsigned *counters;      // pipe kernels: [0] RUNS of run_tiles tiles handed out beyond the first grid-full, [64] workgroups
+                             // through (both zero between launches: the last workgroup re-arms them); NULL: tile += gridDim (static)
+    int run_tiles;           // consecutive tiles per hand-out (>= 2)
 };
 
 // A device-planned FIRArbitrary / FIRFarrow call (ArbArgs::dyn / FarrowArgs::dyn): the output count comes from the call

@@ -100,7 +100,14 @@ int rec_alloc(mrhip_filter *f)
     f->h_rec = static_cast<DevStream *>(h);
     MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_rec, hipEventDisableTiming));
     if (f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW) {      // the schedule's own stream (mrhip_filter.h: s_sched)
-        MRHIP_CHECK_HIP(hipStreamCreateWithFlags(&f->s_sched, hipStreamNonBlocking));
+        // LOWEST priority: the schedule of call i+1 and the filter kernel of call i become runnable at the same moment (both wait
+        // for the filter kernel of call i-1); the filter kernel's persistent workgroups must be placed first and the schedule's fill
+        // what is left, not the other way round (profiles/r04/experiments.md S).  MRHIP_SCHED_PRIO=0: default priority.
+        int prio_least = 0, prio_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = 0; }
+        const char *pv = std::getenv("MRHIP_SCHED_PRIO");
+        if (pv && *pv == '0') prio_least = 0;
+        MRHIP_CHECK_HIP(hipStreamCreateWithPriority(&f->s_sched, hipStreamNonBlocking, prio_least));
         for (int b = 0; b < 2; ++b) {
             MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_fin[b], hipEventDisableTiming));
             MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_filt[b], hipEventDisableTiming));
