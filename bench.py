@@ -269,6 +269,8 @@ def config_rows():
                     "Msamples_per_s_in": r["Msamples_per_s_in"], "Msamples_per_s_in_wall": r["Msamples_per_s_in_wall"],
                     "achieved_GBps": r["algorithmic_GBps"], "frac": r["frac_of_8TBps"], "frac_wall": r["frac_of_8TBps_wall"],
                     "arith": r["arith"], "TFLOPs": r["TFLOPs"], "strict_valu_frac": r["frac_of_strict_valu"]})
+        if "wall_ms_per_call_continuing_stream" in r:      # FIRArbitrary / FIRFarrow: the same calls without the reset (no schedule memo)
+            out[-1]["wall_ms_continuing_stream"] = r["wall_ms_per_call_continuing_stream"]
     return out
 
 
@@ -402,6 +404,8 @@ def run_headline(args, R):
                 if nm[:3] in ("C2 ", "C3a", "C3b", "C4 ", "C4f", "C5 "):
                     base[nm.split()[0]] = {"kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "wall_ms": r["wall_ms"], "frac": r["frac"],
                                            "frac_wall": r["frac_wall"]}
+                    if "wall_ms_continuing_stream" in r:
+                        base[nm.split()[0]]["wall_ms_continuing_stream"] = r["wall_ms_continuing_stream"]
             line["roofline"]["baseline_configs"] = base
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["cpu_baseline_all_cores"] = cpu_baseline(h)
