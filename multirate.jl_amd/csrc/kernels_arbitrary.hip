@@ -53,6 +53,56 @@ __device__ __forceinline__ R mac(R t, R x, R acc)
 //     (16-byte samples -- ComplexF64 -- are one read each and need no second copy).
 // The next tile's samples (and the lanes' schedule entries) are loaded into registers BEFORE the current tile is
 // computed and written to LDS after it, so no wave waits for HBM inside a tile.
+// Tiles handed out in runs (ArbTileArgs::counters; kernels_arb_pipe.hip has the story): the workgroups of a CU do not advance evenly,
+// with tile += gridDim the kernel's tail runs under-occupied.  Two runs are always in hand; lane 0 asks for another when one is
+// taken into use and publishes the answer before the barrier at the top of the next tile.
+struct TileHandout {
+    unsigned *ctr;
+    long long G, q0, q1;
+    int run;
+    static constexpr long long kNone = -1;
+    __device__ __forceinline__ long long first(unsigned *counters, int run_tiles, unsigned *s_grab, int tid)
+    {
+        ctr = counters; G = gridDim.x; run = ctr ? run_tiles : 1; q0 = q1 = kNone;
+        if (ctr) {
+            if (tid == 0) { const unsigned b = atomicAdd(ctr, 2u); s_grab[0] = b; s_grab[1] = b + 1u; }
+            __syncthreads();
+            q0 = (G + s_grab[0]) * run; q1 = (G + s_grab[1]) * run;
+            __syncthreads();
+        }
+        return static_cast<long long>(blockIdx.x) * run;
+    }
+    __device__ __forceinline__ long long after(long long t)
+    {
+        if (!ctr) return t + G;
+        if (((t + 1) & (run - 1)) != 0) return t + 1;          // (run is a power of two)
+        const long long r = q0;
+        q0 = q1; q1 = kNone;
+        return r;
+    }
+    __device__ __forceinline__ bool wants() const { return ctr && q1 == kNone; }
+    __device__ __forceinline__ void take(const unsigned *s_grab, unsigned it) { q1 = (G + s_grab[it & 1]) * run; }
+    __device__ __forceinline__ void leave(int tid) const
+    {
+        if (ctr && tid == 0) {
+            __threadfence();
+            if (atomicAdd(ctr + 64, 1u) == static_cast<unsigned>(G) - 1u) {
+                __threadfence();
+                ctr[0] = 0u; ctr[64] = 0u;                        // re-armed for the next launch
+            }
+        }
+    }
+};
+
+// hand-outs of tiles only where a workgroup has tiles to balance (per_wg tiles each): run length, or 0 for tile += gridDim
+static int handout_run(long long per_wg, long long min_tiles)
+{
+    if (per_wg < min_tiles) return 0;
+    int r = 2;
+    while (r < 32 && per_wg / (2 * r) >= 40) r *= 2;
+    return r;
+}
+
 template <typename TX, typename R, int NC, bool FUSED, int CPL, bool PREFETCH>
 __global__ __launch_bounds__(kArbThreads, 4) void arb_tiled_kernel(ArbArgs a, ArbTileArgs ta)
 {
@@ -128,8 +178,12 @@ __global__ __launch_bounds__(kArbThreads, 4) void arb_tiled_kernel(ArbArgs a, Ar
     };
     const int telems = CPL * MS;
 
-    long long tile = blockIdx.x;
-    if (tile >= ta.total_tiles) return;
+    __shared__ unsigned s_grab[2];
+    TileHandout th;
+    long long tile = th.first(ta.counters, ta.run_tiles, s_grab, tid);
+    if (tile >= ta.total_tiles) { th.leave(tid); return; }
+    unsigned it = 0;
+    bool asked_prev = false;
     TileInfo cur = tile_info(tile);
     Sample pv[PF];
     unsigned pvalid = 0;                                     // bit j: pv[j] lies inside the signal
@@ -159,7 +213,11 @@ __global__ __launch_bounds__(kArbThreads, 4) void arb_tiled_kernel(ArbArgs a, Ar
         }
         __syncthreads();
         // the next tile's loads go out now and land while this tile is computed
-        const long long next = tile + gridDim.x;
+        if (asked_prev) th.take(s_grab, it - 1);               // the answer to the previous tile's request
+        const long long next = th.after(tile);
+        const bool asks = th.wants();                           // (uniform) a run was taken into use: ask for another
+        unsigned grabbed = 0u;
+        if (asks && tid == 0) grabbed = atomicAdd(th.ctr, 1u);
         const bool have_next = next < ta.total_tiles;
         TileInfo nxt = cur;
         const long long n_mine = n_pre;
@@ -251,9 +309,13 @@ __global__ __launch_bounds__(kArbThreads, 4) void arb_tiled_kernel(ArbArgs a, Ar
             }
         }
         if (!have_next) break;
+        if (asks && tid == 0) s_grab[it & 1] = grabbed;        // (read behind the barrier at the top of the next tile)
+        asked_prev = asks;
+        ++it;
         tile = next;
         cur = PREFETCH ? nxt : tile_info(next);
     }
+    th.leave(tid);
 }
 
 template <typename TX, typename R, int NC>
@@ -276,7 +338,10 @@ hipError_t launch_arb(bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_
             std::fprintf(stderr, "[mrhip] arb_tiled T=%d Nphi=%d grid=%lld lds=%zu occ/CU=%d regs=%d tile_out=%lld max_span=%d tiles=%lld\n",
                          a.T, a.Nphi, g, lds, per_cu, fa.numRegs, ta.tile_out, ta.max_span, ta.total_tiles);
         }
-        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, ta);
+        ArbTileArgs tq = ta;
+        tq.run_tiles = tq.counters ? handout_run(ta.total_tiles / g, 64) : 0;
+        if (tq.run_tiles == 0) tq.counters = nullptr;
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, tq);
         return hipGetLastError();
     };
     const bool pf = ta.prefetch != 0;
@@ -321,7 +386,17 @@ __global__ __launch_bounds__(kArbThreads, 3) void farrow_tiled_kernel(FarrowArgs
         tiles_take_dyn(a.n_out, ta, ngroups, a.dyn);                // (a device-planned call: the count from the call record)
     }
 
-    for (long long tile = blockIdx.x; tile < ta.total_tiles; tile += gridDim.x) {
+    __shared__ unsigned s_grab[2];
+    TileHandout th;
+    unsigned it = 0;
+    bool asked_prev = false;
+    for (long long tile = th.first(ta.counters, ta.run_tiles, s_grab, tid); tile < ta.total_tiles; ++it) {
+        // (a tile is a stretch of outputs x ALL channel groups here: there are barriers between this request and the next tile)
+        if (asked_prev) th.take(s_grab, it - 1);
+        const long long tile_after = th.after(tile);
+        const bool asks = th.wants();
+        if (asks && tid == 0) s_grab[it & 1] = atomicAdd(th.ctr, 1u);
+        asked_prev = asks;
         const long long k0 = tile * ta.tile_out;
         const long long klast = (k0 + ta.tile_out < a.n_out ? k0 + ta.tile_out : a.n_out) - 1;
         const long long n_lo = a.n_idx[k0], n_hi = a.n_idx[klast];
@@ -459,7 +534,9 @@ __global__ __launch_bounds__(kArbThreads, 3) void farrow_tiled_kernel(FarrowArgs
             }
         }
         if constexpr (TREG == 0) __syncthreads();   // the tap columns are rewritten by the next tile
+        tile = tile_after;
     }
+    th.leave(tid);
 }
 
 template <typename TX, typename R, int NC>
@@ -473,7 +550,13 @@ hipError_t launch_farrow_t(bool fused, const FarrowArgs &a, const ArbTileArgs &t
         long long g = static_cast<long long>(num_cus) * per_cu;
         if (g > ta.total_tiles) g = ta.total_tiles;
         if (g < 1) g = 1;
-        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, ta);
+        // (a tile is a stretch of outputs x all channel groups: few, long tiles that the workgroups finish evenly -- handing them
+        //  out, one per request, measured 4.22 against 4.18 ms at config 4's shape in ComplexF64: off unless MRHIP_FARROW_TILED_DYNAMIC=1)
+        ArbTileArgs tq = ta;
+        const long long per_wg = ta.total_tiles / g;
+        tq.run_tiles = !tq.counters || per_wg < 8 || MRHIP_ENV_INT("MRHIP_FARROW_TILED_DYNAMIC", 0) == 0 ? 0 : (per_wg >= 128 ? handout_run(per_wg, 128) : 1);
+        if (tq.run_tiles == 0) tq.counters = nullptr;
+        launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kArbThreads), lds, s, a, tq);
         return hipGetLastError();
     };
     if (ta.tap_pitch == 1) {     // taps in registers (T <= 32)
