@@ -311,3 +311,45 @@ def test_falsified_table_in_an_asynchronous_call_is_redone_on_the_device(pkg, O,
     monkeypatch.delenv("MRHIP_SCHED_CORRUPT")
     assert_bit_equal(f.filt(torch.from_numpy(x2).cuda()).cpu().numpy(), fo.filt(x2), "the next call")
     f.close()
+
+
+def test_short_host_loop_call_moves_the_cycle_position_on(pkg, torch_cuda):
+    """Rate 2.5 with N𝜙 = 10 cycles (period 5).  A long synchronous call finds the cycle; a SHORT synchronous call is evaluated by the
+    host's loop; the asynchronous call behind it plans from the cycle position -- which the short call must have moved on (it was
+    left where it was: the plan kernel refused the call, tests/stress_random.py --async-mix seed 111).  Every mix of synchronous and
+    asynchronous calls == the host loop's stream."""
+    import itertools
+    import os
+    torch = torch_cuda
+    rng = np.random.default_rng(0)
+    rate, nphi, nch = 2.5, 10, 3
+    sizes = [17696, 104308, 6459, 21814]
+    h = rng.standard_normal(36).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((nch, sum(sizes))).astype(np.float32)).cuda()
+    os.environ["MRHIP_SCHED_DEVICE"] = "0"
+    try:
+        g = pkg.FIRFilter(h, rate, nphi)
+        ref, pos = [], 0
+        for s in sizes:
+            ref.append(g.filt(x[:, pos:pos + s])); pos += s
+        g.close()
+    finally:
+        os.environ.pop("MRHIP_SCHED_DEVICE", None)
+    for pat in itertools.product([0, 1], repeat=4):
+        f = pkg.FIRFilter(h, rate, nphi).bind(np.float32, nch)
+        cnt = torch.full((4,), -1, dtype=torch.int64, device="cuda")
+        outs, pos = [], 0
+        for i, s in enumerate(sizes):
+            if pat[i]:
+                yb = torch.empty((nch, f.outputlength_bound(s)), dtype=torch.float32, device="cuda")
+                f.filt_into_async(yb, x[:, pos:pos + s], cnt[i:i + 1])
+                outs.append(yb)
+            else:
+                outs.append(f.filt(x[:, pos:pos + s]))
+            pos += s
+        f.sync_state()
+        c = cnt.cpu().tolist()
+        for i, o in enumerate(outs):
+            got = o[:, :c[i]] if pat[i] else o
+            assert got.shape == ref[i].shape and torch.equal(got, ref[i]), (pat, i)
+        f.close()
