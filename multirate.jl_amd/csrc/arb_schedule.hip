@@ -264,7 +264,7 @@ void sched_configure(mrhip_filter *f)
 {
     f->splan = make_sched_plan(f->delta, f->Nphi, static_cast<int>(env_i64("MRHIP_SCHED_WIN_MULT", 1)), static_cast<int>(env_i64("MRHIP_SCHED_WIN_MIN", 4)));
     f->sched_prefix = std::max<int64_t>(env_i64("MRHIP_SCHED_PREFIX", 65536), 0) / kSchedGroup * kSchedGroup;
-    f->sched_pmax = std::max<int64_t>(env_i64("MRHIP_SCHED_PMAX", 1 << 22) / kSchedGroup * kSchedGroup, kSchedGroup);
+    f->sched_pmax = std::max<int64_t>(env_i64("MRHIP_SCHED_PMAX", 1 << 23) / kSchedGroup * kSchedGroup, kSchedGroup);
     // below it a call that is waited for takes the host loop: 60 us + 1.3 ns per output against 75 us for the kernels of one piece
     // and the wait (profiles/r04/experiments.md Q; 2^16 until the baseline of short calls was kept)
     f->sched_device_min = env_i64("MRHIP_SCHED_DEVICE_MIN", 1 << 14);
