@@ -278,10 +278,10 @@ __global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan
 // ---- K3: run every segment from its true start, emit, verify -------------------------------------------------
 // fu.finish (the last piece of a call): the workgroups count themselves off when they are through -- the ones that had
 // nothing to do too -- and the last one is the call's FINISH.
-__device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedPieceArgs &a);
+__device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedPieceArgs &a, bool fold_chain);
 __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, SchedPieceArgs a, SchedFuseArgs fu)
 {
-    sched_emit_body(c, a);
+    sched_emit_body(c, a, fu.fold_chain != 0);
     if (!fu.finish) return;
     static_assert(kGroupSegs == 64, "one wave per workgroup: the count below is a wave's");
     __threadfence();                                          // this workgroup's entries, end and state: out before it counts
@@ -293,13 +293,13 @@ __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, Sch
     if (threadIdx.x == 0) sched_finish_body(c, fu.f);
 }
 
-__device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedPieceArgs &a)
+__device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedPieceArgs &a, bool fold_chain)
 {
     // test hook (MRHIP_SCHED_CORRUPT = -2 - g): group g starts ~0.5 ms late, i.e. after the group that holds the call's end
     // has set `done` -- it must still write its entries (sched_stop)
     if (a.corrupt_group <= -2 && static_cast<int>(blockIdx.x) == -a.corrupt_group - 2)
         for (int i = 0; i < 128; ++i) __builtin_amdgcn_s_sleep(127);
-    if (sched_stop(a.status, a.piece)) return;
+    if (__any(sched_stop(a.status, a.piece))) return;          // (one decision for the wave: the lanes shuffle below)
     // The group's 4096 entries leave through LDS (a lane computes a segment, i.e. 64 CONSECUTIVE entries) in chunks of kEmitChunk
     // steps: 14 KB a workgroup instead of the 50 KB of the whole group at once -- what is left beside the filter kernel's
     // workgroups, next to which this kernel runs (profiles/r04/experiments.md S).
@@ -312,7 +312,34 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
 
     const int g = blockIdx.x, sl = threadIdx.x, nwin = c.nwin;
     const SchedPieceState ps = a.state[a.piece];
-    const SchedGroupStart gs = a.gstart[g];
+    SchedGroupStart gs, gnx;                                // this group's true start and the next group's
+    if (fold_chain) {
+        // a piece of few groups has no chain kernel: the wave (lane = candidate) walks the groups' maps from the piece's true start
+        // to its own group -- what sched_chain_kernel's phases 2 and 3 do, for one group
+        const int lane = sl;
+        const double slope0 = ps.ksteps > 0.0 ? ps.drift / ps.ksteps : 0.0;
+        ChainState st{0, 0.0, 0, false};
+        st.ok = sched_locate(ps.acc, sched_base(sched_anchor(ps.acc, 0.0, slope0, c), c), c, &st.ci, &st.S);
+        auto put = [&](SchedGroupStart &o) { o.cand = st.ok ? st.ci : -1; o.shift = st.S; o.advance = st.W; o.pad = 0; };
+        auto entry = [&](int gg) {
+            SchedGroupEntry ge{};
+            ge.next = -1;
+            if (lane < nwin) ge = a.gtab[static_cast<size_t>(gg) * nwin + lane];
+            return ge;
+        };
+        int gg = 0;
+        for (; gg + 4 <= g; gg += 4) {                      // four maps in flight per round of loads
+            const SchedGroupEntry e0 = entry(gg), e1 = entry(gg + 1), e2 = entry(gg + 2), e3 = entry(gg + 3);
+            chain_apply(st, e0); chain_apply(st, e1); chain_apply(st, e2); chain_apply(st, e3);
+        }
+        for (; gg < g; ++gg) chain_apply(st, entry(gg));
+        put(gs);
+        if (g + 1 < a.ngroups) chain_apply(st, entry(g));
+        put(gnx);
+    } else {
+        gs = a.gstart[g];
+        gnx = g + 1 < a.ngroups ? a.gstart[g + 1] : gs;
+    }
     const long long x_len = a.status->x_len;               // (written by the call's BEGIN kernel, which ran before every piece)
     const long long seg = static_cast<long long>(g) * kGroupSegs + sl;
     bool bad = gs.cand < 0;
@@ -357,7 +384,7 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
     // the next segment's start: the next lane's, or the next group's first segment
     if (sl == kGroupSegs - 1) {
         if (g + 1 < a.ngroups) {
-            const SchedGroupStart gn = a.gstart[g + 1];
+            const SchedGroupStart gn = gnx;
             if (gn.cand < 0) bad = true;
             else {
                 const size_t pn = static_cast<size_t>(seg + 1) * nwin + gn.cand;
@@ -535,7 +562,10 @@ hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hi
     }
     const int tab_threads = std::min(kTabThreads, kGroupSegs * c.nwin);      // (64 * nwin: whole waves)
     hipLaunchKernelGGL(sched_tables_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(static_cast<unsigned>(tab_threads)), lds, s, c, a, fu);
-    hipLaunchKernelGGL(sched_chain_kernel, dim3(1), dim3(kChainWaves * 64), 0, s, c, a);
+    // few groups: no chain kernel, the emit kernel's workgroups walk the maps themselves (MRHIP_SCHED_FOLD: at most that many groups)
+    static const int fold_max = [] { const char *v = std::getenv("MRHIP_SCHED_FOLD"); return v && *v ? std::atoi(v) : 16; }();
+    fu.fold_chain = a.ngroups <= fold_max ? 1 : 0;
+    if (!fu.fold_chain) hipLaunchKernelGGL(sched_chain_kernel, dim3(1), dim3(kChainWaves * 64), 0, s, c, a);
     hipLaunchKernelGGL(sched_emit_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(kGroupSegs), 0, s, c, a, fu);
     return hipGetLastError();
 }

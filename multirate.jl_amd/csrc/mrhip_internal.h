@@ -167,6 +167,7 @@ struct SchedFinishArgs {
 // (SchedStatus::groups_done, release / acquire at device scope); the last one through is the FINISH kernel.
 struct SchedFuseArgs {
     int begin, finish;
+    int fold_chain;               // no chain kernel for this piece (few groups): every emit workgroup walks the groups' maps to its own start
     SchedBeginArgs b;
     long long b_x_len, b_k_first;
     SchedFinishArgs f;
