@@ -155,6 +155,46 @@ __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, 
         eCn[t] = cn;
     }
     __syncthreads();
+    if (tasks == static_cast<int>(blockDim.x)) {
+        // compose by a parallel scan (one thread per (segment, candidate): nwin <= 16): after round d the entry (sl, c) is the map of
+        // segments sl-2d+1 .. sl applied to candidate c -- six rounds instead of 64 dependent look-ups per candidate.  Shifts are
+        // small multiples of G and advances integers: the sums are exact in any order, the tables are the serial walk's.
+        const int t = threadIdx.x, sl = t / nwin, ci0 = t - sl * nwin;
+        for (int d = 1; d < kGroupSegs; d *= 2) {
+            int cn = eCn[t], w = eW[t];
+            double sh = eSh[t];
+            if (sl >= d) {
+                // first the older half (segments sl-2d+1 .. sl-d, candidate ci0), then this entry's half from where that one ends
+                const int tb = (sl - d) * nwin + ci0;
+                const int c1 = eCn[tb];
+                if (c1 < 0) { cn = -1; }
+                else {
+                    const int tt = sl * nwin + c1;
+                    cn = eCn[tt];
+                    sh = eSh[tb] + eSh[tt];
+                    w = eW[tb] + eW[tt];
+                }
+            }
+            __syncthreads();
+            eCn[t] = cn; eSh[t] = sh; eW[t] = w;
+            __syncthreads();
+        }
+        // (sl, c0): the state in front of segment sl when the group starts at candidate c0 = the map of segments 0 .. sl-1
+        int pc = ci0, pw = 0;
+        double ps_ = 0.0;
+        if (sl > 0) { const int tb = (sl - 1) * nwin + ci0; pc = eCn[tb]; ps_ = eSh[tb]; pw = eW[tb]; }
+        const size_t pi = static_cast<size_t>(seg0 + sl) * nwin + ci0;
+        a.pathT[pi] = pc >= 0 ? eC[sl * nwin + pc] + ps_ : __builtin_nan("");
+        a.pathW[pi] = pc >= 0 ? pw : 0;
+        if (sl == kGroupSegs - 1) {
+            SchedGroupEntry ge;
+            ge.shift = eSh[t];
+            ge.advance = eW[t];
+            ge.next = eCn[t];
+            a.gtab[static_cast<size_t>(g) * nwin + ci0] = ge;
+        }
+        return;
+    }
     // compose: candidate c0 of the group's first segment walked through the 64 maps; the path is kept for K3
     for (int c0 = threadIdx.x; c0 < nwin; c0 += static_cast<int>(blockDim.x)) {
         int ci = c0;
