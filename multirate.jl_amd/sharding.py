@@ -191,9 +191,12 @@ class TimeShardedFilter:
 
     ``filter_factory()`` must return an object with ``filt(x)``, ``reset()``, ``advance_state(n)``, ``set_history(h)``
     and ``historyLen`` (the HIP-backed ``FIRFilter`` by default; tests inject a CPU model).  Every slice that has a
-    non-empty successor must be at least ``historyLen`` samples long (its successor's history comes from it alone), except
-    rank 0's in the first block (the stream's own zero history pads it): checked identically on every rank BEFORE any
-    message is posted, so that a bad split raises everywhere instead of leaving a neighbour waiting.
+    non-empty successor must be at least ``historyLen`` samples long (its successor's history comes from it alone).  In the
+    FIRST block two owners are exempt: the first (the stream's own zero history pads its tail) and the last (its tail
+    matters to a second block only -- whose call then raises).  Checked identically on every rank BEFORE any message is
+    posted, so that a bad split raises everywhere instead of leaving a neighbour waiting.
+
+    ``filt`` never resets the filter: calling it again CONTINUES the stream with the next block (``reset()`` starts over).
     """
 
     def __init__(self, h, ratio, n_total: int, *, Nphi: int = 32, polyorder=None, numerics: Optional[int] = None,
@@ -251,7 +254,10 @@ class TimeShardedFilter:
         real = (lambda t: (torch.view_as_real(t.contiguous()).reshape(t.shape[0], -1) if t.is_complex() else t.contiguous()).to(wire))
         me = owners.index(self.rank)
         first, last = me == 0, me == len(owners) - 1
-        tail = real(x2[:, -H:])
+        tail = x2[:, -H:]
+        if tail.shape[1] < H:     # only the first owner of the first block gets here (see filt): the stream's zero history pads it
+            tail = torch.cat([torch.zeros((x2.shape[0], H - tail.shape[1]), dtype=x2.dtype, device=x2.device), tail], dim=1)
+        tail = real(tail)
         reqs, recv = [], None
         send_now = None
         if not last:
@@ -266,7 +272,9 @@ class TimeShardedFilter:
         for r in reqs:
             r.wait()
         if last:
-            self._tail = tail
+            # a PRIVATE copy: for one channel (or count == H) every step above returns a view of the caller's buffer, and a
+            # caller that refills that buffer in place for the next block would send the wrong tail
+            self._tail = tail.clone()
         if recv is None:
             return None
         return torch.view_as_complex(recv.reshape(recv.shape[0], H, 2)) if x2.is_complex() else recv
@@ -277,7 +285,12 @@ class TimeShardedFilter:
         f = self.filter
         H = int(f.historyLen)
         if self.world_size > 1 and len(self._ring()) > 1:
-            for r in self._ring():
+            owners = self._ring()
+            for r in owners:
+                # exempt in the FIRST block: the first owner (zero history in front of it pads its tail) and the last owner
+                # (its tail is needed by a next block only; that block's call raises on every rank if it comes)
+                if self.blocks == 0 and r in (owners[0], owners[-1]):
+                    continue
                 if self.slices[r][1] < H:
                     raise ValueError(f"time slice of rank {r} ({self.slices[r][1]} samples) is shorter than the filter history ({H}): "
                                      f"its successor's history comes from it alone")

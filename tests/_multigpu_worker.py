@@ -92,9 +92,12 @@ def time_sharded(pkg, O, dist, torch, rank, world, backend, dev_index, dev):
         # two consecutive blocks of the stream: the second enters with the state and the halo the first left (the last
         # rank's tail feeds rank 0); over RCCL the halo stays in device memory (mrhip_set_history_device)
         fos = {c: (O.FIRFilter(h, ratio, 32, tx=tx) if isinstance(ratio, float) else O.FIRFilter(h, ratio, tx=tx)) for c in (0, nch - 1)}
+        xl = torch.empty(ts.local_slice(x).shape, dtype=torch.from_numpy(x[:1, :1]).dtype, device=dev)
         for blk in range(2):
             xb = x if blk == 0 else (np.roll(x, 101, axis=1) * np.float32(0.75)).astype(tx)
-            xl = torch.from_numpy(np.ascontiguousarray(ts.local_slice(xb))).to(dev)
+            # ONE device buffer refilled in place block after block, as a streaming caller does (the last
+            # rank's kept tail was a view of it)
+            xl.copy_(torch.from_numpy(np.ascontiguousarray(ts.local_slice(xb))))
             y_local = ts.filt(xl)
             full = ts.gather(y_local if backend == "nccl" else y_local.cpu(), dst=0)
             if rank == 0:

@@ -121,7 +121,8 @@ def _time_worker(rank, world, port, case, q):
     pkg = ge.load_package()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ratio, hl, cplx, nch, n = case
+        ratio, hl, cplx, nch, n = case[:5]
+        reuse = len(case) > 5 and case[5]     # ONE caller buffer refilled in place block after block
         rng = np.random.default_rng(5)
         h = rng.standard_normal(hl).astype(np.float32)
         tx = np.complex64 if cplx else np.float32
@@ -159,8 +160,13 @@ def _time_worker(rank, world, port, case, q):
         xs = [x] + [np.roll(x, 17 * (b + 1), axis=1) * np.float32(0.5 + b) for b in range(nblocks - 1)]
         fos = [mk() for _ in range(nch)]
         ok = True
+        buf = torch.from_numpy(ts.local_slice(x).copy())
         for xb in xs:
-            y_local = ts.filt(torch.from_numpy(ts.local_slice(xb).copy()))
+            if reuse:
+                buf.copy_(torch.from_numpy(ts.local_slice(xb).copy()))
+                y_local = ts.filt(buf)
+            else:
+                y_local = ts.filt(torch.from_numpy(ts.local_slice(xb).copy()))
             full = ts.gather(y_local, dst=0)
             if rank == 0:
                 ref = np.stack([np.concatenate([fos[c].filt(xb[c, a:a + m]) for a, m in ts.slices]) for c in range(nch)])
@@ -174,7 +180,9 @@ def _time_worker(rank, world, port, case, q):
 
 
 @pytest.mark.parametrize("case", [(Fraction(3, 5), 77, False, 3, 1000), (Fraction(147, 160), 147 * 4, True, 1, 2500), (Fraction(1, 4), 64, False, 2, 999),
-                                  (Fraction(4, 1), 64, True, 2, 500), (Fraction(1, 1), 33, False, 1, 700), (float(np.pi / 3), 96, False, 2, 1200)])
+                                  (Fraction(4, 1), 64, True, 2, 500), (Fraction(1, 1), 33, False, 1, 700), (float(np.pi / 3), 96, False, 2, 1200),
+                                  # one channel, one buffer refilled in place: the last rank's kept tail must be a private copy
+                                  (Fraction(147, 160), 147 * 4, False, 1, 2500, True), (Fraction(1, 1), 5, True, 1, 8, True)])
 def test_time_sharded_filter_world2_gloo(pkg, O, case):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
