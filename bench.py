@@ -129,6 +129,68 @@ def cpu_baseline(h, seconds_budget=25.0):
     return one, allc
 
 
+def cpu_baseline_simd(h, strict_value, seconds_budget=8.0):
+    """The same C port built the way the reference's own code generation treats its dot loops -- they are @simd
+    (src/support.jl:9,23,26,37,47,50): vectorised, the reduction reassociated -- for THIS host's CPU (`make -C oracle simd`:
+    -O3 -march=native -fassociative-math -fno-signed-zeros), one thread.  Its bits depend on the vector width: a baseline, never
+    the checker; its output is compared with the strict port's to a tolerance only."""
+    import ctypes as C
+
+    import numpy as np
+    from oracle import oracle as O
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "simd"])
+        lib = C.CDLL(os.path.join(ROOT, "oracle", "libmultirate_oracle_simd.so"))
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+    vp, cl, ci = C.c_void_p, C.c_long, C.c_int
+    lib.mro_create_rational.restype = vp
+    lib.mro_create_rational.argtypes = [vp, cl, ci, cl, cl, ci]
+    lib.mro_filt.restype = cl
+    lib.mro_filt.argtypes = [vp, vp, cl, vp, cl]
+    lib.mro_destroy.argtypes = [vp]
+    n = 100_000_000
+    x = np.random.default_rng(0).random(n, dtype=np.float32)
+    y = np.empty(n * L // M + 16, dtype=np.float32)
+    times, cnt = [], 0
+    t_all = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_all) < seconds_budget:
+        f = lib.mro_create_rational(h.ctypes.data, len(h), 0, L, M, 0)
+        t0 = time.perf_counter()
+        cnt = lib.mro_filt(f, x.ctypes.data, n, y.ctypes.data, len(y))
+        times.append(time.perf_counter() - t0)
+        lib.mro_destroy(f)
+    times.sort()
+    med = times[len(times) // 2]
+    ref = O.FIRFilter(h, Fraction(L, M), tx=np.float32).filt(x[:200_000])
+    dev = float(np.abs(y[:len(ref)] - ref).max())
+    host = host_description()
+    out = {"value": round(n / med / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port", "cpu_model": host["cpu_model"], "runs": len(times),
+           "flags": "gcc -O3 -march=native -ffp-contract=off -fassociative-math -fno-signed-zeros -fno-trapping-math",
+           "max_abs_dev_from_strict_port": dev, "outputs": int(cnt),
+           "sample": f"1 channel x {n} Float32 samples, 147//160, 3528 taps, median of {len(times)} runs; the reference's dot loops are @simd "
+                     "(support.jl:9), i.e. vectorised with a reassociated reduction: this build gives the compiler the same licence"}
+    if strict_value:
+        out["speedup_over_strict_port"] = round(out["value"] / strict_value, 2)
+    return out
+
+
+# What "parity" rests on (DESIGN.md section 3).  GPU == oracle is bit-exact; oracle == reference is ALGORITHMIC: the reference is
+# Julia-0.3 source that nothing in this image can run, and its @simd dot loops make its own bits compiler dependent.
+PARITY_PIN = {
+    "kind": "algorithmic",
+    "gpu_vs_oracle": "bit-exact (every kind, Float32 / Float64 / ComplexF32 / ComplexF64 and the README's mixed case, chunked == unchunked)",
+    "oracle_vs_reference": "restatement of src/support.jl:5-80 and src/Filters.jl:15-846 loop for loop, plus a second independent restatement "
+                           "(tests/strict_restatement.py) bit-equal on 240 cases; no reference executable exists to compare bits with",
+    "reference_held_data": ["taps2pfb([1:9], 4) doc example (src/Filters.jl:276-282)",
+                            "README.md:58-141: 3//17 resampling of 1.0:100 with h = [ones(3); zeros(6)] (Float64), whole and in chunks, counts 1/4/13",
+                            "nextphase table (test/runtests.jl:423-438)",
+                            "FIRFarrow notebook run: 126 outputs (a length only)",
+                            "all four in tests/golden/reference_known_answers.json, checked on oracle and GPU"],
+    "unpinned_by_the_reference": ["every Float32 / complex / FIRArbitrary VALUE", "FIRFarrow's polynomial fit", "firdes tap values (DSP.jl un-vendored)"],
+}
+
+
 # ---------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` started directly (no torch.distributed.run around it)
 # ---------------------------------------------------------------------------------------------
@@ -255,15 +317,26 @@ def traffic_for(bytes_per_launch):
     return None, None
 
 
-def config_rows():
+_BC = None
+
+
+def bench_configs_module():
+    global _BC
+    if _BC is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mrhip_bench_configs", os.path.join(ROOT, "scripts", "bench_configs.py"))
+        _BC = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_BC)
+    return _BC
+
+
+def config_rows(fused=False):
     """Every other BASELINE config on this GPU (and the reference's own FIRArbitrary / FIRFarrow benchmark shape), a few
-    passes each, measured by scripts/bench_configs.py's harness: kernel time from HIP events, wall time with the host."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("mrhip_bench_configs", os.path.join(ROOT, "scripts", "bench_configs.py"))
-    bc = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bc)
+    passes each, measured by scripts/bench_configs.py's harness: kernel time from HIP events, wall time with the host.
+    fused: the BASELINE rows once more under the opt-in FUSED numerics (one fma per tap)."""
+    bc = bench_configs_module()
     out = []
-    for r in bc.run_rows(bc.BENCH_ROWS):
+    for r in bc.run_rows(bc.FUSED_ROWS if fused else bc.BENCH_ROWS, fused=fused):
         out.append({"name": r["config"], "kernel": r["kernel"], "launches_per_pass": r["launches_per_pass"],
                     "kernel_ms": r["kernel_ms_per_pass"], "wall_ms": r["wall_ms_per_pass_incl_host"],
                     "Msamples_per_s_in": r["Msamples_per_s_in"], "Msamples_per_s_in_wall": r["Msamples_per_s_in_wall"],
@@ -353,15 +426,42 @@ def run_headline(args, R):
         got = y[nch - 1, :len(yo)].cpu().numpy()
         assert np.array_equal(got.view(np.uint32), yo.view(np.uint32)), "bench output differs from oracle"
 
-    configs = None
+    # the opt-in FUSED numerics (one fma per tap, same order; the oracle has the same switch) on the SAME workload, after the
+    # timed region: reported under `fused`, never as `value`
+    fused_headline = None
+    if world == 1 and chunk == n and args.numerics == "strict" and not args.no_configs:
+        ff = pkg.FIRFilter(h, Fraction(L, M), device=R.dev_index, numerics=pkg.NUMERICS_FUSED)
+        ff.bind(np.float32, nch)
+        for _ in range(2):
+            ff.reset(); ff.filt_into(y, x)
+        ff.set_timing(1)
+        torch.cuda.synchronize(dev)
+        tf = time.perf_counter()
+        for _ in range(args.steps):
+            ff.reset(); ff.filt_into(y, x)
+        torch.cuda.synchronize(dev)
+        elf = time.perf_counter() - tf
+        nlf, msf = ff.timing_read()
+        ff.set_timing(False)
+        gb = nch * n * BYTES_PER_INPUT_SAMPLE / 1e9
+        fused_headline = {"kernel": ff.last_kernel_name(), "kernel_ms": round(msf / max(nlf, 1), 4), "wall_ms": round(elf / args.steps * 1e3, 4),
+                          "achieved_GBps": round(gb / (msf / max(nlf, 1) / 1e3), 2), "frac": round(gb / (msf / max(nlf, 1) / 1e3) / HBM_PEAK_GBPS, 4)}
+        ff.close()
+
+    configs = fused_rows = None
+    filt.close()
+    del x, y
+    torch.cuda.empty_cache()
     if world == 1 and chunk == n and not args.no_configs:
-        filt.close()
-        del x, y
-        torch.cuda.empty_cache()
         try:
             configs = config_rows()
         except Exception as e:       # the headline line is the contract: a failing side measurement must not take it down
             configs = [{"name": "configs failed", "error": f"{type(e).__name__}: {e}"}]
+        if args.numerics == "strict":
+            try:
+                fused_rows = config_rows(fused=True)
+            except Exception as e:
+                fused_rows = [{"name": "fused rows failed", "error": f"{type(e).__name__}: {e}"}]
 
     total_in = float(nch) * n * args.steps * world
     ms_per_step = elapsed / args.steps * 1e3
@@ -370,6 +470,7 @@ def run_headline(args, R):
     bytes_per_launch = nch * min(chunk, n) * BYTES_PER_INPUT_SAMPLE
     achieved = bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
 
+    line = None
     if rank == 0:
         traffic, traffic_source = traffic_for(bytes_per_launch)
         line = {
@@ -386,12 +487,25 @@ def run_headline(args, R):
                        "backend": R.backend if world > 1 else None},
             "output_msamples_s": round(value * L / M, 3),
             "kernel": last_kernel,
+            "parity_pin": PARITY_PIN["kind"],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5), "launches_timed": n_launch,
                          "whole_step_GBps": round(nch * n * BYTES_PER_INPUT_SAMPLE / (ms_per_step / 1e3) / 1e9, 2)},
+            "parity": PARITY_PIN,
         }
+        if fused_headline is not None or fused_rows is not None:
+            fz = {"note": "opt-in MRHIP_NUMERICS_FUSED: one fma per tap in the reference's order; differs from STRICT by <= 1 rounding per tap; "
+                          "bit-equal to the oracle's fused switch; never `value`"}
+            if fused_headline is not None:
+                fz["headline"] = fused_headline
+            for r in fused_rows or []:
+                if "error" in r:
+                    fz["error"] = r["error"]
+                else:
+                    fz[r["name"].split()[0]] = {"kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "wall_ms": r["wall_ms"], "frac": r["frac"]}
+            line["fused"] = fz
         if streamed is not None:
             line["streamed_1e6_chunks"] = streamed
         if configs is not None:
@@ -401,7 +515,7 @@ def run_headline(args, R):
             base = {}
             for r in configs:
                 nm = r.get("name", "")
-                if nm[:3] in ("C2 ", "C3a", "C3b", "C4 ", "C4f", "C5 "):
+                if nm[:3] in ("C1 ", "C2 ", "C2s", "C2r", "C3a", "C3b", "C4 ", "C4f", "C5 "):
                     base[nm.split()[0]] = {"kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "wall_ms": r["wall_ms"], "frac": r["frac"],
                                            "frac_wall": r["frac_wall"]}
                     if "wall_ms_continuing_stream" in r:
@@ -409,10 +523,8 @@ def run_headline(args, R):
             line["roofline"]["baseline_configs"] = base
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["cpu_baseline_all_cores"] = cpu_baseline(h)
-        # `configs` (long) goes LAST so that its BASELINE rows -- the last of it -- end the line
-        if "configs" in line:
-            line["configs"] = line.pop("configs")
-        print(json.dumps(line), flush=True)
+            line["cpu_baseline_simd"] = cpu_baseline_simd(h, line["cpu_baseline"]["value"])
+    return line
 
 
 def run_c5(args, R):
@@ -509,7 +621,8 @@ def run_c5(args, R):
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5), "launches_timed": n_launch,
                          "note": "rank 0's kernel; per-GPU fraction (every rank runs the same shard size +-1 channel)"},
         }
-        print(json.dumps(line), flush=True)
+        return line
+    return None
 
 
 def main():
@@ -529,6 +642,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs reported as `configs` (N = 1 only)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check (timing experiments)")
     ap.add_argument("--no-gather", action="store_true", help="c5: skip the gather timings")
+    ap.add_argument("--no-c5", action="store_true", help="multi-GPU headline: skip the config-5 pass appended as `c5`")
+    ap.add_argument("--c5-channels", type=int, default=0, help="multi-GPU headline: channels in all of the appended config-5 pass (default 4096)")
+    ap.add_argument("--c5-samples", type=int, default=0, help="... and its samples per channel (default 1e6)")
     args = ap.parse_args()
 
     if "RANK" not in os.environ and args.gpus > 1:
@@ -539,9 +655,27 @@ def main():
     if R.world != args.gpus and R.world > 1:
         args.gpus = R.world
     if args.config == "c5":
-        run_c5(args, R)
+        line = run_c5(args, R)
     else:
-        run_headline(args, R)
+        line = run_headline(args, R)
+        if R.world > 1 and not args.no_c5:
+            # BASELINE.json configs[4] in the SAME line of a multi-GPU run (the driver's scaling runs pass no --config): 4096
+            # ComplexF32 channels sharded by channel over the ranks (strong scaling), compute-only rate, the final RCCL gather
+            # timed apart -- after the headline's timed region, on every rank
+            c5_args = argparse.Namespace(**vars(args))
+            c5_args.channels, c5_args.samples = args.c5_channels, args.c5_samples
+            c5 = run_c5(c5_args, R)
+            if line is not None and c5 is not None:
+                line["c5"] = {"metric": c5["metric"], "value": c5["value"], "unit": c5["unit"], "scaling": c5["scaling"], "ms_per_step": c5["ms_per_step"],
+                              "n_gpus": c5["n_gpus"], "channels_total": c5["config"]["channels_total"], "channels_per_gpu": c5["config"]["channels_per_gpu"],
+                              "samples_per_channel": c5["config"]["samples_per_channel"], "kernel": c5["kernel"], "gather": c5["gather"],
+                              "roofline": {k: c5["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_timed", "note")},
+                              "workload": c5["config"]["workload"]}
+    if line is not None:
+        # `configs` (long) goes LAST so that its BASELINE rows -- the last of it -- end the line
+        if "configs" in line:
+            line["configs"] = line.pop("configs")
+        print(json.dumps(line), flush=True)
     R.finish()      # only on success: a rank that raised must not wait for the others at a barrier (the launcher ends them)
 
 

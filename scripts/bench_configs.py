@@ -119,7 +119,9 @@ DEFAULT_ROWS = ["c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5", "x160", "xf6
 # what bench.py reports next to the headline: every BASELINE config on one GPU, the README's mixed precision, the reference's
 # own FIRArbitrary / FIRFarrow benchmark shape
 # (the BASELINE rows LAST: the driver's record keeps the END of the line)
-BENCH_ROWS = ["xarb", "af", "xdec", "ms", "xmix64", "c2", "c3a", "c3b", "c4", "c4f", "c5"]
+BENCH_ROWS = ["xarb", "af", "xdec", "ms", "xmix64", "c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5"]
+# the opt-in FUSED numerics (one fma per tap, same order) for the BASELINE rows: bench.py reports them under `fused`
+FUSED_ROWS = ["c3a", "c3b", "c4", "c5"]
 
 
 def rows(which):
@@ -257,15 +259,18 @@ def rows(which):
         table[name]()
 
 
-def run_rows(which, reps_note=None):
-    """The rows named in `which` as a list of dicts (bench.py)."""
-    global EMIT
+def run_rows(which, reps_note=None, fused=False):
+    """The rows named in `which` as a list of dicts (bench.py); fused: under the opt-in FUSED numerics."""
+    global EMIT, FUSED
     got = []
     EMIT = lambda line: got.append(json.loads(line))
+    was = FUSED
+    FUSED = bool(fused)
     try:
         rows(which)
     finally:
         EMIT = print
+        FUSED = was
     return got
 
 

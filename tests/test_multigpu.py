@@ -144,9 +144,14 @@ def test_bench_direct_launch_spawns_its_own_ranks():
         pytest.skip("needs a GPU")
     backend, world = ("nccl", min(n, 8)) if n >= 2 else ("gloo", 2)
     small = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-streamed"]
-    line = _bench(["--gpus", str(world), "--channels", "4", "--samples", "2000000"] + small, backend)
+    line = _bench(["--gpus", str(world), "--channels", "4", "--samples", "2000000", "--c5-channels", "64", "--c5-samples", "200000"] + small, backend)
     assert line["n_gpus"] == world and line["scaling"] == "weak"
     assert line["roofline"]["achieved"] > 0
+    # BASELINE config 5 rides in the same line of every multi-GPU run (the driver's scaling runs pass no --config)
+    c5 = line["c5"]
+    assert c5["n_gpus"] == world and c5["scaling"] == "strong" and c5["channels_total"] == 64 and c5["channels_per_gpu"] == 64 // world
+    assert c5["value"] > 0 and c5["roofline"]["frac"] > 0 and c5["kernel"] == "rational_opair_kernel"
+    assert set(c5["gather"]) == {"root", "all"} and c5["gather"]["root"]["ms"] > 0 and c5["gather"]["all"]["ms"] > 0
     line = _bench(["--gpus", str(world), "--config", "c5", "--channels", "64", "--samples", "200000"] + small, backend)
     assert line["n_gpus"] == world and line["scaling"] == "strong"
     assert line["config"]["channels_per_gpu"] == 64 // world
@@ -197,5 +202,6 @@ def test_bench_four_ranks_on_one_gpu_at_config5_channel_count():
     line = _bench(["--gpus", "4", "--config", "c5", "--channels", "4096", "--samples", "50000"] + small, "gloo")
     assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["config"]["channels_per_gpu"] == 1024
     assert set(line["gather"]) == {"root", "all"} and line["gather"]["root"]["ms"] > 0
-    line = _bench(["--gpus", "4", "--channels", "16", "--samples", "1000000"] + small, "gloo")
+    line = _bench(["--gpus", "4", "--channels", "16", "--samples", "1000000", "--c5-channels", "4096", "--c5-samples", "20000"] + small, "gloo")
     assert line["n_gpus"] == 4 and line["scaling"] == "weak" and line["roofline"]["achieved"] > 0
+    assert line["c5"]["channels_per_gpu"] == 1024 and line["c5"]["gather"]["root"]["ms"] > 0
