@@ -326,6 +326,46 @@ int mrhip_cascade_filt_device_async(mrhip_cascade *c, const void *x, int64_t x_l
                                     int64_t y_stride, int64_t *count_out, void *stream);
 int mrhip_cascade_reset(mrhip_cascade *c);
 
+/* ---- a ring of arriving chunks: ONE resident kernel instead of a launch per chunk ------------------------------ */
+/* replaces the reference's streaming usage -- a loop of  y_i = filt(self, x_i)  over the chunks of a signal as they arrive, on one
+ * stateful FIRFilter (README.md:87-141; the state carried from call to call: src/Filters.jl:571-572, history: support.jl:61-80).
+ * mrhip_ring_open starts a kernel that stays resident on the filter's device and consumes chunk descriptors; mrhip_ring_push is
+ * filt!(y, self, x) for the next chunk: it plans the call on the host (the state recurrence in closed form, so *n_written -- the
+ * Int the reference's filt! returns -- is valid on return), writes one descriptor into pinned memory and returns; the kernel
+ * filters the chunk beside the chunks before it (several are in flight at once, the history travels between them on the
+ * device) and raises a flag in pinned memory when its outputs are complete: mrhip_ring_wait / mrhip_ring_drain.  Results, counts,
+ * end state and history are bit for bit those of the same calls made through mrhip_filt_device.
+ *   - x must be COMPLETE in device memory when it is pushed (the resident kernel is not ordered behind any stream: synchronise
+ *     the producer of x first) and x and y must stay untouched until the chunk's flag is up;
+ *   - at most 63 chunks are in flight; a push into a full ring waits for the oldest;
+ *   - while a ring is open the filter's other entry points (filt, reset, set_state, ...) return MRHIP_ERR_INVALID_ARG, and no call
+ *     that waits for the whole DEVICE (hipDeviceSynchronize, hipFree, ...) returns before mrhip_ring_close: the kernel leaves
+ *     only when the ring is closed, or by itself after MRHIP_RING_IDLE_MS (default 2000) without a push -- the next push then
+ *     starts a new one;
+ *   - FIRRational / FIRInterpolator with 24 or 32 taps per phase and M < 2L (the BASELINE shapes; STRICT numerics) run on the
+ *     resident kernel; every other filter takes the same interface as stream-ordered launches, one per chunk, on the ring's
+ *     stream (mrhip_ring_info tells which). */
+typedef struct mrhip_ring mrhip_ring;
+int mrhip_ring_open(mrhip_filter *f, mrhip_ring **out);
+/* filt!(y, self, x) for the next arriving chunk (same argument meaning and errors as mrhip_filt_device); *seq (optional)
+ * receives the chunk's number for mrhip_ring_wait */
+int mrhip_ring_push(mrhip_ring *r, const void *x, int64_t x_len, int64_t x_stride, void *y, int64_t y_capacity, int64_t y_stride,
+                    int64_t *n_written, uint64_t *seq);
+/* the library's chunk loop over a device-resident signal (mrhip_filt_device_chunked's contract): one mrhip_ring_push per `chunk`
+ * samples, outputs back to back in y; *n_written the total, *last_seq the last chunk's number */
+int mrhip_ring_push_chunks(mrhip_ring *r, const void *x, int64_t x_len, int64_t x_stride, int64_t chunk, void *y, int64_t y_capacity,
+                           int64_t y_stride, int64_t *n_written, uint64_t *last_seq);
+/* block until chunk `seq` is complete (its outputs are in device memory); chunks may complete out of order */
+int mrhip_ring_wait(mrhip_ring *r, uint64_t seq);
+/* block until every pushed chunk is complete */
+int mrhip_ring_drain(mrhip_ring *r);
+/* drain, end the resident kernel, hand the stream (state behind the last chunk, history, device record) back to the filter,
+ * free the ring */
+int mrhip_ring_close(mrhip_ring *r);
+/* info[0..n): [0] 1 = resident kernel, 0 = one launch per chunk; [1] ring depth; [2] chunks pushed; [3] kernels restarted after an
+ * idle deadline; [4] steps per grab; [5] outputs per step */
+int mrhip_ring_info(const mrhip_ring *r, int64_t *info, int n);
+
 /* replaces the stateless filt(h, x, ratio), src/Filters.jl:858-861, and
  * filt(h, x, rate, Nphi), :864-867, for host data, one channel: construct, filter once,
  * destroy.  rate <= 0 selects the rational form with num//den; rate > 0 the arbitrary form. */

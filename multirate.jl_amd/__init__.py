@@ -16,6 +16,7 @@ The directory name contains a dot, so import it through ``__graft_entry__.load_p
 from __future__ import annotations
 
 from .host import (  # noqa: F401
+    ChunkRing,
     FIRFilter,
     FilterCascade,
     MultiStream,
@@ -41,7 +42,7 @@ from .design import (BANDPASS, BANDSTOP, HIGHPASS, LOWPASS, firdes, firprototype
 from .sharding import ChannelShardedFilter, TimeShardedFilter, shard_channels, shard_time  # noqa: F401
 
 __all__ = [
-    "FIRFilter", "FilterCascade", "MultiStream", "filt", "filt_", "filt_multi", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
+    "FIRFilter", "ChunkRing", "FilterCascade", "MultiStream", "filt", "filt_", "filt_multi", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
     "setphase", "tapsforphase", "polyfit", "firdes", "firprototype", "kaiserlength", "kaiser", "LOWPASS", "BANDPASS", "HIGHPASS", "BANDSTOP", "ChannelShardedFilter", "TimeShardedFilter", "shard_channels", "shard_time", "load_library",
     "library_path", "MultirateHIPError", "NUMERICS_STRICT", "NUMERICS_FUSED",
 ]

@@ -637,6 +637,7 @@ int mrhip_get_state(const mrhip_filter *f, mrhip_state *st)
 int mrhip_set_state(mrhip_filter *f, int64_t phiIdx, int64_t inputDeficit, double phiAccumulator)
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    if (f->ring_open) return fail(MRHIP_ERR_INVALID_ARG, "the filter feeds a ring (mrhip_ring_open): close it first");
     if (inputDeficit < 1) return fail(MRHIP_ERR_INVALID_ARG, "inputDeficit must be >= 1");
     DeviceGuard guard(f->device);
     hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
@@ -711,6 +712,7 @@ int mrhip_set_history_device(mrhip_filter *f, const void *dev_in, void *stream_)
 int mrhip_reset(mrhip_filter *f)
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    if (f->ring_open) return fail(MRHIP_ERR_INVALID_ARG, "the filter feeds a ring (mrhip_ring_open): close it first");
     DeviceGuard guard(f->device);
     // No host wait: the zeroing is enqueued on the stream the filter last ran on, i.e. after its earlier launches;
     // the next filt call is on that stream too, or waits for it (adopt_stream).
@@ -1302,6 +1304,7 @@ static int filt_device_any(mrhip_filter *f, const void *x, int64_t x_len, int64_
 {
     if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
     if (n_written) *n_written = 0;
+    if (f->ring_open) return fail(MRHIP_ERR_INVALID_ARG, "the filter feeds a ring (mrhip_ring_open): push chunks into the ring, or close it first");
     const bool arb = f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW;
     // samples per launch: inputs AND outputs stay below 2^31 (FIRInterpolator and FIRRational with L > M write more than
     // they read); at most 2^24 schedule entries per FIRArbitrary launch
@@ -1728,3 +1731,5 @@ int mrhip_schedule_info(const mrhip_filter *f, int64_t *info, int n)
 }
 
 }  // extern "C"
+
+#include "ring_api.inc"

@@ -182,6 +182,19 @@ bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int n
     return true;
 }
 
+// Shapes the resident ring consumer is instantiated for (opair_kernel.inc: the RING mode exists where the PLAIN one does -- the BASELINE
+// configs' 24 and 32 taps per phase, STRICT, M < 2L, every sample / tap type); everything else runs a ring as one launch per chunk.
+bool opair_ring_available(const TypeKey &tk, bool fused, const PolyArgs &a)
+{
+    if (fused || a.L < 2 || a.M < 1 || a.M / a.L > 1) return false;
+    if (tk.x_f64 && !tk.r_f64) return false;
+#ifdef MRHIP_PS_FAST_BUILD
+    return a.T == 24;
+#else
+    return a.T == 24 || a.T == 32;
+#endif
+}
+
 hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &pa_in, dim3 block, size_t lds, hipStream_t s,
                                  const char **kname, int num_cus, unsigned *counters)
 {

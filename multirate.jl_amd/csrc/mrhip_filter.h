@@ -137,6 +137,8 @@ struct mrhip_filter {
     hipEvent_t multi_ev = nullptr;
     bool multi_in_flight = false;
 
+    bool ring_open = false;            // the filter feeds a ring of arriving chunks (ring_api.inc): its own entry points refuse calls meanwhile
+
     // measurement
     bool timing = false;
     int timing_stride = 1;            // bracket every timing_stride-th compute launch (1 = all)

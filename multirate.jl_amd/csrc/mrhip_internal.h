@@ -263,6 +263,11 @@ struct PolyArgs {            // rational family: STANDARD / DECIMATOR / INTERPOL
     // planning (the longest stream).
     const struct MultiDesc *multi;
     int multi_n;
+    // THE RESIDENT RING CONSUMER (ring.hip; pair kernels' RING instantiations only): ring_dev != NULL: the launch is the consumer
+    // of a ring of arriving chunks -- signal, output, lengths, call-start state come per chunk from RingDesc records, `hist` is
+    // the ring's array of history slots; everything else above describes the filter (taps, L, M, T, H, nch).
+    struct RingDev *ring_dev;
+    struct RingHost *ring_host;
 };
 
 struct MultiDesc {           // one independent stream (one FIRFilter of the reference: README.md:87-141) of a multi-stream launch
@@ -275,6 +280,48 @@ struct MultiDesc {           // one independent stream (one FIRFilter of the ref
     long long x_stride, y_stride, x_len, n_out, u0, d0, phi_end, d_end;
     unsigned steps_per_channel, total_steps, spc_magic;
     int nch;
+};
+
+// ---------------------------------------------------------------------------------------
+// the resident ring consumer (ring.hip, pair_loader.h: pair_ring_loader_wave)
+// ---------------------------------------------------------------------------------------
+// The reference's streaming usage is a loop of filt(self, chunk) calls on one stateful FIRFilter (README.md:87-141).  One launch per
+// arriving 1e6-sample chunk of one channel is all launch latency (13 us per call round an 8 us kernel that could take 1.5).  Here
+// ONE resident kernel consumes chunk descriptors the host pushes into a ring in pinned memory: a feeder wave copies them into
+// device memory, every other workgroup takes grabs of J steps by ticket (ticket t -> workgroup t mod G) across chunk boundaries,
+// so several chunks are in flight at once; the stream state is planned by the host per chunk (closed form, Filters.jl:558-571),
+// the history (shiftin!, support.jl:61-80) travels between chunks through history slots in device memory, and the host learns
+// of a chunk's completion from a flag in pinned memory.  Every wait in the kernel has a deadline: it ends by itself when the
+// ring stays empty for `idle_ticks`.
+constexpr int kRingDepth = 64;            // descriptor / history slots; at most kRingDepth - 1 chunks in flight
+struct RingDesc {                         // one arriving chunk: 16 quad-words
+    unsigned long long x, y;              // device addresses
+    long long x_stride, y_stride, x_len, n_out;
+    long long u0, d0;                     // call-start state: phi0 - 1, inputDeficit
+    unsigned long long tile_base;         // tickets [tile_base, tile_base + ngrabs) are this chunk's grabs
+    unsigned ngrabs, steps_per_channel;
+    unsigned total_steps, spc_magic;
+    unsigned long long seq;               // chunk number; ~0 while the feeder rewrites the slot
+    unsigned long long pad[4];
+};
+static_assert(sizeof(RingDesc) == 128, "RingDesc is 16 quad-words");
+constexpr int kRingSeqQword = 11;         // index of RingDesc::seq in quad-words
+struct RingHost {                         // pinned host memory: host writes head / close / desc, device writes done / stopped
+    unsigned long long head;              // chunks published
+    unsigned long long close;             // != 0: consume what is published, then leave
+    unsigned long long stopped;           // written by the feeder when the kernel leaves: 1 closed, 2 idle deadline, 3 a wait ran into its deadline
+    unsigned long long pad[5];
+    unsigned long long done[kRingDepth];  // done[seq % depth] = seq + 1 once chunk seq is complete (outputs written through)
+    RingDesc desc[kRingDepth];
+};
+struct RingDev {                          // device memory
+    unsigned long long head;              // chunks whose descriptors are in desc[]
+    unsigned long long closed;            // 0 open; 1 closed by the host; 2 idle deadline; 3 error (a wait ran into its deadline)
+    unsigned long long idle_ticks;        // deadline of every wait, in 100 MHz ticks
+    unsigned long long pad[5];
+    unsigned long long hist_seq[kRingDepth];   // hist_seq[s % depth] == s + 1: slot s % depth holds chunk s's call-start history
+    unsigned chunk_done[kRingDepth];      // grabs of chunk (slot) completed
+    RingDesc desc[kRingDepth];
 };
 
 struct ArbArgs {             // FIRArbitrary

@@ -82,6 +82,46 @@ __device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ void dma16_sc1(const void *gsrc, void *lds_wave_base)   // the same, bypassing this CU's L1 (aux 16 = sc1 on gfx950)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 16);
+}
+
+// ---- hand-offs between workgroups inside ONE launch (the resident ring consumer): L2-served loads and write-through stores ----
+// (MI355X: a CU's L1 is never refreshed by another CU's stores and the per-XCD L2s are not coherent for plain write-back
+//  stores; `sc1` loads bypass the L1, `sc1` stores are written through.  Producer: sc1 stores, s_waitcnt vmcnt(0), sc1 flag store;
+//  consumer: sc1 poll of the flag, then sc1 loads of the bytes.)
+__device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float *p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void st_sc1(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// host-visible (pinned host memory, or device memory the host / another agent reads): system scope
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// write-through stores of N bytes of a lane's registers (N = 4, 8, 16, 32): visible beyond this XCD's L2 once vmcnt has counted them
+template <int N>
+__device__ __forceinline__ void store_wt(void *dst, const void *regs)
+{
+    if constexpr (N == 4) {
+        unsigned v; __builtin_memcpy(&v, regs, 4);
+        asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+    } else if constexpr (N == 8) {
+        v2u_t v; __builtin_memcpy(&v, regs, 8);
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+    } else if constexpr (N == 16) {
+        v4u_t v; __builtin_memcpy(&v, regs, 16);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+    } else {
+        static_assert(N == 32, "store_wt");
+        v4u_t v0, v1; __builtin_memcpy(&v0, regs, 16); __builtin_memcpy(&v1, static_cast<const char *>(regs) + 16, 16);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
+    }
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction only takes an immediate)
 __device__ __forceinline__ void wait_vmcnt_le(int n)
 {

@@ -243,6 +243,326 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
     }
 }
 
+
+// =====================================================================================================================
+// THE RESIDENT RING CONSUMER (mrhip_internal.h: RingDesc / RingHost / RingDev; host side: ring.hip)
+// =====================================================================================================================
+// LDS words of a tile descriptor in ring mode: [0] steps (0: the kernel ends), [1] flags (bit 0: the tile completes a grab),
+// [2,3] address of the tile's first output, [4] outputs of the channel from this tile on, [5] u0 of the chunk,
+// [6] ring slot, [7] grabs of the chunk, [8,9] chunk number
+constexpr unsigned kRingTileWords = 16;
+
+// One grab of chunk `seq` is complete (every wave that stored for it has drained its write-through stores): the grab that
+// completes the chunk tells the host.
+__device__ __forceinline__ void ring_grab_done(RingDev *rd, RingHost *rh, unsigned slot, unsigned ngrabs, unsigned long long seq)
+{
+    const unsigned prev = __hip_atomic_fetch_add(&rd->chunk_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == ngrabs) {
+        st_sc1(&rd->chunk_done[slot], 0u);            // (the slot is reused only after the host has seen the flag below)
+        vm_drain();
+        st_sys(&rh->done[slot], seq + 1ull);
+    }
+}
+
+// Workgroup 0's last wave: descriptors from the host's ring (pinned memory, one PCIe round trip per batch of up to 16) into
+// device memory, `head` behind them; the end of the kernel (the host closed the ring, or it stayed empty for idle_ticks).
+__device__ __forceinline__ void ring_feeder(RingDev *rd, RingHost *rh, int lane)
+{
+    unsigned long long last = 0, t0 = wall_clock64(), code = 0;
+    const unsigned long long idle = ld_sc1(&rd->idle_ticks);
+    const int dq = lane & 15, dk = lane >> 4;
+    for (;;) {
+        const unsigned long long h = ld_sys(&rh->head);
+        if (h > last) {
+            const unsigned nb = h - last < 16ull ? static_cast<unsigned>(h - last) : 16u;
+            // readers that scan a slot while it is rewritten reject what they read (its seq)
+            if (lane < static_cast<int>(nb)) st_sc1(&rd->desc[(last + lane) % kRingDepth].seq, ~0ull);
+            vm_drain();
+            unsigned long long q[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const unsigned k = static_cast<unsigned>(dk + 4 * m);
+                q[m] = k < nb ? ld_sys(reinterpret_cast<const unsigned long long *>(&rh->desc[(last + k) % kRingDepth]) + dq) : 0ull;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const unsigned k = static_cast<unsigned>(dk + 4 * m);
+                if (k < nb && dq != kRingSeqQword) st_sc1(reinterpret_cast<unsigned long long *>(&rd->desc[(last + k) % kRingDepth]) + dq, q[m]);
+            }
+            vm_drain();
+            if (lane < static_cast<int>(nb)) st_sc1(&rd->desc[(last + lane) % kRingDepth].seq, last + lane);
+            vm_drain();
+            last += nb;
+            if (lane == 0) st_sc1(&rd->head, last);
+            vm_drain();
+            t0 = wall_clock64();
+            continue;
+        }
+        if (ld_sc1(&rd->closed) != 0ull) { code = 3; break; }               // a worker ran into its deadline
+        if (ld_sys(&rh->close) != 0ull) {
+            if (ld_sys(&rh->head) == last) { code = 1; break; }
+            continue;
+        }
+        if (wall_clock64() - t0 > idle) { code = 2; break; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (lane == 0) {
+        if (code != 3) st_sc1(&rd->closed, code);
+        vm_drain();
+        st_sys(&rh->stopped, code);
+    }
+    vm_drain();
+}
+
+// The whole life of a worker's loader wave in ring mode.  NW = 32-bit words per input sample, OS = bytes per output sample.
+template <int NC, int OS>
+__device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const PairArgs &pa, unsigned char *smem, int lane)
+{
+    RingDev *const rd = a.ring_dev;
+    RingHost *const rh = a.ring_host;
+    if (blockIdx.x == 0) { ring_feeder(rd, rh, lane); return; }
+    volatile unsigned *const td = reinterpret_cast<volatile unsigned *>(smem + pa.flags_off);   // [ns][kRingTileWords]
+    const unsigned long long idle = ld_sc1(&rd->idle_ticks);
+    const unsigned long long G = gridDim.x - 1u;
+    unsigned long long ticket = blockIdx.x - 1u;          // this workgroup's next grab, counted over the whole life of the ring
+    unsigned long long cur = 0, head_seen = 0;            // chunks below cur cannot hold `ticket`
+    bool aborted = false;
+    // the chunk of the current grab (wave-uniform)
+    unsigned long long c_x = 0, c_y = 0, c_tile_base = 0, c_seq = 0;
+    long long c_xs = 0, c_ys = 0, c_xlen = 0, c_nout = 0, c_u0 = 0, c_o0 = 0;
+    unsigned c_ngrabs = 1, c_spc = 1, c_total = 0, c_magic = 0xffffffffu;
+    const size_t slot_bytes = static_cast<size_t>(a.nch) * a.H * NC * 4u;
+    auto hist_slot = [&](unsigned long long s) -> float * {
+        return reinterpret_cast<float *>(static_cast<unsigned char *>(const_cast<void *>(a.hist)) + (s % kRingDepth) * slot_bytes);
+    };
+    auto rl64 = [&](unsigned long long v, int src_lane) -> unsigned long long {
+        const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffffull), src_lane));
+        const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), src_lane));
+        return (static_cast<unsigned long long>(hi) << 32) | lo;
+    };
+    // chunk s's call-start history is in its slot (written by the workgroup that took the first grab of chunk s - 1: an
+    // earlier ticket, held by a workgroup that is running)
+    auto wait_hist = [&](unsigned long long s) -> bool {
+        const unsigned long long t0 = wall_clock64();
+        while (ld_sc1(&rd->hist_seq[s % kRingDepth]) != s + 1ull) {
+            if (wall_clock64() - t0 > idle) { if (lane == 0) st_sc1(&rd->closed, 3ull); vm_drain(); aborted = true; return false; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        return true;
+    };
+    // positions the chunk context on the chunk that holds `ticket`; false: the ring was closed before that chunk came
+    auto find_chunk = [&]() -> bool {
+        const unsigned long long t0 = wall_clock64();
+        const int dq = lane & 15, dk = lane >> 4;
+        for (;;) {
+            if (cur < head_seen) {
+                // chunks at or below head_seen - depth are complete (the host publishes chunk h - 1 only then) and their slots recycled
+                if (head_seen >= static_cast<unsigned long long>(kRingDepth) && cur + kRingDepth <= head_seen) cur = head_seen - kRingDepth + 1ull;
+                const unsigned nb = head_seen - cur < 16ull ? static_cast<unsigned>(head_seen - cur) : 16u;
+                unsigned long long q[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const unsigned k = static_cast<unsigned>(dk + 4 * m);
+                    q[m] = k < nb ? ld_sc1(reinterpret_cast<const unsigned long long *>(&rd->desc[(cur + k) % kRingDepth]) + dq) : 0ull;
+                }
+                int found = -1;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const unsigned long long tb = rl64(q[k >> 2], (k & 3) * 16 + 8);
+                    const unsigned ng = static_cast<unsigned>(rl64(q[k >> 2], (k & 3) * 16 + 9) & 0xffffffffull);
+                    const unsigned long long sq = rl64(q[k >> 2], (k & 3) * 16 + kRingSeqQword);
+                    if (found < 0 && static_cast<unsigned>(k) < nb && sq == cur + k && ticket >= tb && ticket - tb < ng) found = k;
+                }
+                if (found < 0) { cur += nb; continue; }
+                // the fields were read before this: a slot under rewrite carries an invalid seq from before its first new field
+                const unsigned long long idx = cur + static_cast<unsigned>(found);
+                if (ld_sc1(&rd->desc[idx % kRingDepth].seq) != idx) { cur = idx + 1ull; continue; }
+                unsigned long long d[11];
+                {
+                    const int fq = found >> 2, fl = (found & 3) * 16;     // (wave-uniform: the lane select of v_readlane is a scalar)
+                    const unsigned long long qs = fq == 0 ? q[0] : fq == 1 ? q[1] : fq == 2 ? q[2] : q[3];
+#pragma unroll
+                    for (int w = 0; w < 11; ++w) d[w] = rl64(qs, fl + w);
+                }
+                cur = idx;
+                c_x = d[0]; c_y = d[1];
+                c_xs = static_cast<long long>(d[2]); c_ys = static_cast<long long>(d[3]); c_xlen = static_cast<long long>(d[4]); c_nout = static_cast<long long>(d[5]);
+                c_u0 = static_cast<long long>(d[6]); c_o0 = static_cast<long long>(d[7]) - a.T;
+                c_tile_base = d[8];
+                c_ngrabs = static_cast<unsigned>(d[9] & 0xffffffffull); c_spc = static_cast<unsigned>(d[9] >> 32);
+                c_total = static_cast<unsigned>(d[10] & 0xffffffffull); c_magic = static_cast<unsigned>(d[10] >> 32);
+                c_seq = idx;
+                return true;
+            }
+            head_seen = ld_sc1(&rd->head);
+            if (cur < head_seen) continue;
+            if (ld_sc1(&rd->closed) != 0ull) {
+                head_seen = ld_sc1(&rd->head);            // `closed` is set behind the last `head`: look once more
+                if (cur < head_seen) continue;
+                return false;
+            }
+            if (wall_clock64() - t0 > 2ull * idle + 100000000ull) return false;     // (backstop: the feeder ends an idle ring itself)
+            __builtin_amdgcn_s_sleep(16);
+        }
+    };
+    auto tile_at = [&](unsigned g, unsigned jt) -> TileAt {
+        unsigned q = __umulhi(g, c_magic);
+        unsigned r = g - q * c_spc;
+        if (r >= c_spc) { ++q; r -= c_spc; }
+        if (r >= c_spc) { ++q; r -= c_spc; }
+        return TileAt{static_cast<int>(q), static_cast<int>(r), static_cast<int>(umin(jt, c_spc - r))};
+    };
+    // shiftin! (support.jl:61-80) for the chunk AFTER this one: its call-start history = the last H samples of [history ; x] of this
+    // chunk, every channel, into the next slot -- by the workgroup that takes the chunk's first grab, before anything else
+    auto tail_copy = [&]() -> bool {
+        if (a.H > 0) {
+            if (c_xlen < a.H && !wait_hist(c_seq)) return false;
+            const float *xin = reinterpret_cast<const float *>(c_x);
+            const float *hold = hist_slot(c_seq);
+            float *hnew = hist_slot(c_seq + 1ull);
+            const long long words = static_cast<long long>(a.nch) * a.H * NC;
+            for (long long base = 0; base < words; base += 64 * 8) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const long long w = base + k * 64 + lane;
+                    v[k] = 0.f;
+                    if (w < words) {
+                        const long long smp = w / NC, cc = w - smp * NC;
+                        const long long c2 = smp / a.H, i = smp - c2 * a.H;
+                        const long long e = i + c_xlen;                       // index into [history ; x]
+                        v[k] = e < a.H ? ld_sc1(hold + (c2 * a.H + e) * NC + cc) : ld_sc1(xin + (c2 * c_xs + (e - a.H)) * NC + cc);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const long long w = base + k * 64 + lane;
+                    if (w < words) st_sc1(hnew + w, v[k]);
+                }
+            }
+            vm_drain();
+        }
+        if (lane == 0) st_sc1(&rd->hist_seq[(c_seq + 1ull) % kRingDepth], c_seq + 2ull);
+        vm_drain();
+        return true;
+    };
+    unsigned ra = 0, rb = 0;                                  // the current grab's steps [ra, rb) still to be staged
+    // the next grab of this workgroup that has steps; false: the ring is closed (or a wait ran into its deadline)
+    auto next_grab = [&]() -> bool {
+        for (;;) {
+            if (!find_chunk()) return false;
+            const unsigned g = static_cast<unsigned>(ticket - c_tile_base);
+            ticket += G;
+            if (g == 0u && !tail_copy()) return false;
+            const unsigned long long lo = static_cast<unsigned long long>(g) * static_cast<unsigned>(pa.J);
+            if (lo < c_total) { ra = static_cast<unsigned>(lo); rb = umin(ra + static_cast<unsigned>(pa.J), c_total); return true; }
+            // a chunk without outputs (a short input, Filters.jl:543-547) has one grab without steps: nothing is stored for it
+            if (lane == 0) ring_grab_done(rd, rh, static_cast<unsigned>(c_seq % kRingDepth), c_ngrabs, c_seq);
+            vm_drain();
+        }
+    };
+    const unsigned pad_magic = pa.pad_every > 0 ? 0xffffffffu / static_cast<unsigned>(pa.pad_every + 1) + 1u : 0u;
+    auto stage_tile = [&](const TileAt &ta, int stage) -> int {
+        constexpr int EPC = 4 / NC;
+        const int tlen = (ta.jt * pa.cM + pa.tail + EPC - 1) / EPC * EPC;
+        const int nchunks = tlen / EPC;
+        const int cd = pa.pad_every;
+        const int nlds = cd > 0 ? (nchunks + cd - 1) / cd * (cd + 1) : nchunks;
+        const int nslots = (nlds + 63) >> 6;
+        const float *xc = reinterpret_cast<const float *>(c_x) + static_cast<long long>(ta.ch) * c_xs * NC;
+        const long long o = c_o0 + static_cast<long long>(ta.st) * pa.cM;
+        unsigned char *st = smem + static_cast<size_t>(stage) * pa.stage_bytes;
+        const bool interior = o >= 0 && o + tlen <= c_xlen;
+        if (interior) {
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
+            for (int slot = 0; slot < nslots; ++slot) {
+                const int ci = slot * 64 + lane;
+                int d = ci;
+                if (cd > 0) { const int g = static_cast<int>(__umulhi(static_cast<unsigned>(ci), pad_magic)), r = ci - g * (cd + 1); d = r == cd ? 0 : g * cd + r; }
+                const int cis = d < nchunks ? d : 0;
+                dma16_sc1(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
+            }
+            return nslots;
+        }
+        // first / last tile of a channel: history seam and end of input, element-wise checked (L2-served loads: the history slot
+        // was written by another workgroup of this launch, the signal by whoever filled the caller's buffer)
+        if (o < 0 && !wait_hist(c_seq)) return 0;
+        const float *hc = hist_slot(c_seq) + static_cast<long long>(ta.ch) * a.H * NC;
+        float *l = reinterpret_cast<float *>(st);
+        for (int ci = lane; ci < nchunks; ci += 64) {
+            float4 v;
+            float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const long long gi = o + static_cast<long long>(EPC) * ci + e;
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                    float val = 0.f;
+                    if (gi >= 0) { if (gi < c_xlen) val = ld_sc1(xc + gi * NC + cc); }
+                    else if (gi >= -static_cast<long long>(a.H)) val = ld_sc1(hc + (a.H + gi) * NC + cc);
+                    pv[e * NC + cc] = val;
+                }
+            }
+            *reinterpret_cast<float4 *>(l + (cd > 0 ? ci + ci / cd : ci) * 4) = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        return 0;
+    };
+    unsigned long long ops = 0;
+    auto newest_ops = [&](int ntiles) -> int {
+        int n = 0;
+        for (int k = 0; k < ntiles; ++k) n += static_cast<int>((ops >> (6 * k)) & 63u);
+        return n < 60 ? n : 60;
+    };
+    auto produce = [&](int stage) -> bool {
+        if (ra >= rb && !aborted && !next_grab()) ra = rb = 0;
+        if (ra >= rb || aborted) {
+            if (lane == 0) { td[kRingTileWords * stage] = 0u; td[kRingTileWords * stage + 1] = 0u; }
+            ops <<= 6;
+            return false;
+        }
+        const TileAt ta = tile_at(ra, rb - ra);
+        const int n_ops = stage_tile(ta, stage);
+        if (aborted) {
+            if (lane == 0) { td[kRingTileWords * stage] = 0u; td[kRingTileWords * stage + 1] = 0u; }
+            ops <<= 6;
+            return false;
+        }
+        if (lane == 0) {
+            volatile unsigned *t = td + kRingTileWords * stage;
+            const unsigned long long yaddr = c_y + (static_cast<unsigned long long>(ta.ch) * static_cast<unsigned long long>(c_ys) +
+                                                    static_cast<unsigned long long>(ta.st) * static_cast<unsigned>(pa.P)) * OS;
+            const long long rem = c_nout - static_cast<long long>(ta.st) * pa.P;
+            t[0] = static_cast<unsigned>(ta.jt);
+            t[1] = ra + static_cast<unsigned>(ta.jt) >= rb ? 1u : 0u;
+            t[2] = static_cast<unsigned>(yaddr & 0xffffffffull); t[3] = static_cast<unsigned>(yaddr >> 32);
+            t[4] = static_cast<unsigned>(rem < 0x7fffffffLL ? rem : 0x7fffffffLL);
+            t[5] = static_cast<unsigned>(c_u0);
+            t[6] = static_cast<unsigned>(c_seq % kRingDepth);
+            t[7] = c_ngrabs;
+            t[8] = static_cast<unsigned>(c_seq & 0xffffffffull); t[9] = static_cast<unsigned>(c_seq >> 32);
+        }
+        ops = (ops << 6) | static_cast<unsigned>(n_ops);
+        ra += static_cast<unsigned>(ta.jt);
+        return true;
+    };
+    if (lane < pa.ns) td[kRingTileWords * pa.ns + lane] = 0u;   // per stage: compute waves through with a grab's last tile (opair_kernel.inc)
+    unsigned pipeline = 0;
+    for (int k = 0; k < pa.ns - 1; ++k)
+        if (produce(k)) pipeline |= 1u << k;
+    wait_vmcnt_le(newest_ops(pa.ns - 2));
+    int pstage = pa.ns - 1;
+    for (;;) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!(pipeline & 1u)) break;
+        pipeline >>= 1;
+        if (produce(pstage)) pipeline |= 1u << (pa.ns - 2);
+        pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
+        wait_vmcnt_le(newest_ops(pa.ns - 2));
+    }
+}
+
 }  // namespace dev
 }  // namespace mrhip
 #endif

@@ -116,6 +116,13 @@ ABI = [
     ("mrhip_timing_read", _i, [_vp, _pi64, C.POINTER(C.c_double)]),
     ("mrhip_last_kernel_name", C.c_char_p, [_vp]),
     ("mrhip_schedule_info", _i, [_vp, _pi64, _i]),
+    ("mrhip_ring_open", _i, [_vp, C.POINTER(_vp)]),
+    ("mrhip_ring_push", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, C.POINTER(C.c_uint64)]),
+    ("mrhip_ring_push_chunks", _i, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _pi64, C.POINTER(C.c_uint64)]),
+    ("mrhip_ring_wait", _i, [_vp, C.c_uint64]),
+    ("mrhip_ring_drain", _i, [_vp]),
+    ("mrhip_ring_close", _i, [_vp]),
+    ("mrhip_ring_info", _i, [_vp, _pi64, _i]),
 ]
 
 _lib = None
@@ -599,6 +606,15 @@ class FIRFilter:
                                                    C.c_void_p(buffer.data_ptr()), cap, ys, C.byref(nw), C.c_void_p(stream)))
         return nw.value
 
+    def open_ring(self, dtype=None, nchannels: int = None) -> "ChunkRing":
+        """A ring of arriving chunks on this filter (``mrhip_ring_open``): one resident kernel instead of a launch per chunk.  The
+        filter must be bound (``bind()`` / a first ``filt``), or ``dtype`` and ``nchannels`` given.  Use as a context manager."""
+        if dtype is not None:
+            self._ensure(np.dtype(dtype), int(nchannels or 1))
+        if self._handle is None:
+            raise MultirateHIPError(1, "open_ring needs a bound filter (bind(), or pass dtype and nchannels)")
+        return ChunkRing(self)
+
     def filt(self, x):
         """filt(self, x): allocate the output, run filt!, trim to the samples written
         (src/Filters.jl:475,519,577,633,744)."""
@@ -630,6 +646,86 @@ class FIRFilter:
         if est_mode:
             y = np.ascontiguousarray(y[:, :got])
         return y[0] if one else y
+
+
+class ChunkRing:
+    """The reference's streaming loop ``for x_i in chunks: y_i = filt(self, x_i)`` (README.md:87-141) fed through a ring into ONE
+    resident kernel (``mrhip_ring_*``): ``push(buffer, x)`` is ``filt!(buffer, self, x)`` for the next arriving chunk -- it returns
+    the per-channel output count at once and the chunk's number; ``wait(seq)`` / ``drain()`` block until outputs are complete;
+    ``close()`` hands the stream back to the filter.  ``x`` must be complete on the device when pushed (the resident kernel is not
+    ordered behind any stream) and ``x`` / ``buffer`` must stay untouched until the chunk is complete."""
+
+    def __init__(self, f: "FIRFilter"):
+        self.filter = f
+        self._lib = f._lib
+        h = C.c_void_p()
+        _check(self._lib.mrhip_ring_open(f._handle, C.byref(h)))
+        self._h = h
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> dict:
+        v = (C.c_int64 * 6)()
+        _check(self._lib.mrhip_ring_info(self._h, v, 6))
+        return {"resident": bool(v[0]), "depth": v[1], "pushed": v[2], "restarts": v[3], "steps_per_grab": v[4], "outputs_per_step": v[5]}
+
+    def _args(self, buffer, x):
+        f = self.filter
+        if not _is_torch(x) or not x.is_cuda or not _is_torch(buffer) or not buffer.is_cuda:
+            raise MultirateHIPError(1, "a ring takes torch device tensors")
+        if x.stride(-1) != 1 or buffer.stride(-1) != 1:
+            raise MultirateHIPError(1, "x and buffer must be contiguous along time (planar channels)")
+        nch, n, _ = f._shape(x)
+        if _torch_np_dtype(x.dtype) != f._tx or nch != f._nch:
+            raise MultirateHIPError(1, "x does not match the sample type / channel count the filter is bound to")
+        if _torch_np_dtype(buffer.dtype) != f.output_dtype:
+            raise MultirateHIPError(1, f"buffer dtype must be {f.output_dtype}")
+        if x.device.index != f.device or buffer.device != x.device:
+            raise MultirateHIPError(1, "x / buffer are not on the filter's device")
+        if buffer.ndim != x.ndim or (x.ndim == 2 and buffer.shape[0] != nch):
+            raise MultirateHIPError(1, "buffer must have one row per channel")
+        cap = buffer.shape[-1]
+        xs = x.stride(0) if x.ndim == 2 and nch > 1 else n
+        ys = buffer.stride(0) if buffer.ndim == 2 and nch > 1 else cap
+        return n, xs, cap, ys
+
+    def push(self, buffer, x):
+        """filt!(buffer, self, x) for the next chunk: (per-channel output count, chunk number)"""
+        n, xs, cap, ys = self._args(buffer, x)
+        nw, seq = C.c_int64(0), C.c_uint64(0)
+        _check(self._lib.mrhip_ring_push(self._h, C.c_void_p(x.data_ptr()), n, xs, C.c_void_p(buffer.data_ptr()), cap, ys, C.byref(nw), C.byref(seq)))
+        return nw.value, seq.value
+
+    def push_chunks(self, buffer, x, chunk: int):
+        """the library's loop of ``push`` over consecutive ``chunk``-sample pieces of a resident signal, outputs back to back in
+        ``buffer``: (total per-channel output count, number of the last chunk)"""
+        n, xs, cap, ys = self._args(buffer, x)
+        nw, seq = C.c_int64(0), C.c_uint64(0)
+        _check(self._lib.mrhip_ring_push_chunks(self._h, C.c_void_p(x.data_ptr()), n, xs, int(chunk), C.c_void_p(buffer.data_ptr()), cap, ys,
+                                                C.byref(nw), C.byref(seq)))
+        return nw.value, seq.value
+
+    def wait(self, seq: int) -> None:
+        _check(self._lib.mrhip_ring_wait(self._h, C.c_uint64(seq)))
+
+    def drain(self) -> None:
+        _check(self._lib.mrhip_ring_drain(self._h))
+
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _check(self._lib.mrhip_ring_close(h))
 
 
 def filt_multi(filters, xs):

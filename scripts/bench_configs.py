@@ -119,7 +119,7 @@ DEFAULT_ROWS = ["c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5", "x160", "xf6
 # what bench.py reports next to the headline: every BASELINE config on one GPU, the README's mixed precision, the reference's
 # own FIRArbitrary / FIRFarrow benchmark shape
 # (the BASELINE rows LAST: the driver's record keeps the END of the line)
-BENCH_ROWS = ["xarb", "af", "xdec", "ms", "xmix64", "c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5"]
+BENCH_ROWS = ["xarb", "af", "xdec", "ms", "xmix64", "c1", "c2", "c2s", "c2r", "c3a", "c3b", "c4", "c4f", "c5"]
 # the opt-in FUSED numerics (one fma per tap, same order) for the BASELINE rows: bench.py reports them under `fused`
 FUSED_ROWS = ["c3a", "c3b", "c4", "c5"]
 
@@ -136,6 +136,51 @@ def rows(which):
         run("C2 rational 147//160 f32 1ch x 1e8 in 1e6 chunks (resident signal: mrhip_filt_device_chunked)", h147, Fraction(147, 160), 32, 1, 100_000_000, torch.float32, 7.675, 48 * R147, reps=3, chunk=1_000_000)
     def _c2s():
         run("C2s the same, one launch per arriving 1e6-sample chunk (MRHIP_CHUNKED_PER_CALL=1)", h147, Fraction(147, 160), 32, 1, 100_000_000, torch.float32, 7.675, 48 * R147, reps=2, chunk=1_000_000, per_call=True)
+    def _c2r():
+        # BASELINE config 2 as stated -- ONE channel, 1e8 samples ARRIVING in 1e6-sample chunks, state carried from chunk to chunk -- through
+        # the ring of arriving chunks (mrhip_ring_*): one descriptor per chunk into ONE resident kernel instead of one launch per chunk.
+        # No launch to bracket with events: the times are the host's, from the first push to the last chunk's completion flag.
+        n, chunk, reps = 100_000_000, 1_000_000, 3
+        x = rand((1, n), torch.float32)
+        f = pkg.FIRFilter(h147, Fraction(147, 160), device=dev.index or 0).bind(np.float32, 1)
+        y = torch.empty((1, f.outputlength(n) + 8), dtype=torch.float32, device=dev)
+        gb = n * 7.675 / 1e9
+        for tag, label, how in (("C2r", "pushed by the library's chunk loop (mrhip_ring_push_chunks)", "lib"), ("C2rp", "pushed one by one from Python (mrhip_ring_push)", "py")):
+            t_push, t_all = [], []
+            for rep in range(reps + 1):
+                f.reset()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ring = f.open_ring()
+                t1 = time.perf_counter()
+                if how == "lib":
+                    total, _ = ring.push_chunks(y, x, chunk)
+                else:
+                    k = 0
+                    for a in range(0, n, chunk):
+                        cnt, _ = ring.push(y[:, k:], x[:, a:a + chunk])
+                        k += cnt
+                ring.drain()
+                t2 = time.perf_counter()
+                resident = ring.info()["resident"]
+                ring.close()
+                t3 = time.perf_counter()
+                if rep:                                    # (the first pass settles the clocks)
+                    t_push.append(t2 - t1); t_all.append(t3 - t0)
+            ms, ms_all = 1e3 * sorted(t_push)[len(t_push) // 2], 1e3 * sorted(t_all)[len(t_all) // 2]
+            EMIT(json.dumps({"config": f"{tag} the same through the ring of arriving chunks: 100 descriptors into one resident kernel, {label}", "kernel": "rational_opair_kernel (resident)" if resident else f.last_kernel_name(),
+                             "numerics": "strict", "channels": 1, "samples_per_channel": n, "kernel_ms_per_pass": round(ms, 4),
+                             "wall_ms_per_pass_incl_host": round(ms_all, 3), "launches_per_pass": 1, "chunks_per_pass": n // chunk,
+                             "us_per_chunk": round(1e3 * ms / (n // chunk), 3),
+                             "Msamples_per_s_in": round(n / (ms * 1e-3) / 1e6, 1), "Msamples_per_s_in_wall": round(n / (ms_all * 1e-3) / 1e6, 1),
+                             "algorithmic_GBps": round(gb / (ms * 1e-3), 1), "frac_of_8TBps": round(gb / (ms * 1e-3) / HBM_GBPS, 4),
+                             "frac_of_8TBps_wall": round(gb / (ms_all * 1e-3) / HBM_GBPS, 4), "flops_per_input_sample": round(48 * R147, 2),
+                             "TFLOPs": round(n * 48 * R147 / (ms * 1e-3) / 1e12, 2), "arith": "f32",
+                             "frac_of_strict_valu": round(n * 48 * R147 / (ms * 1e-3) / 1e12 / (FMA_TF[False] / 2), 4), "frac_of_fma_valu": round(n * 48 * R147 / (ms * 1e-3) / 1e12 / FMA_TF[False], 4),
+                             "note": "kernel_ms = first push -> last chunk's completion flag (host clock; ring already open); wall_ms adds opening the ring (one launch) and closing it"}))
+        f.close()
+        del x, y
+        torch.cuda.empty_cache()
     def _c3a():
         run("C3a interpolator 4//1 128 taps c64 256ch x 1e6", h128, Fraction(4, 1), 32, 256, 1_000_000, torch.complex64, 40.0, 2 * 2 * 32 * 4)
     def _c3b():
@@ -254,7 +299,7 @@ def rows(which):
         for f in fs:
             f.close()
 
-    table = {"ms": _ms, "c1": _c1, "c2": _c2, "c2s": _c2s, "c3a": _c3a, "c3b": _c3b, "c4": _c4, "c4f": _c4f, "c5": _c5, "x160": _x160, "xf64": _xf64, "xmix": _xmix, "xstd": _xstd, "x32": _x32, "xc32": _xc32, "xarb": _xarb, "xmix64": _xmix64, "af": _af, "xdec": _xdec}
+    table = {"ms": _ms, "c1": _c1, "c2": _c2, "c2s": _c2s, "c2r": _c2r, "c3a": _c3a, "c3b": _c3b, "c4": _c4, "c4f": _c4f, "c5": _c5, "x160": _x160, "xf64": _xf64, "xmix": _xmix, "xstd": _xstd, "x32": _x32, "xc32": _xc32, "xarb": _xarb, "xmix64": _xmix64, "af": _af, "xdec": _xdec}
     for name in which:                # in the order asked for (bench.py wants the BASELINE rows last)
         table[name]()
 

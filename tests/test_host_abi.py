@@ -235,13 +235,13 @@ def test_julia_shim_ccalls_match_header():
             return "ptr"
         base = t.split()[0] if t.split() else t
         return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "double": "f64", "void": "void", "mrhip_status": "i32",
-                "mrhip_dtype": "i32", "mrhip_kind": "i32", "mrhip_numerics": "i32", "size_t": "u64"}[base]
+                "mrhip_dtype": "i32", "mrhip_kind": "i32", "mrhip_numerics": "i32", "size_t": "u64", "uint64_t": "u64"}[base]
 
     def jl_class(t):
         t = t.strip()
         if t.startswith("Ptr") or t.startswith("Ref") or t == "Cstring":
             return "ptr"
-        return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Cdouble": "f64", "Float64": "f64", "Cvoid": "void", "Csize_t": "u64"}[t]
+        return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Cdouble": "f64", "Float64": "f64", "Cvoid": "void", "Csize_t": "u64", "UInt64": "u64"}[t]
 
     proto = {}
     for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(mrhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
