@@ -213,6 +213,14 @@ int mrhip_set_history_device(mrhip_filter *f, const void *device_in, void *strea
  * constructor's (the reference resets 𝜙Idx only and is broken for FIRArbitrary, :247-253). */
 int mrhip_reset(mrhip_filter *f);
 int mrhip_set_numerics(mrhip_filter *f, int numerics);
+/* FIRArbitrary / FIRFarrow: which floating-point mod() update() wraps the phase accumulator with (src/Filters.jl:668, :786).
+ * form 0 (default): the exact remainder -- Julia >= 0.4.  form 1: rem(y + rem(x, y), y) -- how Julia's Base computed mod() for
+ * floats before 0.4; the reference is Julia-0.3 code and nothing in its tree says which Base it ran on.  The two agree bit for bit
+ * whenever Nphi is a power of two (BASELINE config 4: Nphi = 32); for other Nphi form 1 differs by one rounding of y + rem(x, y)
+ * every few outputs (a random walk of ~1e-10 phase steps per 1e6 outputs).  With form 1 and such an Nphi the phase schedule is
+ * evaluated by the host's serial loop (the device evaluation implements the exact remainder) and asynchronous / captured calls
+ * are MRHIP_ERR_UNSUPPORTED.  The oracle has the same switch (oracle.set_mod_form). */
+int mrhip_set_mod_form(mrhip_filter *f, int form);
 /* the polyphase taps as stored on the device, converted back to tap_dtype (which = 0: h flipped or
  * pfb; which = 1: dpfb).  Column-major tapsPerPhi x Nphi.  For tests / tapsforphase. */
 int mrhip_get_taps(mrhip_filter *f, int which, void *host_out);

@@ -536,7 +536,7 @@ static int64_t arb_schedule(mrhip_filter *f, int64_t x_len, ArbState *end_state)
         if (f->sched_in_flight) { (void)hipEventSynchronize(f->sched_copied); f->sched_in_flight = false; }
         ArbState st{f->phiAcc, f->phiIdx, f->alpha, f->xIdx, f->inputDeficit};
         f->sched_acc0 = f->phiAcc; f->sched_deficit0 = f->inputDeficit; f->sched_xlen = x_len;
-        f->sched_count = run_arbitrary_schedule(st, f->delta, f->Nphi, x_len, &f->sched_n, &f->sched_acc);
+        f->sched_count = run_arbitrary_schedule(st, f->delta, f->Nphi, x_len, &f->sched_n, &f->sched_acc, f->mod_form);
         f->sched_end = st;
         f->sched_cached = true;
     }
@@ -589,7 +589,7 @@ int64_t mrhip_advance_state(mrhip_filter *f, int64_t n)
                 if (so.periodic || f->per_valid) f->per_pos = so.per_pos_end;
                 f->memo_valid = false;                      // (the entries in the buffer belong to a call that was never made)
             } else {
-                got = run_arbitrary_schedule(st, f->delta, f->Nphi, len, nullptr, nullptr);    // (count only: no entries kept)
+                got = run_arbitrary_schedule(st, f->delta, f->Nphi, len, nullptr, nullptr, f->mod_form);    // (count only: no entries kept)
                 sched_forget(f);
             }
             f->phiAcc = st.acc; f->phiIdx = st.phiIdx; f->alpha = st.alpha; f->xIdx = st.xIdx;   // Filters.jl:731-735
@@ -750,6 +750,20 @@ int mrhip_set_numerics(mrhip_filter *f, int numerics)
     if (numerics != MRHIP_NUMERICS_STRICT && numerics != MRHIP_NUMERICS_FUSED)
         return fail(MRHIP_ERR_INVALID_ARG, "unknown numerics mode");
     f->numerics = numerics;
+    return MRHIP_OK;
+}
+
+int mrhip_set_mod_form(mrhip_filter *f, int form)
+{
+    if (!f) return fail(MRHIP_ERR_INVALID_ARG, "NULL filter");
+    if (form != 0 && form != 1) return fail(MRHIP_ERR_INVALID_ARG, "mod form must be 0 (exact remainder) or 1 (rem(y + rem(x, y), y))");
+    if (f->kind != MRHIP_FIR_ARBITRARY && f->kind != MRHIP_FIR_FARROW) return fail(MRHIP_ERR_INVALID_ARG, "not a FIRArbitrary / FIRFarrow filter");
+    if (f->mod_form != form) {
+        f->mod_form = form;
+        f->sched_cached = false;
+        sched_forget(f);           // drift estimate, cycle and memo belong to the other recurrence
+        f->memo_valid = false;
+    }
     return MRHIP_OK;
 }
 
@@ -950,6 +964,8 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
     if (!dev_planned && !f->mirror_valid)
         if (int rc = rec_pull(f)) return rc;
     if (x_from && !dev_planned) return fail(MRHIP_ERR_UNSUPPORTED, "a chained call is an asynchronous or captured call");
+    if (dev_planned && arb && f->mod_form != 0 && (f->Nphi & (f->Nphi - 1)) != 0)
+        return fail(MRHIP_ERR_UNSUPPORTED, "mod form 1 (Julia Base before 0.4) with an N𝜙 that is not a power of two runs the host's serial schedule: no asynchronous or captured calls");
     if (x_len == 0) {                  // nothing to do: zero outputs, history and state unchanged
         f->last_call_dev_planned = false;                      // (no plan kernel ran: the call record still holds an older call's count)
         if (count_dev) MRHIP_CHECK_HIP(hipMemsetAsync(count_dev, 0, sizeof(long long), stream));
@@ -1151,7 +1167,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 const int64_t room = std::min<int64_t>(piece, est - k0);
                 if (room <= 0) return bail(fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small"));   // cannot happen: est is an upper bound
                 const double t0 = prof ? now() : 0;
-                const int64_t cnt = run_arbitrary_schedule_piece(st, f->delta, f->Nphi, x_len, pn, pa, room, &done);
+                const int64_t cnt = run_arbitrary_schedule_piece(st, f->delta, f->Nphi, x_len, pn, pa, room, &done, f->mod_form);
                 const double t1 = prof ? now() : 0;
                 if (cnt > 0) {
                     if (hipMemcpyAsync(static_cast<int32_t *>(f->d_sched_n) + k0, pn, static_cast<size_t>(cnt) * sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess ||

@@ -296,6 +296,8 @@ void sched_free(mrhip_filter *f)
 
 bool sched_wants_device(const mrhip_filter *f, int64_t est)
 {
+    // (the device evaluation implements the exact remainder: the older mod() form differs from it unless N𝜙 is a power of two)
+    if (f->mod_form != 0 && (f->Nphi & (f->Nphi - 1)) != 0) return false;
     return f->splan.ok && est >= f->sched_device_min && est < 0x7fffffffLL;
 }
 
@@ -464,7 +466,7 @@ int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacit
         if (int rc = wait_pinned_free(f)) return rc;
         const int64_t want = (f->sched_prefix - static_cast<int64_t>(ksteps) + kSchedGroup - 1) / kSchedGroup * kSchedGroup;
         const double acc_start = st.acc;
-        const int64_t cnt = run_arbitrary_schedule_piece(st, f->delta, f->Nphi, x_len, static_cast<int32_t *>(f->pin_n), static_cast<double *>(f->pin_acc), want, &done);
+        const int64_t cnt = run_arbitrary_schedule_piece(st, f->delta, f->Nphi, x_len, static_cast<int32_t *>(f->pin_n), static_cast<double *>(f->pin_acc), want, &done, f->mod_form);
         if (!done && f->sched_use_cycle)
             if (int rc = try_find_cycle(f, cnt, st, s)) return rc;
         if (int rc = upload_entries(f, b, 0, cnt, s)) return rc;

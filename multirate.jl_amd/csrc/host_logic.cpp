@@ -112,9 +112,30 @@ namespace {
 struct ArbConsts {
     double delta, N, invN;
     bool n_pow2;
-    ArbConsts(double delta_, int64_t Nphi) : delta(delta_), N(static_cast<double>(Nphi)), invN(1.0 / static_cast<double>(Nphi)),
-                                             n_pow2((Nphi & (Nphi - 1)) == 0) {}
+    bool old_mod;      // mrhip_set_mod_form(f, 1) on a N𝜙 that is not a power of two: the plain loop below with mod() as older Julia Base versions computed it
+    ArbConsts(double delta_, int64_t Nphi, int mod_form = 0) : delta(delta_), N(static_cast<double>(Nphi)), invN(1.0 / static_cast<double>(Nphi)),
+                                             n_pow2((Nphi & (Nphi - 1)) == 0), old_mod(mod_form != 0 && (Nphi & (Nphi - 1)) != 0) {}
 };
+
+// update() (src/Filters.jl:663-673) one expression at a time, with mod(x, y) = rem(y + rem(x, y), y): the form Julia's Base used for
+// floats before 0.4 -- the reference is Julia-0.3 code and nothing in its tree says which Base it ran on.  Identical to the exact
+// remainder whenever N𝜙 is a power of two, so only other N𝜙 come here.
+int64_t arb_run_old_mod(const ArbConsts &c, double &acc, int64_t &xIdx, int64_t xLen, int32_t *n_idx, double *acc_out, int64_t max_outputs)
+{
+    int64_t count = 0;
+    while (xIdx <= xLen && count < max_outputs) {          // :717
+        if (n_idx) n_idx[count] = static_cast<int32_t>(xIdx);
+        if (acc_out) acc_out[count] = acc;
+        ++count;
+        acc += c.delta;                                      // :664
+        if (acc > c.N) {
+            const double am1 = acc - 1.0;
+            xIdx += static_cast<int64_t>(std::floor(am1 / c.N));              // :667
+            acc = std::fmod(c.N + std::fmod(am1, c.N), c.N) + 1.0;           // :668, old Base
+        }
+    }
+    return count;
+}
 
 struct SlowStep { double acc; int64_t dx; };
 __attribute__((noinline)) SlowStep arb_slow_step(double a1, double N, double invN, bool n_pow2)
@@ -160,6 +181,7 @@ inline int64_t arb_hot_loop(const ArbConsts &c, double &acc_io, int64_t &xIdx_io
 // up to max_outputs schedule entries from (acc, xIdx); returns the number written
 int64_t arb_run(const ArbConsts &c, double &acc, int64_t &xIdx, int64_t xLen, int32_t *n_idx, double *acc_out, int64_t max_outputs)
 {
+    if (c.old_mod) return arb_run_old_mod(c, acc, xIdx, xLen, n_idx, acc_out, max_outputs);
     int64_t count = 0;
     while (xIdx <= xLen && count < max_outputs) {
         bool need_slow = false;
@@ -180,13 +202,13 @@ int64_t arb_run(const ArbConsts &c, double &acc, int64_t &xIdx, int64_t xLen, in
 }  // namespace
 
 int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t xLen,
-                               std::vector<int32_t> *n_idx, std::vector<double> *acc_out)
+                               std::vector<int32_t> *n_idx, std::vector<double> *acc_out, int mod_form)
 {
     if (xLen < st.inputDeficit) {          // src/Filters.jl:705-709
         st.inputDeficit -= xLen;
         return 0;
     }
-    const ArbConsts c(delta, Nphi);
+    const ArbConsts c(delta, Nphi, mod_form);
     double acc = st.acc;
     int64_t xIdx = st.inputDeficit;        // :715
     int64_t count = 0;
@@ -213,9 +235,9 @@ int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t
 // point st holds the call-end state exactly as run_arbitrary_schedule leaves it.  Lets filt! overlap the serial
 // host recurrence of one long call with the kernels of the pieces already scheduled.
 int64_t run_arbitrary_schedule_piece(ArbState &st, double delta, int64_t Nphi, int64_t xLen, int32_t *n_idx, double *acc_out,
-                                     int64_t max_outputs, bool *done)
+                                     int64_t max_outputs, bool *done, int mod_form)
 {
-    const ArbConsts c(delta, Nphi);
+    const ArbConsts c(delta, Nphi, mod_form);
     double acc = st.acc;
     int64_t xIdx = st.xIdx;
     const int64_t count = arb_run(c, acc, xIdx, xLen, n_idx, acc_out, max_outputs);

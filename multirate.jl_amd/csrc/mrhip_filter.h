@@ -137,6 +137,7 @@ struct mrhip_filter {
     hipEvent_t multi_ev = nullptr;
     bool multi_in_flight = false;
 
+    int mod_form = 0;                  // FIRArbitrary / FIRFarrow: 1 = update()'s mod() as Julia Base before 0.4 computed it (mrhip_set_mod_form)
     bool ring_open = false;            // the filter feeds a ring of arriving chunks (ring_api.inc): its own entry points refuse calls meanwhile
 
     // measurement

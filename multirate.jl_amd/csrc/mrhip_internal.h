@@ -67,10 +67,11 @@ struct ArbState {
 // Runs the schedule for one call.  If n_idx/acc_out are non-null they receive, per output, the
 // 1-based input index and the phase accumulator value used (phiIdx = floor(acc), alpha = acc - phiIdx).
 // Returns the number of outputs; `st` is advanced to the post-call state.
+// mod_form != 0: mod() of update() (Filters.jl:668) as rem(y + rem(x, y), y), the form of Julia Base before 0.4 (mrhip_set_mod_form)
 int64_t run_arbitrary_schedule(ArbState &st, double delta, int64_t Nphi, int64_t xLen,
-                               std::vector<int32_t> *n_idx, std::vector<double> *acc_out);
+                               std::vector<int32_t> *n_idx, std::vector<double> *acc_out, int mod_form = 0);
 int64_t run_arbitrary_schedule_piece(ArbState &st, double delta, int64_t Nphi, int64_t xLen, int32_t *n_idx, double *acc_out,
-                                     int64_t max_outputs, bool *done);
+                                     int64_t max_outputs, bool *done, int mod_form = 0);
 
 // ---------------------------------------------------------------------------------------
 // FIRArbitrary / FIRFarrow phase schedule on the device (kernels_schedule.hip; model: scripts/sched_model.py)
@@ -298,14 +299,18 @@ struct RingDesc {                         // one arriving chunk: 16 quad-words
     unsigned long long x, y;              // device addresses
     long long x_stride, y_stride, x_len, n_out;
     long long u0, d0;                     // call-start state: phi0 - 1, inputDeficit
+    // the KEY (quad-words 8 and 9: one aligned 16-byte unit, written and read by ONE instruction each): whoever reads a key whose
+    // seq_lo names the chunk it expects in this slot, and whose tickets hold a grab that is still to be done, reads a descriptor
+    // that cannot be under rewrite (a slot is recycled only when its chunk is complete)
     unsigned long long tile_base;         // tickets [tile_base, tile_base + ngrabs) are this chunk's grabs
-    unsigned ngrabs, steps_per_channel;
-    unsigned total_steps, spc_magic;
-    unsigned long long seq;               // chunk number; ~0 while the feeder rewrites the slot
-    unsigned long long pad[4];
+    unsigned ngrabs, seq_lo;              // seq_lo: low half of the chunk number (~0: the feeder is rewriting the slot)
+    unsigned steps_per_channel, total_steps;
+    unsigned spc_magic, pad0;
+    unsigned long long seq;               // chunk number (host's copy; the device goes by the key)
+    unsigned long long pad[3];
 };
 static_assert(sizeof(RingDesc) == 128, "RingDesc is 16 quad-words");
-constexpr int kRingSeqQword = 11;         // index of RingDesc::seq in quad-words
+constexpr int kRingKeyQword = 8;          // index of the key in quad-words (16-byte aligned)
 struct RingHost {                         // pinned host memory: host writes head / close / desc, device writes done / stopped
     unsigned long long head;              // chunks published
     unsigned long long close;             // != 0: consume what is published, then leave
@@ -318,10 +323,11 @@ struct RingDev {                          // device memory
     unsigned long long head;              // chunks whose descriptors are in desc[]
     unsigned long long closed;            // 0 open; 1 closed by the host; 2 idle deadline; 3 error (a wait ran into its deadline)
     unsigned long long idle_ticks;        // deadline of every wait, in 100 MHz ticks
-    unsigned long long pad[5];
+    unsigned long long opts;              // experiments (MRHIP_RING_OPTS): bit 0 no descriptor prefetch, bit 1 grabs reported at their own end
+    unsigned long long pad[4];
     unsigned long long hist_seq[kRingDepth];   // hist_seq[s % depth] == s + 1: slot s % depth holds chunk s's call-start history
     unsigned chunk_done[kRingDepth];      // grabs of chunk (slot) completed
-    RingDesc desc[kRingDepth];
+    __attribute__((aligned(128))) RingDesc desc[kRingDepth];
 };
 
 struct ArbArgs {             // FIRArbitrary

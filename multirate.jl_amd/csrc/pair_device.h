@@ -102,6 +102,23 @@ __device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(r
 __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Six aligned 16-byte units (96 consecutive bytes), L2-served, each by ONE instruction, AND the wait for them in one statement: the
+// compiler never sees a register with a load in flight (it may park registers in scratch wherever it likes -- a parked destination
+// would receive the data behind its back and whatever it parked there instead would be overwritten).  The wait is vmcnt(0): it also
+// covers LDS-DMA transfers issued before it, which is what the ring's loader wants at that point anyway.
+__device__ __forceinline__ void ld96_sc1(const void *p, v4u_t (&d)[6])
+{
+    asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
+                 "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %6, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %6, off offset:64 sc1\n\t"
+                 "global_load_dwordx4 %5, %6, off offset:80 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
+                 : "v"(p)
+                 : "memory");
+}
 // write-through stores of N bytes of a lane's registers (N = 4, 8, 16, 32): visible beyond this XCD's L2 once vmcnt has counted them
 template <int N>
 __device__ __forceinline__ void store_wt(void *dst, const void *regs)

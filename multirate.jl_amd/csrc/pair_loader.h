@@ -271,12 +271,20 @@ __device__ __forceinline__ void ring_feeder(RingDev *rd, RingHost *rh, int lane)
     unsigned long long last = 0, t0 = wall_clock64(), code = 0;
     const unsigned long long idle = ld_sc1(&rd->idle_ticks);
     const int dq = lane & 15, dk = lane >> 4;
+    auto rl64 = [&](unsigned long long v, int src_lane) -> unsigned long long {
+        const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffffull), src_lane));
+        const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), src_lane));
+        return (static_cast<unsigned long long>(hi) << 32) | lo;
+    };
     for (;;) {
         const unsigned long long h = ld_sys(&rh->head);
         if (h > last) {
             const unsigned nb = h - last < 16ull ? static_cast<unsigned>(h - last) : 16u;
-            // readers that scan a slot while it is rewritten reject what they read (its seq)
-            if (lane < static_cast<int>(nb)) st_sc1(&rd->desc[(last + lane) % kRingDepth].seq, ~0ull);
+            // the keys first: a reader that meets a slot under rewrite finds no chunk in it
+            if (lane < static_cast<int>(nb)) {
+                const v4u_t dead = {~0u, ~0u, ~0u, ~0u};
+                store_wt<16>(reinterpret_cast<unsigned long long *>(&rd->desc[(last + lane) % kRingDepth]) + kRingKeyQword, &dead);
+            }
             vm_drain();
             unsigned long long q[4];
 #pragma unroll
@@ -287,10 +295,22 @@ __device__ __forceinline__ void ring_feeder(RingDev *rd, RingHost *rh, int lane)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const unsigned k = static_cast<unsigned>(dk + 4 * m);
-                if (k < nb && dq != kRingSeqQword) st_sc1(reinterpret_cast<unsigned long long *>(&rd->desc[(last + k) % kRingDepth]) + dq, q[m]);
+                if (k < nb && dq != kRingKeyQword && dq != kRingKeyQword + 1) st_sc1(reinterpret_cast<unsigned long long *>(&rd->desc[(last + k) % kRingDepth]) + dq, q[m]);
             }
             vm_drain();
-            if (lane < static_cast<int>(nb)) st_sc1(&rd->desc[(last + lane) % kRingDepth].seq, last + lane);
+            // ... and the keys last, each by one 16-byte store: (tile_base, ngrabs, low half of the chunk number)
+            unsigned long long key_tb = 0, key_ng = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned long long tb = rl64(q[k >> 2], (k & 3) * 16 + kRingKeyQword), ng = rl64(q[k >> 2], (k & 3) * 16 + kRingKeyQword + 1);
+                if (lane == k) { key_tb = tb; key_ng = ng; }
+            }
+            if (lane < static_cast<int>(nb)) {
+                const unsigned long long sq = last + static_cast<unsigned>(lane);
+                const v4u_t key = {static_cast<unsigned>(key_tb & 0xffffffffull), static_cast<unsigned>(key_tb >> 32),
+                                   static_cast<unsigned>(key_ng & 0xffffffffull), static_cast<unsigned>(sq & 0xffffffffull)};
+                store_wt<16>(reinterpret_cast<unsigned long long *>(&rd->desc[sq % kRingDepth]) + kRingKeyQword, &key);
+            }
             vm_drain();
             last += nb;
             if (lane == 0) st_sc1(&rd->head, last);
@@ -323,6 +343,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     if (blockIdx.x == 0) { ring_feeder(rd, rh, lane); return; }
     volatile unsigned *const td = reinterpret_cast<volatile unsigned *>(smem + pa.flags_off);   // [ns][kRingTileWords]
     const unsigned long long idle = ld_sc1(&rd->idle_ticks);
+    const unsigned opts = static_cast<unsigned>(ld_sc1(&rd->opts));
     const unsigned long long G = gridDim.x - 1u;
     unsigned long long ticket = blockIdx.x - 1u;          // this workgroup's next grab, counted over the whole life of the ring
     unsigned long long cur = 0, head_seen = 0;            // chunks below cur cannot hold `ticket`
@@ -335,11 +356,6 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     auto hist_slot = [&](unsigned long long s) -> float * {
         return reinterpret_cast<float *>(static_cast<unsigned char *>(const_cast<void *>(a.hist)) + (s % kRingDepth) * slot_bytes);
     };
-    auto rl64 = [&](unsigned long long v, int src_lane) -> unsigned long long {
-        const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffffull), src_lane));
-        const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), src_lane));
-        return (static_cast<unsigned long long>(hi) << 32) | lo;
-    };
     // chunk s's call-start history is in its slot (written by the workgroup that took the first grab of chunk s - 1: an
     // earlier ticket, held by a workgroup that is running)
     auto wait_hist = [&](unsigned long long s) -> bool {
@@ -350,58 +366,64 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         }
         return true;
     };
-    // positions the chunk context on the chunk that holds `ticket`; false: the ring was closed before that chunk came
-    auto find_chunk = [&]() -> bool {
+    // ---- which chunk holds `ticket`: lane k < nb reads the whole descriptor of chunk cur + k (six 16-byte units, the key among
+    // them), AHEAD of need: right behind the staging of the tile before, so that the round trip overlaps that tile's landing (one wait
+    // covers both) ----
+    v4u_t dsc[6];
+    unsigned long long pf_cur = ~0ull;                     // the prefetch in dsc[] is for chunks [pf_cur, pf_cur + pf_nb) and `ticket`
+    unsigned pf_nb = 0;
+    auto prefetch_issue = [&]() {
+        pf_cur = ~0ull;
+        if (cur >= head_seen) return;
+        if (head_seen >= static_cast<unsigned long long>(kRingDepth) && cur + kRingDepth <= head_seen) cur = head_seen - kRingDepth + 1ull;   // (complete long ago, slots recycled)
+        pf_nb = head_seen - cur < 16ull ? static_cast<unsigned>(head_seen - cur) : 16u;
+        pf_cur = cur;
+        const unsigned long long *base = reinterpret_cast<const unsigned long long *>(&rd->desc[(cur + static_cast<unsigned>(lane < 16 ? lane : 0)) % kRingDepth]);
+        if (lane < static_cast<int>(pf_nb)) ld96_sc1(base, dsc);     // (loads and their wait in one statement: pair_device.h)
+    };
+    enum { kFound = 0, kClosed = 1, kWouldBlock = 2 };
+    // positions the chunk context on the chunk that holds `ticket`; may_block = false: returns kWouldBlock instead of polling
+    auto find_chunk = [&](bool may_block) -> int {
         const unsigned long long t0 = wall_clock64();
-        const int dq = lane & 15, dk = lane >> 4;
         for (;;) {
             if (cur < head_seen) {
-                // chunks at or below head_seen - depth are complete (the host publishes chunk h - 1 only then) and their slots recycled
-                if (head_seen >= static_cast<unsigned long long>(kRingDepth) && cur + kRingDepth <= head_seen) cur = head_seen - kRingDepth + 1ull;
-                const unsigned nb = head_seen - cur < 16ull ? static_cast<unsigned>(head_seen - cur) : 16u;
-                unsigned long long q[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const unsigned k = static_cast<unsigned>(dk + 4 * m);
-                    q[m] = k < nb ? ld_sc1(reinterpret_cast<const unsigned long long *>(&rd->desc[(cur + k) % kRingDepth]) + dq) : 0ull;
+                if (pf_cur != cur) prefetch_issue();
+                const unsigned nb = pf_nb;
+                pf_cur = ~0ull;
+                // key: dsc[4] = (tile_base lo, hi, ngrabs, seq_lo)
+                const unsigned long long tb = (static_cast<unsigned long long>(dsc[4].y) << 32) | dsc[4].x;
+                const bool mine = lane < static_cast<int>(nb) && dsc[4].w == static_cast<unsigned>((cur + static_cast<unsigned>(lane)) & 0xffffffffull) &&
+                                  ticket >= tb && ticket - tb < dsc[4].z;
+                const unsigned long long hit = __ballot(mine);
+                if (hit == 0ull) { cur += nb; continue; }
+                const int fl = __builtin_ctzll(hit);
+                auto rl = [&](unsigned v) -> unsigned { return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), fl)); };
+                auto rq = [&](unsigned lo, unsigned hi) -> unsigned long long { return (static_cast<unsigned long long>(rl(hi)) << 32) | rl(lo); };
+                cur += static_cast<unsigned>(fl);
+                c_x = rq(dsc[0].x, dsc[0].y); c_y = rq(dsc[0].z, dsc[0].w);
+                c_xs = static_cast<long long>(rq(dsc[1].x, dsc[1].y)); c_ys = static_cast<long long>(rq(dsc[1].z, dsc[1].w));
+                c_xlen = static_cast<long long>(rq(dsc[2].x, dsc[2].y)); c_nout = static_cast<long long>(rq(dsc[2].z, dsc[2].w));
+                c_u0 = static_cast<long long>(rq(dsc[3].x, dsc[3].y)); c_o0 = static_cast<long long>(rq(dsc[3].z, dsc[3].w)) - a.T;
+                c_tile_base = rq(dsc[4].x, dsc[4].y); c_ngrabs = rl(dsc[4].z);
+                c_spc = rl(dsc[5].x); c_total = rl(dsc[5].y); c_magic = rl(dsc[5].z);
+                c_seq = cur;
+                if (c_total > 0u && (c_x == 0ull || c_y == 0ull || c_spc == 0u)) {   // (never: a descriptor that cannot be one -- leave rather than fault)
+                    if (lane == 0) st_sc1(&rd->closed, 3ull);
+                    vm_drain();
+                    aborted = true;
+                    return kClosed;
                 }
-                int found = -1;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const unsigned long long tb = rl64(q[k >> 2], (k & 3) * 16 + 8);
-                    const unsigned ng = static_cast<unsigned>(rl64(q[k >> 2], (k & 3) * 16 + 9) & 0xffffffffull);
-                    const unsigned long long sq = rl64(q[k >> 2], (k & 3) * 16 + kRingSeqQword);
-                    if (found < 0 && static_cast<unsigned>(k) < nb && sq == cur + k && ticket >= tb && ticket - tb < ng) found = k;
-                }
-                if (found < 0) { cur += nb; continue; }
-                // the fields were read before this: a slot under rewrite carries an invalid seq from before its first new field
-                const unsigned long long idx = cur + static_cast<unsigned>(found);
-                if (ld_sc1(&rd->desc[idx % kRingDepth].seq) != idx) { cur = idx + 1ull; continue; }
-                unsigned long long d[11];
-                {
-                    const int fq = found >> 2, fl = (found & 3) * 16;     // (wave-uniform: the lane select of v_readlane is a scalar)
-                    const unsigned long long qs = fq == 0 ? q[0] : fq == 1 ? q[1] : fq == 2 ? q[2] : q[3];
-#pragma unroll
-                    for (int w = 0; w < 11; ++w) d[w] = rl64(qs, fl + w);
-                }
-                cur = idx;
-                c_x = d[0]; c_y = d[1];
-                c_xs = static_cast<long long>(d[2]); c_ys = static_cast<long long>(d[3]); c_xlen = static_cast<long long>(d[4]); c_nout = static_cast<long long>(d[5]);
-                c_u0 = static_cast<long long>(d[6]); c_o0 = static_cast<long long>(d[7]) - a.T;
-                c_tile_base = d[8];
-                c_ngrabs = static_cast<unsigned>(d[9] & 0xffffffffull); c_spc = static_cast<unsigned>(d[9] >> 32);
-                c_total = static_cast<unsigned>(d[10] & 0xffffffffull); c_magic = static_cast<unsigned>(d[10] >> 32);
-                c_seq = idx;
-                return true;
+                return kFound;
             }
             head_seen = ld_sc1(&rd->head);
             if (cur < head_seen) continue;
             if (ld_sc1(&rd->closed) != 0ull) {
                 head_seen = ld_sc1(&rd->head);            // `closed` is set behind the last `head`: look once more
                 if (cur < head_seen) continue;
-                return false;
+                return kClosed;
             }
-            if (wall_clock64() - t0 > 2ull * idle + 100000000ull) return false;     // (backstop: the feeder ends an idle ring itself)
+            if (!may_block) return kWouldBlock;
+            if (wall_clock64() - t0 > 2ull * idle + 100000000ull) return kClosed;     // (backstop: the feeder ends an idle ring itself)
             __builtin_amdgcn_s_sleep(16);
         }
     };
@@ -421,10 +443,10 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
             const float *hold = hist_slot(c_seq);
             float *hnew = hist_slot(c_seq + 1ull);
             const long long words = static_cast<long long>(a.nch) * a.H * NC;
-            for (long long base = 0; base < words; base += 64 * 8) {
-                float v[8];
+            for (long long base = 0; base < words; base += 64 * 4) {
+                float v[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 4; ++k) {
                     const long long w = base + k * 64 + lane;
                     v[k] = 0.f;
                     if (w < words) {
@@ -435,7 +457,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 4; ++k) {
                     const long long w = base + k * 64 + lane;
                     if (w < words) st_sc1(hnew + w, v[k]);
                 }
@@ -447,15 +469,17 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         return true;
     };
     unsigned ra = 0, rb = 0;                                  // the current grab's steps [ra, rb) still to be staged
-    // the next grab of this workgroup that has steps; false: the ring is closed (or a wait ran into its deadline)
-    auto next_grab = [&]() -> bool {
+    // the next grab of this workgroup that has steps: kFound; kClosed: the ring is closed (or a wait ran into its deadline);
+    // kWouldBlock (only with may_block = false): nothing published yet
+    auto next_grab = [&](bool may_block) -> int {
         for (;;) {
-            if (!find_chunk()) return false;
+            const int fc = find_chunk(may_block);
+            if (fc != kFound) return fc;
             const unsigned g = static_cast<unsigned>(ticket - c_tile_base);
             ticket += G;
-            if (g == 0u && !tail_copy()) return false;
+            if (g == 0u && !tail_copy()) return kClosed;
             const unsigned long long lo = static_cast<unsigned long long>(g) * static_cast<unsigned>(pa.J);
-            if (lo < c_total) { ra = static_cast<unsigned>(lo); rb = umin(ra + static_cast<unsigned>(pa.J), c_total); return true; }
+            if (lo < c_total) { ra = static_cast<unsigned>(lo); rb = umin(ra + static_cast<unsigned>(pa.J), c_total); return kFound; }
             // a chunk without outputs (a short input, Filters.jl:543-547) has one grab without steps: nothing is stored for it
             if (lane == 0) ring_grab_done(rd, rh, static_cast<unsigned>(c_seq % kRingDepth), c_ngrabs, c_seq);
             vm_drain();
@@ -514,20 +538,29 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         for (int k = 0; k < ntiles; ++k) n += static_cast<int>((ops >> (6 * k)) & 63u);
         return n < 60 ? n : 60;
     };
+    auto end_marker = [&](int stage) {
+        if (lane == 0) { td[kRingTileWords * stage] = 0u; td[kRingTileWords * stage + 1] = 0u; }
+        ops <<= 6;
+    };
+    // The compute waves report a grab at the START of the tile after it (their write-through stores have had that tile's landing time
+    // to drain).  When nothing is published and grabs are still unreported, a FLUSH tile (no steps) takes them through the barrier to
+    // report; only then does this wave sit down and poll.
+    bool unreported = false;
     auto produce = [&](int stage) -> bool {
-        if (ra >= rb && !aborted && !next_grab()) ra = rb = 0;
-        if (ra >= rb || aborted) {
-            if (lane == 0) { td[kRingTileWords * stage] = 0u; td[kRingTileWords * stage + 1] = 0u; }
-            ops <<= 6;
-            return false;
+        if (ra >= rb && !aborted) {
+            int ng = next_grab(!unreported);
+            if (ng == kWouldBlock) {
+                if (lane == 0) { td[kRingTileWords * stage] = 1u; td[kRingTileWords * stage + 1] = 2u; }   // FLUSH
+                ops <<= 6;
+                unreported = false;
+                return true;
+            }
+            if (ng != kFound) ra = rb = 0;
         }
+        if (ra >= rb || aborted) { end_marker(stage); return false; }
         const TileAt ta = tile_at(ra, rb - ra);
         const int n_ops = stage_tile(ta, stage);
-        if (aborted) {
-            if (lane == 0) { td[kRingTileWords * stage] = 0u; td[kRingTileWords * stage + 1] = 0u; }
-            ops <<= 6;
-            return false;
-        }
+        if (aborted) { end_marker(stage); return false; }
         if (lane == 0) {
             volatile unsigned *t = td + kRingTileWords * stage;
             const unsigned long long yaddr = c_y + (static_cast<unsigned long long>(ta.ch) * static_cast<unsigned long long>(c_ys) +
@@ -544,13 +577,16 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         }
         ops = (ops << 6) | static_cast<unsigned>(n_ops);
         ra += static_cast<unsigned>(ta.jt);
+        unreported = !(opts & 2u);
+        // the descriptors the NEXT grab will be looked up in, requested behind this tile's transfers (the same wait covers both)
+        if (ra >= rb && pf_cur == ~0ull && !(opts & 1u)) prefetch_issue();
         return true;
     };
     if (lane < pa.ns) td[kRingTileWords * pa.ns + lane] = 0u;   // per stage: compute waves through with a grab's last tile (opair_kernel.inc)
     unsigned pipeline = 0;
     for (int k = 0; k < pa.ns - 1; ++k)
         if (produce(k)) pipeline |= 1u << k;
-    wait_vmcnt_le(newest_ops(pa.ns - 2));
+    vm_drain();                               // (ring mode waits for everything: descriptor prefetches ride along with the transfers)
     int pstage = pa.ns - 1;
     for (;;) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -559,7 +595,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         pipeline >>= 1;
         if (produce(pstage)) pipeline |= 1u << (pa.ns - 2);
         pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
-        wait_vmcnt_le(newest_ops(pa.ns - 2));
+        if (pa.ns > 2) wait_vmcnt_le(newest_ops(pa.ns - 2)); else vm_drain();
     }
 }
 

@@ -93,6 +93,7 @@ ABI = [
     ("mrhip_set_history", _i, [_vp, _vp]),
     ("mrhip_reset", _i, [_vp]),
     ("mrhip_set_numerics", _i, [_vp, _i]),
+    ("mrhip_set_mod_form", _i, [_vp, _i]),
     ("mrhip_get_taps", _i, [_vp, _i, _vp]),
     ("mrhip_filt_device", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, _vp]),
     ("mrhip_filt_device_async", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
@@ -412,6 +413,13 @@ class FIRFilter:
             self.set_state(1, st.inputDeficit, acc)
             return acc
         raise MultirateHIPError(5, f"setphase is not defined for {self.kernel_name}")
+
+    def set_mod_form(self, julia03: bool):
+        """FIRArbitrary / FIRFarrow: update()'s mod() (src/Filters.jl:668) as rem(y + rem(x, y), y) -- Julia Base before 0.4 -- instead
+        of the exact remainder (``mrhip_set_mod_form``); identical for a power-of-two N𝜙."""
+        if self._handle is None:
+            raise MultirateHIPError(1, "set_mod_form needs a bound filter (call filt once, or bind())")
+        _check(self._lib.mrhip_set_mod_form(self._handle, 1 if julia03 else 0))
 
     def set_timing(self, enabled=True):
         """True/False, or an int n > 1 to bracket every n-th compute launch only."""

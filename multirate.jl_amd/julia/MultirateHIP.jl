@@ -15,7 +15,7 @@ module MultirateHIP
 export FIRFilter, FIRKernel, FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary, FIRFarrow,
        filt, filt!, taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, tapsforphase!, polyfit,
        firdes, firprototype, kaiserlength, kaiser, FIRResponse, LOWPASS, BANDPASS, HIGHPASS, BANDSTOP,
-       FilterCascade, filt_device!, filt_device_chunked!, scheduleinfo, advancestate!
+       FilterCascade, filt_device!, filt_device_chunked!, scheduleinfo, advancestate!, ChunkRing, pushchunks!, drain, ringinfo
 
 const libmr = get(ENV, "MRHIP_LIB_PATH", joinpath(@__DIR__, "..", "libmultirate_hip.so"))
 
@@ -26,15 +26,16 @@ dtypecode(::Type{Float64}) = MRHIP_F64
 dtypecode(::Type{ComplexF32}) = MRHIP_C64
 dtypecode(::Type{ComplexF64}) = MRHIP_C128
 
-# kernel kinds == the reference's FIRKernel subtypes (src/Filters.jl:15-117); kept as marker types so
-# that FIRFilter{FIRRational} etc. dispatch and print like the reference's
+# kernel kinds == the reference's FIRKernel subtypes (src/Filters.jl:15-117), PARAMETRIC in the tap type like theirs
+# (`type FIRRational{T} <: FIRKernel`, :62): user code that names FIRFilter{FIRRational{Float32}} loads and dispatches as it does
+# on the reference.  Marker types: the fields live behind the C ABI (see KernelProxy below).
 abstract type FIRKernel end
-struct FIRStandard <: FIRKernel end
-struct FIRDecimator <: FIRKernel end
-struct FIRInterpolator <: FIRKernel end
-struct FIRRational <: FIRKernel end
-struct FIRArbitrary <: FIRKernel end
-struct FIRFarrow <: FIRKernel end
+struct FIRStandard{T} <: FIRKernel end
+struct FIRDecimator{T} <: FIRKernel end
+struct FIRInterpolator{T} <: FIRKernel end
+struct FIRRational{T} <: FIRKernel end
+struct FIRArbitrary{T} <: FIRKernel end
+struct FIRFarrow{T} <: FIRKernel end
 const KINDS = (FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary, FIRFarrow)
 
 struct MRHIPState                      # mirror of `mrhip_state`
@@ -70,19 +71,19 @@ end
 # FIRFilter(h, resampleRatio::Rational = 1//1)            src/Filters.jl:158-180
 function FIRFilter(h::Vector{Th}, ratio::Rational = 1//1; device::Integer = 0) where {Th<:Union{Float32,Float64}}
     r = Rational{Int}(ratio)
-    f = FIRFilter{kindof(r)}(copy(h), r, 0.0, 0, -1, device, C_NULL, nothing, 0)
+    f = FIRFilter{kindof(r){Th}}(copy(h), r, 0.0, 0, -1, device, C_NULL, nothing, 0)
     finalizer(destroy!, f)
 end
 # FIRFilter(h, rate::AbstractFloat, Nphi = 32)            src/Filters.jl:183-189
 function FIRFilter(h::Vector{Th}, rate::AbstractFloat, Nphi::Integer = 32; device::Integer = 0) where {Th<:Union{Float32,Float64}}
     rate > 0.0 || error("rate must be greater than 0")
-    f = FIRFilter{FIRArbitrary}(copy(h), nothing, Float64(rate), Nphi, -1, device, C_NULL, nothing, 0)
+    f = FIRFilter{FIRArbitrary{Th}}(copy(h), nothing, Float64(rate), Nphi, -1, device, C_NULL, nothing, 0)
     finalizer(destroy!, f)
 end
 # FIRFilter(h, rate::AbstractFloat, Nphi, polyorder)      src/Filters.jl:192-198  (FIRFarrow)
 function FIRFilter(h::Vector{Th}, rate::AbstractFloat, Nphi::Integer, polyorder::Integer; device::Integer = 0) where {Th<:Union{Float32,Float64}}
     rate > 0.0 || error("rate must be greater than 0")
-    f = FIRFilter{FIRFarrow}(copy(h), nothing, Float64(rate), Nphi, polyorder, device, C_NULL, nothing, 0)
+    f = FIRFilter{FIRFarrow{Th}}(copy(h), nothing, Float64(rate), Nphi, polyorder, device, C_NULL, nothing, 0)
     finalizer(destroy!, f)
 end
 
@@ -140,7 +141,7 @@ function Base.getproperty(k::KernelProxy, name::Symbol)
     getfield(f, :handle) == C_NULL && error("the kernel fields need a bound filter (call filt once)")
     st = state(f)
     name === :inputDeficit ? Int(st.inputDeficit) :
-    name === Symbol("𝜙Idx") ? (f isa FIRFilter{FIRFarrow} ? st.phiAccumulator : Int(st.phiIdx)) :     # FIRFarrow.𝜙Idx is the Float64 phase (:131)
+    name === Symbol("𝜙Idx") ? (f isa FIRFilter{<:FIRFarrow} ? st.phiAccumulator : Int(st.phiIdx)) :     # FIRFarrow.𝜙Idx is the Float64 phase (:131)
     name === Symbol("𝜙Accumulator") ? st.phiAccumulator :
     name === Symbol("α") ? st.alpha :
     name === Symbol("Δ") ? st.delta :
@@ -161,7 +162,7 @@ function Base.setproperty!(k::KernelProxy, name::Symbol, v)
     if name === :inputDeficit
         setstate!(f, st.phiIdx, Int(v), st.phiAccumulator)
     elseif name === Symbol("𝜙Idx")
-        f isa FIRFilter{FIRFarrow} ? setstate!(f, 1, st.inputDeficit, Float64(v)) : setstate!(f, Int(v), st.inputDeficit, st.phiAccumulator)
+        f isa FIRFilter{<:FIRFarrow} ? setstate!(f, 1, st.inputDeficit, Float64(v)) : setstate!(f, Int(v), st.inputDeficit, st.phiAccumulator)
     elseif name === Symbol("𝜙Accumulator")
         setstate!(f, st.phiIdx, st.inputDeficit, Float64(v))
     elseif name === Symbol("α")                        # 𝜙Accumulator = 𝜙Idx + α (Filters.jl:671-672)
@@ -195,6 +196,11 @@ function reset(f::FIRFilter)
     f
 end
 
+# update()'s mod() (src/Filters.jl:668) as Julia Base before 0.4 computed it for floats (rem(y + rem(x, y), y)) instead of the exact
+# remainder: the reference is Julia-0.3 code; identical for a power-of-two N𝜙 (mrhip_set_mod_form)
+setmodform!(f::FIRFilter{Tk}, julia03::Bool) where {Tk<:Union{FIRArbitrary,FIRFarrow}} =
+    check(ccall((:mrhip_set_mod_form, libmr), Cint, (Ptr{Cvoid}, Cint), f.handle, julia03 ? 1 : 0))
+
 # polyfit(y, polyorder)                                    src/support.jl:85-88 (coefficients, ascending powers)
 function polyfit(y::AbstractVector, polyorder::Integer)
     yd = Vector{Float64}(y)
@@ -203,14 +209,14 @@ function polyfit(y::AbstractVector, polyorder::Integer)
     coef
 end
 # tapsforphase(kernel::FIRFarrow, phase)                   src/Filters.jl:764-775
-function tapsforphase(f::FIRFilter{FIRFarrow}, phase::Real)
+function tapsforphase(f::FIRFilter{<:FIRFarrow}, phase::Real)
     f.handle == C_NULL && error("tapsforphase needs a bound filter (call filt once)")
     taps = Vector{eltype(f.h)}(undef, state(f).tapsPerPhi)
     check(ccall((:mrhip_farrow_tapsforphase, libmr), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Cvoid}), f.handle, Float64(phase), taps))
     taps
 end
 # tapsforphase(kernel::FIRArbitrary, phase)                src/Filters.jl:677-690
-function tapsforphase(f::FIRFilter{FIRArbitrary}, phase::Real)
+function tapsforphase(f::FIRFilter{<:FIRArbitrary}, phase::Real)
     f.handle == C_NULL && error("tapsforphase needs a bound filter (call filt once)")
     taps = Vector{eltype(f.h)}(undef, state(f).tapsPerPhi)
     check(ccall((:mrhip_arbitrary_tapsforphase, libmr), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Cvoid}), f.handle, Float64(phase), taps))
@@ -236,7 +242,9 @@ end
 
 # setphase(self::FIRFilter, 𝜙), 𝜙 in [0, 1]                src/Filters.jl:210-235.  The reference's methods for
 # FIRInterpolator/FIRRational read an undefined variable (:212); implemented with the evident intent
-# (𝜙Idx = floor(𝜙*N𝜙)+1 clipped to N𝜙); FIRArbitrary and FIRFarrow as written (:217-229).
+# (𝜙Idx = floor(𝜙*N𝜙)+1 clipped to N𝜙).  FIRFarrow as written (:225-229).  FIRArbitrary: the reference sets 𝜙Idx and α and leaves
+# 𝜙Accumulator alone (:217-222) -- its next update() then overwrites both from the untouched accumulator; here the ACCUMULATOR is set
+# to 𝜙Idx + α (clamped into [1, N𝜙 + 1)), from which 𝜙Idx and α follow as update() derives them: the phase the call asked for survives.
 setstate!(f::FIRFilter, phiIdx::Integer, deficit::Integer, acc::Real) =
     check(ccall((:mrhip_set_state, libmr), Cint, (Ptr{Cvoid}, Int64, Int64, Cdouble), f.handle, phiIdx, deficit, Float64(acc)))
 function setphase(f::FIRFilter{Tk}, phi::Real) where {Tk<:Union{FIRInterpolator,FIRRational}}
@@ -244,12 +252,12 @@ function setphase(f::FIRFilter{Tk}, phi::Real) where {Tk<:Union{FIRInterpolator,
     st = state(f); idx = min(floor(Int, phi * st.Nphi) + 1, st.Nphi)
     setstate!(f, idx, st.inputDeficit, 1.0); idx
 end
-function setphase(f::FIRFilter{FIRArbitrary}, phi::Real)
+function setphase(f::FIRFilter{<:FIRArbitrary}, phi::Real)
     @assert 0 <= phi <= 1
     st = state(f); (alpha, idx) = modf(phi * st.Nphi)
     setstate!(f, 1, st.inputDeficit, clamp(idx + alpha, 1.0, prevfloat(st.Nphi + 1.0))); (idx, alpha)
 end
-function setphase(f::FIRFilter{FIRFarrow}, phi::Real)
+function setphase(f::FIRFilter{<:FIRFarrow}, phi::Real)
     @assert 0 <= phi <= 1
     st = state(f); acc = phi * (st.Nphi - 1) + 1
     setstate!(f, 1, st.inputDeficit, acc); acc
@@ -323,14 +331,14 @@ function filt!(buffer::VecOrMat{Tb}, f::FIRFilter{Tk}, x::VecOrMat{Tx}) where {T
     check(ccall((:mrhip_filt_host, libmr), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}),
                 f.handle, x, size(x, 1), size(x, 1), buffer, size(buffer, 1), size(buffer, 1), nw))
-    (Tk === FIRStandard || Tk === FIRInterpolator) ? buffer : Int(nw[])
+    (Tk <: FIRStandard || Tk <: FIRInterpolator) ? buffer : Int(nw[])
 end
 
 # filt(self, x): allocate, filt!, trim to the samples written (src/Filters.jl:475,519,577,633,744,841)
 function filt(f::FIRFilter{Tk}, x::VecOrMat{Tx}) where {Tk,Tx}
     bind!(f, Tx, size(x, 2))
     Tb = promote_out(eltype(f.h), Tx)
-    if Tk === FIRArbitrary || Tk === FIRFarrow
+    if Tk <: FIRArbitrary || Tk <: FIRFarrow
         # like the reference (:744-752, :841-849): allocate the outputlength estimate (+2, it is only a guess there) and
         # trim to the count filt! returns; the library pipelines the serial phase recurrence with the kernels
         cap = max(outputlength(f, size(x, 1)), 0) + 2
@@ -430,6 +438,50 @@ end
 function filt_device_chunked!(buffer, f::FIRFilter, x, chunk::Integer; stream::Ptr{Cvoid} = C_NULL)
     stride(x, 1) == 1 && stride(buffer, 1) == 1 || error("x and buffer must be contiguous along time (one channel per column)")
     filt_device_chunked!(f, devptr(buffer), size(buffer, 1), colstride(buffer), devptr(x), size(x, 1), colstride(x), chunk, eltype(x), size(x, 2); stream = stream)
+end
+
+# ---- a ring of arriving chunks (mrhip_ring_*): the streaming loop `for x_i in chunks; y_i = filt(f, x_i); end` (README.md:87-141) fed to ONE
+# resident kernel instead of one launch per chunk.  push! is filt!(y, f, x) for the next chunk on device arrays: it returns the
+# per-channel output count (the Int the reference's filt! returns) and the chunk's number at once; wait / drain block until outputs are
+# complete; close hands the stream (state, history) back to `f`.  x must be complete on the device when pushed.
+mutable struct ChunkRing
+    filter::FIRFilter
+    handle::Ptr{Cvoid}
+end
+function ChunkRing(f::FIRFilter, ::Type{Tx}, nch::Integer = 1) where {Tx}
+    bind!(f, Tx, nch)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mrhip_ring_open, libmr), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), f.handle, out))
+    r = ChunkRing(f, out[])
+    finalizer(close, r)
+end
+function Base.push!(r::ChunkRing, buffer, x)
+    stride(x, 1) == 1 && stride(buffer, 1) == 1 || error("x and buffer must be contiguous along time (one channel per column)")
+    nw = Ref{Int64}(0); seq = Ref{UInt64}(0)
+    check(ccall((:mrhip_ring_push, libmr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{UInt64}),
+                r.handle, devptr(x), size(x, 1), colstride(x), devptr(buffer), size(buffer, 1), colstride(buffer), nw, seq))
+    (Int(nw[]), seq[])
+end
+# the library's loop of push! over consecutive `chunk`-sample pieces of a device-resident signal, outputs back to back in `buffer`
+function pushchunks!(r::ChunkRing, buffer, x, chunk::Integer)
+    nw = Ref{Int64}(0); seq = Ref{UInt64}(0)
+    check(ccall((:mrhip_ring_push_chunks, libmr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{UInt64}),
+                r.handle, devptr(x), size(x, 1), colstride(x), chunk, devptr(buffer), size(buffer, 1), colstride(buffer), nw, seq))
+    (Int(nw[]), seq[])
+end
+Base.wait(r::ChunkRing, seq::Integer) = check(ccall((:mrhip_ring_wait, libmr), Cint, (Ptr{Cvoid}, UInt64), r.handle, UInt64(seq)))
+drain(r::ChunkRing) = check(ccall((:mrhip_ring_drain, libmr), Cint, (Ptr{Cvoid},), r.handle))
+function Base.close(r::ChunkRing)
+    r.handle == C_NULL || check(ccall((:mrhip_ring_close, libmr), Cint, (Ptr{Cvoid},), r.handle))
+    r.handle = C_NULL
+    nothing
+end
+function ringinfo(r::ChunkRing)
+    v = zeros(Int64, 6)
+    check(ccall((:mrhip_ring_info, libmr), Cint, (Ptr{Cvoid}, Ptr{Int64}, Cint), r.handle, v, 6))
+    (resident = v[1] != 0, depth = v[2], pushed = v[3], restarts = v[4], steps_per_grab = v[5], outputs_per_step = v[6])
 end
 
 # ---- cascades (mrhip_cascade_*): stages chained on the device, intermediates resident in HBM -------------------

@@ -353,3 +353,44 @@ def test_short_host_loop_call_moves_the_cycle_position_on(pkg, torch_cuda):
             got = o[:, :c[i]] if pat[i] else o
             assert got.shape == ref[i].shape and torch.equal(got, ref[i]), (pat, i)
         f.close()
+
+
+@pytest.mark.parametrize("Nphi,rate", [(10, float(np.pi / 3)), (7, 1.7), (12, 0.37), (32, float(np.pi / 3))])
+def test_mod_form_of_julia_0_3_in_the_product(pkg, O, Nphi, rate):
+    """update() wraps the phase accumulator with mod(acc - 1, N𝜙) (src/Filters.jl:668); Julia's Base before 0.4 computed a float
+    mod as rem(y + rem(x, y), y).  Oracle AND product run either form (mrhip_set_mod_form / oracle.set_mod_form): bit-equal outputs,
+    counts and end state in both; for a power-of-two N𝜙 the two forms are the same stream."""
+    import torch
+    rng = np.random.default_rng(Nphi)
+    h = (pkg.firdes(Nphi * 12, 0.45 / Nphi, beta=7.0) * Nphi).astype(np.float64)
+    x = rng.standard_normal(300_000)
+    got = {}
+    for form in (False, True):
+        O.set_mod_form(form)
+        try:
+            fo = O.FIRFilter(h, rate, Nphi, tx=np.float64)
+            ref = [fo.filt(x[:100_003]), fo.filt(x[100_003:])]
+            so = fo.state
+        finally:
+            O.set_mod_form(False)
+        f = pkg.FIRFilter(h, rate, Nphi, device=0).bind(np.float64, 1)
+        f.set_mod_form(form)
+        xd = torch.from_numpy(x).cuda()
+        y = [f.filt(xd[:100_003]).cpu().numpy(), f.filt(xd[100_003:]).cpu().numpy()]
+        for i in range(2):
+            assert_bit_equal(y[i], ref[i], f"N𝜙 {Nphi} rate {rate} form {int(form)} call {i}")
+        st = f.state
+        assert (st.inputDeficit, st.phiAccumulator) == (so.inputDeficit, so.phiAccumulator)
+        info = f.schedule_info()
+        if form and Nphi & (Nphi - 1):
+            assert info["device_pieces"] == 0, "the older mod() form runs the host's serial schedule"
+            with pytest.raises(pkg.MultirateHIPError, match="mod form 1"):
+                f.filt_into_async(torch.empty(f.outputlength_bound(1000), dtype=torch.float64, device="cuda"), xd[:1000])
+        got[form] = np.concatenate(y)
+        got[("acc", form)] = st.phiAccumulator
+        f.close()
+    if Nphi & (Nphi - 1) == 0:
+        assert_bit_equal(got[False], got[True], "power-of-two N𝜙: the two forms are one stream")
+    elif (Nphi, rate) != (12, 0.37):
+        assert got[("acc", False)] != got[("acc", True)] or got[False].shape != got[True].shape or not np.array_equal(got[False], got[True]), \
+            "the forms differ for this N𝜙 (DESIGN.md 3.4)"
