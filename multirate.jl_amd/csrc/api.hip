@@ -193,6 +193,72 @@ int check_create_args(const void *h, int64_t hLen, int th, int tx, int64_t nch, 
     return MRHIP_OK;
 }
 
+// Descriptor staging of the multi-stream launches a filter leads (mrhip_filt_device_multi; period blocks below): pinned host +
+// device memory, one event that guards the pinned half against the upload still in flight.
+int multi_staging(mrhip_filter *f, size_t bytes)
+{
+    if (bytes > f->multi_cap) {
+        if (f->multi_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->multi_ev)); f->multi_in_flight = false; }
+        if (int rc = drain_filter(f)) return rc;
+        if (f->multi_pin) (void)hipHostFree(f->multi_pin);
+        if (f->multi_dev) (void)hipFree(f->multi_dev);
+        f->multi_pin = f->multi_dev = nullptr; f->multi_cap = 0;
+        MRHIP_CHECK_HIP(hipHostMalloc(&f->multi_pin, bytes * 2, hipHostMallocDefault));
+        MRHIP_CHECK_HIP(hipMalloc(&f->multi_dev, bytes * 2));
+        f->multi_cap = bytes * 2;
+        if (!f->multi_ev) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->multi_ev, hipEventDisableTiming));
+    }
+    if (f->multi_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f->multi_ev)); f->multi_in_flight = false; }
+    return MRHIP_OK;
+}
+
+// FIRRational / FIRInterpolator with L > 512 on the output-pair kernel: one stream descriptor per BLOCK of the period
+// (kernels_rational_opair.hip: plan_rational_opair_blocks).  Block 0 carries the call's bookkeeping (record, shiftin!).
+hipError_t launch_opair_blocks(mrhip_filter *f, const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s, const char **kname, bool *launched)
+{
+    *launched = false;
+    PairArgs pa;
+    dim3 block;
+    size_t lds = 0;
+    int nblocks = 0;
+    if (!plan_rational_opair_blocks(tk, fused, a, f->num_cus, &pa, &block, &lds, &nblocks)) return hipSuccess;
+    const size_t bytes = static_cast<size_t>(nblocks) * sizeof(MultiDesc);
+    if (multi_staging(f, bytes) != MRHIP_OK) return hipErrorOutOfMemory;
+    MultiDesc *d = static_cast<MultiDesc *>(f->multi_pin);
+    const size_t osz = dtype_scalar_size(f->ty) * static_cast<size_t>(f->nc);
+    unsigned steps_max = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        MultiDesc &m = d[b];
+        const long long first = static_cast<long long>(b) * pa.P;                      // the block's first output within the period
+        const long long Pb = std::min<long long>(pa.P, static_cast<long long>(pa.Sout) - first);
+        const long long n_rel = a.n_out - first;                                         // outputs from the block's first one on
+        const long long spc = n_rel > 0 ? (n_rel + pa.Sout - 1) / pa.Sout : 0;
+        const long long u0b = a.u0 + first * a.M;
+        m.x = a.x; m.y = static_cast<unsigned char *>(a.y) + static_cast<size_t>(first) * osz;
+        m.hist = a.hist; m.hist_new = a.hist_new; m.taps = a.taps; m.rec = b == 0 ? a.rec : nullptr;
+        m.x_stride = a.x_stride; m.y_stride = a.y_stride; m.x_len = a.x_len; m.n_out = std::max<long long>(n_rel, 0);
+        m.u0 = u0b; m.d0 = a.d0; m.phi_end = a.phi_end; m.d_end = a.d_end;
+        m.steps_per_channel = static_cast<unsigned>(std::max<long long>(spc, 1));
+        m.total_steps = static_cast<unsigned>(spc * a.nch);
+        m.spc_magic = spc <= 1 ? 0xffffffffu : static_cast<unsigned>((1ULL << 32) / static_cast<unsigned long long>(spc));
+        m.nch = b == 0 ? a.nch : 0;                                                      // (shiftin! and the record: once per call)
+        m.P_blk = static_cast<int>(Pb);
+        m.q0 = static_cast<int>((u0b / a.L) & ~1LL);                                    // even: the lanes' run starts keep their parity
+        steps_max = std::max(steps_max, m.total_steps);
+    }
+    hipError_t e = hipMemcpyAsync(f->multi_dev, f->multi_pin, bytes, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(f->multi_ev, s);
+    if (e != hipSuccess) return e;
+    f->multi_in_flight = true;
+    PolyArgs am = a;
+    am.multi = static_cast<const MultiDesc *>(f->multi_dev); am.multi_n = nblocks;
+    pa.total_steps = steps_max;
+    e = launch_rational_opair(fused, am, pa, block, lds, s, kname, f->num_cus, f->d_counters);
+    *launched = e == hipSuccess;
+    return e;
+}
+
 // Kernel selection for the rational family.  Tuned kernels are tried first; the universal
 // one-thread-per-output kernel accepts everything.
 hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s,
@@ -220,6 +286,10 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
                 *did_shiftin = a.H > 0;
                 return launch_rational_opair(fused, a, pa, block, lds, s, kname, f->num_cus, counters);
             }
+            bool launched = false;                 // L > 512: a workgroup per block of the period
+            const hipError_t eb = launch_opair_blocks(const_cast<mrhip_filter *>(f), tk, fused, a, s, kname, &launched);
+            if (eb != hipSuccess) return eb;
+            if (launched) { *rec_written = true; *did_shiftin = a.H > 0; return hipSuccess; }
         }
         TileArgs ta;
         dim3 grid, block;
@@ -1454,18 +1524,7 @@ int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *con
     if (!(column ? plan_fir_stream(tk, a, f0->num_cus, &pa, &block, &lds) : plan_rational_opair(tk, fused, a, f0->num_cus, &pa, &block, &lds))) return single_calls();
     // descriptors: pinned staging -> device, owned by the first filter of the call
     const size_t bytes = static_cast<size_t>(n) * sizeof(MultiDesc);
-    if (bytes > f0->multi_cap) {
-        if (f0->multi_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f0->multi_ev)); f0->multi_in_flight = false; }
-        if (int rc = drain_filter(f0)) return rc;
-        if (f0->multi_pin) (void)hipHostFree(f0->multi_pin);
-        if (f0->multi_dev) (void)hipFree(f0->multi_dev);
-        f0->multi_pin = f0->multi_dev = nullptr; f0->multi_cap = 0;
-        MRHIP_CHECK_HIP(hipHostMalloc(&f0->multi_pin, bytes * 2, hipHostMallocDefault));
-        MRHIP_CHECK_HIP(hipMalloc(&f0->multi_dev, bytes * 2));
-        f0->multi_cap = bytes * 2;
-        if (!f0->multi_ev) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f0->multi_ev, hipEventDisableTiming));
-    }
-    if (f0->multi_in_flight) { MRHIP_CHECK_HIP(hipEventSynchronize(f0->multi_ev)); f0->multi_in_flight = false; }
+    if (int rc = multi_staging(f0, bytes)) return rc;
     MultiDesc *d = static_cast<MultiDesc *>(f0->multi_pin);
     unsigned steps_max = 0;
     for (int i = 0; i < n; ++i) {
@@ -1482,6 +1541,7 @@ int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *con
         m.total_steps = static_cast<unsigned>(spc * f->nch);
         m.spc_magic = spc <= 1 ? 0xffffffffu : static_cast<unsigned>((1ULL << 32) / static_cast<unsigned long long>(spc));
         m.nch = static_cast<int>(f->nch);
+        m.P_blk = 0; m.q0 = 0;
         steps_max = std::max(steps_max, m.total_steps);
     }
     MRHIP_CHECK_HIP(hipMemcpyAsync(f0->multi_dev, f0->multi_pin, bytes, hipMemcpyHostToDevice, stream));

@@ -149,6 +149,7 @@ bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int n
     if (nslots > max_slots || ns * stage_bytes > 156 * 1024) return false;
     PairArgs pa{};
     pa.c = c; pa.P = static_cast<int>(cL); pa.cM = static_cast<int>(cM);
+    pa.Sout = pa.P; pa.lds_step = pa.cM; pa.run_chunks = 0; pa.q0 = 0; pa.run_magic = 0;
     pa.J = static_cast<int>(J);
     pa.tile_len = static_cast<int>(tile_len);
     pa.tail = tail;
@@ -179,6 +180,96 @@ bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int n
     *out = pa;
     *block = dim3(static_cast<unsigned>(padded + 64));   // + the loader wave
     *lds = ns * stage_bytes + 8 * ns;
+    return true;
+}
+
+// L > 512 (625//512, 1000//999, 640//441: ordinary clock-trim ratios): a lane pair per output pair of the whole period no longer fits a
+// workgroup.  The period of 2L outputs (2M input positions: both even, so the lanes' runs keep their parity from step to step) is cut into
+// `nblocks` BLOCKS of P consecutive outputs; a workgroup owns ONE block for its whole life -- phase-stationary as before: output
+// b*P + t of every period has phase (u0 + (b*P + t)*M) mod L -- and walks the periods: steps are 2L outputs apart in y and 2M samples
+// apart in x, of which the block's windows touch one run of about P*M/L + T samples: only that run is staged (pair_loader.h:
+// stage_runs), packed in LDS.  Blocks ride on the multi-stream machinery (group = block: MultiDesc::P_blk, q0; api.hip fills one
+// descriptor per block and call).  Same slots, same order, same roundings as every other shape of the kernel.
+bool plan_rational_opair_blocks(const TypeKey &tk, bool fused, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds, int *nblocks_out)
+{
+    if (!opair_env_int("MRHIP_OPAIR", 1) || !opair_env_int("MRHIP_OPAIR_BLOCKS", 1)) return false;
+    if (tk.x_f64 && !tk.r_f64) return false;
+    if (a.L <= 512 || a.L > 4096 || a.M < 1 || a.zero_start_below > 0 || a.dyn || a.multi) return false;
+    const int smin = static_cast<int>(a.M / a.L);
+    if (smin > 1 || !opair_instantiated(fused, smin, a.T)) return false;
+    if (a.T < 1 || a.T > (tk.r_f64 ? (tk.complex_x ? 32 : 48) : 64)) return false;
+#ifdef MRHIP_PS_FAST_BUILD
+    if (a.T != 24) return false;
+#endif
+    const int nc = tk.complex_x ? 2 : 1;
+    const long long es = (tk.x_f64 ? 8 : 4) * nc;
+    const int epc = static_cast<int>(16 / es) > 0 ? static_cast<int>(16 / es) : 1;     // samples per 16-byte chunk
+    const long long Sout = 2LL * a.L, Sin = 2LL * a.M;
+    // lanes per workgroup: up to seven compute waves (Float64 arithmetic with many taps: fewer registers, see plan_rational_opair)
+    int max_lanes = opair_env_int("MRHIP_OPAIR_BLK_LANES", 0);
+    if (max_lanes < 64 || max_lanes > 448) max_lanes = tk.r_f64 ? 320 : 448;
+    int nblocks = static_cast<int>((Sout / 2 + max_lanes - 1) / max_lanes);
+    if (nblocks < 2) nblocks = 2;
+    long long P = (Sout + nblocks - 1) / nblocks;
+    P = (P + 1) / 2 * 2;
+    nblocks = static_cast<int>((Sout + P - 1) / P);
+    const int lanes = static_cast<int>(P / 2), padded = (lanes + 63) / 64 * 64, nwaves = padded / 64;
+    if (tk.r_f64 && a.T > 32 && nwaves > 7) return false;
+    // the run a block's lanes touch within one step: window starts span floor(((P - 2) * M + L - 1) / L) + 1 samples, + the run of a lane
+    // (T + smin + 2), + 2 for the even rounding of the block's base and of the lanes' run starts
+    long long span = ((P - 2) * a.M + a.L - 1) / a.L + 1 + a.T + smin + 2 + 2;
+    const long long rc = (span + epc - 1) / epc;                           // chunks per run
+    long long lds_step = rc * epc;
+    // (lds_step is even whenever a ring unit holds two samples (epc >= 2): the lanes' aligned reads keep their parity from step to step;
+    //  ComplexF64 -- one sample per 16-byte read -- has no parity to keep)
+    const int vgpr_est = (2 * a.T + (nc == 2 ? 36 : 30) + 7) / 8 * 8;
+    const int waves_per_cu = tk.r_f64 ? 12 : 4 * std::min(8, 512 / vgpr_est);
+    int wg_per_cu = std::max(1, std::min(4, waves_per_cu / (nwaves + 1)));
+    if (nwaves + 1 == 6 && !tk.r_f64) wg_per_cu = 3;
+    const int ns = wg_per_cu == 1 ? 3 : 2;
+    const long long budget = ((wg_per_cu <= 3 ? 150 : 160) * 1024 / wg_per_cu - 64) / ns;
+    long long J = budget / (lds_step * es);
+    if (const int env_j = opair_env_int("MRHIP_OPAIR_J", 0); env_j > 0) J = env_j;
+    if (J > 64) J = 64;
+    if (J < 1) return false;
+    const long long max_slots = 60 / (ns > 2 ? ns - 2 : 1);
+    auto slots_for = [&](long long j) { return (j * rc + 63) / 64; };
+    while (J > 1 && slots_for(J) > max_slots) --J;
+    {   // small problems: enough tiles to give every CU a few workgroups
+        const long long want_tiles = 4LL * num_cus;
+        const long long spc0 = (a.n_out + Sout - 1) / Sout;
+        while (J > 2 && ((spc0 + J - 1) / J) * a.nch * nblocks < want_tiles) J = (J + 1) / 2;
+    }
+    const long long nslots = slots_for(J);
+    const size_t stage_bytes = static_cast<size_t>(nslots) * 1024;
+    if (nslots > max_slots || ns * stage_bytes > 156 * 1024) return false;
+    const long long spc = (a.n_out + Sout - 1) / Sout;
+    if (spc * a.nch >= (1LL << 31) || a.n_out >= (1LL << 31) - Sout * J) return false;
+    if ((a.u0 + Sout * a.M) >= (1LL << 31)) return false;                   // 32-bit phase arithmetic in the kernel
+    PairArgs pa{};
+    pa.c = 2; pa.P = static_cast<int>(P); pa.cM = static_cast<int>(Sin);
+    pa.Sout = static_cast<int>(Sout); pa.lds_step = static_cast<int>(lds_step); pa.run_chunks = static_cast<int>(rc); pa.q0 = 0;
+    pa.run_magic = static_cast<unsigned>(0xffffffffu / static_cast<unsigned>(rc) + 1u);
+    pa.J = static_cast<int>(J);
+    pa.tile_len = static_cast<int>(J * lds_step);
+    pa.tail = a.T + smin + 4;
+    pa.dma_rounds = static_cast<int>(nslots);
+    pa.stage_bytes = static_cast<int>(stage_bytes);
+    pa.ns = ns; pa.nc = nc;
+    pa.x_f64 = tk.x_f64 ? 1 : 0; pa.r_f64 = tk.r_f64 ? 1 : 0;
+    pa.o0 = a.d0 - a.T;
+    pa.tile_in = J * Sin; pa.tile_out = J * Sout;
+    pa.tiles_per_channel = (a.n_out + pa.tile_out - 1) / pa.tile_out;
+    pa.total_tiles = pa.tiles_per_channel * a.nch * nblocks;
+    pa.steps_per_channel = static_cast<unsigned>(spc);
+    pa.total_steps = static_cast<unsigned>(spc * a.nch);
+    pa.spc_magic = spc <= 1 ? 0xffffffffu : static_cast<unsigned>((1ULL << 32) / static_cast<unsigned long long>(spc));
+    pa.flags_off = static_cast<int>(ns * stage_bytes);
+    pa.bank_off = -1;                                                       // (a bank of L > 512 columns does not fit a stage: the two columns of a lane come straight from global memory, once per workgroup)
+    *out = pa;
+    *block = dim3(static_cast<unsigned>(padded + 64));
+    *lds = ns * stage_bytes + 8 * ns;
+    *nblocks_out = nblocks;
     return true;
 }
 

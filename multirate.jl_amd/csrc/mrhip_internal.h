@@ -281,6 +281,9 @@ struct MultiDesc {           // one independent stream (one FIRFilter of the ref
     long long x_stride, y_stride, x_len, n_out, u0, d0, phi_end, d_end;
     unsigned steps_per_channel, total_steps, spc_magic;
     int nch;
+    // PERIOD BLOCKS (rational_opair_kernel for L > 512, kernels_rational_opair.hip: plan_rational_opair_blocks): the "stream" is one
+    // block of P_blk consecutive outputs of every period of 2L; q0 = first sample of the block's sub-range of a step's input
+    int P_blk, q0;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -416,6 +419,11 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     int rt_rd;
     unsigned *counters;           // device: [g*64] next grab of group g, [ngroups*64] workgroups finished (re-arms all)
     unsigned spc_magic;           // floor(2^32 / steps_per_channel) (0xffffffff for 1): step number -> channel by multiply-high
+    // steps of a workgroup are Sout outputs apart in y and lds_step samples apart in LDS (P and cM unless the workgroup works on a
+    // BLOCK of the period: L > 512); run_chunks > 0: a tile is staged as one run of run_chunks 16-byte chunks PER STEP, cM samples apart
+    // in the signal and packed in LDS (run_magic = ceil(2^32 / run_chunks)); q0: first sample of the block's runs within a step's input
+    int Sout, lds_step, run_chunks, q0;
+    unsigned run_magic;
     long long o0;            // d0 - T: x index of LDS sample 0 of tile 0 (negative => history)
     long long tile_in;       // J*c*M
     long long tile_out;      // J*c*L
@@ -516,6 +524,7 @@ hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
 // least-squares polynomial fit of y[0..n) at x = 1..n (support.jl:85-88); coef receives polyorder+1 ascending powers
 bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef);
 bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
+bool plan_rational_opair_blocks(const TypeKey &tk, bool fused, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds, int *nblocks);   // L > 512: a workgroup owns a block of the period
 hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                                  const char **kname, int num_cus, unsigned *counters);   // FIRRational and FIRInterpolator, two outputs per lane; also performs shiftin!
 // rational_opair_kernel: STRICT (the product: bit-identical to the reference) is instantiated for every tapsPerPhi of every M/L class;

@@ -39,6 +39,7 @@ __device__ __forceinline__ void pair_take_dyn(PolyArgs &a, PairArgs &pa)
         a.x_stride = d->x_stride; a.y_stride = d->y_stride; a.x_len = d->x_len; a.n_out = d->n_out;
         a.u0 = d->u0; a.d0 = d->d0; a.phi_end = d->phi_end; a.d_end = d->d_end; a.nch = d->nch;
         pa.o0 = d->d0 - a.T;
+        if (d->P_blk > 0) { pa.P = d->P_blk; pa.q0 = d->q0; pa.o0 += d->q0; }   // a block of the period (L > 512): its outputs, its sub-range of the input
         pa.steps_per_channel = d->steps_per_channel;
         pa.total_steps = d->total_steps;
         pa.spc_magic = d->spc_magic;
@@ -69,10 +70,13 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
     // Stages one tile; returns the number of LDS-DMA operations it left in flight (0 for the
     // checked register path, which drains everything before returning).
     const unsigned pad_magic = pa.pad_every > 0 ? 0xffffffffu / static_cast<unsigned>(pa.pad_every + 1) + 1u : 0u;   // ceil(2^32 / (cd + 1)) (cd + 1 is no power of two's divisor issue: cd + 1 >= 3 odd)
+    // (pa.run_chunks = rc > 0: the workgroup owns a BLOCK of the period (L > 512) and stages, per step, only the run of samples its
+    //  lanes' windows touch: ta.jt runs of rc chunks, pa.cM samples apart in the signal, packed in LDS)
     auto stage_tile = [&](const TileAt &ta, int stage) -> int {
         const int sch = ta.ch;
         constexpr int EPC = 4 / NC;                                 // samples per 16-byte DMA chunk
-        const int tlen = (ta.jt * pa.cM + pa.tail + EPC - 1) / EPC * EPC;   // samples this tile needs, whole chunks
+        const int rc = pa.run_chunks;
+        const int tlen = rc > 0 ? ta.jt * rc * EPC : (ta.jt * pa.cM + pa.tail + EPC - 1) / EPC * EPC;   // samples this tile stages, whole chunks
         const int nchunks = tlen / EPC;
         // pa.pad_every = cd > 0: one 16-byte pad chunk after every cd data chunks (data chunk d lives at LDS chunk
         // d + d / cd), so that lanes whose runs start cd chunks apart hit different banks (kernels_fir_stream.hip)
@@ -82,7 +86,16 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
         const float *__restrict__ xc = static_cast<const float *>(a.x) + static_cast<long long>(sch) * a.x_stride * NC;
         const long long o = pa.o0 + static_cast<long long>(ta.st) * pa.cM;   // x index of LDS sample 0 (may be < 0)
         unsigned char *st = smem + static_cast<size_t>(stage) * pa.stage_bytes;
-        const bool interior = o >= 0 && o + tlen <= a.x_len;             // wave-uniform
+        const long long o_end = rc > 0 ? o + static_cast<long long>(ta.jt - 1) * pa.cM + rc * EPC : o + tlen;
+        const bool interior = o >= 0 && o_end <= a.x_len;                // wave-uniform
+        // chunk number within the staged tile -> sample offset from o (runs: chunk / rc by multiply-high, exact below 2^16 chunks)
+        auto chunk_sample = [&](int c) -> long long {
+            if (rc <= 0) return static_cast<long long>(EPC) * c;
+            unsigned j = __umulhi(static_cast<unsigned>(c), pa.run_magic);
+            int w = c - static_cast<int>(j) * rc;
+            if (w < 0) { --j; w += rc; }
+            return static_cast<long long>(j) * pa.cM + static_cast<long long>(EPC) * w;
+        };
         if (interior) {
             const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
             for (int slot = 0; slot < nslots; ++slot) {
@@ -93,7 +106,7 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
                 //  compute wave: a third of C3b's VALU instructions were this, profiles/r04/item7/)
                 if (cd > 0) { const int g = static_cast<int>(__umulhi(static_cast<unsigned>(ci), pad_magic)), r = ci - g * (cd + 1); d = r == cd ? 0 : g * cd + r; }
                 const int cis = d < nchunks ? d : 0;                     // pad chunks and padding lanes re-read chunk 0
-                dma16(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
+                dma16(src + static_cast<size_t>(chunk_sample(cis)) * (NC * 4u), st + static_cast<size_t>(slot) * 1024);
             }
             return nslots;
         }
@@ -103,9 +116,10 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
         for (int ci = lane; ci < nchunks; ci += 64) {
             float4 v;
             float *pv = reinterpret_cast<float *>(&v);
+            const long long g0 = o + chunk_sample(ci);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                const long long gi = o + static_cast<long long>(EPC) * ci + e;
+                const long long gi = g0 + e;
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) {
                     float val = 0.f;
@@ -564,8 +578,8 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         if (lane == 0) {
             volatile unsigned *t = td + kRingTileWords * stage;
             const unsigned long long yaddr = c_y + (static_cast<unsigned long long>(ta.ch) * static_cast<unsigned long long>(c_ys) +
-                                                    static_cast<unsigned long long>(ta.st) * static_cast<unsigned>(pa.P)) * OS;
-            const long long rem = c_nout - static_cast<long long>(ta.st) * pa.P;
+                                                    static_cast<unsigned long long>(ta.st) * static_cast<unsigned>(pa.Sout)) * OS;
+            const long long rem = c_nout - static_cast<long long>(ta.st) * pa.Sout;
             t[0] = static_cast<unsigned>(ta.jt);
             t[1] = ra + static_cast<unsigned>(ta.jt) >= rb ? 1u : 0u;
             t[2] = static_cast<unsigned>(yaddr & 0xffffffffull); t[3] = static_cast<unsigned>(yaddr >> 32);

@@ -119,7 +119,7 @@ DEFAULT_ROWS = ["c1", "c2", "c2s", "c3a", "c3b", "c4", "c4f", "c5", "x160", "xf6
 # what bench.py reports next to the headline: every BASELINE config on one GPU, the README's mixed precision, the reference's
 # own FIRArbitrary / FIRFarrow benchmark shape
 # (the BASELINE rows LAST: the driver's record keeps the END of the line)
-BENCH_ROWS = ["xarb", "af", "xdec", "ms", "xmix64", "c1", "c2", "c2s", "c2r", "c3a", "c3b", "c4", "c4f", "c5"]
+BENCH_ROWS = ["xarb", "af", "xdec", "xlarge", "ms", "xmix64", "c1", "c2", "c2s", "c2r", "c3a", "c3b", "c4", "c4f", "c5"]
 # the opt-in FUSED numerics (one fma per tap, same order) for the BASELINE rows: bench.py reports them under `fused`
 FUSED_ROWS = ["c3a", "c3b", "c4", "c5"]
 
@@ -199,6 +199,12 @@ def rows(which):
             hd = pkg.firdes(128, 0.5 / M, beta=7.8562).astype(np.float32)
             nc = 2 if dt == torch.complex64 else 1
             run(f"X decimator 1//{M} 128 taps {nm} 64ch x 4e6", hd, Fraction(1, M), 32, 64, 4_000_000, dt, es + es / M, nc * 2 * 128 / M)
+
+    def _xlarge():
+        # L > 512: ordinary clock-trim ratios (1-14 % of the roofline on poly_tiled / poly_generic): the output-pair kernel in period blocks
+        for L_, M_ in ((625, 512), (1000, 999), (640, 441), (4096, 4095)):
+            hl = pkg.firdes(24 * L_, 0.5 / max(L_, M_), beta=7.8562).astype(np.float32)
+            run(f"X rational {L_}//{M_} 24 taps per phase f32 64ch x 1e6", hl, Fraction(L_, M_), 32, 64, 1_000_000, torch.float32, 4 + 4 * L_ / M_, 48 * L_ / M_)
 
     # shapes outside BASELINE.json (where the non-headline kernels stand)
     def _x160():
@@ -299,7 +305,7 @@ def rows(which):
         for f in fs:
             f.close()
 
-    table = {"ms": _ms, "c1": _c1, "c2": _c2, "c2s": _c2s, "c2r": _c2r, "c3a": _c3a, "c3b": _c3b, "c4": _c4, "c4f": _c4f, "c5": _c5, "x160": _x160, "xf64": _xf64, "xmix": _xmix, "xstd": _xstd, "x32": _x32, "xc32": _xc32, "xarb": _xarb, "xmix64": _xmix64, "af": _af, "xdec": _xdec}
+    table = {"ms": _ms, "c1": _c1, "c2": _c2, "c2s": _c2s, "c2r": _c2r, "c3a": _c3a, "c3b": _c3b, "c4": _c4, "c4f": _c4f, "c5": _c5, "x160": _x160, "xf64": _xf64, "xmix": _xmix, "xstd": _xstd, "x32": _x32, "xc32": _xc32, "xarb": _xarb, "xmix64": _xmix64, "af": _af, "xdec": _xdec, "xlarge": _xlarge}
     for name in which:                # in the order asked for (bench.py wants the BASELINE rows last)
         table[name]()
 

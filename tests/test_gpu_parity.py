@@ -1320,3 +1320,50 @@ def test_arb_pipe_exact_32_taps(pkg, O, torch_cuda, monkeypatch):
                     fo = O.FIRFilter(h, float(rate), Nphi, tx=tx)
                     yo = np.concatenate(_run_chunks(fo, x[nch - 1], sizes))
                     assert_bit_equal(ys["exact"][0][nch - 1], yo, "unrolled vs oracle " + tag)
+
+
+def test_large_L_runs_on_the_output_pair_kernel_in_period_blocks(pkg, O, torch_cuda, monkeypatch):
+    """L > 512 (625//512, 1000//999, 640//441: ordinary clock-trim ratios) used to fall off the tuned kernels onto poly_tiled /
+    poly_generic at 1-9 % of the HBM roofline.  The output-pair kernel now cuts the period of 2L outputs into BLOCKS, one workgroup
+    per block for its whole life (kernels_rational_opair.hip: plan_rational_opair_blocks): outputs, end state and history must be
+    bit for bit those of the universal kernel and of the oracle -- every tap / sample type, a prime L (ragged last block), L just
+    above the old limit, the largest L, chunkings that change the phase every call, a chunk shorter than the history, and the
+    special values (-0.0, +-Inf, NaN) the exact no-op slots must not disturb."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    cases = [(625, 512, 24, np.float32, np.float32, 3), (1000, 999, 24, np.float32, np.float32, 2), (640, 441, 24, np.float32, np.complex64, 2),
+             (1009, 1000, 24, np.float32, np.float32, 1), (513, 512, 32, np.float32, np.float32, 2), (999, 1000, 24, np.float64, np.float32, 2),
+             (1000, 999, 24, np.float64, np.float64, 1), (640, 441, 16, np.float64, np.complex128, 1), (4096, 4095, 24, np.float32, np.float32, 1),
+             (2048, 1375, 7, np.float32, np.complex64, 2), (779, 1400, 24, np.float32, np.float32, 2)]
+    for (L, M, T, th, tx, nch) in cases:
+        h = (rng.standard_normal(T * L) / 8).astype(th)
+        n = 120_000
+        x = _rand(rng, (nch, n), tx) - 0.5
+        flat = x.view(np.float32 if np.dtype(tx).itemsize // (2 if np.dtype(tx).kind == "c" else 1) == 4 else np.float64)
+        flat[0, 5] = -0.0; flat[0, 1000] = np.inf; flat[0, 1001] = -np.inf; flat[0, 70_000] = np.nan
+        xd = torch.from_numpy(x).cuda()
+        sizes = [40_009, 3, 1, 30_011, n - 70_024]
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        f = pkg.FIRFilter(h, Fraction(L, M))
+        y_t = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+        assert f.last_kernel_name() == "rational_opair_kernel", (L, M, T, f.last_kernel_name())
+        monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+        g = pkg.FIRFilter(h, Fraction(L, M))
+        y_g = torch.cat(_run_chunks(g, xd, sizes), dim=-1).cpu().numpy()
+        assert g.last_kernel_name() == "poly_generic_kernel"
+        monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+        assert_bit_equal(y_t, y_g, f"blocks vs universal kernel L={L} M={M} T={T} {th} {tx}")
+        assert_bit_equal(f.history, g.history, "history")
+        assert (f.state.phiIdx, f.state.inputDeficit) == (g.state.phiIdx, g.state.inputDeficit)
+        fo = O.FIRFilter(h, Fraction(L, M), tx=tx)
+        pos, ref = 0, []
+        for s_ in sizes:
+            ref.append(fo.filt(x[0, pos:pos + s_])); pos += s_
+        # (NaN payloads / signs are the host FPU's on the oracle side: NaNs in the same places, everything else bit for bit)
+        want = np.concatenate(ref)
+        ft = np.float64 if want.dtype in (np.float64, np.complex128) else np.float32
+        got_r, want_r = np.ascontiguousarray(y_t.reshape(nch, -1)[0]).view(ft), want.view(ft)
+        assert np.array_equal(np.isnan(got_r), np.isnan(want_r)), f"NaN positions L={L} M={M}"
+        assert_bit_equal(got_r[~np.isnan(want_r)], want_r[~np.isnan(want_r)], f"blocks vs oracle L={L} M={M}")
+        assert (f.state.phiIdx, f.state.inputDeficit) == (fo.state.phiIdx, fo.state.inputDeficit)
+        f.close(); g.close()
