@@ -374,6 +374,42 @@ int mrhip_ring_close(mrhip_ring *r);
  * idle deadline; [4] steps per grab; [5] outputs per step */
 int mrhip_ring_info(const mrhip_ring *r, int64_t *info, int n);
 
+/* ---- one FIRFilter whose channels are split over several GPUs (BASELINE.json config 5) ------------------------ */
+/* replaces filt(self, x) (src/Filters.jl:577-587 and its siblings :475,519,633,744,841) for a multi-channel signal -- in the
+ * reference: one FIRFilter per channel, nothing shared but the read-only taps -- split by CHANNEL over `ndevices` GPUs of one
+ * process: shard i is an ordinary filter on devices[i] with channels [start_i, start_i + count_i) (contiguous; the first
+ * nchannels % ndevices shards take one channel more), a stream of its own, and no exchange with the others during compute.  The
+ * only traffic between devices is the final gather of the outputs (mrhip_sharded_gather: peer copies over xGMI on the shards'
+ * streams).  The same device may be named more than once (two shards on one GPU).
+ * ctor selects the reference constructor: 0 = FIRFilter(h, num//den) (:158), 1 = FIRFilter(h, rate, Nphi) (:183),
+ * 2 = FIRFilter(h, rate, Nphi, polyorder) (:192); arguments a constructor does not take are ignored. */
+typedef struct mrhip_sharded mrhip_sharded;
+int mrhip_sharded_create(int ctor, const void *h, int64_t hLen, int tap_dtype, int64_t num, int64_t den, double rate, int64_t Nphi,
+                         int64_t polyorder, int sample_dtype, int64_t nchannels, const int *devices, int ndevices, mrhip_sharded **out);
+void mrhip_sharded_destroy(mrhip_sharded *s);
+int mrhip_sharded_nshards(const mrhip_sharded *s);
+/* shard i: first channel, channel count, device, and the shard's filter itself (borrowed: state, history, timing ... through the
+ * ordinary entry points; NULL for a shard without channels); any of the four may be NULL */
+int mrhip_sharded_shard(const mrhip_sharded *s, int i, int64_t *start, int64_t *count, int *device, mrhip_filter **filter);
+/* outputlength / the exact count of the next call (the state machine is data independent: every shard agrees) / reset */
+int64_t mrhip_sharded_outputlength(const mrhip_sharded *s, int64_t inputlength);
+int64_t mrhip_sharded_next_output_count(const mrhip_sharded *s, int64_t inputlength);
+int mrhip_sharded_reset(mrhip_sharded *s);
+/* filt!(buffer, self, x) with device-resident data: x[i] / y[i] are device pointers ON SHARD i's DEVICE holding its count_i channels
+ * (channel c at + c * stride[i]; NULL strides: x_len / y_capacity); same contract as mrhip_filt_device per shard, each on the
+ * shard's own stream (asynchronous: mrhip_sharded_synchronize waits for all); *n_written = the per-channel count. */
+int mrhip_sharded_filt_device(mrhip_sharded *s, const void *const *x, int64_t x_len, const int64_t *x_stride, void *const *y, int64_t y_capacity,
+                              const int64_t *y_stride, int64_t *n_written);
+/* filt!(buffer, self, X) for a HOST matrix with one channel per column (Julia's layout; x_stride / y_stride in samples): the columns
+ * are split over the shards, one host thread per shard runs its copies and kernels (mrhip_filt_host), all devices at once; blocks
+ * until y holds every channel's outputs.  What the Julia shim's filt(::ShardedFIRFilter, X::Matrix) calls. */
+int mrhip_sharded_filt_host(mrhip_sharded *s, const void *x, int64_t x_len, int64_t x_stride, void *y, int64_t y_capacity, int64_t y_stride,
+                            int64_t *n_written);
+/* the final gather: rows [start_i, start_i + count_i) of a (nchannels x n_out) result at `dst` on `dst_device` (row stride dst_stride
+ * samples) from y[i] on shard i's device, asynchronous on the shards' streams behind their filter kernels */
+int mrhip_sharded_gather(mrhip_sharded *s, const void *const *y, int64_t n_out, const int64_t *y_stride, void *dst, int64_t dst_stride, int dst_device);
+int mrhip_sharded_synchronize(mrhip_sharded *s);
+
 /* replaces the stateless filt(h, x, ratio), src/Filters.jl:858-861, and
  * filt(h, x, rate, Nphi), :864-867, for host data, one channel: construct, filter once,
  * destroy.  rate <= 0 selects the rational form with num//den; rate > 0 the arbitrary form. */

@@ -23,6 +23,7 @@ from .host import (  # noqa: F401
     MultirateHIPError,
     NUMERICS_FUSED,
     NUMERICS_STRICT,
+    ShardedFIRFilter,
     filt,
     filt_,
     filt_multi,
@@ -42,7 +43,7 @@ from .design import (BANDPASS, BANDSTOP, HIGHPASS, LOWPASS, firdes, firprototype
 from .sharding import ChannelShardedFilter, TimeShardedFilter, shard_channels, shard_time  # noqa: F401
 
 __all__ = [
-    "FIRFilter", "ChunkRing", "FilterCascade", "MultiStream", "filt", "filt_", "filt_multi", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
+    "FIRFilter", "ChunkRing", "ShardedFIRFilter", "FilterCascade", "MultiStream", "filt", "filt_", "filt_multi", "taps2pfb", "outputlength", "inputlength", "reset", "nextphase",
     "setphase", "tapsforphase", "polyfit", "firdes", "firprototype", "kaiserlength", "kaiser", "LOWPASS", "BANDPASS", "HIGHPASS", "BANDSTOP", "ChannelShardedFilter", "TimeShardedFilter", "shard_channels", "shard_time", "load_library",
     "library_path", "MultirateHIPError", "NUMERICS_STRICT", "NUMERICS_FUSED",
 ]

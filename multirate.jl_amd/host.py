@@ -117,6 +117,17 @@ ABI = [
     ("mrhip_timing_read", _i, [_vp, _pi64, C.POINTER(C.c_double)]),
     ("mrhip_last_kernel_name", C.c_char_p, [_vp]),
     ("mrhip_schedule_info", _i, [_vp, _pi64, _i]),
+    ("mrhip_sharded_create", _i, [_i, _vp, _i64, _i, _i64, _i64, _d, _i64, _i64, _i, _i64, C.POINTER(_i), _i, C.POINTER(_vp)]),
+    ("mrhip_sharded_destroy", None, [_vp]),
+    ("mrhip_sharded_nshards", _i, [_vp]),
+    ("mrhip_sharded_shard", _i, [_vp, _i, _pi64, _pi64, C.POINTER(_i), C.POINTER(_vp)]),
+    ("mrhip_sharded_outputlength", _i64, [_vp, _i64]),
+    ("mrhip_sharded_next_output_count", _i64, [_vp, _i64]),
+    ("mrhip_sharded_reset", _i, [_vp]),
+    ("mrhip_sharded_filt_device", _i, [_vp, C.POINTER(_vp), _i64, _pi64, C.POINTER(_vp), _i64, _pi64, _pi64]),
+    ("mrhip_sharded_filt_host", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64]),
+    ("mrhip_sharded_gather", _i, [_vp, C.POINTER(_vp), _i64, _pi64, _vp, _i64, _i]),
+    ("mrhip_sharded_synchronize", _i, [_vp]),
     ("mrhip_ring_open", _i, [_vp, C.POINTER(_vp)]),
     ("mrhip_ring_push", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, C.POINTER(C.c_uint64)]),
     ("mrhip_ring_push_chunks", _i, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _pi64, C.POINTER(C.c_uint64)]),
@@ -734,6 +745,108 @@ class ChunkRing:
         h, self._h = getattr(self, "_h", None), None
         if h:
             _check(self._lib.mrhip_ring_close(h))
+
+
+class ShardedFIRFilter:
+    """One FIRFilter whose channels are split over several GPUs of THIS process (``mrhip_sharded_*``; the one-process counterpart of
+    sharding.py's one-rank-per-GPU ``ChannelShardedFilter``): shard i holds channels ``[start_i, start_i + count_i)`` on
+    ``devices[i]``, no exchange during compute, one gather of the outputs at the end.
+
+    ``filt(X)`` with a host (numpy) matrix ``(nchannels, n)`` filters every column split on all devices at once and returns the host
+    result; ``filt_shards(xs)`` takes one CUDA tensor per shard (on that shard's device) and returns the per-shard outputs, which
+    ``gather(ys, device)`` brings together on one device (peer copies)."""
+
+    def __init__(self, h, ratio, nchannels: int, devices, *, Nphi: int = 32, polyorder=None, dtype=np.float32):
+        self._lib = load_library()
+        self.h = _as_taps(h)
+        self._tx = np.dtype(dtype)
+        self.nchannels = int(nchannels)
+        self.devices = [int(d) for d in devices]
+        ctor, num, den, rate = 0, 1, 1, 0.0
+        if isinstance(ratio, float):
+            ctor, rate = (2 if polyorder is not None else 1), float(ratio)
+        else:
+            r = Fraction(*ratio) if isinstance(ratio, tuple) else Fraction(ratio)
+            num, den = r.numerator, r.denominator
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        out = C.c_void_p()
+        _check(self._lib.mrhip_sharded_create(ctor, _ptr(self.h), len(self.h), _NP2DT[self.h.dtype], num, den, rate, int(Nphi),
+                                              int(polyorder or 0), _NP2DT[self._tx], self.nchannels, devs, len(self.devices), C.byref(out)))
+        self._h = out
+        self.output_dtype = _DT2NP[self._lib.mrhip_output_dtype(_NP2DT[self.h.dtype], _NP2DT[self._tx])]
+        self.shards = []
+        for i in range(self._lib.mrhip_sharded_nshards(self._h)):
+            st, cnt, dev = C.c_int64(0), C.c_int64(0), C.c_int(0)
+            _check(self._lib.mrhip_sharded_shard(self._h, i, C.byref(st), C.byref(cnt), C.byref(dev), None))
+            self.shards.append((st.value, cnt.value, dev.value))
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mrhip_sharded_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _check(self._lib.mrhip_sharded_reset(self._h))
+        return self
+
+    def outputlength(self, n: int) -> int:
+        return self._lib.mrhip_sharded_outputlength(self._h, int(n))
+
+    def next_output_count(self, n: int) -> int:
+        return self._lib.mrhip_sharded_next_output_count(self._h, int(n))
+
+    def filt(self, X):
+        """filt(self, X) for a host matrix with one channel per row: (nchannels, n) -> (nchannels, n_out)"""
+        X = np.ascontiguousarray(X, dtype=self._tx)
+        if X.ndim != 2 or X.shape[0] != self.nchannels:
+            raise MultirateHIPError(1, f"X must be ({self.nchannels}, n)")
+        n = X.shape[1]
+        cap = max(self.outputlength(n), 0) + 2
+        Y = np.empty((self.nchannels, cap), dtype=self.output_dtype)
+        nw = C.c_int64(0)
+        _check(self._lib.mrhip_sharded_filt_host(self._h, _ptr(X), n, n, _ptr(Y), cap, cap, C.byref(nw)))
+        return np.ascontiguousarray(Y[:, :nw.value])
+
+    def filt_shards(self, xs):
+        """filt on device-resident data: xs[i] a (count_i, n) CUDA tensor on shard i's device; returns the per-shard outputs
+        (asynchronous on the shards' streams: ``synchronize()`` or ``gather`` + ``synchronize()`` before reading)"""
+        n = None
+        for (st, cnt, dev), x in zip(self.shards, xs):
+            if cnt and (not _is_torch(x) or not x.is_cuda or x.device.index != dev or x.shape != (cnt, x.shape[-1]) or x.stride(-1) != 1):
+                raise MultirateHIPError(1, "xs[i] must be a (count_i, n) CUDA tensor on shard i's device")
+            if cnt:
+                n = x.shape[-1] if n is None else n
+                if x.shape[-1] != n:
+                    raise MultirateHIPError(1, "every shard takes the same number of samples per channel")
+        cap = max(self.outputlength(n), 0) + 2
+        ys = [torch.empty((cnt, cap), dtype=_np_torch_dtype(self.output_dtype), device=f"cuda:{dev}") if cnt else None for (st, cnt, dev) in self.shards]
+        k = len(self.shards)
+        xp = (C.c_void_p * k)(*[C.c_void_p(x.data_ptr()) if cnt else None for (st, cnt, dev), x in zip(self.shards, xs)])
+        yp = (C.c_void_p * k)(*[C.c_void_p(y.data_ptr()) if y is not None else None for y in ys])
+        xst = (C.c_int64 * k)(*[x.stride(0) if cnt else 0 for (st, cnt, dev), x in zip(self.shards, xs)])
+        yst = (C.c_int64 * k)(*[cap] * k)
+        nw = C.c_int64(0)
+        _check(self._lib.mrhip_sharded_filt_device(self._h, xp, n, xst, yp, cap, yst, C.byref(nw)))
+        return [y[:, :nw.value] if y is not None else None for y in ys]
+
+    def gather(self, ys, device: int):
+        """(nchannels, n_out) on ``device`` from the per-shard outputs (views as ``filt_shards`` returns them)"""
+        n_out = next(y.shape[-1] for y in ys if y is not None)
+        out = torch.empty((self.nchannels, n_out), dtype=_np_torch_dtype(self.output_dtype), device=f"cuda:{device}")
+        k = len(self.shards)
+        yp = (C.c_void_p * k)(*[C.c_void_p(y.data_ptr()) if y is not None else None for y in ys])
+        yst = (C.c_int64 * k)(*[y.stride(0) if y is not None else 0 for y in ys])
+        _check(self._lib.mrhip_sharded_gather(self._h, yp, n_out, yst, C.c_void_p(out.data_ptr()), n_out, int(device)))
+        return out
+
+    def synchronize(self):
+        _check(self._lib.mrhip_sharded_synchronize(self._h))
 
 
 def filt_multi(filters, xs):

@@ -15,7 +15,7 @@ module MultirateHIP
 export FIRFilter, FIRKernel, FIRStandard, FIRDecimator, FIRInterpolator, FIRRational, FIRArbitrary, FIRFarrow,
        filt, filt!, taps2pfb, outputlength, inputlength, reset, nextphase, setphase, tapsforphase, tapsforphase!, polyfit,
        firdes, firprototype, kaiserlength, kaiser, FIRResponse, LOWPASS, BANDPASS, HIGHPASS, BANDSTOP,
-       FilterCascade, filt_device!, filt_device_chunked!, scheduleinfo, advancestate!, ChunkRing, pushchunks!, drain, ringinfo
+       FilterCascade, filt_device!, filt_device_chunked!, scheduleinfo, advancestate!, ChunkRing, pushchunks!, drain, ringinfo, ShardedFIRFilter
 
 const libmr = get(ENV, "MRHIP_LIB_PATH", joinpath(@__DIR__, "..", "libmultirate_hip.so"))
 
@@ -482,6 +482,50 @@ function ringinfo(r::ChunkRing)
     v = zeros(Int64, 6)
     check(ccall((:mrhip_ring_info, libmr), Cint, (Ptr{Cvoid}, Ptr{Int64}, Cint), r.handle, v, 6))
     (resident = v[1] != 0, depth = v[2], pushed = v[3], restarts = v[4], steps_per_grab = v[5], outputs_per_step = v[6])
+end
+
+# ---- one FIRFilter whose channels are split over several GPUs (mrhip_sharded_*; BASELINE config 5 from Julia) ----------------------
+# filt(f, X::Matrix) with one channel per column: the columns are split contiguously over `devices`, every device filters its
+# share at the same time (no exchange: channels are independent), the result comes back as one Matrix.  The seam it replaces is
+# filt(self, x), src/Filters.jl:577-587, applied column by column with one FIRFilter per column.
+mutable struct ShardedFIRFilter
+    h::Vector
+    nchannels::Int
+    devices::Vector{Cint}
+    Tx::DataType
+    handle::Ptr{Cvoid}
+end
+function sharded(ctor::Integer, h::Vector{Th}, num, den, rate, Nphi, polyorder, ::Type{Tx}, nch::Integer, devices) where {Th<:Union{Float32,Float64},Tx}
+    devs = Cint[d for d in devices]
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mrhip_sharded_create, libmr), Cint,
+                (Cint, Ptr{Cvoid}, Int64, Cint, Int64, Int64, Cdouble, Int64, Int64, Cint, Int64, Ptr{Cint}, Cint, Ptr{Ptr{Cvoid}}),
+                ctor, h, length(h), dtypecode(Th), num, den, Float64(rate), Nphi, polyorder, dtypecode(Tx), nch, devs, length(devs), out))
+    s = ShardedFIRFilter(copy(h), nch, devs, Tx, out[])
+    finalizer(s -> (s.handle == C_NULL || ccall((:mrhip_sharded_destroy, libmr), Cvoid, (Ptr{Cvoid},), s.handle); s.handle = C_NULL), s)
+end
+# the reference's three constructors (src/Filters.jl:158,183,192) + sample type, channel count and the devices
+ShardedFIRFilter(h::Vector, ratio::Rational, ::Type{Tx}, nch::Integer, devices) where {Tx} =
+    sharded(0, h, numerator(ratio), denominator(ratio), 0.0, 0, 0, Tx, nch, devices)
+ShardedFIRFilter(h::Vector, rate::AbstractFloat, Nphi::Integer, ::Type{Tx}, nch::Integer, devices) where {Tx} =
+    (rate > 0.0 || error("rate must be greater than 0"); sharded(1, h, 1, 1, rate, Nphi, 0, Tx, nch, devices))
+ShardedFIRFilter(h::Vector, rate::AbstractFloat, Nphi::Integer, polyorder::Integer, ::Type{Tx}, nch::Integer, devices) where {Tx} =
+    (rate > 0.0 || error("rate must be greater than 0"); sharded(2, h, 1, 1, rate, Nphi, polyorder, Tx, nch, devices))
+outputlength(s::ShardedFIRFilter, n::Integer) = Int(ccall((:mrhip_sharded_outputlength, libmr), Int64, (Ptr{Cvoid}, Int64), s.handle, n))
+reset(s::ShardedFIRFilter) = (check(ccall((:mrhip_sharded_reset, libmr), Cint, (Ptr{Cvoid},), s.handle)); s)
+function filt!(buffer::Matrix{Tb}, s::ShardedFIRFilter, X::Matrix{Tx}) where {Tb,Tx}
+    Tx === s.Tx && size(X, 2) == s.nchannels || error("X must be a Matrix{$(s.Tx)} with $(s.nchannels) columns")
+    Tb === promote_out(eltype(s.h), Tx) && size(buffer, 2) == s.nchannels || error("buffer must be a Matrix{$(promote_out(eltype(s.h), Tx))} with $(s.nchannels) columns")
+    nw = Ref{Int64}(0)
+    check(ccall((:mrhip_sharded_filt_host, libmr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int64}),
+                s.handle, X, size(X, 1), size(X, 1), buffer, size(buffer, 1), size(buffer, 1), nw))
+    Int(nw[])
+end
+function filt(s::ShardedFIRFilter, X::Matrix{Tx}) where {Tx}
+    buffer = Matrix{promote_out(eltype(s.h), Tx)}(undef, max(outputlength(s, size(X, 1)), 0) + 2, s.nchannels)
+    n = size(X, 1) == 0 ? 0 : filt!(buffer, s, X)
+    buffer[1:n, :]
 end
 
 # ---- cascades (mrhip_cascade_*): stages chained on the device, intermediates resident in HBM -------------------

@@ -205,3 +205,56 @@ def test_bench_four_ranks_on_one_gpu_at_config5_channel_count():
     line = _bench(["--gpus", "4", "--channels", "16", "--samples", "1000000", "--c5-channels", "4096", "--c5-samples", "20000"] + small, "gloo")
     assert line["n_gpus"] == 4 and line["scaling"] == "weak" and line["roofline"]["achieved"] > 0
     assert line["c5"]["channels_per_gpu"] == 1024 and line["c5"]["gather"]["root"]["ms"] > 0
+
+
+@pytest.mark.gpu
+def test_sharded_filter_behind_the_c_abi(pkg, O):
+    """mrhip_sharded_*: one FIRFilter whose channels are split over several devices of ONE process, behind the C ABI (what a Julia
+    caller reaches config 5 through: filt(::ShardedFIRFilter, X::Matrix)).  On a box with one GPU the same device is named twice
+    (devices = [0, 0]: two shards, two streams); with more GPUs every device takes a shard.  Host-matrix path, device path + gather,
+    unequal shards, a shard without channels, streaming state across calls, every constructor -- against the oracle and against
+    ChannelShardedFilter's split."""
+    import torch
+    from fractions import Fraction
+    import numpy as np
+    ndev = torch.cuda.device_count()
+    devices = list(range(ndev)) if ndev >= 2 else [0, 0]
+    rng = np.random.default_rng(41)
+    h147 = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    for ratio, h, tx, nch, kw in ((Fraction(147, 160), h147, np.complex64, 5, {}),
+                                  (Fraction(1, 4), pkg.firdes(128, 0.125, beta=7.0).astype(np.float32), np.float32, 1, {}),       # one channel: the second shard is empty
+                                  (float(np.pi / 3), (pkg.firdes(32 * 12, 0.45 / 32, beta=7.0) * 32).astype(np.float64), np.float64, 3, {"Nphi": 32})):
+        x = rng.standard_normal((nch, 40_000)).astype(np.float32)
+        if np.dtype(tx).kind == "c":
+            x = x + 1j * rng.standard_normal((nch, 40_000)).astype(np.float32)
+        x = x.astype(tx)
+        sf = pkg.ShardedFIRFilter(h, ratio, nch, devices, dtype=tx, **kw)
+        assert [(s, c) for s, c, _ in sf.shards] == [pkg.shard_channels(nch, len(devices), r) for r in range(len(devices))]
+        fos = [O.FIRFilter(h, ratio, 32, tx=tx) if isinstance(ratio, float) else O.FIRFilter(h, ratio, tx=tx) for _ in range(nch)]
+        # host matrix, two calls (the stream continues on every shard)
+        for a, b in ((0, 15_007), (15_007, 40_000)):
+            y = sf.filt(x[:, a:b])
+            for c in range(nch):
+                ref = fos[c].filt(x[c, a:b])
+                assert y[c].shape == ref.shape and np.array_equal(y[c].view(np.uint8), ref.view(np.uint8)), f"{ratio} host path channel {c}"
+        # device-resident shards + the final gather on device 0
+        sf.reset()
+        fos = [O.FIRFilter(h, ratio, 32, tx=tx) if isinstance(ratio, float) else O.FIRFilter(h, ratio, tx=tx) for _ in range(nch)]
+        xs = [torch.from_numpy(np.ascontiguousarray(x[s:s + c])).to(f"cuda:{d}") if c else None for s, c, d in sf.shards]
+        ys = sf.filt_shards(xs)
+        full = sf.gather(ys, devices[0])
+        sf.synchronize()
+        got = full.cpu().numpy()
+        for c in range(nch):
+            ref = fos[c].filt(x[c])
+            assert got[c].shape == ref.shape and np.array_equal(got[c].view(np.uint8), ref.view(np.uint8)), f"{ratio} device path channel {c}"
+        sf.close()
+    # reference: error() before any work, on every shard (Filters.jl:550)
+    sf = pkg.ShardedFIRFilter(h147, Fraction(147, 160), 4, devices, dtype=np.float32)
+    lib = pkg.load_library()
+    import ctypes as C
+    X = np.zeros((4, 1000), dtype=np.float32); Y = np.zeros((4, 10), dtype=np.float32)
+    rc = lib.mrhip_sharded_filt_host(sf._h, X.ctypes.data, 1000, 1000, Y.ctypes.data, 10, 10, None)
+    assert rc == 2 and b"buffer is too small" in lib.mrhip_last_error()
+    assert sf.filt(X).shape == (4, 919)                      # nothing was consumed by the refused call
+    sf.close()
