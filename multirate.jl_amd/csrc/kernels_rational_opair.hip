@@ -68,7 +68,7 @@ constexpr int kOMaxThreads = 512;
 // SMIN >= 2: Float32 arithmetic and tapsPerPhi <= 32) for Float32 arithmetic (Float32 or ComplexF32 samples, Float32 taps)
 // and Float64 arithmetic (Float64 or ComplexF64 samples; Float64 taps x Float32 or ComplexF32 samples).  Returns false otherwise
 // (the caller tries the next kernel).
-bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds)
+bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds, int force_wgpc)
 {
     if (!opair_env_int("MRHIP_OPAIR", 1)) return false;   // read per call: tests switch kernels at run time
     if (tk.x_f64 && !tk.r_f64) return false;
@@ -120,6 +120,7 @@ bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int n
     const int waves_per_cu = tk.r_f64 ? 12 : 4 * std::min(8, 512 / vgpr_est);
     int wg_per_cu = std::max(1, std::min(4, waves_per_cu / (nwaves + 1)));
     if (nwaves + 1 == 6 && !tk.r_f64) wg_per_cu = 3;
+    if (force_wgpc > 0) wg_per_cu = force_wgpc;   // (the ring's RING instantiation holds 128 VGPRs: two workgroups per CU, larger tiles)
     if (const int env_w = opair_env_int("MRHIP_OPAIR_WGPC", 0); env_w > 0) wg_per_cu = env_w;   // experiments
     // TWO pipeline stages of tiles as large as the LDS allows (the DMA runs one tile ahead, far more than the HBM
     // latency; every tile costs ~1000 cycles of barrier skew, ring priming and drain).  Measured on 147//160 Float32,

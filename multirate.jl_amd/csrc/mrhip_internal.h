@@ -298,6 +298,7 @@ struct MultiDesc {           // one independent stream (one FIRFilter of the ref
 // of a chunk's completion from a flag in pinned memory.  Every wait in the kernel has a deadline: it ends by itself when the
 // ring stays empty for `idle_ticks`.
 constexpr int kRingDepth = 64;            // descriptor / history slots; at most kRingDepth - 1 chunks in flight
+constexpr int kRingShards = 32;           // completion counters per chunk: a grab counts on shard (ticket mod 32), each on a line of its own
 struct RingDesc {                         // one arriving chunk: 16 quad-words
     unsigned long long x, y;              // device addresses
     long long x_stride, y_stride, x_len, n_out;
@@ -329,7 +330,15 @@ struct RingDev {                          // device memory
     unsigned long long opts;              // experiments (MRHIP_RING_OPTS): bit 0 no descriptor prefetch, bit 1 grabs reported at their own end
     unsigned long long pad[4];
     unsigned long long hist_seq[kRingDepth];   // hist_seq[s % depth] == s + 1: slot s % depth holds chunk s's call-start history
-    unsigned chunk_done[kRingDepth];      // grabs of chunk (slot) completed
+    unsigned chunk_done[kRingDepth];      // SHARDS of chunk (slot) complete
+    // grabs of chunk (slot) completed, counted per shard: ONE counter per chunk took every grab's atomic add on one address -- 13 ns each, in
+    // series: 174 grabs of a 1e6-sample chunk = 2.3 us per chunk, which WAS the ring's rate (profiles/r05/experiments.md)
+    unsigned shard_done[kRingDepth][kRingShards][32];
+    // diagnostics (MRHIP_RING_OPTS bit 8 = 256), 100 MHz ticks summed over the waves that report: [0] compute waves: whole life, [1] ... at the
+    // tile barrier, [2] ... draining stores before a report, [3] compute waves reporting; [4] loader waves: whole life, [5] ... polling for
+    // chunks, [6] ... in stage_tile + descriptor prefetch (issue and landing), [7] ... at the tile barrier, [8] loader waves reporting,
+    // [9] tiles, [10] FLUSH tiles, [11] ... waiting for a history slot, [12] ... in find_chunk with descriptors at hand
+    unsigned long long stats[16];
     __attribute__((aligned(128))) RingDesc desc[kRingDepth];
 };
 
@@ -523,7 +532,7 @@ hipError_t launch_farrow_tiled(const TypeKey &tk, bool fused, const FarrowArgs &
 hipError_t launch_shiftin(const TypeKey &tk, const HistArgs &a, hipStream_t s);
 // least-squares polynomial fit of y[0..n) at x = 1..n (support.jl:85-88); coef receives polyorder+1 ascending powers
 bool polyfit_rows(const double *y, int64_t n, int polyorder, double *coef);
-bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds);
+bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds, int force_wgpc = 0);
 bool plan_rational_opair_blocks(const TypeKey &tk, bool fused, const PolyArgs &a, int num_cus, PairArgs *out, dim3 *block, size_t *lds, int *nblocks);   // L > 512: a workgroup owns a block of the period
 hipError_t launch_rational_opair(bool fused, const PolyArgs &a, const PairArgs &pa, dim3 block, size_t lds, hipStream_t s,
                                  const char **kname, int num_cus, unsigned *counters);   // FIRRational and FIRInterpolator, two outputs per lane; also performs shiftin!

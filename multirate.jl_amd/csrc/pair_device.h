@@ -88,6 +88,12 @@ __device__ __forceinline__ void dma16_sc1(const void *gsrc, void *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 16);
 }
 
+__device__ __forceinline__ void dma16_nt(const void *gsrc, void *lds_wave_base)    // ... streaming (aux 2 = nt): L2-served as well, no L1 allocation
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2);
+}
+
 // ---- hand-offs between workgroups inside ONE launch (the resident ring consumer): L2-served loads and write-through stores ----
 // (MI355X: a CU's L1 is never refreshed by another CU's stores and the per-XCD L2s are not coherent for plain write-back
 //  stores; `sc1` loads bypass the L1, `sc1` stores are written through.  Producer: sc1 stores, s_waitcnt vmcnt(0), sc1 flag store;

@@ -263,19 +263,34 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
 // =====================================================================================================================
 // LDS words of a tile descriptor in ring mode: [0] steps (0: the kernel ends), [1] flags (bit 0: the tile completes a grab),
 // [2,3] address of the tile's first output, [4] outputs of the channel from this tile on, [5] u0 of the chunk,
-// [6] ring slot, [7] grabs of the chunk, [8,9] chunk number
+// [6] ring slot, [7] the grab's shard of the chunk's completion counters, [8,9] chunk number, [10] grabs of the chunk on that shard,
+// [11] non-empty shards of the chunk
 constexpr unsigned kRingTileWords = 16;
 
-// One grab of chunk `seq` is complete (every wave that stored for it has drained its write-through stores): the grab that
-// completes the chunk tells the host.
-__device__ __forceinline__ void ring_grab_done(RingDev *rd, RingHost *rh, unsigned slot, unsigned ngrabs, unsigned long long seq)
+// One grab of chunk `seq` is complete (every wave that stored for it has drained its write-through stores).  The grab counts on ITS
+// shard of the chunk's counters (ticket mod kRingShards; `cnt` grabs of the chunk land there); the grab that completes a shard counts
+// the shard, the one that completes the last of the chunk's `nshards` non-empty shards tells the host.
+__device__ __forceinline__ void ring_grab_done(RingDev *rd, RingHost *rh, unsigned slot, unsigned long long seq, unsigned shard, unsigned cnt, unsigned nshards)
 {
-    const unsigned prev = __hip_atomic_fetch_add(&rd->chunk_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev + 1u == ngrabs) {
-        st_sc1(&rd->chunk_done[slot], 0u);            // (the slot is reused only after the host has seen the flag below)
+    const unsigned prev = __hip_atomic_fetch_add(&rd->shard_done[slot][shard][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == cnt) {
+        st_sc1(&rd->shard_done[slot][shard][0], 0u);  // (the slot is reused only after the host has seen the flag below)
         vm_drain();
-        st_sys(&rh->done[slot], seq + 1ull);
+        const unsigned top = __hip_atomic_fetch_add(&rd->chunk_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (top + 1u == nshards) {
+            st_sc1(&rd->chunk_done[slot], 0u);
+            vm_drain();
+            st_sys(&rh->done[slot], seq + 1ull);
+        }
     }
+}
+// tickets [tb, tb + n) of a chunk: how many fall on shard s, and how many shards get any
+__device__ __forceinline__ unsigned ring_shard_count(unsigned long long tb, unsigned n, unsigned s)
+{
+    const unsigned long long S = kRingShards;
+    // integers congruent to s modulo S in [tb, tb + n): those below tb + n minus those below tb
+    auto below = [&](unsigned long long e) -> unsigned long long { return e > s ? (e - s + S - 1ull) / S : 0ull; };
+    return static_cast<unsigned>(below(tb + n) - below(tb));
 }
 
 // Workgroup 0's last wave: descriptors from the host's ring (pinned memory, one PCIe round trip per batch of up to 16) into
@@ -358,10 +373,14 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     volatile unsigned *const td = reinterpret_cast<volatile unsigned *>(smem + pa.flags_off);   // [ns][kRingTileWords]
     const unsigned long long idle = ld_sc1(&rd->idle_ticks);
     const unsigned opts = static_cast<unsigned>(ld_sc1(&rd->opts));
+    // the loader's instruction stream is long in ring mode (descriptor look-up, bookkeeping) and shares its SIMD with compute waves that
+    // never stall: let it issue first (experiment switch: bit 9 = 512 keeps the default priority)
+    if (!(opts & 512u)) __builtin_amdgcn_s_setprio(3);
     const unsigned long long G = gridDim.x - 1u;
     unsigned long long ticket = blockIdx.x - 1u;          // this workgroup's next grab, counted over the whole life of the ring
     unsigned long long cur = 0, head_seen = 0;            // chunks below cur cannot hold `ticket`
     bool aborted = false;
+    unsigned long long st_poll = 0, st_flush = 0, st_hist = 0;      // diagnostics (opts bit 8)
     // the chunk of the current grab (wave-uniform)
     unsigned long long c_x = 0, c_y = 0, c_tile_base = 0, c_seq = 0;
     long long c_xs = 0, c_ys = 0, c_xlen = 0, c_nout = 0, c_u0 = 0, c_o0 = 0;
@@ -378,6 +397,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
             if (wall_clock64() - t0 > idle) { if (lane == 0) st_sc1(&rd->closed, 3ull); vm_drain(); aborted = true; return false; }
             __builtin_amdgcn_s_sleep(8);
         }
+        st_hist += wall_clock64() - t0;
         return true;
     };
     // ---- which chunk holds `ticket`: lane k < nb reads the whole descriptor of chunk cur + k (six 16-byte units, the key among
@@ -430,7 +450,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
                 return kFound;
             }
             head_seen = ld_sc1(&rd->head);
-            if (cur < head_seen) continue;
+            if (cur < head_seen) { st_poll += wall_clock64() - t0; continue; }
             if (ld_sc1(&rd->closed) != 0ull) {
                 head_seen = ld_sc1(&rd->head);            // `closed` is set behind the last `head`: look once more
                 if (cur < head_seen) continue;
@@ -483,6 +503,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         return true;
     };
     unsigned ra = 0, rb = 0;                                  // the current grab's steps [ra, rb) still to be staged
+    unsigned g_shard = 0, g_cnt = 1;                          // ... its shard of the chunk's completion counters, the grabs that count there
     // the next grab of this workgroup that has steps: kFound; kClosed: the ring is closed (or a wait ran into its deadline);
     // kWouldBlock (only with may_block = false): nothing published yet
     auto next_grab = [&](bool may_block) -> int {
@@ -490,12 +511,15 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
             const int fc = find_chunk(may_block);
             if (fc != kFound) return fc;
             const unsigned g = static_cast<unsigned>(ticket - c_tile_base);
+            g_shard = static_cast<unsigned>(ticket % kRingShards);
+            g_cnt = ring_shard_count(c_tile_base, c_ngrabs, g_shard);
             ticket += G;
             if (g == 0u && !tail_copy()) return kClosed;
-            const unsigned long long lo = static_cast<unsigned long long>(g) * static_cast<unsigned>(pa.J);
-            if (lo < c_total) { ra = static_cast<unsigned>(lo); rb = umin(ra + static_cast<unsigned>(pa.J), c_total); return kFound; }
+            // a grab = pa.steps_per_group steps = several tiles: one descriptor look-up per grab, not per tile
+            const unsigned long long lo = static_cast<unsigned long long>(g) * pa.steps_per_group;
+            if (lo < c_total) { ra = static_cast<unsigned>(lo); rb = umin(ra + pa.steps_per_group, c_total); return kFound; }
             // a chunk without outputs (a short input, Filters.jl:543-547) has one grab without steps: nothing is stored for it
-            if (lane == 0) ring_grab_done(rd, rh, static_cast<unsigned>(c_seq % kRingDepth), c_ngrabs, c_seq);
+            if (lane == 0) ring_grab_done(rd, rh, static_cast<unsigned>(c_seq % kRingDepth), c_seq, g_shard, g_cnt, c_ngrabs < kRingShards ? c_ngrabs : kRingShards);
             vm_drain();
         }
     };
@@ -518,7 +542,9 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
                 int d = ci;
                 if (cd > 0) { const int g = static_cast<int>(__umulhi(static_cast<unsigned>(ci), pad_magic)), r = ci - g * (cd + 1); d = r == cd ? 0 : g * cd + r; }
                 const int cis = d < nchunks ? d : 0;
-                dma16_sc1(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
+                if (opts & 32u) dma16(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);            // (experiments: plain / nt)
+                else if (opts & 64u) dma16_nt(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
+                else dma16_sc1(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
             }
             return nslots;
         }
@@ -560,19 +586,32 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     // to drain).  When nothing is published and grabs are still unreported, a FLUSH tile (no steps) takes them through the barrier to
     // report; only then does this wave sit down and poll.
     bool unreported = false;
+    unsigned long long idle_since = 0;                        // != 0: nothing to stage since then
     auto produce = [&](int stage) -> bool {
         if (ra >= rb && !aborted) {
-            int ng = next_grab(!unreported);
+            // never a wait in here: tiles published earlier may still be on their way through the barriers (with more than two stages
+            // the compute waves would never reach them).  Nothing published yet: an idle tile (no steps) goes round instead.
+            int ng = next_grab(false);
             if (ng == kWouldBlock) {
-                if (lane == 0) { td[kRingTileWords * stage] = 1u; td[kRingTileWords * stage + 1] = 2u; }   // FLUSH
-                ops <<= 6;
-                unreported = false;
-                return true;
+                if (!unreported) {
+                    const unsigned long long now = wall_clock64();
+                    if (idle_since == 0ull) idle_since = now;
+                    if (now - idle_since > 2ull * idle + 100000000ull) ng = kClosed;     // (backstop: the feeder ends an idle ring itself)
+                    else __builtin_amdgcn_s_sleep(32);
+                }
+                if (ng == kWouldBlock) {
+                    if (lane == 0) { td[kRingTileWords * stage] = 1u; td[kRingTileWords * stage + 1] = 2u; }   // FLUSH / idle
+                    ++st_flush;
+                    ops <<= 6;
+                    unreported = false;
+                    return true;
+                }
             }
+            idle_since = 0ull;
             if (ng != kFound) ra = rb = 0;
         }
         if (ra >= rb || aborted) { end_marker(stage); return false; }
-        const TileAt ta = tile_at(ra, rb - ra);
+        const TileAt ta = tile_at(ra, umin(rb - ra, static_cast<unsigned>(pa.J)));
         const int n_ops = stage_tile(ta, stage);
         if (aborted) { end_marker(stage); return false; }
         if (lane == 0) {
@@ -586,8 +625,10 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
             t[4] = static_cast<unsigned>(rem < 0x7fffffffLL ? rem : 0x7fffffffLL);
             t[5] = static_cast<unsigned>(c_u0);
             t[6] = static_cast<unsigned>(c_seq % kRingDepth);
-            t[7] = c_ngrabs;
+            t[7] = g_shard;
             t[8] = static_cast<unsigned>(c_seq & 0xffffffffull); t[9] = static_cast<unsigned>(c_seq >> 32);
+            t[10] = g_cnt;
+            t[11] = c_ngrabs < static_cast<unsigned>(kRingShards) ? c_ngrabs : static_cast<unsigned>(kRingShards);
         }
         ops = (ops << 6) | static_cast<unsigned>(n_ops);
         ra += static_cast<unsigned>(ta.jt);
@@ -597,6 +638,9 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         return true;
     };
     if (lane < pa.ns) td[kRingTileWords * pa.ns + lane] = 0u;   // per stage: compute waves through with a grab's last tile (opair_kernel.inc)
+    const bool stats = (opts & 256u) != 0u;
+    const unsigned long long st_t0 = wall_clock64();
+    unsigned long long st_bar = 0, st_prod = 0, st_tiles = 0;
     unsigned pipeline = 0;
     for (int k = 0; k < pa.ns - 1; ++k)
         if (produce(k)) pipeline |= 1u << k;
@@ -604,12 +648,26 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     int pstage = pa.ns - 1;
     for (;;) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long tb0 = stats ? wall_clock64() : 0ull;
         __builtin_amdgcn_s_barrier();
+        const unsigned long long tb1 = stats ? wall_clock64() : 0ull;
+        st_bar += tb1 - tb0;
         if (!(pipeline & 1u)) break;
         pipeline >>= 1;
         if (produce(pstage)) pipeline |= 1u << (pa.ns - 2);
         pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
         if (pa.ns > 2) wait_vmcnt_le(newest_ops(pa.ns - 2)); else vm_drain();
+        if (stats) { st_prod += wall_clock64() - tb1; ++st_tiles; }
+    }
+    if (stats && lane == 0) {
+        atomicAdd(&rd->stats[4], wall_clock64() - st_t0);
+        atomicAdd(&rd->stats[5], st_poll);
+        atomicAdd(&rd->stats[6], st_prod - st_poll);
+        atomicAdd(&rd->stats[7], st_bar);
+        atomicAdd(&rd->stats[8], 1ull);
+        atomicAdd(&rd->stats[9], st_tiles);
+        atomicAdd(&rd->stats[10], st_flush);
+        atomicAdd(&rd->stats[11], st_hist);
     }
 }
 
