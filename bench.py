@@ -342,8 +342,12 @@ def config_rows(fused=False):
                     "Msamples_per_s_in": r["Msamples_per_s_in"], "Msamples_per_s_in_wall": r["Msamples_per_s_in_wall"],
                     "achieved_GBps": r["algorithmic_GBps"], "frac": r["frac_of_8TBps"], "frac_wall": r["frac_of_8TBps_wall"],
                     "arith": r["arith"], "TFLOPs": r["TFLOPs"], "strict_valu_frac": r["frac_of_strict_valu"]})
-        if "wall_ms_per_call_continuing_stream" in r:      # FIRArbitrary / FIRFarrow: the same calls without the reset (no schedule memo)
+        if "wall_ms_per_call_continuing_stream" in r:      # FIRArbitrary / FIRFarrow: wall_ms IS the continuing stream's (no schedule memo); the memo figure beside it
             out[-1]["wall_ms_continuing_stream"] = r["wall_ms_per_call_continuing_stream"]
+            out[-1]["wall_ms_with_schedule_memo"] = r.get("wall_ms_with_schedule_memo")
+        for k in ("us_per_chunk", "chunks_per_pass", "note"):
+            if k in r and r["config"][:3] in ("C2r", "C2s", "C1 "):
+                out[-1][k] = r[k]
     return out
 
 

@@ -553,6 +553,7 @@ void mrhip_destroy(mrhip_filter *f)
     rec_free(f);
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
         if (st) (void)hipStreamDestroy(st);
+    if (f->ev_chain) (void)hipEventDestroy(f->ev_chain);
     for (hipEvent_t e : {f->sched_copied, f->xs_event, f->ev_in[0], f->ev_in[1], f->ev_k[0], f->ev_k[1], f->ev_out[0], f->ev_out[1]})
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_pool) (void)hipEventDestroy(e);
@@ -562,9 +563,23 @@ void mrhip_destroy(mrhip_filter *f)
 // The host's state written into the device record, in stream order behind whatever the filter enqueued last (the stream of
 // its last call; when that stream no longer exists -- torch side streams come and go -- behind the whole device, on the
 // filter's own stream).
+// the filter's schedule stream behind a chained call's schedule, which ran on the caller's stream (filt_device_one)
+static int sched_stream_behind_chain(mrhip_filter *f)
+{
+    if (f->s_sched && f->chain_pending) {
+        MRHIP_CHECK_HIP(hipStreamWaitEvent(f->s_sched, f->ev_chain, 0));
+        f->chain_pending = false;
+    }
+    return MRHIP_OK;
+}
+
 static int push_state(mrhip_filter *f)
 {
-    if (f->s_sched) { f->async_pending = true; return rec_push(f, f->s_sched); }   // FIRArbitrary / FIRFarrow: every write of the record, in program order
+    if (f->s_sched) {
+        if (int rc = sched_stream_behind_chain(f)) return rc;
+        f->async_pending = true;
+        return rec_push(f, f->s_sched);
+    }   // FIRArbitrary / FIRFarrow: every write of the record, in program order
     hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
     if (rec_push(f, s) != MRHIP_OK) {
         (void)hipGetLastError();
@@ -810,7 +825,10 @@ int mrhip_reset(mrhip_filter *f)
     // (rate 1.0: the cycle IS that state); otherwise forget the cycle (the prefix finds it again).
     if (f->per_valid && f->per_reset_pos >= 0 && MRHIP_ENV_INT("MRHIP_SCHED_KEEP_DRIFT", 1) != 0) f->per_pos = f->per_reset_pos;
     else if (f->per_valid || MRHIP_ENV_INT("MRHIP_SCHED_KEEP_DRIFT", 1) == 0) sched_forget(f);
-    if (f->s_sched) f->async_pending = true;
+    if (f->s_sched) {
+        f->async_pending = true;
+        if (int rc = sched_stream_behind_chain(f)) return rc;
+    }
     return f->s_sched ? rec_push(f, f->s_sched) : rec_push(f, s);   // the device record: constructor state, in stream order
 }
 
@@ -1132,6 +1150,12 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             // alternate, events order writer and reader of each (mrhip_filter.h: s_sched).  Inside a capture: one stream.
             // (a chained call's schedule reads the previous stage's call record, which is written on the caller's stream: it runs there)
             hipStream_t ss = capturing || !f->s_sched || x_from ? stream : f->s_sched;
+            // a chained call's schedule ran on the CALLER's stream (it reads the previous stage's call record there) and wrote the record,
+            // the piece states and the path tables: a schedule on the filter's own schedule stream must come behind it
+            if (ss == f->s_sched && f->chain_pending) {
+                MRHIP_CHECK_HIP(hipStreamWaitEvent(ss, f->ev_chain, 0));
+                f->chain_pending = false;
+            }
             SchedOut so{};
             so.buf = capturing ? 0 : f->flip;
             if (!capturing) f->flip ^= 1;
@@ -1210,6 +1234,10 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             if (ss != stream) {                                          // buffer b's next writer waits for this reader
                 MRHIP_CHECK_HIP(hipEventRecord(f->ev_filt[b], stream));
                 f->ev_filt_valid[b] = true;
+            } else if (!capturing && f->s_sched) {                       // (see chain_pending above; also orders buffer b's next writer)
+                if (!f->ev_chain) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_chain, hipEventDisableTiming));
+                MRHIP_CHECK_HIP(hipEventRecord(f->ev_chain, stream));
+                f->chain_pending = true;
             }
         } else if (!cached && est > 2 * piece && y && y_capacity >= est && (f->nch == 1 || y_stride >= est) && est < 0x7fffffffLL) {
             host_loop = true;
@@ -1352,7 +1380,9 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         f->inputDeficit = p.d_end;
     }
     // the device record follows every call in stream order: a call whose kernels did not file its end state pushes it
-    if (!rec_current && (f->kind != MRHIP_FIR_STANDARD && f->kind != MRHIP_FIR_INTERPOLATOR))
+    // (FIRStandard / FIRInterpolator have no state to carry, but the record's count and call counter -- what mrhip_sync_state returns --
+    //  follow every call of every kind)
+    if (!rec_current)
     {
         const bool on_sched = arb && f->s_sched && !capturing;
         if (int rc = rec_push(f, on_sched ? f->s_sched : stream, -1, std::max<int64_t>(n_out, 0))) return rc;

@@ -80,6 +80,8 @@ struct mrhip_filter {
     hipEvent_t ev_fin[2] = {nullptr, nullptr}, ev_filt[2] = {nullptr, nullptr};
     bool ev_filt_valid[2] = {false, false};
     int flip = 0;
+    hipEvent_t ev_chain = nullptr;          // recorded behind a schedule that ran on the CALLER's stream (a chained call): the schedule stream's next use waits for it
+    bool chain_pending = false;
     // memo: the schedule is a pure function of (accumulator, inputDeficit, x_len): a call that repeats the call whose
     // entries buffer memo_buf still holds reuses them (reset + the same block again: benchmarks, batches of equal files)
     bool memo_valid = false;
