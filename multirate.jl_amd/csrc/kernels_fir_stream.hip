@@ -136,9 +136,15 @@ bool plan_fir_stream(const TypeKey &tk, const PolyArgs &a, int num_cus, PairArgs
     pa.total_steps = static_cast<unsigned>(spc * a.nch);
     pa.spc_magic = spc == 1 ? 0xffffffffu : static_cast<unsigned>((1ULL << 32) / static_cast<unsigned long long>(spc));
     pa.flags_off = static_cast<int>(ns * stage_bytes);
+    *lds = ns * stage_bytes + 8 * ns;
+#if MRHIP_STREAM_TAPS_LDS
+    if (!rt) {                               // the per-M instantiations read their taps from LDS (fir_stream_kernel.inc)
+        pa.bank_off = static_cast<int>((*lds + 15) / 16 * 16);
+        *lds = static_cast<size_t>(pa.bank_off) + static_cast<size_t>(a.T) * (tk.r_f64 ? 8 : 4) + 64;
+    }
+#endif
     *out = pa;
     *block = dim3(static_cast<unsigned>(64 * (ncw + 1)));
-    *lds = ns * stage_bytes + 8 * ns;
     return true;
 }
 

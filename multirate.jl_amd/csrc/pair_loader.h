@@ -98,6 +98,14 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
         };
         if (interior) {
             const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
+            if (rc > 0) {                                                // runs (period blocks): chunk -> (run, chunk within the run)
+                for (int slot = 0; slot < nslots; ++slot) {
+                    const int ci = slot * 64 + lane;
+                    const int cis = ci < nchunks ? ci : 0;               // (padding lanes re-read chunk 0)
+                    dma16(src + static_cast<size_t>(chunk_sample(cis)) * (NC * 4u), st + static_cast<size_t>(slot) * 1024);
+                }
+                return nslots;
+            }
             for (int slot = 0; slot < nslots; ++slot) {
                 const int ci = slot * 64 + lane;
                 int d = ci;
@@ -106,7 +114,7 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
                 //  compute wave: a third of C3b's VALU instructions were this, profiles/r04/item7/)
                 if (cd > 0) { const int g = static_cast<int>(__umulhi(static_cast<unsigned>(ci), pad_magic)), r = ci - g * (cd + 1); d = r == cd ? 0 : g * cd + r; }
                 const int cis = d < nchunks ? d : 0;                     // pad chunks and padding lanes re-read chunk 0
-                dma16(src + static_cast<size_t>(chunk_sample(cis)) * (NC * 4u), st + static_cast<size_t>(slot) * 1024);
+                dma16(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
             }
             return nslots;
         }

@@ -816,13 +816,13 @@ def test_chunked_streaming_entry_matches_caller_loop(pkg, torch_cuda):
 
 
 def test_poly_tiled_kernel_long_filters(pkg, O, torch_cuda, monkeypatch):
-    """Filters the register-resident kernels do not take (tapsPerPhi > 64, > 48 for Float64 arithmetic, > 32 for complex samples with Float64 arithmetic, L > 512 phases, a decimation whose step does not fit the streaming kernels' LDS stage) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
+    """Filters the register-resident kernels do not take (tapsPerPhi > 64, > 48 for Float64 arithmetic, > 32 for complex samples with Float64 arithmetic, L > 4096 phases (512 < L <= 4096: the output-pair kernel in period blocks), a decimation whose step does not fit the streaming kernels' LDS stage) run on poly_tiled_kernel: bit-identical to the one-thread-per-output kernel and to the oracle,
     across chunk seams, for every dtype combination, 1..35 channels (all channels-per-lane variants + ragged group)."""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     cases = [(2, 3, 140, np.float32, np.float32, 35), (3, 2, 200, np.float32, np.complex64, 9), (147, 160, 147 * 70, np.float32, np.float32, 33),
              (2, 3, 100, np.float64, np.float64, 4),
-             (7, 1, 7 * 50, np.float64, np.float64, 3), (521, 500, 521 * 3, np.float32, np.float32, 8), (1, 250, 700, np.float32, np.float32, 5),
+             (7, 1, 7 * 50, np.float64, np.float64, 3), (4099, 4000, 4099 * 3, np.float32, np.float32, 8), (1, 250, 700, np.float32, np.float32, 5),
              (1, 33, 600, np.float64, np.complex128, 2), (5, 64, 5 * 40, np.float64, np.float32, 32), (4, 7, 4 * 49, np.float32, np.float64, 1)]
     for (L, M, hl, th, tx, nch) in cases:
         h = rng.standard_normal(hl).astype(th)

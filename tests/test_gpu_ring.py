@@ -222,6 +222,39 @@ def test_ring_interface_on_filters_without_a_resident_kernel(pkg, O, torch_cuda)
         f.close()
 
 
+def test_two_rings_at_once_one_resident(pkg, O, torch_cuda, monkeypatch):
+    """One resident consumer per device (its workgroups must all be on the chip at once): a ring opened while another is resident runs
+    as stream-ordered launches behind the same interface; both streams come out bit-equal to the oracle, interleaved pushes included."""
+    torch = torch_cuda
+    monkeypatch.setenv("MRHIP_RING_IDLE_MS", "500")
+    ratio = Fraction(147, 160)
+    h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    rng = np.random.default_rng(12)
+    xs = [_signal(rng, np.float32, 1, 120_000) for _ in range(2)]
+    fs = [pkg.FIRFilter(h, ratio, device=0).bind(np.float32, 1) for _ in range(2)]
+    fos = [O.FIRFilter(h, ratio, tx=np.float32) for _ in range(2)]
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    ys = [torch.zeros((4, 1, fs[0].outputlength_bound(30_000)), dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.current_stream().synchronize()
+    r0 = fs[0].open_ring()
+    r1 = fs[1].open_ring()
+    assert r0.info()["resident"] and not r1.info()["resident"]
+    got = [[], []]
+    for i in range(4):
+        for k, ring in enumerate((r0, r1)):
+            got[k].append(ring.push(ys[k][i], xd[k][:, i * 30_000:(i + 1) * 30_000]))
+    r1.drain(); r0.drain()
+    r0.close()
+    r2 = fs[0].open_ring()                                  # the place is free again
+    assert r2.info()["resident"]
+    r2.close(); r1.close()
+    for k in range(2):
+        for i in range(4):
+            cnt = got[k][i][0]
+            assert_bit_equal(ys[k][i, 0, :cnt].cpu().numpy(), fos[k].filt(xs[k][0, i * 30_000:(i + 1) * 30_000]), f"ring {k} chunk {i}")
+        fs[k].close()
+
+
 def test_ring_errors(pkg, torch_cuda):
     torch = torch_cuda
     h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
