@@ -59,7 +59,10 @@ __device__ __forceinline__ void pair_take_dyn(PolyArgs &a, PairArgs &pa)
 
 // The whole life of the loader wave (the last wave of the workgroup).  A tile of jt steps needs
 // jt * pa.cM + pa.tail samples of one channel; NC = components per sample (1: Float32, 2: ComplexF32 / one Float64).
-template <int NC>
+// FAST_SEAM = false (the PLAIN instantiations: big one-filter launches, where a channel's two seam tiles are nothing): the first / last
+// tile of a channel is staged element by element as in rounds 1-4 -- the DMA variant below costs the headline 1.3 % (its loader code, A/B
+// against the round-4 library) and buys it nothing.
+template <int NC, bool FAST_SEAM = true>
 __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairArgs &pa, unsigned char *smem, int lane)
 {
     volatile unsigned *const tile_flag = reinterpret_cast<volatile unsigned *>(smem + pa.flags_off);   // [ns][2]: first step, steps (0 = end)
@@ -118,13 +121,32 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
             }
             return nslots;
         }
-        // first / last tile of a channel: history seam and end of input, element-wise checked
+        // First / last tile of a channel: the history seam and the end of the input.  Every 16-byte chunk that lies inside x goes by
+        // LDS-DMA like an interior tile's (the others from a dummy source); the few chunks at the seam and past the end are then put
+        // right element by element.  (Round 4 staged the WHOLE tile element-wise: 2 000 chunks of dependent loads per seam tile -- most
+        // of a one-channel 1e6-sample call.)
+        if constexpr (FAST_SEAM) {
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
+            const unsigned char *dummy = static_cast<const unsigned char *>(a.taps);       // (library-owned, padded: upload_taps)
+            for (int slot = 0; slot < nslots; ++slot) {
+                const int ci = slot * 64 + lane;
+                int d = ci;
+                bool data = ci < nlds;
+                if (cd > 0) { const int g = static_cast<int>(__umulhi(static_cast<unsigned>(ci), pad_magic)), r = ci - g * (cd + 1); data = data && r != cd; d = g * cd + r; }
+                data = data && d < nchunks;
+                const long long smp = data ? chunk_sample(d) : 0;
+                const bool inside = data && o + smp >= 0 && o + smp + EPC <= a.x_len;
+                dma16(inside ? src + smp * (NC * 4) : dummy, st + static_cast<size_t>(slot) * 1024);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const float *__restrict__ hc = static_cast<const float *>(a.hist) + static_cast<long long>(sch) * a.H * NC;
         float *l = reinterpret_cast<float *>(st);
         for (int ci = lane; ci < nchunks; ci += 64) {
+            const long long g0 = o + chunk_sample(ci);
+            if constexpr (FAST_SEAM) { if (g0 >= 0 && g0 + EPC <= a.x_len) continue; }   // staged above
             float4 v;
             float *pv = reinterpret_cast<float *>(&v);
-            const long long g0 = o + chunk_sample(ci);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const long long gi = g0 + e;
@@ -556,17 +578,32 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
             }
             return nslots;
         }
-        // first / last tile of a channel: history seam and end of input, element-wise checked (L2-served loads: the history slot
-        // was written by another workgroup of this launch, the signal by whoever filled the caller's buffer)
+        // first / last tile of a channel: history seam and end of input.  As in pair_loader_wave: what lies inside x by LDS-DMA, the few
+        // chunks at the seam and past the end element by element afterwards (L2-served loads: the history slot was written by another
+        // workgroup of this launch, the signal by whoever filled the caller's buffer)
         if (o < 0 && !wait_hist(c_seq)) return 0;
+        {
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
+            const unsigned char *dummy = static_cast<const unsigned char *>(a.taps);
+            for (int slot = 0; slot < nslots; ++slot) {
+                const int ci = slot * 64 + lane;
+                const bool data = ci < nchunks;
+                const long long smp = static_cast<long long>(EPC) * (data ? ci : 0);
+                const bool inside = data && o + smp >= 0 && o + smp + EPC <= c_xlen;
+                dma16_sc1(inside ? src + smp * (NC * 4) : dummy, st + static_cast<size_t>(slot) * 1024);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const float *hc = hist_slot(c_seq) + static_cast<long long>(ta.ch) * a.H * NC;
         float *l = reinterpret_cast<float *>(st);
         for (int ci = lane; ci < nchunks; ci += 64) {
+            const long long g0 = o + static_cast<long long>(EPC) * ci;
+            if (g0 >= 0 && g0 + EPC <= c_xlen) continue;              // staged above
             float4 v;
             float *pv = reinterpret_cast<float *>(&v);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                const long long gi = o + static_cast<long long>(EPC) * ci + e;
+                const long long gi = g0 + e;
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) {
                     float val = 0.f;
