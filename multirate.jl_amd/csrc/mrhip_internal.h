@@ -339,6 +339,9 @@ struct RingDev {                          // device memory
     // chunks, [6] ... in stage_tile + descriptor prefetch (issue and landing), [7] ... at the tile barrier, [8] loader waves reporting,
     // [9] tiles, [10] FLUSH tiles, [11] ... waiting for a history slot, [12] ... in find_chunk with descriptors at hand
     unsigned long long stats[16];
+    // experiment (MRHIP_RING_OPTS bit 10): tickets HANDED OUT instead of dealt -- eight queues (ticket t in queue t mod 8 at position t div 8),
+    // one per group of workgroups that share an XCD; next_ticket[q][0] = positions of queue q taken so far.  Slower than dealing (experiments.md L).
+    unsigned long long next_ticket[8][16];
     __attribute__((aligned(128))) RingDesc desc[kRingDepth];
 };
 

@@ -406,8 +406,27 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     // the loader's instruction stream is long in ring mode (descriptor look-up, bookkeeping) and shares its SIMD with compute waves that
     // never stall: let it issue first (experiment switch: bit 9 = 512 keeps the default priority)
     if (!(opts & 512u)) __builtin_amdgcn_s_setprio(3);
+    // tickets are dealt statically (ticket t -> workgroup t mod G).  MRHIP_RING_OPTS bit 10 = 1024: HANDED OUT instead, from the queue of
+    // this workgroup's XCD group (RingDev::next_ticket) -- measured slower (1 ch 2.65 against 2.38 us per chunk, 64 ch 42.8 against 45.7 %:
+    // the loader is the long leg and the draw is one more thing in it; profiles/r05/experiments.md L)
     const unsigned long long G = gridDim.x - 1u;
-    unsigned long long ticket = blockIdx.x - 1u;          // this workgroup's next grab, counted over the whole life of the ring
+    const unsigned tq = (blockIdx.x - 1u) & 7u;
+    const bool static_deal = (opts & 1024u) == 0u;
+    // (the position drawn for the grab AFTER the next is always in flight: `pend` is issued when a ticket is consumed and read when
+    //  the next one is -- its round trip never stalls the wave)
+    unsigned long long pend = 0;
+    auto ticket_issue = [&]() {
+        if (!static_deal && lane == 0) pend = __hip_atomic_fetch_add(&rd->next_ticket[tq][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto ticket_take = [&](unsigned long long prev) -> unsigned long long {
+        if (static_deal) return prev + G;
+        const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(pend & 0xffffffffull)));
+        const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(pend >> 32)));
+        ticket_issue();
+        return ((static_cast<unsigned long long>(hi) << 32) | lo) * 8ull + tq;
+    };
+    ticket_issue();
+    unsigned long long ticket = static_deal ? blockIdx.x - 1u : ticket_take(0);          // this workgroup's next grab, counted over the whole life of the ring
     unsigned long long cur = 0, head_seen = 0;            // chunks below cur cannot hold `ticket`
     bool aborted = false;
     unsigned long long st_poll = 0, st_flush = 0, st_hist = 0;      // diagnostics (opts bit 8)
@@ -543,7 +562,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
             const unsigned g = static_cast<unsigned>(ticket - c_tile_base);
             g_shard = static_cast<unsigned>(ticket % kRingShards);
             g_cnt = ring_shard_count(c_tile_base, c_ngrabs, g_shard);
-            ticket += G;
+            ticket = ticket_take(ticket);
             if (g == 0u && !tail_copy()) return kClosed;
             // a grab = pa.steps_per_group steps = several tiles: one descriptor look-up per grab, not per tile
             const unsigned long long lo = static_cast<unsigned long long>(g) * pa.steps_per_group;

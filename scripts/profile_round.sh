@@ -21,8 +21,14 @@ if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
   rm -rf "$OUT/prof_cfg" "$OUT/prof_c2"
   rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_full" -o full -- python3 "$R/bench.py" --no-streamed --no-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/prof_full.log"
   rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_chunk" -o chunk -- python3 "$R/bench.py" --chunk 1000000 --no-cpu-baseline > "$OUT/bench_chunked_under_rocprof.json" 2> "$OUT/prof_chunk.log"
-  rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_cfg" -o cfg -- python3 "$R/scripts/bench_configs.py" c3a c3b c4 c4f c5 xmix64 af ms xdec > "$OUT/configs_under_rocprof.jsonl" 2> "$OUT/prof_cfg.log"
+  rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_cfg" -o cfg -- python3 "$R/scripts/bench_configs.py" c3a c3b c4 c4f c5 xmix64 af ms xdec xlarge > "$OUT/configs_under_rocprof.jsonl" 2> "$OUT/prof_cfg.log"
   rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_c2" -o c2 -- python3 "$R/scripts/bench_configs.py" c2 > "$OUT/c2_under_rocprof.jsonl" 2> "$OUT/prof_c2.log"
+  # BASELINE configs 1 and 2 as stated: one 1e6-sample call; one launch per arriving chunk; the ring (ONE resident launch per pass: its
+  # duration in the trace is the whole pass)
+  rm -rf "$OUT/prof_c1" "$OUT/prof_c2s" "$OUT/prof_c2r"
+  rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_c1" -o c1 -- python3 "$R/scripts/bench_configs.py" c1 > "$OUT/c1_under_rocprof.jsonl" 2> "$OUT/prof_c1.log"
+  rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_c2s" -o c2s -- python3 "$R/scripts/bench_configs.py" c2s > "$OUT/c2s_under_rocprof.jsonl" 2> "$OUT/prof_c2s.log"
+  rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/prof_c2r" -o c2r -- python3 "$R/scripts/bench_configs.py" c2r > "$OUT/c2r_under_rocprof.jsonl" 2> "$OUT/prof_c2r.log"
 fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
   for p in fetch write fetch_chunk write_chunk sq sq2 stall; do rm -rf "$OUT/prof_$p"; done
