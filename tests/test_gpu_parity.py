@@ -1367,3 +1367,18 @@ def test_large_L_runs_on_the_output_pair_kernel_in_period_blocks(pkg, O, torch_c
         assert_bit_equal(got_r[~np.isnan(want_r)], want_r[~np.isnan(want_r)], f"blocks vs oracle L={L} M={M}")
         assert (f.state.phiIdx, f.state.inputDeficit) == (fo.state.phiIdx, fo.state.inputDeficit)
         f.close(); g.close()
+    # the opt-in FUSED numerics take the same road (instantiated for tapsPerPhi a multiple of 4) and match the oracle's fused switch
+    L, M, T = 1000, 999, 24
+    h = (rng.standard_normal(T * L) / 8).astype(np.float32)
+    x = (_rand(rng, (2, 60_000), np.float32) - 0.5).astype(np.float32)
+    f = pkg.FIRFilter(h, Fraction(L, M), numerics=pkg.NUMERICS_FUSED)
+    y = torch.cat(_run_chunks(f, torch.from_numpy(x).cuda(), [25_001, 34_999]), dim=-1).cpu().numpy()
+    assert f.last_kernel_name() == "rational_opair_kernel"
+    O.set_fused(True)
+    try:
+        fo = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
+        ref = np.concatenate([fo.filt(x[1, :25_001]), fo.filt(x[1, 25_001:])])
+    finally:
+        O.set_fused(False)
+    assert_bit_equal(y[1], ref, "blocks, FUSED numerics vs the oracle's fused switch")
+    f.close()
