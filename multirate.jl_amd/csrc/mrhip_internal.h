@@ -298,6 +298,7 @@ struct MultiDesc {           // one independent stream (one FIRFilter of the ref
 // of a chunk's completion from a flag in pinned memory.  Every wait in the kernel has a deadline: it ends by itself when the
 // ring stays empty for `idle_ticks`.
 constexpr int kRingDepth = 64;            // descriptor / history slots; at most kRingDepth - 1 chunks in flight
+constexpr int kRingTraceRows = 512, kRingTraceTiles = 32;   // diagnostics: RingDev::trace
 constexpr int kRingShards = 32;           // completion counters per chunk: a grab counts on shard (ticket mod 32), each on a line of its own
 struct RingDesc {                         // one arriving chunk: 16 quad-words
     unsigned long long x, y;              // device addresses
@@ -338,11 +339,16 @@ struct RingDev {                          // device memory
     // tile barrier, [2] ... draining stores before a report, [3] compute waves reporting; [4] loader waves: whole life, [5] ... polling for
     // chunks, [6] ... in stage_tile + descriptor prefetch (issue and landing), [7] ... at the tile barrier, [8] loader waves reporting,
     // [9] tiles, [10] FLUSH tiles, [11] ... waiting for a history slot, [12] ... in find_chunk with descriptors at hand
-    unsigned long long stats[16];
+    // [13] feeder batches, [14] ... ticks from seeing `head` move to having published, [15] descriptors; per loader: [16] idle tiles BEFORE its
+    // last real tile, [17] / [18] min / max over loaders of the time of the last real tile, [19] max of the first, [20] / [21] min / max real tiles
+    unsigned long long stats[24];
     // experiment (MRHIP_RING_OPTS bit 10): tickets HANDED OUT instead of dealt -- eight queues (ticket t in queue t mod 8 at position t div 8),
     // one per group of workgroups that share an XCD; next_ticket[q][0] = positions of queue q taken so far.  Slower than dealing (experiments.md L).
     unsigned long long next_ticket[8][16];
     __attribute__((aligned(128))) RingDesc desc[kRingDepth];
+    // diagnostics (MRHIP_RING_OPTS bit 8): per workgroup, (time a real tile's staging began, time it was published, ticket) of its first
+    // kRingTraceTiles real tiles; row 0: the feeder's (time, head) pairs.  Dumped to the file MRHIP_RING_TRACE names when the kernel has left.
+    unsigned long long trace[kRingTraceRows][3 * kRingTraceTiles];
 };
 
 struct ArbArgs {             // FIRArbitrary

@@ -125,6 +125,16 @@ __device__ __forceinline__ void ld96_sc1(const void *p, v4u_t (&d)[6])
                  : "v"(p)
                  : "memory");
 }
+// two aligned 16-byte units from HOST (pinned) memory, system scope, and the wait for them in one statement (see ld96_sc1)
+__device__ __forceinline__ void ld32_sys(const void *p0, const void *p1, v4u_t &d0, v4u_t &d1)
+{
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(d0), "=&v"(d1)
+                 : "v"(p0), "v"(p1)
+                 : "memory");
+}
 // write-through stores of N bytes of a lane's registers (N = 4, 8, 16, 32): visible beyond this XCD's L2 once vmcnt has counted them
 template <int N>
 __device__ __forceinline__ void store_wt(void *dst, const void *regs)

@@ -323,58 +323,49 @@ __device__ __forceinline__ unsigned ring_shard_count(unsigned long long tb, unsi
     return static_cast<unsigned>(below(tb + n) - below(tb));
 }
 
-// Workgroup 0's last wave: descriptors from the host's ring (pinned memory, one PCIe round trip per batch of up to 16) into
-// device memory, `head` behind them; the end of the kernel (the host closed the ring, or it stayed empty for idle_ticks).
+// Workgroup 0's last wave: descriptors from the host's ring (pinned memory) into device memory, `head` behind them; the end of the
+// kernel (the host closed the ring, or it stayed empty for idle_ticks).  A descriptor crosses PCIe as six 16-byte reads (its first 96
+// bytes; lane 8k + j reads unit j of descriptor k: sixteen descriptors per round trip: 3.5 us per batch, measured;
+// the first version read sixteen 8-byte words per descriptor -- the same ring rate either way, profiles/r05/experiments.md N).
 __device__ __forceinline__ void ring_feeder(RingDev *rd, RingHost *rh, int lane)
 {
     unsigned long long last = 0, t0 = wall_clock64(), code = 0;
+    unsigned long long fb = 0, ft = 0, fd = 0;
     const unsigned long long idle = ld_sc1(&rd->idle_ticks);
-    const int dq = lane & 15, dk = lane >> 4;
-    auto rl64 = [&](unsigned long long v, int src_lane) -> unsigned long long {
-        const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffffull), src_lane));
-        const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), src_lane));
-        return (static_cast<unsigned long long>(hi) << 32) | lo;
-    };
+    const int du = lane & 7, dk = lane >> 3;                // 16-byte unit of the descriptor, descriptor of the round (two rounds: dk, dk + 8)
+    constexpr int KU = kRingKeyQword / 2;                   // the key's unit
     for (;;) {
         const unsigned long long h = ld_sys(&rh->head);
+        const unsigned long long tseen = wall_clock64();
         if (h > last) {
             const unsigned nb = h - last < 16ull ? static_cast<unsigned>(h - last) : 16u;
-            // the keys first: a reader that meets a slot under rewrite finds no chunk in it
-            if (lane < static_cast<int>(nb)) {
-                const v4u_t dead = {~0u, ~0u, ~0u, ~0u};
-                store_wt<16>(reinterpret_cast<unsigned long long *>(&rd->desc[(last + lane) % kRingDepth]) + kRingKeyQword, &dead);
-            }
+            const unsigned k0 = static_cast<unsigned>(dk), k1 = static_cast<unsigned>(dk) + 8u;
+            const bool on0 = k0 < nb && du < 6, on1 = k1 < nb && du < 6;
+            const unsigned char *h0 = reinterpret_cast<const unsigned char *>(&rh->desc[(last + (on0 ? k0 : 0u)) % kRingDepth]) + 16 * (du < 6 ? du : 0);
+            const unsigned char *h1 = reinterpret_cast<const unsigned char *>(&rh->desc[(last + (on1 ? k1 : 0u)) % kRingDepth]) + 16 * (du < 6 ? du : 0);
+            v4u_t u0, u1;
+            ld32_sys(h0, h1, u0, u1);                       // (every lane loads: the inactive ones re-read descriptor `last`)
+            // fields first ...
+            unsigned char *d0 = reinterpret_cast<unsigned char *>(&rd->desc[(last + k0) % kRingDepth]) + 16 * du;
+            unsigned char *d1 = reinterpret_cast<unsigned char *>(&rd->desc[(last + k1) % kRingDepth]) + 16 * du;
+            if (on0 && du != KU) store_wt<16>(d0, &u0);
+            if (on1 && du != KU) store_wt<16>(d1, &u1);
             vm_drain();
-            unsigned long long q[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const unsigned k = static_cast<unsigned>(dk + 4 * m);
-                q[m] = k < nb ? ld_sys(reinterpret_cast<const unsigned long long *>(&rh->desc[(last + k) % kRingDepth]) + dq) : 0ull;
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const unsigned k = static_cast<unsigned>(dk + 4 * m);
-                if (k < nb && dq != kRingKeyQword && dq != kRingKeyQword + 1) st_sc1(reinterpret_cast<unsigned long long *>(&rd->desc[(last + k) % kRingDepth]) + dq, q[m]);
-            }
-            vm_drain();
-            // ... and the keys last, each by one 16-byte store: (tile_base, ngrabs, low half of the chunk number)
-            unsigned long long key_tb = 0, key_ng = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const unsigned long long tb = rl64(q[k >> 2], (k & 3) * 16 + kRingKeyQword), ng = rl64(q[k >> 2], (k & 3) * 16 + kRingKeyQword + 1);
-                if (lane == k) { key_tb = tb; key_ng = ng; }
-            }
-            if (lane < static_cast<int>(nb)) {
-                const unsigned long long sq = last + static_cast<unsigned>(lane);
-                const v4u_t key = {static_cast<unsigned>(key_tb & 0xffffffffull), static_cast<unsigned>(key_tb >> 32),
-                                   static_cast<unsigned>(key_ng & 0xffffffffull), static_cast<unsigned>(sq & 0xffffffffull)};
-                store_wt<16>(reinterpret_cast<unsigned long long *>(&rd->desc[sq % kRingDepth]) + kRingKeyQword, &key);
-            }
+            // ... then the key, by ONE 16-byte store: (tile_base, ngrabs, low half of the chunk number).  A reader that meets the slot's OLD
+            // key next to new fields finds no pending ticket in it (that chunk is complete): no need to kill the key first.
+            if (on0 && du == KU) { u0.w = static_cast<unsigned>((last + k0) & 0xffffffffull); store_wt<16>(d0, &u0); }
+            if (on1 && du == KU) { u1.w = static_cast<unsigned>((last + k1) & 0xffffffffull); store_wt<16>(d1, &u1); }
             vm_drain();
             last += nb;
             if (lane == 0) st_sc1(&rd->head, last);
-            vm_drain();
-            t0 = wall_clock64();
+            {   // diagnostics (RingDev::stats [13] batches, [14] ticks from seeing `head` move to having published it, [15] descriptors)
+                const unsigned long long t1 = wall_clock64();
+                if (lane == 0) {
+                    if (fb < static_cast<unsigned long long>(kRingTraceTiles)) { rd->trace[0][3 * fb] = tseen; rd->trace[0][3 * fb + 1] = t1; rd->trace[0][3 * fb + 2] = last; }
+                    fb += 1; ft += t1 - tseen; fd += nb;
+                }
+                t0 = t1;
+            }
             continue;
         }
         if (ld_sc1(&rd->closed) != 0ull) { code = 3; break; }               // a worker ran into its deadline
@@ -383,9 +374,11 @@ __device__ __forceinline__ void ring_feeder(RingDev *rd, RingHost *rh, int lane)
             continue;
         }
         if (wall_clock64() - t0 > idle) { code = 2; break; }
-        __builtin_amdgcn_s_sleep(32);
+        __builtin_amdgcn_s_sleep(8);
     }
+    vm_drain();
     if (lane == 0) {
+        atomicAdd(&rd->stats[13], fb); atomicAdd(&rd->stats[14], ft); atomicAdd(&rd->stats[15], fd);
         if (code != 3) st_sc1(&rd->closed, code);
         vm_drain();
         st_sys(&rh->stopped, code);
@@ -430,6 +423,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     unsigned long long cur = 0, head_seen = 0;            // chunks below cur cannot hold `ticket`
     bool aborted = false;
     unsigned long long st_poll = 0, st_flush = 0, st_hist = 0;      // diagnostics (opts bit 8)
+    unsigned long long st_flush_run = 0, st_flush_mid = 0, st_first = 0, st_last = 0, st_real = 0;
     // the chunk of the current grab (wave-uniform)
     unsigned long long c_x = 0, c_y = 0, c_tile_base = 0, c_seq = 0;
     long long c_xs = 0, c_ys = 0, c_xlen = 0, c_nout = 0, c_u0 = 0, c_o0 = 0;
@@ -591,9 +585,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
                 int d = ci;
                 if (cd > 0) { const int g = static_cast<int>(__umulhi(static_cast<unsigned>(ci), pad_magic)), r = ci - g * (cd + 1); d = r == cd ? 0 : g * cd + r; }
                 const int cis = d < nchunks ? d : 0;
-                if (opts & 32u) dma16(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);            // (experiments: plain / nt)
-                else if (opts & 64u) dma16_nt(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
-                else dma16_sc1(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
+                dma16_sc1(src + static_cast<size_t>(cis) * 16, st + static_cast<size_t>(slot) * 1024);
             }
             return nslots;
         }
@@ -652,6 +644,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     bool unreported = false;
     unsigned long long idle_since = 0;                        // != 0: nothing to stage since then
     auto produce = [&](int stage) -> bool {
+        const unsigned long long tr_begin = (opts & 256u) ? wall_clock64() : 0ull;
         if (ra >= rb && !aborted) {
             // never a wait in here: tiles published earlier may still be on their way through the barriers (with more than two stages
             // the compute waves would never reach them).  Nothing published yet: an idle tile (no steps) goes round instead.
@@ -665,7 +658,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
                 }
                 if (ng == kWouldBlock) {
                     if (lane == 0) { td[kRingTileWords * stage] = 1u; td[kRingTileWords * stage + 1] = 2u; }   // FLUSH / idle
-                    ++st_flush;
+                    ++st_flush; ++st_flush_run;
                     ops <<= 6;
                     unreported = false;
                     return true;
@@ -676,7 +669,10 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         }
         if (ra >= rb || aborted) { end_marker(stage); return false; }
         const TileAt ta = tile_at(ra, umin(rb - ra, static_cast<unsigned>(pa.J)));
+        const unsigned long long tr_ticket = ticket;
+        const unsigned long long tr_found = (opts & 256u) ? wall_clock64() : 0ull;
         const int n_ops = stage_tile(ta, stage);
+        const unsigned long long tr_issued = (opts & 256u) ? wall_clock64() : 0ull;
         if (aborted) { end_marker(stage); return false; }
         if (lane == 0) {
             volatile unsigned *t = td + kRingTileWords * stage;
@@ -698,7 +694,21 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         ra += static_cast<unsigned>(ta.jt);
         unreported = !(opts & 2u);
         // the descriptors the NEXT grab will be looked up in, requested behind this tile's transfers (the same wait covers both)
+        const unsigned long long tr_pub = (opts & 256u) ? wall_clock64() : 0ull;
         if (ra >= rb && pf_cur == ~0ull && !(opts & 1u)) prefetch_issue();
+        if (opts & 256u) {
+            st_last = wall_clock64();
+            if (st_real == 0ull) st_first = st_last;
+            if (lane == 0 && st_real < static_cast<unsigned long long>(kRingTraceTiles) && blockIdx.x < static_cast<unsigned>(kRingTraceRows)) {
+                unsigned long long *tr = &rd->trace[blockIdx.x][3 * st_real];
+                auto q = [](unsigned long long d) { return d < 0xffffull ? d : 0xffffull; };
+                // [0] produce() began, [1] ticks to: chunk found | DMA issued | descriptor published | prefetch landed, [2] the NEXT ticket, idle tiles before
+                tr[0] = tr_begin;
+                tr[1] = q(tr_found - tr_begin) | (q(tr_issued - tr_found) << 16) | (q(tr_pub - tr_issued) << 32) | (q(st_last - tr_pub) << 48);
+                tr[2] = (tr_ticket << 16) | (st_flush_run & 0xffffull);
+            }
+            ++st_real; st_flush_mid += st_flush_run; st_flush_run = 0;
+        }
         return true;
     };
     if (lane < pa.ns) td[kRingTileWords * pa.ns + lane] = 0u;   // per stage: compute waves through with a grab's last tile (opair_kernel.inc)
@@ -732,6 +742,11 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         atomicAdd(&rd->stats[9], st_tiles);
         atomicAdd(&rd->stats[10], st_flush);
         atomicAdd(&rd->stats[11], st_hist);
+        atomicAdd(&rd->stats[16], st_flush_mid);
+        if (st_real) {
+            atomicMax(&rd->stats[17], ~(st_last - st_t0)); atomicMax(&rd->stats[18], st_last - st_t0); atomicMax(&rd->stats[19], st_first - st_t0);
+        }
+        atomicMax(&rd->stats[20], ~st_real); atomicMax(&rd->stats[21], st_real);
     }
 }
 

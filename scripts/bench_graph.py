@@ -84,10 +84,11 @@ def stream_row(name, make, nch, chunk, ncalls, dtype, reps=5):
 
 def main():
     global stream_row
-    only = [a for a in sys.argv[1:] if not a.startswith("-")]
-    if only:                       # rows whose name contains any of the words given
+    only = [a for a in sys.argv[1:] if not a.startswith("-") and not a.startswith("chunk=")]
+    chunks = [int(a[6:]) for a in sys.argv[1:] if a.startswith("chunk=")]
+    if only or chunks:             # rows whose name contains any of the words given (and whose chunk size is one of chunk=<n>)
         all_rows = stream_row
-        stream_row = lambda name, *a, **k: all_rows(name, *a, **k) if any(w in name for w in only) else None
+        stream_row = lambda name, make, nch, chunk, *a, **k: all_rows(name, make, nch, chunk, *a, **k) if (not only or any(w in name for w in only)) and (not chunks or chunk in chunks) else None
     h147 = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
     h128 = pkg.firdes(128, 0.5 / 4, beta=7.8562).astype(np.float32)
     haf = pkg.firdes(320, 0.45 / 32, beta=7.8562) * 32

@@ -16,15 +16,17 @@ f = pkg.FIRFilter(h, Fraction(147, 160), device=0).bind(np.float32, nch)
 y = torch.empty((nch, f.outputlength(n) + 8), device="cuda")
 for opts in [int(v) for v in (sys.argv[1:] or ["0", "1", "2", "3", "0"])]:
     os.environ["MRHIP_RING_OPTS"] = str(opts)
-    ts = []
+    ts, tps = [], []
     for rep in range(5):
         f.reset(); torch.cuda.synchronize()
         ring = f.open_ring()
         t1 = time.perf_counter()
-        ring.push_chunks(y, x, chunk); ring.drain()
+        ring.push_chunks(y, x, chunk)
+        tp = time.perf_counter()
+        ring.drain()
         t2 = time.perf_counter()
         ring.close()
-        ts.append(t2 - t1)
+        ts.append(t2 - t1); tps.append(tp - t1)
     ts = sorted(ts[1:])
     ms = 1e3 * ts[len(ts) // 2]
-    print(json.dumps({"opts": opts, "nch": nch, "chunk": chunk, "ms": round(ms, 4), "us_per_chunk": round(1e3 * ms / (n // chunk), 3), "frac": round(nch * n * 7.675 / (ms * 1e-3) / 8e12, 4), "all_ms": [round(1e3 * t, 3) for t in ts]}), flush=True)
+    print(json.dumps({"opts": opts, "nch": nch, "chunk": chunk, "ms": round(ms, 4), "us_per_chunk": round(1e3 * ms / (n // chunk), 3), "frac": round(nch * n * 7.675 / (ms * 1e-3) / 8e12, 4), "all_ms": [round(1e3 * t, 3) for t in ts], "push_returned_ms": [round(1e3 * t, 3) for t in tps[1:]]}), flush=True)
