@@ -554,6 +554,7 @@ void mrhip_destroy(mrhip_filter *f)
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
         if (st) (void)hipStreamDestroy(st);
     if (f->ev_chain) (void)hipEventDestroy(f->ev_chain);
+    if (f->ev_sdirty) (void)hipEventDestroy(f->ev_sdirty);
     for (hipEvent_t e : {f->sched_copied, f->xs_event, f->ev_in[0], f->ev_in[1], f->ev_k[0], f->ev_k[1], f->ev_out[0], f->ev_out[1]})
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_pool) (void)hipEventDestroy(e);
@@ -578,6 +579,7 @@ static int push_state(mrhip_filter *f)
     if (f->s_sched) {
         if (int rc = sched_stream_behind_chain(f)) return rc;
         f->async_pending = true;
+        f->sched_dirty = true;
         return rec_push(f, f->s_sched);
     }   // FIRArbitrary / FIRFarrow: every write of the record, in program order
     hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
@@ -663,6 +665,7 @@ int64_t mrhip_advance_state(mrhip_filter *f, int64_t n)
                 SchedOut so{};
                 so.buf = f->flip; f->flip ^= 1;
                 if (f->ev_filt_valid[so.buf] && hipStreamWaitEvent(f->s_sched, f->ev_filt[so.buf], 0) != hipSuccess) return -1;
+                f->sched_dirty = true;
                 if (sched_enqueue(f, len, est, INT64_MAX, nullptr, true, f->s_sched, &so)) return -1;
                 for (;;) {
                     bool relaunch = false;
@@ -829,6 +832,7 @@ int mrhip_reset(mrhip_filter *f)
         f->async_pending = true;
         if (int rc = sched_stream_behind_chain(f)) return rc;
     }
+    if (f->s_sched) f->sched_dirty = true;
     return f->s_sched ? rec_push(f, f->s_sched) : rec_push(f, s);   // the device record: constructor state, in stream order
 }
 
@@ -1071,6 +1075,8 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
 
     int64_t n_out = 0;
     bool did_shiftin = false;
+    bool sched_inline = false;         // FIRArbitrary / FIRFarrow: this call's schedule ran on the caller's stream although the filter has a schedule stream
+    bool hist_in_place = false;        // ... by a filter kernel inside a capture, straight into the slot the replay reads (ShiftFold)
     bool rec_current = false;          // the device record has (or will have, in stream order) this call's end state
     const int hist_next = f->hist_cur ^ 1;
     if (arb) {
@@ -1081,8 +1087,16 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         //  from the call record, cnt is its upper bound)
         const void *sched_dn = nullptr, *sched_dacc = nullptr;      // set by the branch that filled them, before its launch_range
         const int *sched_spans = nullptr;
-        auto launch_range = [&](int64_t k0, int64_t cnt, const int32_t *n_host, const DevCall *dyn) -> int {
+        // whole_call: the range is the call (not a piece of a long one): the kernels that can (arb_pipe_kernel, farrow_wave_kernel) then write the
+        // next call's history themselves (ShiftFold) -- inside a capture straight into the slot the replay reads, which takes x_len >= H
+        auto launch_range = [&](int64_t k0, int64_t cnt, const int32_t *n_host, const DevCall *dyn, bool whole_call = false) -> int {
             if (!sched_dn || !sched_dacc) return fail(MRHIP_ERR_HIP, "no phase schedule on the device (internal)");
+            ShiftFold sf{};
+            const bool in_place = capturing;
+            if (whole_call && f->H > 0 && !x_from && (!in_place || x_len >= f->H) && MRHIP_ENV_INT("MRHIP_FOLD_SHIFTIN", 1) != 0) {
+                sf.hist_new = f->d_hist[in_place ? f->hist_cur : hist_next];
+                sf.done = in_place ? f->d_counters + 128 : nullptr;
+            }
             void *yk = static_cast<unsigned char *>(y) + static_cast<size_t>(k0) * yelt;
             if (f->kind == MRHIP_FIR_FARROW) {
                 FarrowArgs fa{};
@@ -1099,6 +1113,8 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 if (!f->force_generic && f->d_pnfb_t && plan_farrow_wave(fa)) {
                     FarrowArgs fw = fa;
                     fw.pnfb = f->d_pnfb_t;                              // degree-major, padded: [polyorder+1][32]
+                    fw.fold = sf;
+                    if (sf.hist_new) { did_shiftin = true; hist_in_place = in_place; }
                     MRHIP_CHECK_HIP(launch_farrow_wave(tk, fused, fw, stream, &f->last_kernel, f->num_cus));
                 }
                 else if (!f->force_generic && plan_farrow_tiled(tk, fa, n_host, sched_spans, f->num_cus, &fta, &flds)) {
@@ -1123,6 +1139,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 // the pipe kernel's tiles are handed out from a counter of the filter (its launches are stream-ordered: one at a
                 // time); MRHIP_PIPE_DYNAMIC=0: every workgroup takes every gridDim-th tile
                 ta.counters = MRHIP_ENV_INT("MRHIP_PIPE_DYNAMIC", 1) != 0 ? f->d_counters : nullptr;
+                if (ta.pipe && sf.hist_new) { a.fold = sf; did_shiftin = true; hist_in_place = in_place; }
                 MRHIP_CHECK_HIP(launch_arb_tiled(tk, fused, a, ta, lds, stream, &f->last_kernel, f->num_cus));
             }
             else
@@ -1149,13 +1166,24 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             // the record, which moved on with that call's FINISH kernel, and nothing else); schedule buffers and call records
             // alternate, events order writer and reader of each (mrhip_filter.h: s_sched).  Inside a capture: one stream.
             // (a chained call's schedule reads the previous stage's call record, which is written on the caller's stream: it runs there)
-            hipStream_t ss = capturing || !f->s_sched || x_from ? stream : f->s_sched;
+            // (a call of one small piece -- at most MRHIP_SCHED_INLINE_MAX outputs, default 65 536 -- is launch-bound: its three kernels go down ONE
+            //  queue without the three event operations the second stream costs the host; profiles/r05/experiments.md O)
+            const bool inline_sched = est <= MRHIP_ENV_INT("MRHIP_SCHED_INLINE_MAX", 65536);
+            hipStream_t ss = capturing || !f->s_sched || x_from || inline_sched ? stream : f->s_sched;
             // a chained call's schedule ran on the CALLER's stream (it reads the previous stage's call record there) and wrote the record,
             // the piece states and the path tables: a schedule on the filter's own schedule stream must come behind it
             if (ss == f->s_sched && f->chain_pending) {
                 MRHIP_CHECK_HIP(hipStreamWaitEvent(ss, f->ev_chain, 0));
                 f->chain_pending = false;
             }
+            if (ss == f->s_sched) f->sched_dirty = true;
+            else if (!capturing && f->s_sched && f->sched_dirty) {        // (mrhip_filter.h: sched_dirty)
+                if (!f->ev_sdirty) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_sdirty, hipEventDisableTiming));
+                MRHIP_CHECK_HIP(hipEventRecord(f->ev_sdirty, f->s_sched));
+                MRHIP_CHECK_HIP(hipStreamWaitEvent(stream, f->ev_sdirty, 0));
+                f->sched_dirty = false;
+            }
+            sched_inline = ss == stream && !capturing && f->s_sched != nullptr;
             SchedOut so{};
             so.buf = capturing ? 0 : f->flip;
             if (!capturing) f->flip ^= 1;
@@ -1173,7 +1201,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             bool launched = false;
             if (so.pending && room && est > 0) {
                 if (int rc = join()) return rc;
-                if (int rc = launch_range(0, est, nullptr, f->d_calls[b])) return rc;
+                if (int rc = launch_range(0, est, nullptr, f->d_calls[b], true)) return rc;
                 launched = true;
             }
             rec_current = so.pending;
@@ -1202,7 +1230,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                     rec_current = so.pending;
                     if (so.pending && room) {
                         if (int rc = join()) return rc;
-                        if (int rc = launch_range(0, est, nullptr, f->d_calls[b])) return rc;
+                        if (int rc = launch_range(0, est, nullptr, f->d_calls[b], true)) return rc;
                     } else launched = false;
                 }
                 n_out = so.count;
@@ -1219,7 +1247,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                     if (!y) return fail(MRHIP_ERR_INVALID_ARG, "y is NULL");
                     if (f->nch > 1 && y_stride < n_out) return fail(MRHIP_ERR_INVALID_ARG, "y_stride < output count");
                     if (int rc = join()) return rc;
-                    if (int rc = launch_range(0, n_out, nullptr, nullptr)) return rc;
+                    if (int rc = launch_range(0, n_out, nullptr, nullptr, true)) return rc;
                 }
                 f->sched_drift = so.drift; f->sched_ksteps = so.ksteps;
                 if (so.periodic || f->per_valid) f->per_pos = so.per_pos_end;
@@ -1298,7 +1326,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_sched_acc, f->pin_acc, static_cast<size_t>(n_out) * sizeof(double), hipMemcpyHostToDevice, stream));
             MRHIP_CHECK_HIP(hipEventRecord(f->sched_copied, stream));
             f->sched_in_flight = true;
-            if (int rc = launch_range(0, n_out, f->sched_n.data(), nullptr)) return rc;
+            if (int rc = launch_range(0, n_out, f->sched_n.data(), nullptr, true)) return rc;
         }
         }
         // commit the post-call state (Filters.jl:731-735)
@@ -1384,9 +1412,18 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
     //  follow every call of every kind)
     if (!rec_current)
     {
-        const bool on_sched = arb && f->s_sched && !capturing;
+        // (every write of a FIRArbitrary / FIRFarrow record in program order: on the schedule stream, behind whatever the caller's stream wrote
+        //  last -- or, when this call's schedule ran on the caller's stream, there, with the schedule stream's next user behind it)
+        const bool on_sched = arb && f->s_sched && !capturing && !sched_inline;
+        if (on_sched) { if (int rc = sched_stream_behind_chain(f)) return rc; f->sched_dirty = true; }
         if (int rc = rec_push(f, on_sched ? f->s_sched : stream, -1, std::max<int64_t>(n_out, 0))) return rc;
         if (on_sched) f->async_pending = true;       // (nobody waits for that push: a capture must not start before it has run)
+        if (sched_inline) {
+            if (!f->ev_chain) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_chain, hipEventDisableTiming));
+            MRHIP_CHECK_HIP(hipEventRecord(f->ev_chain, stream));
+            f->chain_pending = true;
+            f->async_pending = true;
+        }
     }
 
     // history <- last H samples of [history ; x]   (shiftin!, support.jl:61-80), ping-pong buffers
@@ -1398,7 +1435,9 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         MRHIP_CHECK_HIP(launch_shiftin(tk, ha, stream));
     }
     if (f->H > 0) {
-        if (capturing) {
+        if (capturing && hist_in_place) {
+            // (the filter kernel wrote the slot the replay reads)
+        } else if (capturing) {
             // a replay reads the slot baked into the node: bring the new history back into it instead of moving on
             MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_hist[f->hist_cur], f->d_hist[hist_next],
                                            static_cast<size_t>(f->nch) * f->H * x_elt(f), hipMemcpyDeviceToDevice, stream));

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
         }
     };
     if (ctr) tile *= RUN;
-    if (tile >= ta.total_tiles) { leave(); return; }
+    if (tile >= ta.total_tiles) { leave(); dev::shiftin_by_last_workgroup<TX, NC>(a.fold, a.x, a.hist, a.x_stride, a.x_len, a.H, a.nch); return; }
     long long tau = tile / ngroups;
     int cg = static_cast<int>(tile - tau * ngroups);
     constexpr long long kNoRun = -1;
@@ -548,6 +548,7 @@ __global__ __launch_bounds__(kPipeThreads, 4) void arb_pipe_kernel(ArbArgs a, Ar
         ++it;
     }
     leave();
+    dev::shiftin_by_last_workgroup<TX, NC>(a.fold, a.x, a.hist, a.x_stride, a.x_len, a.H, a.nch);
 #ifdef MRHIP_AP_TRACE
     if (tid == 0 && blockIdx.x < 2048) g_ap_trace[g_ap_slot & 63][blockIdx.x][1] = wall_clock64();
 #endif

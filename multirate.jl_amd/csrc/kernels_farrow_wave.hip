@@ -17,6 +17,7 @@
 #include <cstdio>
 
 #include "mrhip_internal.h"
+#include "pair_device.h"
 
 #pragma clang fp contract(off)
 
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kFwThreads) void farrow_wave_kernel(FarrowArgs a)
     const long long step = static_cast<long long>(gridDim.x) * kFwThreads;
     const int lane = threadIdx.x & 63;
     long long kw = static_cast<long long>(blockIdx.x) * kFwThreads + (threadIdx.x & ~63);   // this wave's first output
-    if (kw >= n_out) return;
+    const bool work = kw < n_out;                                        // (a wave without outputs still takes part in the epilogue below)
     constexpr bool EARLY = TREG <= 16;                                   // channel 0's samples are requested before the Horner steps
     constexpr int DEAD = TREG <= 16 ? 3 : 7;                             // slot classes 4, 8, 12, 16 | 24, 32 (launch_fw_t)
     // (the entry's index stays the 32-bit value the load delivers until the top of the iteration that uses it: widened right
@@ -67,10 +68,10 @@ __global__ __launch_bounds__(kFwThreads) void farrow_wave_kernel(FarrowArgs a)
         *n_ = a.n_idx[kk];
         *ph_ = a.acc[kk];
     };
-    int n32;
-    double phase;
-    entry(kw, &n32, &phase);
-    for (;;) {                                                           // (wave-uniform trip count)
+    int n32 = 0;
+    double phase = 0.0;
+    if (work) entry(kw, &n32, &phase);
+    while (work) {                                                       // (wave-uniform trip count)
         const long long n = n32;
         const long long k = kw + lane;
         const bool have = k < n_out;
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(kFwThreads) void farrow_wave_kernel(FarrowArgs a)
         if (!more) break;
         kw = kw_next; n32 = n_next; phase = phase_next;
     }
+    dev::shiftin_by_last_workgroup<TX, NC>(a.fold, a.x, a.hist, a.x_stride, a.x_len, a.H, a.nch);
 }
 
 template <typename TX, typename R, int NC>

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "mrhip_internal.h"
 
@@ -51,6 +52,26 @@ __device__ __forceinline__ void sched_step(double &acc, long long &x, const Sche
     } else {
         acc = a1;
     }
+}
+
+// The same step without a branch, for the 64-step runs of the tables and emit kernels (a lone wave there pays ~170 cycles a step for the
+// form above: four branches, a run-time test of `pow2` per step and a Float64 -> Int64 conversion of k in five instructions).  The same
+// operations on the same values in the same order -- the results of the path not taken are discarded -- and k, an integer below 2^18 + 1
+// (make_sched_plan), goes through Int32.
+template <bool POW2>
+__device__ __forceinline__ void sched_step_nb(double &acc, long long &x, const SchedPlan &c)
+{
+    const double a1 = acc + c.delta;                                  // :664
+    const double am1 = a1 - 1.0;
+    const double q = POW2 ? am1 * c.invN : am1 / c.N;                 // :667
+    const double k = __builtin_floor(q);
+    double r = am1 - k * c.N;
+    // (a power of two: the scaling, the floor, k * N and the difference are all exact -- r is am1 mod N, never negative; only a ROUNDED
+    //  quotient can overshoot an integer: the comment above sched_step)
+    if constexpr (!POW2) r = r < 0.0 ? r + c.N : r;
+    const bool wrap = a1 > c.N;                                       // :666
+    acc = wrap ? r + 1.0 : a1;                                        // :668
+    x += wrap ? static_cast<long long>(__double2int_rz(k)) : 0LL;
 }
 
 // Predicted phase after k steps from the piece's start: the un-rounded recurrence (double-double product) plus the
@@ -114,6 +135,22 @@ __device__ __forceinline__ bool sched_stop(const SchedStatus *st, int piece)
     return fp != kSchedNoFail || (dn != 0 && dn - 1 < piece);
 }
 
+// MRHIP_SCHED_TRACE (a build switch, diagnostics): the 100 MHz clock at stations of the tables and emit kernels, per workgroup of the LAST
+// launch of each; printed at exit (per station: the earliest and the latest workgroup, relative to the kernel's first stamp).
+#ifdef MRHIP_SCHED_TRACE
+__device__ unsigned long long g_sched_trace[2][64][16];
+#define SCHED_STAMP(k, i) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_sched_trace[k][blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define SCHED_STAMP(k, i) do { } while (0)
+#endif
+
+// write-through stores / L2-served loads of 4- and 8-byte fields (the hand-off inside the emit kernel: see sched_emit_kernel)
+__device__ __forceinline__ void st_wt(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_wt(double *p, double v) { __hip_atomic_store(reinterpret_cast<long long *>(p), __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long ld_wt(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_wt(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_wt(const double *p) { return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+
 __device__ __forceinline__ SchedPieceState sched_begin_body(const SchedBeginArgs &a, long long x_len, long long k_first, bool file);
 __device__ __noinline__ void sched_finish_body(const SchedPlan &c, SchedFinishArgs a);
 
@@ -122,6 +159,7 @@ __device__ __noinline__ void sched_finish_body(const SchedPlan &c, SchedFinishAr
 // itself (the status word is still the previous call's: nothing here reads it), one thread files it for the kernels behind.
 __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, SchedPieceArgs a, SchedFuseArgs fu)
 {
+    SCHED_STAMP(0, 0);
     if (!fu.begin && sched_stop(a.status, a.piece)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nwin = c.nwin;
@@ -135,6 +173,7 @@ __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, 
     const int g = blockIdx.x;
     const long long seg0 = static_cast<long long>(g) * kGroupSegs;
     const int tasks = kGroupSegs * nwin;
+    SCHED_STAMP(0, 1);
     for (int t = threadIdx.x; t < tasks; t += static_cast<int>(blockDim.x)) {
         const int sl = t / nwin, ci = t - sl * nwin;
         const double k0 = static_cast<double>((seg0 + sl) * kSeg);
@@ -143,8 +182,13 @@ __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, 
         const double start = sched_cand(base, ci, c);
         double acc = start;
         long long x = 0;
+        if (c.pow2) {
 #pragma unroll 4
-        for (int i = 0; i < kSeg; ++i) sched_step(acc, x, c);
+            for (int i = 0; i < kSeg; ++i) sched_step_nb<true>(acc, x, c);
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < kSeg; ++i) sched_step_nb<false>(acc, x, c);
+        }
         if (a.corrupt_group == g && sl == 7) acc += c.G;                 // test hook (MRHIP_SCHED_CORRUPT): a wrong table must be caught
         int cn = -1;
         double sh = 0.0;
@@ -155,6 +199,7 @@ __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, 
         eCn[t] = cn;
     }
     __syncthreads();
+    SCHED_STAMP(0, 2);
     if (tasks == static_cast<int>(blockDim.x)) {
         // compose by a parallel scan (one thread per (segment, candidate): nwin <= 16): after round d the entry (sl, c) is the map of
         // segments sl-2d+1 .. sl applied to candidate c -- six rounds instead of 64 dependent look-ups per candidate.  Shifts are
@@ -180,6 +225,7 @@ __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, 
             __syncthreads();
         }
         // (sl, c0): the state in front of segment sl when the group starts at candidate c0 = the map of segments 0 .. sl-1
+        SCHED_STAMP(0, 3);
         int pc = ci0, pw = 0;
         double ps_ = 0.0;
         if (sl > 0) { const int tb = (sl - 1) * nwin + ci0; pc = eCn[tb]; ps_ = eSh[tb]; pw = eW[tb]; }
@@ -193,6 +239,7 @@ __global__ __launch_bounds__(kTabThreads) void sched_tables_kernel(SchedPlan c, 
             ge.next = eCn[t];
             a.gtab[static_cast<size_t>(g) * nwin + ci0] = ge;
         }
+        SCHED_STAMP(0, 4);
         return;
     }
     // compose: candidate c0 of the group's first segment walked through the 64 maps; the path is kept for K3
@@ -238,6 +285,25 @@ __device__ __forceinline__ void chain_apply(ChainState &st, const SchedGroupEntr
     const double gsh = __shfl(ge.shift, src);
     const int gadv = __shfl(ge.advance, src);
     const int gnext = __shfl(ge.next, src);
+    if (st.ok) {
+        st.S += gsh;
+        st.W += gadv;
+        st.ci = gnext;
+        st.ok = gnext >= 0;
+    }
+}
+
+// The same when EVERY lane carries the same state (the walk from the piece's true start): the source lane is wave-uniform, so the three
+// values come by v_readlane instead of a shuffle through the LDS crossbar (a dependent ~100 cycles each, sixteen groups deep).
+__device__ __forceinline__ void chain_apply_uniform(ChainState &st, const SchedGroupEntry &ge)
+{
+    const int src = __builtin_amdgcn_readfirstlane(st.ok ? st.ci : 0);
+    const long long shb = __double_as_longlong(ge.shift);
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(shb & 0xffffffffLL), src));
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(shb >> 32), src));
+    const double gsh = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+    const int gadv = __builtin_amdgcn_readlane(ge.advance, src);
+    const int gnext = __builtin_amdgcn_readlane(ge.next, src);
     if (st.ok) {
         st.S += gsh;
         st.W += gadv;
@@ -321,16 +387,24 @@ __global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan
 __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedPieceArgs &a, bool fold_chain);
 __global__ __launch_bounds__(kGroupSegs) void sched_emit_kernel(SchedPlan c, SchedPieceArgs a, SchedFuseArgs fu)
 {
+    SCHED_STAMP(1, 0);
     sched_emit_body(c, a, fu.fold_chain != 0);
+    SCHED_STAMP(1, 6);
     if (!fu.finish) return;
     static_assert(kGroupSegs == 64, "one wave per workgroup: the count below is a wave's");
-    __threadfence();                                          // this workgroup's entries, end and state: out before it counts
+    // What the FINISH reads of this kernel's work -- the status word's fields and the state behind the piece -- was stored WRITE-THROUGH
+    // (st_wt below) and is drained here, before this workgroup counts itself off; the FINISH reads it past its L1 (ld_wt).  The two
+    // __threadfence() of rounds 3-4 wrote back every dirty line of the XCD's L2 -- 48 KB of schedule entries per workgroup, which only
+    // the NEXT kernel reads -- in front of a count: most of this kernel's 18 us in a one-piece call (profiles/r05/experiments.md O).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SCHED_STAMP(1, 7);
     int last = 0;
-    if (threadIdx.x == 0) last = atomicAdd(&a.status->groups_done, 1) == a.ngroups - 1 ? 1 : 0;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&a.status->groups_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ngroups - 1 ? 1 : 0;
     last = __shfl(last, 0);
+    SCHED_STAMP(1, 8);
     if (!last) return;
-    __threadfence();                                          // ... and everyone else's in before the FINISH reads them
     if (threadIdx.x == 0) sched_finish_body(c, fu.f);
+    SCHED_STAMP(1, 9);
 }
 
 __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedPieceArgs &a, bool fold_chain)
@@ -339,19 +413,28 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
     // has set `done` -- it must still write its entries (sched_stop)
     if (a.corrupt_group <= -2 && static_cast<int>(blockIdx.x) == -a.corrupt_group - 2)
         for (int i = 0; i < 128; ++i) __builtin_amdgcn_s_sleep(127);
-    if (__any(sched_stop(a.status, a.piece))) return;          // (one decision for the wave: the lanes shuffle below)
-    // The group's 4096 entries leave through LDS (a lane computes a segment, i.e. 64 CONSECUTIVE entries) in chunks of kEmitChunk
-    // steps: 14 KB a workgroup instead of the 50 KB of the whole group at once -- what is left beside the filter kernel's
-    // workgroups, next to which this kernel runs (profiles/r04/experiments.md S).
-    constexpr int kEmitChunk = 16;
-    static_assert(kSeg % kEmitChunk == 0 && kGroupSegs == 64, "whole chunks; one wave per workgroup");
-    __shared__ int s_n[kGroupSegs * (kEmitChunk + 1)];
-    __shared__ double s_acc[kGroupSegs * (kEmitChunk + 1)];
+    static_assert(kGroupSegs == 64 && kSeg % 4 == 0, "one wave per workgroup; four steps per 16-byte store");
     __shared__ double s_T[kGroupSegs + 1];
     __shared__ long long s_X[kGroupSegs + 1];
-
     const int g = blockIdx.x, sl = threadIdx.x, nwin = c.nwin;
+    // Everything this workgroup needs from memory before its run is requested in ONE round -- the status word, the piece's state, the call's
+    // length, the maps of the groups in front of it (a piece of few groups) -- and used only behind the last request: three dependent round
+    // trips in front of the run were 2.8 of this kernel's 10.9 us in a one-piece call (profiles/r05/experiments.md O).
+    constexpr int kFoldMax = 16;
+    const bool fold_wide = fold_chain && a.ngroups <= kFoldMax + 1;
+    const int st_fail = __hip_atomic_load(&a.status->fail_piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (sched_stop)
+    const int st_done = __hip_atomic_load(&a.status->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const SchedPieceState ps = a.state[a.piece];
+    const long long x_len = a.status->x_len;               // (written by the call's BEGIN kernel, which ran before every piece)
+    SchedGroupEntry e[kFoldMax + 1];
+#pragma unroll
+    for (int q = 0; q <= kFoldMax; ++q) {
+        e[q] = SchedGroupEntry{};
+        e[q].next = -1;
+        if (fold_wide && sl < nwin) e[q] = a.gtab[static_cast<size_t>(q <= g && q < a.ngroups ? q : 0) * nwin + sl];
+    }
+    if (__any(st_fail != kSchedNoFail || (st_done != 0 && st_done - 1 < a.piece))) return;   // (one decision for the wave: the lanes shuffle below)
+    SCHED_STAMP(1, 1);
     SchedGroupStart gs, gnx;                                // this group's true start and the next group's
     if (fold_chain) {
         // a piece of few groups has no chain kernel: the wave (lane = candidate) walks the groups' maps from the piece's true start
@@ -367,20 +450,31 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
             if (lane < nwin) ge = a.gtab[static_cast<size_t>(gg) * nwin + lane];
             return ge;
         };
-        int gg = 0;
-        for (; gg + 4 <= g; gg += 4) {                      // four maps in flight per round of loads
-            const SchedGroupEntry e0 = entry(gg), e1 = entry(gg + 1), e2 = entry(gg + 2), e3 = entry(gg + 3);
-            chain_apply(st, e0); chain_apply(st, e1); chain_apply(st, e2); chain_apply(st, e3);
+        // (at most 17 maps: all of them came with the first round of loads -- the last group, which is the kernel's critical path, took one
+        //  round trip per four maps)
+        if (fold_wide) {
+#pragma unroll
+            for (int q = 0; q <= kFoldMax; ++q) {
+                if (q == g) put(gs);
+                if (q < g || (q == g && g + 1 < a.ngroups)) chain_apply_uniform(st, e[q]);
+            }
+            put(gnx);
+        } else {
+            int gg = 0;
+            for (; gg + 4 <= g; gg += 4) {                      // four maps in flight per round of loads
+                const SchedGroupEntry e0 = entry(gg), e1 = entry(gg + 1), e2 = entry(gg + 2), e3 = entry(gg + 3);
+                chain_apply(st, e0); chain_apply(st, e1); chain_apply(st, e2); chain_apply(st, e3);
+            }
+            for (; gg < g; ++gg) chain_apply(st, entry(gg));
+            put(gs);
+            if (g + 1 < a.ngroups) chain_apply(st, entry(g));
+            put(gnx);
         }
-        for (; gg < g; ++gg) chain_apply(st, entry(gg));
-        put(gs);
-        if (g + 1 < a.ngroups) chain_apply(st, entry(g));
-        put(gnx);
     } else {
         gs = a.gstart[g];
         gnx = g + 1 < a.ngroups ? a.gstart[g + 1] : gs;
     }
-    const long long x_len = a.status->x_len;               // (written by the call's BEGIN kernel, which ran before every piece)
+    SCHED_STAMP(1, 2);
     const long long seg = static_cast<long long>(g) * kGroupSegs + sl;
     bool bad = gs.cand < 0;
     double T = ps.acc;
@@ -393,34 +487,55 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
     }
     s_T[sl] = T;
     s_X[sl] = X;
+    SCHED_STAMP(1, 3);
     double acc = T;
     long long x = X;
     long long end_k = -1;
     double end_acc = 0.0;
     long long end_x = 0;
     const long long kbase = a.k0 + seg * kSeg;            // step number of this segment's first output within the call
-    long long prev_x = X;
     int *__restrict__ gn = a.sched_n + a.k0 + static_cast<long long>(g) * kGroupSegs * kSeg;
     double *__restrict__ ga = a.sched_acc + a.k0 + static_cast<long long>(g) * kGroupSegs * kSeg;
-    for (int i0 = 0; i0 < kSeg; i0 += kEmitChunk) {
-#pragma unroll 4
-        for (int ii = 0; ii < kEmitChunk; ++ii) {
-            const int i = i0 + ii;
-            s_n[sl * (kEmitChunk + 1) + ii] = static_cast<int>(x);
-            s_acc[sl * (kEmitChunk + 1) + ii] = acc;
-            if (i > 0 && x > x_len && prev_x <= x_len) { end_k = kbase + i; end_acc = acc; end_x = x; }
-            prev_x = x;
-            sched_step(acc, x, c);
+    // A lane owns 64 CONSECUTIVE entries: it keeps four steps in registers and stores them as 16-byte units (one for the indices, two for the
+    // phases) straight from there -- 48 store instructions per lane that nobody waits for.  (Rounds 3-4 transposed 16 steps at a time
+    // through LDS for coalesced rows: two barriers and 64 LDS operations per 16 steps, all in the one wave that also walks the dependent
+    // chain -- 10.7 of this kernel's 17.8 us in a one-piece call, profiles/r05/experiments.md O.)
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(gn) | reinterpret_cast<uintptr_t>(ga)) & 15u) == 0;
+    int *__restrict__ ln = gn + sl * kSeg;
+    double *__restrict__ la = ga + sl * kSeg;
+    auto run = [&](auto pow2_tag) {
+        constexpr bool P2 = decltype(pow2_tag)::value;
+        for (int i0 = 0; i0 < kSeg; i0 += 4) {
+            int nn[4];
+            double aa[4];
+            const long long xb = x;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                nn[ii] = static_cast<int>(x);
+                aa[ii] = acc;
+                sched_step_nb<P2>(acc, x, c);
+            }
+            // the call's end -- the one step whose xIdx is the first beyond x_len (xIdx never decreases) -- is looked for once per four
+            // steps: steps i0 + 1 .. i0 + 4 of the segment (step 64 is the next segment's step 0: "the call ends between two segments")
+            if (xb <= x_len && x > x_len) {
+#pragma unroll
+                for (int j = 1; j <= 4; ++j) {
+                    const long long xj = j < 4 ? static_cast<long long>(nn[j < 4 ? j : 0]) : x, xp = nn[j - 1];
+                    if (xj > x_len && xp <= x_len) { end_k = kbase + i0 + j; end_acc = j < 4 ? aa[j < 4 ? j : 0] : acc; end_x = xj; }
+                }
+            }
+            if (vec_ok) {
+                *reinterpret_cast<int4 *>(ln + i0) = make_int4(nn[0], nn[1], nn[2], nn[3]);
+                *reinterpret_cast<double2 *>(la + i0) = make_double2(aa[0], aa[1]);
+                *reinterpret_cast<double2 *>(la + i0 + 2) = make_double2(aa[2], aa[3]);
+            } else {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) { ln[i0 + ii] = nn[ii]; la[i0 + ii] = aa[ii]; }
+            }
         }
-        __syncthreads();
-        // 16 lanes write 16 consecutive entries of one segment: runs of 64 / 128 bytes
-        for (int e = sl; e < kGroupSegs * kEmitChunk; e += kGroupSegs) {
-            const int r = e / kEmitChunk, ii = e - r * kEmitChunk;
-            gn[r * kSeg + i0 + ii] = s_n[r * (kEmitChunk + 1) + ii];
-            ga[r * kSeg + i0 + ii] = s_acc[r * (kEmitChunk + 1) + ii];
-        }
-        __syncthreads();
-    }
+    };
+    if (c.pow2) run(std::true_type{}); else run(std::false_type{});
+    SCHED_STAMP(1, 4);
     // the next segment's start: the next lane's, or the next group's first segment
     if (sl == kGroupSegs - 1) {
         if (g + 1 < a.ngroups) {
@@ -438,19 +553,19 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
     }
     __syncthreads();
     if (!bad && !(acc == s_T[sl + 1] && x == s_X[sl + 1])) bad = true;
-    if (prev_x <= x_len && x > x_len) { end_k = kbase + kSeg; end_acc = acc; end_x = x; }   // the call ends between two segments
+    SCHED_STAMP(1, 5);
     if (bad) atomicMin(&a.status->fail_piece, a.piece);
     if (end_k >= 0) {                                     // unique: xIdx never decreases
-        a.status->end_k = end_k;
-        a.status->end_acc = end_acc;
-        a.status->end_xIdx = end_x;
+        st_wt(&a.status->end_k, end_k);
+        st_wt(&a.status->end_acc, end_acc);
+        st_wt(&a.status->end_xIdx, end_x);
         // the drift baseline at the call's end (the next call starts there): this piece's, plus what its first end_k - k0 steps show
         const double steps = static_cast<double>(end_k - a.k0);
         double de = end_acc - sched_anchor(ps.acc, steps, 0.0, c);
         if (de > 0.5 * c.N) de -= c.N;
         else if (de < -0.5 * c.N) de += c.N;
-        a.status->end_drift = ps.drift + de;
-        a.status->end_ksteps = ps.ksteps + steps;
+        st_wt(&a.status->end_drift, ps.drift + de);
+        st_wt(&a.status->end_ksteps, ps.ksteps + steps);
         __hip_atomic_store(&a.status->done, a.piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (sl == kGroupSegs - 1 && g + 1 == a.ngroups) {     // state of the next piece (used only if this piece verified)
@@ -462,7 +577,8 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
         else if (d < -0.5 * c.N) d += c.N;
         ns.drift = ps.drift + d;
         ns.ksteps = ps.ksteps + static_cast<double>(static_cast<long long>(a.ngroups) * kGroupSegs * kSeg);
-        a.state[a.piece + 1] = ns;
+        SchedPieceState *o = &a.state[a.piece + 1];          // (the FINISH of this very kernel may read it: the serial tail of a call the pieces did not reach the end of)
+        st_wt(&o->acc, ns.acc); st_wt(&o->xIdx, ns.xIdx); st_wt(&o->drift, ns.drift); st_wt(&o->ksteps, ns.ksteps);
     }
     // (rounds 1-3 reported the largest input span of the aligned tiles here, for the filter kernels' planners; they size their
     //  tiles from an a-priori bound now -- api.hip: span_bounds -- because the filter kernel is enqueued before this one has run)
@@ -505,7 +621,10 @@ __global__ __launch_bounds__(64) void sched_begin_kernel(SchedBeginArgs a, long 
 __device__ __noinline__ void sched_finish_body(const SchedPlan &c, SchedFinishArgs a)
 {
     DevStream r = *a.rec;
-    const SchedStatus st = *a.status;
+    SchedStatus st{};                 // (fields other workgroups of this kernel wrote: L2-served loads, see sched_emit_kernel)
+    st.fail_piece = ld_wt(&a.status->fail_piece); st.done = ld_wt(&a.status->done);
+    st.end_k = ld_wt(&a.status->end_k); st.end_acc = ld_wt(&a.status->end_acc); st.end_xIdx = ld_wt(&a.status->end_xIdx);
+    st.x_len = ld_wt(&a.status->x_len); st.end_drift = ld_wt(&a.status->end_drift); st.end_ksteps = ld_wt(&a.status->end_ksteps);
     a.x_len = st.x_len;               // (as the BEGIN kernel resolved it: a chained call's comes from the stage before)
     const int fail = st.fail_piece;
     DevCall call{};
@@ -515,7 +634,11 @@ __device__ __noinline__ void sched_finish_body(const SchedPlan &c, SchedFinishAr
         // the host waits for this call anyway: it redoes the piece with its own serial loop and continues from there
         // (arb_schedule.hip: sched_collect); nothing of the stream state moves, the filter kernel finds no outputs
         r.sched_fail = fail;
-        *a.fail_state = a.state[fail];
+        {
+            SchedPieceState fs;
+            fs.acc = ld_wt(&a.state[fail].acc); fs.xIdx = ld_wt(&a.state[fail].xIdx); fs.drift = ld_wt(&a.state[fail].drift); fs.ksteps = ld_wt(&a.state[fail].ksteps);
+            *a.fail_state = fs;
+        }
         call.n_out = 0;
         *a.call = call;
         *a.rec = r;
@@ -538,7 +661,8 @@ __device__ __noinline__ void sched_finish_body(const SchedPlan &c, SchedFinishAr
         long long k = a.k_first;
         double ks = a.ks_first;
         for (int p = 0; p < p0; ++p) { const long long P = sched_piece_steps(ks, a.pmax); k += P; ks += static_cast<double>(P); }
-        const SchedPieceState ps = a.state[p0];
+        SchedPieceState ps;
+        ps.acc = ld_wt(&a.state[p0].acc); ps.xIdx = ld_wt(&a.state[p0].xIdx); ps.drift = ld_wt(&a.state[p0].drift); ps.ksteps = ld_wt(&a.state[p0].ksteps);
         double acc = ps.acc;
         long long x = ps.xIdx;
         const long long k_start = k;
@@ -600,6 +724,32 @@ hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hi
         hipError_t e = occupancy_cached(reinterpret_cast<const void *>(sched_tables_kernel), kTabThreads, lds, &per_cu);
         if (e != hipSuccess) return e;
     }
+#ifdef MRHIP_SCHED_TRACE
+    {
+        static bool armed = false;
+        static int last_groups = 0;
+        last_groups = a.ngroups;
+        if (!armed) {
+            armed = true;
+            std::atexit([] {
+                (void)hipDeviceSynchronize();
+                static unsigned long long h[2][64][16];
+                if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sched_trace), sizeof(h)) != hipSuccess) return;
+                for (int k = 0; k < 2; ++k) {
+                    const int ng = std::min(last_groups, 64);
+                    unsigned long long t0 = ~0ull;
+                    for (int g = 0; g < ng; ++g) if (h[k][g][0]) t0 = std::min(t0, h[k][g][0]);
+                    std::fprintf(stderr, "[sched_trace] %s kernel, %d workgroups; station: earliest .. latest workgroup (us from the first stamp)\n", k ? "emit" : "tables", ng);
+                    for (int i = 0; i < 10; ++i) {
+                        unsigned long long lo = ~0ull, hi = 0;
+                        for (int g = 0; g < ng; ++g) if (h[k][g][i]) { lo = std::min(lo, h[k][g][i]); hi = std::max(hi, h[k][g][i]); }
+                        if (hi) std::fprintf(stderr, "[sched_trace]   %d: %.2f .. %.2f\n", i, (lo - t0) / 100.0, (hi - t0) / 100.0);
+                    }
+                }
+            });
+        }
+    }
+#endif
     const int tab_threads = std::min(kTabThreads, kGroupSegs * c.nwin);      // (64 * nwin: whole waves)
     hipLaunchKernelGGL(sched_tables_kernel, dim3(static_cast<unsigned>(a.ngroups)), dim3(static_cast<unsigned>(tab_threads)), lds, s, c, a, fu);
     // few groups: no chain kernel, the emit kernel's workgroups walk the maps themselves (MRHIP_SCHED_FOLD: at most that many groups)

@@ -77,6 +77,10 @@ struct mrhip_filter {
     // next writer of buffer b behind the filter kernel that read it.  Every write of the record of such a filter goes
     // through s_sched (in program order).  Inside a HIP-graph capture everything stays on the capturing stream.
     hipStream_t s_sched = nullptr;
+    // small calls run their schedule on the CALLER's stream instead (api.hip: inline_sched): whatever was enqueued on s_sched since the
+    // caller's stream last waited for it (a reset's or set_state's record, a long call's schedule) must be waited for first
+    bool sched_dirty = false;
+    hipEvent_t ev_sdirty = nullptr;
     hipEvent_t ev_fin[2] = {nullptr, nullptr}, ev_filt[2] = {nullptr, nullptr};
     bool ev_filt_valid[2] = {false, false};
     int flip = 0;

@@ -351,6 +351,16 @@ struct RingDev {                          // device memory
     unsigned long long trace[kRingTraceRows][3 * kRingTraceTiles];
 };
 
+// shiftin! (support.jl:61-80) folded into a FIRArbitrary / FIRFarrow filter kernel: the workgroup that leaves LAST writes the next call's
+// history -- one launch less per call (small calls are launch-bound: DESIGN.md §9), and inside a stream capture no copy node either:
+// there `hist_new` is the slot `hist` itself (everybody else is through with it; the host folds only when x_len >= H, so the new history
+// comes from x alone).
+struct ShiftFold {
+    void *hist_new;          // NULL: not folded (a launch of shiftin_kernel follows)
+    unsigned *done;          // workgroups through; zero between launches (the last workgroup re-arms it).  NULL: hist_new is the OTHER buffer --
+                             // nothing to wait for, the grid's last workgroup copies
+};
+
 struct ArbArgs {             // FIRArbitrary
     const void *x;
     void *y;
@@ -365,6 +375,7 @@ struct ArbArgs {             // FIRArbitrary
     int T, H, Nphi;
     int nch;
     const DevCall *dyn;      // != NULL: n_out is read from it (a device-planned call; the value above is an upper bound)
+    ShiftFold fold;          // arb_pipe_kernel only
 };
 
 struct FarrowArgs {          // FIRFarrow
@@ -383,6 +394,7 @@ struct FarrowArgs {          // FIRFarrow
     int seam_below;          // outputs whose 1-based input index n < this start from +0 (support.jl:46): T, or 0 for a
                              // piece that continues a call (mrhip_filt_device splits long calls)
     const DevCall *dyn;      // != NULL: n_out is read from it
+    ShiftFold fold;          // farrow_wave_kernel only
 };
 
 struct HistArgs {            // shiftin! (src/support.jl:61-80) for every channel

@@ -94,6 +94,41 @@ __device__ __forceinline__ void dma16_nt(const void *gsrc, void *lds_wave_base) 
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2);
 }
 
+// shiftin! by the workgroup that leaves last (mrhip_internal.h: ShiftFold).  Called by EVERY thread of EVERY workgroup, at its very end.
+// No fence: the barrier says this workgroup's waves have consumed every sample of `hist` they asked for; the last counter increment
+// therefore follows every read of `hist` in the grid, and what the last workgroup writes is read by the next launch only.
+template <typename TX, int NC>
+__device__ __forceinline__ void shiftin_by_last_workgroup(const ShiftFold &sf, const void *x, const void *hist, long long x_stride, long long x_len, int H, int nch)
+{
+    if (!sf.hist_new) return;                                  // (kernel argument: uniform)
+    __shared__ int s_last;
+    if (!sf.done) {
+        // into the OTHER history buffer (not a captured call): nobody in this launch reads what is written -- no counting, no waiting: the
+        // last workgroup of the grid copies when it gets here
+        if (blockIdx.x + 1u != gridDim.x) return;
+        s_last = 1;
+    } else {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const bool last = __hip_atomic_fetch_add(sf.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u;
+        if (last) __hip_atomic_store(sf.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last ? 1 : 0;
+    }
+    __syncthreads();
+    }
+    if (!s_last) return;
+    const long long total = static_cast<long long>(nch) * H;
+    for (long long t = threadIdx.x; t < total; t += blockDim.x) {
+        const long long ch = t / H, i = t - ch * H;
+        const long long e = i + x_len;                         // index into [hist ; x]
+        const TX *src = e < H ? static_cast<const TX *>(hist) + (ch * H + e) * NC : static_cast<const TX *>(x) + (ch * x_stride + (e - H)) * NC;
+        TX *dst = static_cast<TX *>(sf.hist_new) + t * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dst[c] = src[c];
+    }
+}
+
 // ---- hand-offs between workgroups inside ONE launch (the resident ring consumer): L2-served loads and write-through stores ----
 // (MI355X: a CU's L1 is never refreshed by another CU's stores and the per-XCD L2s are not coherent for plain write-back
 //  stores; `sc1` loads bypass the L1, `sc1` stores are written through.  Producer: sc1 stores, s_waitcnt vmcnt(0), sc1 flag store;
