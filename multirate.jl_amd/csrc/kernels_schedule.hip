@@ -144,6 +144,10 @@ __device__ unsigned long long g_sched_trace[2][64][16];
 #define SCHED_STAMP(k, i) do { } while (0)
 #endif
 
+#ifndef MRHIP_SCHED_WIDE_MIN
+#define MRHIP_SCHED_WIDE_MIN 48     // groups of a piece from which the emit kernel stores through LDS (whole sectors) instead of straight from registers
+#endif
+
 // write-through stores / L2-served loads of 4- and 8-byte fields (the hand-off inside the emit kernel: see sched_emit_kernel)
 __device__ __forceinline__ void st_wt(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_wt(double *p, double v) { __hip_atomic_store(reinterpret_cast<long long *>(p), __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -314,6 +318,7 @@ __device__ __forceinline__ void chain_apply_uniform(ChainState &st, const SchedG
 
 __global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan c, SchedPieceArgs a)
 {
+    SCHED_STAMP(0, 8);
     if (sched_stop(a.status, a.piece)) return;
     __shared__ SchedGroupEntry s_run[kChainWaves][64];      // phase 1 result: the map of every wave's run
     __shared__ int s_ci[kChainWaves];
@@ -333,6 +338,15 @@ __global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan
     {   // phase 1: lane's candidate carried through the run
         ChainState st{lane, 0.0, 0, lane < nwin};
         int g = g0;
+        // (sixteen maps in flight per round of loads, then four: a run of 72 groups -- a piece of 1 150 -- took 18 dependent round trips
+        //  with four, here and again in phase 3: 36 of this kernel's 48 us, profiles/r05/experiments.md O)
+        for (; g + 16 <= g1; g += 16) {
+            SchedGroupEntry e[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) e[q] = entry(g + q);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) chain_apply(st, e[q]);
+        }
         for (; g + 4 <= g1; g += 4) {                       // four maps in flight per round of loads
             const SchedGroupEntry e0 = entry(g), e1 = entry(g + 1), e2 = entry(g + 2), e3 = entry(g + 3);
             chain_apply(st, e0); chain_apply(st, e1); chain_apply(st, e2); chain_apply(st, e3);
@@ -344,7 +358,9 @@ __global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan
         r.next = st.ok ? st.ci : -1;
         s_run[wave][lane] = r;
     }
+    SCHED_STAMP(0, 9);
     __syncthreads();
+    SCHED_STAMP(0, 10);
     if (wave == 0) {   // phase 2: the runs chained from the piece's true start
         const SchedPieceState ps = a.state[a.piece];
         const double slope = ps.ksteps > 0.0 ? ps.drift / ps.ksteps : 0.0;
@@ -352,11 +368,13 @@ __global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan
         st.ok = sched_locate(ps.acc, sched_base(sched_anchor(ps.acc, 0.0, slope, c), c), c, &st.ci, &st.S);
         for (int w = 0; w < kChainWaves; ++w) {
             if (lane == 0) { s_ci[w] = st.ci; s_S[w] = st.S; s_W[w] = st.W; s_ok[w] = st.ok; }
-            if (w * per < a.ngroups) chain_apply(st, s_run[w][lane]);
+            if (w * per < a.ngroups) chain_apply_uniform(st, s_run[w][lane]);
         }
         if (lane == 0 && !st.ok) atomicMin(&a.status->fail_piece, a.piece);
     }
+    SCHED_STAMP(0, 11);
     __syncthreads();
+    SCHED_STAMP(0, 12);
     {   // phase 3: every group's start
         ChainState st{s_ci[wave], s_S[wave], s_W[wave], s_ok[wave] != 0};
         auto put = [&](int g) {
@@ -370,15 +388,23 @@ __global__ __launch_bounds__(kChainWaves * 64) void sched_chain_kernel(SchedPlan
             }
         };
         int g = g0;
+        for (; g + 16 <= g1; g += 16) {
+            SchedGroupEntry e[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) e[q] = entry(g + q);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { put(g + q); chain_apply_uniform(st, e[q]); }
+        }
         for (; g + 4 <= g1; g += 4) {
             const SchedGroupEntry e0 = entry(g), e1 = entry(g + 1), e2 = entry(g + 2), e3 = entry(g + 3);
-            put(g); chain_apply(st, e0);
-            put(g + 1); chain_apply(st, e1);
-            put(g + 2); chain_apply(st, e2);
-            put(g + 3); chain_apply(st, e3);
+            put(g); chain_apply_uniform(st, e0);
+            put(g + 1); chain_apply_uniform(st, e1);
+            put(g + 2); chain_apply_uniform(st, e2);
+            put(g + 3); chain_apply_uniform(st, e3);
         }
-        for (; g < g1; ++g) { put(g); chain_apply(st, entry(g)); }
+        for (; g < g1; ++g) { put(g); chain_apply_uniform(st, entry(g)); }
     }
+    SCHED_STAMP(0, 13);
 }
 
 // ---- K3: run every segment from its true start, emit, verify -------------------------------------------------
@@ -463,11 +489,11 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
             int gg = 0;
             for (; gg + 4 <= g; gg += 4) {                      // four maps in flight per round of loads
                 const SchedGroupEntry e0 = entry(gg), e1 = entry(gg + 1), e2 = entry(gg + 2), e3 = entry(gg + 3);
-                chain_apply(st, e0); chain_apply(st, e1); chain_apply(st, e2); chain_apply(st, e3);
+                chain_apply_uniform(st, e0); chain_apply_uniform(st, e1); chain_apply_uniform(st, e2); chain_apply_uniform(st, e3);
             }
-            for (; gg < g; ++gg) chain_apply(st, entry(gg));
+            for (; gg < g; ++gg) chain_apply_uniform(st, entry(gg));
             put(gs);
-            if (g + 1 < a.ngroups) chain_apply(st, entry(g));
+            if (g + 1 < a.ngroups) chain_apply_uniform(st, entry(g));
             put(gnx);
         }
     } else {
@@ -534,7 +560,55 @@ __device__ __forceinline__ void sched_emit_body(const SchedPlan &c, const SchedP
             }
         }
     };
-    if (c.pow2) run(std::true_type{}); else run(std::false_type{});
+    // A long piece (hundreds of groups: its entries together are far more than the L2 holds) goes through LDS all the same, in the 16-byte
+    // units: sixteen steps per lane, then four (eight) neighbouring lanes store one segment's 64 (128) contiguous bytes -- whole sectors for
+    // the HBM, where the direct form above leaves 16-byte pieces of lines that are evicted before their neighbours arrive (emit kernel of a
+    // 1 150-group piece: 39 us with the direct stores).  One wave per workgroup: the barriers only order the LDS traffic.
+    __shared__ int4 s_nu[kGroupSegs * 5];                  // [segment][4 units + 1 pad]
+    __shared__ double2 s_au[kGroupSegs * 9];               // [segment][8 units + 1 pad]
+    auto run_wide = [&](auto pow2_tag) {
+        constexpr bool P2 = decltype(pow2_tag)::value;
+        for (int i16 = 0; i16 < kSeg; i16 += 16) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const int i0 = i16 + 4 * blk;
+                int nn[4];
+                double aa[4];
+                const long long xb = x;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    nn[ii] = static_cast<int>(x);
+                    aa[ii] = acc;
+                    sched_step_nb<P2>(acc, x, c);
+                }
+                if (xb <= x_len && x > x_len) {
+#pragma unroll
+                    for (int j = 1; j <= 4; ++j) {
+                        const long long xj = j < 4 ? static_cast<long long>(nn[j < 4 ? j : 0]) : x, xp = nn[j - 1];
+                        if (xj > x_len && xp <= x_len) { end_k = kbase + i0 + j; end_acc = j < 4 ? aa[j < 4 ? j : 0] : acc; end_x = xj; }
+                    }
+                }
+                s_nu[sl * 5 + blk] = make_int4(nn[0], nn[1], nn[2], nn[3]);
+                s_au[sl * 9 + 2 * blk] = make_double2(aa[0], aa[1]);
+                s_au[sl * 9 + 2 * blk + 1] = make_double2(aa[2], aa[3]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sg = (sl >> 2) + 16 * j, u = sl & 3;
+                *reinterpret_cast<int4 *>(gn + sg * kSeg + i16 + 4 * u) = s_nu[sg * 5 + u];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int sg = (sl >> 3) + 8 * j, u = sl & 7;
+                *reinterpret_cast<double2 *>(ga + sg * kSeg + i16 + 2 * u) = s_au[sg * 9 + u];
+            }
+            __syncthreads();
+        }
+    };
+    const bool wide = vec_ok && a.ngroups > MRHIP_SCHED_WIDE_MIN;
+    if (wide) { if (c.pow2) run_wide(std::true_type{}); else run_wide(std::false_type{}); }
+    else if (c.pow2) run(std::true_type{}); else run(std::false_type{});
     SCHED_STAMP(1, 4);
     // the next segment's start: the next lane's, or the next group's first segment
     if (sl == kGroupSegs - 1) {
@@ -740,7 +814,7 @@ hipError_t launch_schedule_piece(const SchedPlan &c, const SchedPieceArgs &a, hi
                     unsigned long long t0 = ~0ull;
                     for (int g = 0; g < ng; ++g) if (h[k][g][0]) t0 = std::min(t0, h[k][g][0]);
                     std::fprintf(stderr, "[sched_trace] %s kernel, %d workgroups; station: earliest .. latest workgroup (us from the first stamp)\n", k ? "emit" : "tables", ng);
-                    for (int i = 0; i < 10; ++i) {
+                    for (int i = 0; i < 16; ++i) {
                         unsigned long long lo = ~0ull, hi = 0;
                         for (int g = 0; g < ng; ++g) if (h[k][g][i]) { lo = std::min(lo, h[k][g][i]); hi = std::max(hi, h[k][g][i]); }
                         if (hi) std::fprintf(stderr, "[sched_trace]   %d: %.2f .. %.2f\n", i, (lo - t0) / 100.0, (hi - t0) / 100.0);
