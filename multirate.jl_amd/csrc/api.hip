@@ -1178,7 +1178,6 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             }
             if (ss == f->s_sched) f->sched_dirty = true;
             else if (!capturing && f->s_sched && f->sched_dirty) {        // (mrhip_filter.h: sched_dirty)
-                if (!f->ev_sdirty) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_sdirty, hipEventDisableTiming));
                 MRHIP_CHECK_HIP(hipEventRecord(f->ev_sdirty, f->s_sched));
                 MRHIP_CHECK_HIP(hipStreamWaitEvent(stream, f->ev_sdirty, 0));
                 f->sched_dirty = false;

@@ -112,6 +112,7 @@ int rec_alloc(mrhip_filter *f)
             MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_fin[b], hipEventDisableTiming));
             MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_filt[b], hipEventDisableTiming));
         }
+        MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_sdirty, hipEventDisableTiming));
     }
     DevStream v{};
     v.phiIdx = 1; v.inputDeficit = 1; v.acc = 1.0;
