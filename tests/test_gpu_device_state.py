@@ -206,6 +206,58 @@ def test_async_calls_never_wait_and_match_the_plain_loop(pkg, O, torch_cuda, kin
     f.close(); g.close()
 
 
+@pytest.mark.parametrize("kind", ["arbitrary", "farrow"])
+@pytest.mark.parametrize("nch", [1, 3])
+def test_small_and_long_asynchronous_calls_share_the_record(pkg, O, torch_cuda, kind, nch):
+    """A call of at most 65 536 outputs runs its schedule on the caller's stream, a longer one on the filter's schedule stream beside the
+    filter kernel before it (api.hip: inline_sched); both write the device record, and so do reset / set_state (on the schedule stream):
+    any mix of them, never waited for in the middle, is the oracle's loop of plain calls -- outputs, counts, end state, history.  (The
+    filter kernel of these calls also writes the next call's history: ShiftFold; inputs shorter than the history included.)"""
+    torch = torch_cuda
+    rng = np.random.default_rng(23 + nch)
+    po = 3 if kind == "farrow" else None
+    h = (pkg.firdes(32 * 6, 0.45 / 32, beta=7.0) * 32).astype(np.float32)
+    rate = 0.8123
+    sizes = [300_000, 5, 70_000, 400_000, 20_000, 1, 250_000, 60_000, 3, 330_000]
+    xh = rng.standard_normal((nch, sum(sizes))).astype(np.float32)
+    x = torch.from_numpy(xh).cuda()
+    f = pkg.FIRFilter(h, rate, 32, po).bind(np.float32, nch)
+    fo = [O.FIRFilter(h, rate, 32, tx=np.float32, polyorder=po, pnfb=f.pnfb()) if po else O.FIRFilter(h, rate, 32, tx=np.float32) for _ in range(nch)]
+    for rnd in range(3):
+        cnt = torch.zeros(len(sizes), dtype=torch.int64, device="cuda")
+        ys, pos = [], 0
+        for i, s in enumerate(sizes):
+            y = torch.empty((nch, f.outputlength_bound(s)), dtype=_tdtype(torch, f.output_dtype), device="cuda")
+            if rnd == 2 and i == 4:            # a plain call (the host waits for its count) in the middle of the asynchronous ones
+                k = f.filt_into(y, x[:, pos:pos + s])
+                cnt[i] = k
+            else:
+                f.filt_into_async(y, x[:, pos:pos + s], cnt[i:i + 1])
+            ys.append(y)
+            pos += s
+        f.sync_state()
+        c = cnt.cpu().tolist()
+        pos = 0
+        for i, s in enumerate(sizes):
+            for ch in range(nch):
+                r = fo[ch].filt(xh[ch, pos:pos + s])
+                assert c[i] == len(r), (kind, nch, rnd, i, c[i], len(r))
+                assert_bit_equal(ys[i][ch, :c[i]].cpu().numpy(), r, f"{kind} nch={nch} round {rnd} call {i} channel {ch}")
+            pos += s
+        st, so = f.state, fo[0].state
+        assert (st.phiAccumulator, st.inputDeficit) == (so.phiAccumulator, so.inputDeficit)
+        assert_bit_equal(np.atleast_2d(f.history)[0], fo[0].history, "history")
+        if rnd == 0:
+            f.reset()
+            for o in fo:
+                o.reset()
+        elif rnd == 1:
+            f.set_state(1, 2, 7.25)
+            for o in fo:
+                o.set_state(1, 2, 7.25)
+    f.close()
+
+
 def test_async_call_needs_room_for_the_bound(pkg, torch_cuda):
     torch = torch_cuda
     h = np.ones(24 * 3, dtype=np.float32)
