@@ -129,6 +129,15 @@ __device__ __forceinline__ void shiftin_by_last_workgroup(const ShiftFold &sf, c
     }
 }
 
+// A 16-byte LDS read, complete when the statement is (read and wait are one asm statement: no register with a read in flight, and the
+// compiler's own wait insertion -- which puts a vmcnt(0) in front of every LDS read it sees behind an LDS-DMA operation -- stays out of it)
+__device__ __forceinline__ v4u_t lds_read16_now(unsigned byte_addr)
+{
+    v4u_t v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(byte_addr) : "memory");
+    return v;
+}
+
 // ---- hand-offs between workgroups inside ONE launch (the resident ring consumer): L2-served loads and write-through stores ----
 // (MI355X: a CU's L1 is never refreshed by another CU's stores and the per-XCD L2s are not coherent for plain write-back
 //  stores; `sc1` loads bypass the L1, `sc1` stores are written through.  Producer: sc1 stores, s_waitcnt vmcnt(0), sc1 flag store;

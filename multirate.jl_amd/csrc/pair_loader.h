@@ -386,6 +386,75 @@ __device__ __forceinline__ void ring_feeder(RingDev *rd, RingHost *rh, int lane)
     vm_drain();
 }
 
+// The ring loader's COLD paths as functions of their own (never inlined): a seam tile happens twice per channel and chunk, the tail copy
+// once per chunk, and inlined they raised the loader's register demand to 168 VGPRs -- the kernel is built for 128, and the allocator then
+// parked values in scratch memory INSIDE the LDS-DMA loop of every tile, where the reload's s_waitcnt vmcnt(0) also waits for the transfer
+// issued just before it: one memory round trip per kilobyte (profiles/r05/experiments.md P).
+template <int NC>
+__device__ __attribute__((noinline)) void ring_stage_seam(const float *xc, long long o, long long xlen, const float *hc, int H, int nchunks, int cd,
+                                                          unsigned char *st, const unsigned char *dummy, int nslots, int lane)
+{
+    constexpr int EPC = 4 / NC;
+    {
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
+        for (int slot = 0; slot < nslots; ++slot) {
+            const int ci = slot * 64 + lane;
+            const bool data = ci < nchunks;
+            const long long smp = static_cast<long long>(EPC) * (data ? ci : 0);
+            const bool inside = data && o + smp >= 0 && o + smp + EPC <= xlen;
+            dma16_sc1(inside ? src + smp * (NC * 4) : dummy, st + static_cast<size_t>(slot) * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float *l = reinterpret_cast<float *>(st);
+    for (int ci = lane; ci < nchunks; ci += 64) {
+        const long long g0 = o + static_cast<long long>(EPC) * ci;
+        if (g0 >= 0 && g0 + EPC <= xlen) continue;              // staged above
+        float4 v;
+        float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const long long gi = g0 + e;
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) {
+                float val = 0.f;
+                if (gi >= 0) { if (gi < xlen) val = ld_sc1(xc + gi * NC + cc); }
+                else if (gi >= -static_cast<long long>(H)) val = ld_sc1(hc + (H + gi) * NC + cc);
+                pv[e * NC + cc] = val;
+            }
+        }
+        *reinterpret_cast<float4 *>(l + (cd > 0 ? ci + ci / cd : ci) * 4) = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// shiftin! (support.jl:61-80) for the chunk AFTER this one: hnew <- the last H samples of [hold ; x], every channel
+template <int NC>
+__device__ __attribute__((noinline)) void ring_tail_copy(const float *xin, const float *hold, float *hnew, long long xs, long long xlen, int H, int nch, int lane)
+{
+    const long long words = static_cast<long long>(nch) * H * NC;
+    for (long long base = 0; base < words; base += 64 * 4) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long w = base + k * 64 + lane;
+            v[k] = 0.f;
+            if (w < words) {
+                const long long smp = w / NC, cc = w - smp * NC;
+                const long long c2 = smp / H, i = smp - c2 * H;
+                const long long e = i + xlen;                       // index into [history ; x]
+                v[k] = e < H ? ld_sc1(hold + (c2 * H + e) * NC + cc) : ld_sc1(xin + (c2 * xs + (e - H)) * NC + cc);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long w = base + k * 64 + lane;
+            if (w < words) st_sc1(hnew + w, v[k]);
+        }
+    }
+    vm_drain();
+}
+
 // The whole life of a worker's loader wave in ring mode.  NW = 32-bit words per input sample, OS = bytes per output sample.
 template <int NC, int OS>
 __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const PairArgs &pa, unsigned char *smem, int lane)
@@ -394,8 +463,15 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     RingHost *const rh = a.ring_host;
     if (blockIdx.x == 0) { ring_feeder(rd, rh, lane); return; }
     volatile unsigned *const td = reinterpret_cast<volatile unsigned *>(smem + pa.flags_off);   // [ns][kRingTileWords]
-    const unsigned long long idle = ld_sc1(&rd->idle_ticks);
-    const unsigned opts = static_cast<unsigned>(ld_sc1(&rd->opts));
+    // (what every lane loads alike goes to scalar registers at once: the compiler takes a vector load's result for divergent, and with it every
+    //  branch on it and every value assigned under such a branch -- the chunk context, the scan position -- which then live in VGPRs)
+    auto uni = [](unsigned long long v) -> unsigned long long {
+        const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v & 0xffffffffull)));
+        const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32)));
+        return (static_cast<unsigned long long>(hi) << 32) | lo;
+    };
+    const unsigned long long idle = uni(ld_sc1(&rd->idle_ticks));
+    const unsigned opts = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ld_sc1(&rd->opts))));
     // the loader's instruction stream is long in ring mode (descriptor look-up, bookkeeping) and shares its SIMD with compute waves that
     // never stall: let it issue first (experiment switch: bit 9 = 512 keeps the default priority)
     if (!(opts & 512u)) __builtin_amdgcn_s_setprio(3);
@@ -436,18 +512,22 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     // earlier ticket, held by a workgroup that is running)
     auto wait_hist = [&](unsigned long long s) -> bool {
         const unsigned long long t0 = wall_clock64();
-        while (ld_sc1(&rd->hist_seq[s % kRingDepth]) != s + 1ull) {
+        while (uni(ld_sc1(&rd->hist_seq[s % kRingDepth])) != s + 1ull) {
             if (wall_clock64() - t0 > idle) { if (lane == 0) st_sc1(&rd->closed, 3ull); vm_drain(); aborted = true; return false; }
             __builtin_amdgcn_s_sleep(8);
         }
         st_hist += wall_clock64() - t0;
         return true;
     };
-    // ---- which chunk holds `ticket`: lane k < nb reads the whole descriptor of chunk cur + k (six 16-byte units, the key among
-    // them), AHEAD of need: right behind the staging of the tile before, so that the round trip overlaps that tile's landing (one wait
-    // covers both) ----
-    v4u_t dsc[6];
-    unsigned long long pf_cur = ~0ull;                     // the prefetch in dsc[] is for chunks [pf_cur, pf_cur + pf_nb) and `ticket`
+    // ---- which chunk holds `ticket`: the descriptors of chunks [cur, cur + 16) come into LDS by two LDS-DMA operations (lane 8k + j moves
+    // unit j of descriptor k: the 2 KiB are the sixteen descriptors as the feeder wrote them), AHEAD of need: issued right behind the look-up
+    // of the grab before, IN FRONT of that grab's tile -- LDS-DMA operations land in order, so "everything but the newest tile has landed"
+    // (the wait this wave does anyway before it opens a tile to the compute waves) says the descriptors are there.  No registers are
+    // held across the barrier for them and nothing drains the newest tile's transfers (round 5's first form loaded them into 24 VGPRs
+    // with a vmcnt(0) of their own: with three pipeline stages that wait emptied the pipeline, profiles/r05/experiments.md N, P) ----
+    unsigned char *const dbuf = smem + ((static_cast<unsigned>(pa.flags_off) + (kRingTileWords * 4u + 4u) * static_cast<unsigned>(pa.ns) + 15u) & ~15u);
+    auto lds_offset_of = [](const void *q) -> unsigned { return static_cast<unsigned>(reinterpret_cast<size_t>((const __attribute__((address_space(3))) void *)q)); };
+    unsigned long long pf_cur = ~0ull;                     // dbuf holds (or will hold) chunks [pf_cur, pf_cur + pf_nb)
     unsigned pf_nb = 0;
     auto prefetch_issue = [&]() {
         pf_cur = ~0ull;
@@ -455,8 +535,12 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         if (head_seen >= static_cast<unsigned long long>(kRingDepth) && cur + kRingDepth <= head_seen) cur = head_seen - kRingDepth + 1ull;   // (complete long ago, slots recycled)
         pf_nb = head_seen - cur < 16ull ? static_cast<unsigned>(head_seen - cur) : 16u;
         pf_cur = cur;
-        const unsigned long long *base = reinterpret_cast<const unsigned long long *>(&rd->desc[(cur + static_cast<unsigned>(lane < 16 ? lane : 0)) % kRingDepth]);
-        if (lane < static_cast<int>(pf_nb)) ld96_sc1(base, dsc);     // (loads and their wait in one statement: pair_device.h)
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            const unsigned k = static_cast<unsigned>(op) * 8u + (static_cast<unsigned>(lane) >> 3);
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(&rd->desc[(cur + (k < pf_nb ? k : 0u)) % kRingDepth]) + 16u * (static_cast<unsigned>(lane) & 7u);
+            dma16_sc1(src, dbuf + op * 1024);
+        }
     };
     enum { kFound = 0, kClosed = 1, kWouldBlock = 2 };
     // positions the chunk context on the chunk that holds `ticket`; may_block = false: returns kWouldBlock instead of polling
@@ -464,25 +548,28 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         const unsigned long long t0 = wall_clock64();
         for (;;) {
             if (cur < head_seen) {
-                if (pf_cur != cur) prefetch_issue();
+                if (pf_cur != cur) { prefetch_issue(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // (nothing requested ahead: first grab, or the window moved)
                 const unsigned nb = pf_nb;
                 pf_cur = ~0ull;
-                // key: dsc[4] = (tile_base lo, hi, ngrabs, seq_lo)
-                const unsigned long long tb = (static_cast<unsigned long long>(dsc[4].y) << 32) | dsc[4].x;
-                const bool mine = lane < static_cast<int>(nb) && dsc[4].w == static_cast<unsigned>((cur + static_cast<unsigned>(lane)) & 0xffffffffull) &&
-                                  ticket >= tb && ticket - tb < dsc[4].z;
+                // key of descriptor `lane` (lanes 0..15): (tile_base lo, hi, ngrabs, seq_lo)
+                const v4u_t key = lds_read16_now(lds_offset_of(dbuf) + (static_cast<unsigned>(lane) & 15u) * 128u + kRingKeyQword * 8u);
+                const unsigned long long tb = (static_cast<unsigned long long>(key.y) << 32) | key.x;
+                const bool mine = lane < static_cast<int>(nb) && key.w == static_cast<unsigned>((cur + static_cast<unsigned>(lane)) & 0xffffffffull) &&
+                                  ticket >= tb && ticket - tb < key.z;
                 const unsigned long long hit = __ballot(mine);
                 if (hit == 0ull) { cur += nb; continue; }
                 const int fl = __builtin_ctzll(hit);
-                auto rl = [&](unsigned v) -> unsigned { return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), fl)); };
-                auto rq = [&](unsigned lo, unsigned hi) -> unsigned long long { return (static_cast<unsigned long long>(rl(hi)) << 32) | rl(lo); };
+                // the six units of that descriptor: lane j reads unit j, the fields come by v_readlane
+                const v4u_t un = lds_read16_now(lds_offset_of(dbuf) + static_cast<unsigned>(fl) * 128u + (static_cast<unsigned>(lane) < 6u ? static_cast<unsigned>(lane) : 0u) * 16u);
+                auto rl = [&](unsigned v, int u) -> unsigned { return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), u)); };
+                auto rq = [&](unsigned lo, unsigned hi, int u) -> unsigned long long { return (static_cast<unsigned long long>(rl(hi, u)) << 32) | rl(lo, u); };
                 cur += static_cast<unsigned>(fl);
-                c_x = rq(dsc[0].x, dsc[0].y); c_y = rq(dsc[0].z, dsc[0].w);
-                c_xs = static_cast<long long>(rq(dsc[1].x, dsc[1].y)); c_ys = static_cast<long long>(rq(dsc[1].z, dsc[1].w));
-                c_xlen = static_cast<long long>(rq(dsc[2].x, dsc[2].y)); c_nout = static_cast<long long>(rq(dsc[2].z, dsc[2].w));
-                c_u0 = static_cast<long long>(rq(dsc[3].x, dsc[3].y)); c_o0 = static_cast<long long>(rq(dsc[3].z, dsc[3].w)) - a.T;
-                c_tile_base = rq(dsc[4].x, dsc[4].y); c_ngrabs = rl(dsc[4].z);
-                c_spc = rl(dsc[5].x); c_total = rl(dsc[5].y); c_magic = rl(dsc[5].z);
+                c_x = rq(un.x, un.y, 0); c_y = rq(un.z, un.w, 0);
+                c_xs = static_cast<long long>(rq(un.x, un.y, 1)); c_ys = static_cast<long long>(rq(un.z, un.w, 1));
+                c_xlen = static_cast<long long>(rq(un.x, un.y, 2)); c_nout = static_cast<long long>(rq(un.z, un.w, 2));
+                c_u0 = static_cast<long long>(rq(un.x, un.y, 3)); c_o0 = static_cast<long long>(rq(un.z, un.w, 3)) - a.T;
+                c_tile_base = rq(un.x, un.y, 4); c_ngrabs = rl(un.z, 4);
+                c_spc = rl(un.x, 5); c_total = rl(un.y, 5); c_magic = rl(un.z, 5);
                 c_seq = cur;
                 if (c_total > 0u && (c_x == 0ull || c_y == 0ull || c_spc == 0u)) {   // (never: a descriptor that cannot be one -- leave rather than fault)
                     if (lane == 0) st_sc1(&rd->closed, 3ull);
@@ -492,10 +579,10 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
                 }
                 return kFound;
             }
-            head_seen = ld_sc1(&rd->head);
+            head_seen = uni(ld_sc1(&rd->head));
             if (cur < head_seen) { st_poll += wall_clock64() - t0; continue; }
-            if (ld_sc1(&rd->closed) != 0ull) {
-                head_seen = ld_sc1(&rd->head);            // `closed` is set behind the last `head`: look once more
+            if (uni(ld_sc1(&rd->closed)) != 0ull) {
+                head_seen = uni(ld_sc1(&rd->head));       // `closed` is set behind the last `head`: look once more
                 if (cur < head_seen) continue;
                 return kClosed;
             }
@@ -516,30 +603,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     auto tail_copy = [&]() -> bool {
         if (a.H > 0) {
             if (c_xlen < a.H && !wait_hist(c_seq)) return false;
-            const float *xin = reinterpret_cast<const float *>(c_x);
-            const float *hold = hist_slot(c_seq);
-            float *hnew = hist_slot(c_seq + 1ull);
-            const long long words = static_cast<long long>(a.nch) * a.H * NC;
-            for (long long base = 0; base < words; base += 64 * 4) {
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const long long w = base + k * 64 + lane;
-                    v[k] = 0.f;
-                    if (w < words) {
-                        const long long smp = w / NC, cc = w - smp * NC;
-                        const long long c2 = smp / a.H, i = smp - c2 * a.H;
-                        const long long e = i + c_xlen;                       // index into [history ; x]
-                        v[k] = e < a.H ? ld_sc1(hold + (c2 * a.H + e) * NC + cc) : ld_sc1(xin + (c2 * c_xs + (e - a.H)) * NC + cc);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const long long w = base + k * 64 + lane;
-                    if (w < words) st_sc1(hnew + w, v[k]);
-                }
-            }
-            vm_drain();
+            ring_tail_copy<NC>(reinterpret_cast<const float *>(c_x), hist_slot(c_seq), hist_slot(c_seq + 1ull), c_xs, c_xlen, a.H, a.nch, lane);
         }
         if (lane == 0) st_sc1(&rd->hist_seq[(c_seq + 1ull) % kRingDepth], c_seq + 2ull);
         vm_drain();
@@ -593,39 +657,8 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         // chunks at the seam and past the end element by element afterwards (L2-served loads: the history slot was written by another
         // workgroup of this launch, the signal by whoever filled the caller's buffer)
         if (o < 0 && !wait_hist(c_seq)) return 0;
-        {
-            const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + o * NC);
-            const unsigned char *dummy = static_cast<const unsigned char *>(a.taps);
-            for (int slot = 0; slot < nslots; ++slot) {
-                const int ci = slot * 64 + lane;
-                const bool data = ci < nchunks;
-                const long long smp = static_cast<long long>(EPC) * (data ? ci : 0);
-                const bool inside = data && o + smp >= 0 && o + smp + EPC <= c_xlen;
-                dma16_sc1(inside ? src + smp * (NC * 4) : dummy, st + static_cast<size_t>(slot) * 1024);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const float *hc = hist_slot(c_seq) + static_cast<long long>(ta.ch) * a.H * NC;
-        float *l = reinterpret_cast<float *>(st);
-        for (int ci = lane; ci < nchunks; ci += 64) {
-            const long long g0 = o + static_cast<long long>(EPC) * ci;
-            if (g0 >= 0 && g0 + EPC <= c_xlen) continue;              // staged above
-            float4 v;
-            float *pv = reinterpret_cast<float *>(&v);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const long long gi = g0 + e;
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) {
-                    float val = 0.f;
-                    if (gi >= 0) { if (gi < c_xlen) val = ld_sc1(xc + gi * NC + cc); }
-                    else if (gi >= -static_cast<long long>(a.H)) val = ld_sc1(hc + (a.H + gi) * NC + cc);
-                    pv[e * NC + cc] = val;
-                }
-            }
-            *reinterpret_cast<float4 *>(l + (cd > 0 ? ci + ci / cd : ci) * 4) = v;
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        ring_stage_seam<NC>(xc, o, c_xlen, hist_slot(c_seq) + static_cast<long long>(ta.ch) * a.H * NC, a.H, nchunks, cd, st,
+                            static_cast<const unsigned char *>(a.taps), nslots, lane);
         return 0;
     };
     unsigned long long ops = 0;
@@ -671,31 +704,30 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         const TileAt ta = tile_at(ra, umin(rb - ra, static_cast<unsigned>(pa.J)));
         const unsigned long long tr_ticket = ticket;
         const unsigned long long tr_found = (opts & 256u) ? wall_clock64() : 0ull;
+        // the descriptors the NEXT grab will be looked up in, requested IN FRONT of this tile's transfers (see prefetch_issue)
+        if (ra + static_cast<unsigned>(ta.jt) >= rb && pf_cur == ~0ull && !(opts & 1u)) prefetch_issue();
         const int n_ops = stage_tile(ta, stage);
         const unsigned long long tr_issued = (opts & 256u) ? wall_clock64() : 0ull;
         if (aborted) { end_marker(stage); return false; }
-        if (lane == 0) {
-            volatile unsigned *t = td + kRingTileWords * stage;
+        {   // the tile's descriptor: twelve wave-uniform words, lane k stores word k (one LDS store; computed on the scalar side)
             const unsigned long long yaddr = c_y + (static_cast<unsigned long long>(ta.ch) * static_cast<unsigned long long>(c_ys) +
                                                     static_cast<unsigned long long>(ta.st) * static_cast<unsigned>(pa.Sout)) * OS;
             const long long rem = c_nout - static_cast<long long>(ta.st) * pa.Sout;
-            t[0] = static_cast<unsigned>(ta.jt);
-            t[1] = ra + static_cast<unsigned>(ta.jt) >= rb ? 1u : 0u;
-            t[2] = static_cast<unsigned>(yaddr & 0xffffffffull); t[3] = static_cast<unsigned>(yaddr >> 32);
-            t[4] = static_cast<unsigned>(rem < 0x7fffffffLL ? rem : 0x7fffffffLL);
-            t[5] = static_cast<unsigned>(c_u0);
-            t[6] = static_cast<unsigned>(c_seq % kRingDepth);
-            t[7] = g_shard;
-            t[8] = static_cast<unsigned>(c_seq & 0xffffffffull); t[9] = static_cast<unsigned>(c_seq >> 32);
-            t[10] = g_cnt;
-            t[11] = c_ngrabs < static_cast<unsigned>(kRingShards) ? c_ngrabs : static_cast<unsigned>(kRingShards);
+            const unsigned w[12] = {static_cast<unsigned>(ta.jt), ra + static_cast<unsigned>(ta.jt) >= rb ? 1u : 0u,
+                                    static_cast<unsigned>(yaddr & 0xffffffffull), static_cast<unsigned>(yaddr >> 32),
+                                    static_cast<unsigned>(rem < 0x7fffffffLL ? rem : 0x7fffffffLL), static_cast<unsigned>(c_u0),
+                                    static_cast<unsigned>(c_seq % kRingDepth), g_shard,
+                                    static_cast<unsigned>(c_seq & 0xffffffffull), static_cast<unsigned>(c_seq >> 32), g_cnt,
+                                    c_ngrabs < static_cast<unsigned>(kRingShards) ? c_ngrabs : static_cast<unsigned>(kRingShards)};
+            unsigned mine = w[0];
+#pragma unroll
+            for (int k = 1; k < 12; ++k) mine = lane == k ? w[k] : mine;
+            if (lane < 12) td[kRingTileWords * stage + lane] = mine;
         }
         ops = (ops << 6) | static_cast<unsigned>(n_ops);
         ra += static_cast<unsigned>(ta.jt);
         unreported = !(opts & 2u);
-        // the descriptors the NEXT grab will be looked up in, requested behind this tile's transfers (the same wait covers both)
         const unsigned long long tr_pub = (opts & 256u) ? wall_clock64() : 0ull;
-        if (ra >= rb && pf_cur == ~0ull && !(opts & 1u)) prefetch_issue();
         if (opts & 256u) {
             st_last = wall_clock64();
             if (st_real == 0ull) st_first = st_last;
@@ -715,23 +747,28 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     const bool stats = (opts & 256u) != 0u;
     const unsigned long long st_t0 = wall_clock64();
     unsigned long long st_bar = 0, st_prod = 0, st_tiles = 0;
+    // ONE site of produce(): the pa.ns - 1 tiles of the prologue and the steady state share the loop (inlined twice, the loader's code --
+    // 34 KB, most of it produce() -- also held 26 more VGPRs: profiles/r05/experiments.md P)
     unsigned pipeline = 0;
-    for (int k = 0; k < pa.ns - 1; ++k)
-        if (produce(k)) pipeline |= 1u << k;
-    vm_drain();                               // (ring mode waits for everything: descriptor prefetches ride along with the transfers)
-    int pstage = pa.ns - 1;
+    int pstage = 0, primed = 0;
     for (;;) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long tb0 = stats ? wall_clock64() : 0ull;
-        __builtin_amdgcn_s_barrier();
-        const unsigned long long tb1 = stats ? wall_clock64() : 0ull;
-        st_bar += tb1 - tb0;
-        if (!(pipeline & 1u)) break;
-        pipeline >>= 1;
-        if (produce(pstage)) pipeline |= 1u << (pa.ns - 2);
+        const bool steady = primed >= pa.ns - 1;
+        unsigned long long tb1 = 0;
+        if (steady) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tb0 = stats ? wall_clock64() : 0ull;
+            __builtin_amdgcn_s_barrier();
+            tb1 = stats ? wall_clock64() : 0ull;
+            st_bar += tb1 - tb0;
+            if (!(pipeline & 1u)) break;
+            pipeline >>= 1;
+        }
+        const unsigned bit = steady ? 1u << (pa.ns - 2) : 1u << primed;
+        if (produce(pstage)) pipeline |= bit;
+        if (!steady) ++primed;
         pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
-        if (pa.ns > 2) wait_vmcnt_le(newest_ops(pa.ns - 2)); else vm_drain();
-        if (stats) { st_prod += wall_clock64() - tb1; ++st_tiles; }
+        if (primed >= pa.ns - 1) { if (pa.ns > 2) wait_vmcnt_le(newest_ops(pa.ns - 2)); else vm_drain(); }
+        if (stats && steady) { st_prod += wall_clock64() - tb1; ++st_tiles; }
     }
     if (stats && lane == 0) {
         atomicAdd(&rd->stats[4], wall_clock64() - st_t0);
