@@ -179,23 +179,25 @@ __device__ __forceinline__ void ld32_sys(const void *p0, const void *p1, v4u_t &
                  : "v"(p0), "v"(p1)
                  : "memory");
 }
-// write-through stores of N bytes of a lane's registers (N = 4, 8, 16, 32): visible beyond this XCD's L2 once vmcnt has counted them
+// write-through stores of N bytes of a lane's registers (N = 4, 8, 16, 32): visible beyond this XCD's L2 once vmcnt has counted them.
+// AGENT scope (`sc1`): the readers are later kernels and copy engines of this device (what the host reads of a ring lives in pinned memory and
+// is stored by st_sys).  Rounds' first form stored at system scope (`sc0 sc1`): 1-3 % slower in the ring (profiles/r05/experiments.md Q).
 template <int N>
 __device__ __forceinline__ void store_wt(void *dst, const void *regs)
 {
     if constexpr (N == 4) {
         unsigned v; __builtin_memcpy(&v, regs, 4);
-        asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
     } else if constexpr (N == 8) {
         v2u_t v; __builtin_memcpy(&v, regs, 8);
-        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
     } else if constexpr (N == 16) {
         v4u_t v; __builtin_memcpy(&v, regs, 16);
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
     } else {
         static_assert(N == 32, "store_wt");
         v4u_t v0, v1; __builtin_memcpy(&v0, regs, 16); __builtin_memcpy(&v1, static_cast<const char *>(regs) + 16, 16);
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
     }
 }
 
