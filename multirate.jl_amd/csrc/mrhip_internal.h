@@ -310,7 +310,7 @@ struct RingDesc {                         // one arriving chunk: 16 quad-words
     unsigned long long tile_base;         // tickets [tile_base, tile_base + ngrabs) are this chunk's grabs
     unsigned ngrabs, seq_lo;              // seq_lo: low half of the chunk number (~0: the feeder is rewriting the slot)
     unsigned steps_per_channel, total_steps;
-    unsigned spc_magic, pad0;
+    unsigned spc_magic, flags;            // flags bit 0: the outputs of this (small) chunk are stored write-through and its completion raised at once (RingDev::flush_req)
     unsigned long long seq;               // chunk number (host's copy; the device goes by the key)
     unsigned long long pad[3];
 };
@@ -342,6 +342,17 @@ struct RingDev {                          // device memory
     // [13] feeder batches, [14] ... ticks from seeing `head` move to having published, [15] descriptors; per loader: [16] idle tiles BEFORE its
     // last real tile, [17] / [18] min / max over loaders of the time of the last real tile, [19] max of the first, [20] / [21] min / max real tiles
     unsigned long long stats[24];
+    // Completion by ONE L2 write-back per XCD and chunk (the default; MRHIP_RING_OPTS bit 13 = 8192: write-through output stores instead, the round's
+    // first form -- a fifth slower, experiments.md Q, R).  The compute waves store plainly; the workgroup that reports a chunk's last grab (every
+    // grab's stores are in its XCD's L2 by then) files REQUEST r = ++flush_req with the chunk's number; every loader wave looks at flush_req once
+    // per tile, and the first of an XCD to see a request its XCD has not taken on (flush_claim) writes that XCD's L2 back (buffer_wbl2) and
+    // raises flush_done; whoever then finds every XCD past requests (flush_pub, F] raises the host's flags of those chunks, in request order.
+    unsigned long long flush_req;
+    unsigned long long flush_pub;
+    unsigned long long flush_pad[14];
+    unsigned long long flush_ent[kRingDepth][2];       // request r at [r % depth]: (r, chunk number), one 16-byte store
+    unsigned long long flush_claim[8][16];             // per XCD, a line of its own
+    unsigned long long flush_done[8][16];
     // experiment (MRHIP_RING_OPTS bit 10): tickets HANDED OUT instead of dealt -- eight queues (ticket t in queue t mod 8 at position t div 8),
     // one per group of workgroups that share an XCD; next_ticket[q][0] = positions of queue q taken so far.  Slower than dealing (experiments.md L).
     unsigned long long next_ticket[8][16];

@@ -294,14 +294,17 @@ __device__ __forceinline__ void pair_loader_wave(const PolyArgs &a, const PairAr
 // LDS words of a tile descriptor in ring mode: [0] steps (0: the kernel ends), [1] flags (bit 0: the tile completes a grab),
 // [2,3] address of the tile's first output, [4] outputs of the channel from this tile on, [5] u0 of the chunk,
 // [6] ring slot, [7] the grab's shard of the chunk's completion counters, [8,9] chunk number, [10] grabs of the chunk on that shard,
-// [11] non-empty shards of the chunk
+// [11] non-empty shards of the chunk; bit 31: its outputs are stored write-through (RingDesc::flags)
 constexpr unsigned kRingTileWords = 16;
 
 // One grab of chunk `seq` is complete (every wave that stored for it has drained its write-through stores).  The grab counts on ITS
 // shard of the chunk's counters (ticket mod kRingShards; `cnt` grabs of the chunk land there); the grab that completes a shard counts
 // the shard, the one that completes the last of the chunk's `nshards` non-empty shards tells the host.
-__device__ __forceinline__ void ring_grab_done(RingDev *rd, RingHost *rh, unsigned slot, unsigned long long seq, unsigned shard, unsigned cnt, unsigned nshards)
+// (nshards bit 31: the chunk's outputs were stored write-through)
+__device__ __forceinline__ void ring_grab_done(RingDev *rd, RingHost *rh, unsigned slot, unsigned long long seq, unsigned shard, unsigned cnt, unsigned nshards_wt)
 {
+    const bool wt = (nshards_wt >> 31) != 0u;
+    const unsigned nshards = nshards_wt & 0x7fffffffu;
     const unsigned prev = __hip_atomic_fetch_add(&rd->shard_done[slot][shard][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev + 1u == cnt) {
         st_sc1(&rd->shard_done[slot][shard][0], 0u);  // (the slot is reused only after the host has seen the flag below)
@@ -310,7 +313,13 @@ __device__ __forceinline__ void ring_grab_done(RingDev *rd, RingHost *rh, unsign
         if (top + 1u == nshards) {
             st_sc1(&rd->chunk_done[slot], 0u);
             vm_drain();
-            st_sys(&rh->done[slot], seq + 1ull);
+            if (wt) st_sys(&rh->done[slot], seq + 1ull);                               // write-through stores: the outputs are in memory
+            else {                                                                     // plain stores: in the L2s -- a request for their write-back
+                const unsigned long long r = __hip_atomic_fetch_add(&rd->flush_req, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+                const unsigned long long ent[2] = {r, seq};
+                store_wt<16>(&rd->flush_ent[r % kRingDepth][0], ent);
+                vm_drain();
+            }
         }
     }
 }
@@ -384,6 +393,37 @@ __device__ __forceinline__ void ring_feeder(RingDev *rd, RingHost *rh, int lane)
         st_sys(&rh->stopped, code);
     }
     vm_drain();
+}
+
+// The write-back duty of a loader wave (RingDev::flush_req): `req` = flush_req and `claimed` = flush_claim[xcc] as loaded a moment ago.  Rare (once per
+// chunk and XCD), hence a function of its own.
+__device__ __attribute__((noinline)) void ring_flush_duty(RingDev *rd, RingHost *rh, unsigned xcc, unsigned long long req, int lane)
+{
+    unsigned long long won = 0;
+    if (lane == 0) won = __hip_atomic_fetch_max(&rd->flush_claim[xcc][0], req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < req ? 1ull : 0ull;
+    if (!__builtin_amdgcn_readfirstlane(static_cast<int>(won))) return;                 // another workgroup of this XCD has taken these requests on
+    // every store of the chunks behind requests 1..req reached this XCD's L2 before its grab was counted: write the L2 back
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane != 0) return;
+    (void)__hip_atomic_fetch_max(&rd->flush_done[xcc][0], req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the requests every XCD is past (read by atomics: at the point of coherence, in program order behind this XCD's own)
+    unsigned long long F = ~0ull;
+    for (int x = 0; x < 8; ++x) {
+        const unsigned long long d = __hip_atomic_fetch_max(&rd->flush_done[x][0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        F = d < F ? d : F;
+    }
+    const unsigned long long P = __hip_atomic_fetch_max(&rd->flush_pub, F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned long long r = P + 1ull; r <= F; ++r) {                                  // (empty unless this lane raised flush_pub: published once)
+        unsigned long long seq;
+        for (;;) {                                                                         // (the entry is written right behind the request's number)
+            v4u_t e;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(e) : "v"(&rd->flush_ent[r % kRingDepth][0]) : "memory");
+            if (((static_cast<unsigned long long>(e.y) << 32) | e.x) == r) { seq = (static_cast<unsigned long long>(e.w) << 32) | e.z; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        st_sys(&rh->done[seq % kRingDepth], seq + 1ull);
+    }
 }
 
 // The ring loader's COLD paths as functions of their own (never inlined): a seam tile happens twice per channel and chunk, the tail copy
@@ -504,6 +544,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     unsigned long long c_x = 0, c_y = 0, c_tile_base = 0, c_seq = 0;
     long long c_xs = 0, c_ys = 0, c_xlen = 0, c_nout = 0, c_u0 = 0, c_o0 = 0;
     unsigned c_ngrabs = 1, c_spc = 1, c_total = 0, c_magic = 0xffffffffu;
+    bool c_wt = true;                                         // the chunk's outputs go write-through (RingDesc::flags bit 0)
     const size_t slot_bytes = static_cast<size_t>(a.nch) * a.H * NC * 4u;
     auto hist_slot = [&](unsigned long long s) -> float * {
         return reinterpret_cast<float *>(static_cast<unsigned char *>(const_cast<void *>(a.hist)) + (s % kRingDepth) * slot_bytes);
@@ -569,7 +610,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
                 c_xlen = static_cast<long long>(rq(un.x, un.y, 2)); c_nout = static_cast<long long>(rq(un.z, un.w, 2));
                 c_u0 = static_cast<long long>(rq(un.x, un.y, 3)); c_o0 = static_cast<long long>(rq(un.z, un.w, 3)) - a.T;
                 c_tile_base = rq(un.x, un.y, 4); c_ngrabs = rl(un.z, 4);
-                c_spc = rl(un.x, 5); c_total = rl(un.y, 5); c_magic = rl(un.z, 5);
+                c_spc = rl(un.x, 5); c_total = rl(un.y, 5); c_magic = rl(un.z, 5); c_wt = (rl(un.w, 5) & 1u) != 0u;
                 c_seq = cur;
                 if (c_total > 0u && (c_x == 0ull || c_y == 0ull || c_spc == 0u)) {   // (never: a descriptor that cannot be one -- leave rather than fault)
                     if (lane == 0) st_sc1(&rd->closed, 3ull);
@@ -626,7 +667,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
             const unsigned long long lo = static_cast<unsigned long long>(g) * pa.steps_per_group;
             if (lo < c_total) { ra = static_cast<unsigned>(lo); rb = umin(ra + pa.steps_per_group, c_total); return kFound; }
             // a chunk without outputs (a short input, Filters.jl:543-547) has one grab without steps: nothing is stored for it
-            if (lane == 0) ring_grab_done(rd, rh, static_cast<unsigned>(c_seq % kRingDepth), c_seq, g_shard, g_cnt, c_ngrabs < kRingShards ? c_ngrabs : kRingShards);
+            if (lane == 0) ring_grab_done(rd, rh, static_cast<unsigned>(c_seq % kRingDepth), c_seq, g_shard, g_cnt, (c_ngrabs < kRingShards ? c_ngrabs : kRingShards) | (c_wt ? 0x80000000u : 0u));
             vm_drain();
         }
     };
@@ -718,7 +759,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
                                     static_cast<unsigned>(rem < 0x7fffffffLL ? rem : 0x7fffffffLL), static_cast<unsigned>(c_u0),
                                     static_cast<unsigned>(c_seq % kRingDepth), g_shard,
                                     static_cast<unsigned>(c_seq & 0xffffffffull), static_cast<unsigned>(c_seq >> 32), g_cnt,
-                                    c_ngrabs < static_cast<unsigned>(kRingShards) ? c_ngrabs : static_cast<unsigned>(kRingShards)};
+                                    (c_ngrabs < static_cast<unsigned>(kRingShards) ? c_ngrabs : static_cast<unsigned>(kRingShards)) | (c_wt ? 0x80000000u : 0u)};
             unsigned mine = w[0];
 #pragma unroll
             for (int k = 1; k < 12; ++k) mine = lane == k ? w[k] : mine;
@@ -745,6 +786,9 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     };
     if (lane < pa.ns) td[kRingTileWords * pa.ns + lane] = 0u;   // per stage: compute waves through with a grab's last tile (opair_kernel.inc)
     const bool stats = (opts & 256u) != 0u;
+    const bool flush_mode = true;                             // (every loader does the write-back duty; chunks choose their protocol: RingDesc::flags)
+    unsigned long long fl_since = 0;                          // when this wave first saw a request its XCD has not taken on
+    const unsigned xcc = static_cast<unsigned>(__builtin_amdgcn_s_getreg(0xF814)) & 7u;     // XCC_ID: the XCD this workgroup runs on
     const unsigned long long st_t0 = wall_clock64();
     unsigned long long st_bar = 0, st_prod = 0, st_tiles = 0;
     // ONE site of produce(): the pa.ns - 1 tiles of the prologue and the steady state share the loop (inlined twice, the loader's code --
@@ -767,7 +811,20 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         if (produce(pstage)) pipeline |= bit;
         if (!steady) ++primed;
         pstage = pstage + 1 == pa.ns ? 0 : pstage + 1;
+        // (the write-back duty: two loads in front of the wait this wave does anyway)
+        unsigned long long fl_req = 0, fl_claim = 0;
+        if (flush_mode) { fl_req = ld_sc1(&rd->flush_req); fl_claim = ld_sc1(&rd->flush_claim[xcc][0]); }
         if (primed >= pa.ns - 1) { if (pa.ns > 2) wait_vmcnt_le(newest_ops(pa.ns - 2)); else vm_drain(); }
+        // (one write-back serves every request filed so far: small chunks are batched -- eight requests, or the oldest of them 5 us old:
+        //  at one channel a write-back per chunk and XCD, 8 per 2.5 us, cost more than the write-through stores it replaces)
+        if (flush_mode) {
+            const unsigned long long fr = uni(fl_req), fc = uni(fl_claim);
+            if (fr > fc) {
+                const unsigned long long now = wall_clock64();
+                if (fl_since == 0ull) fl_since = now;
+                if (fr - fc >= 8ull || now - fl_since > 500ull) { ring_flush_duty(rd, rh, xcc, fr, lane); fl_since = 0ull; }
+            } else fl_since = 0ull;
+        }
         if (stats && steady) { st_prod += wall_clock64() - tb1; ++st_tiles; }
     }
     if (stats && lane == 0) {
