@@ -787,7 +787,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     if (lane < pa.ns) td[kRingTileWords * pa.ns + lane] = 0u;   // per stage: compute waves through with a grab's last tile (opair_kernel.inc)
     const bool stats = (opts & 256u) != 0u;
     const bool flush_mode = true;                             // (every loader does the write-back duty; chunks choose their protocol: RingDesc::flags)
-    unsigned long long fl_since = 0;                          // when this wave first saw a request its XCD has not taken on
+    unsigned long long fl_since = 0, fl_last = 0, fl_changed = 0;   // when this wave first saw a request its XCD has not taken on; the newest request it has seen, since when
     const unsigned xcc = static_cast<unsigned>(__builtin_amdgcn_s_getreg(0xF814)) & 7u;     // XCC_ID: the XCD this workgroup runs on
     const unsigned long long st_t0 = wall_clock64();
     unsigned long long st_bar = 0, st_prod = 0, st_tiles = 0;
@@ -815,14 +815,15 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
         unsigned long long fl_req = 0, fl_claim = 0;
         if (flush_mode) { fl_req = ld_sc1(&rd->flush_req); fl_claim = ld_sc1(&rd->flush_claim[xcc][0]); }
         if (primed >= pa.ns - 1) { if (pa.ns > 2) wait_vmcnt_le(newest_ops(pa.ns - 2)); else vm_drain(); }
-        // (one write-back serves every request filed so far: small chunks are batched -- eight requests, or the oldest of them 5 us old:
-        //  at one channel a write-back per chunk and XCD, 8 per 2.5 us, cost more than the write-through stores it replaces)
+        // (one write-back serves every request filed so far and costs the same whatever the L2 holds: requests are batched -- 32 of them, or the
+        //  oldest 40 us old, or none new for 5 us: a stream that went quiet, a lone chunk)
         if (flush_mode) {
             const unsigned long long fr = uni(fl_req), fc = uni(fl_claim);
             if (fr > fc) {
                 const unsigned long long now = wall_clock64();
                 if (fl_since == 0ull) fl_since = now;
-                if (fr - fc >= 8ull || now - fl_since > 500ull) { ring_flush_duty(rd, rh, xcc, fr, lane); fl_since = 0ull; }
+                if (fr != fl_last) { fl_last = fr; fl_changed = now; }
+                if (fr - fc >= 32ull || now - fl_since > 4000ull || now - fl_changed > 500ull) { ring_flush_duty(rd, rh, xcc, fr, lane); fl_since = 0ull; }
             } else fl_since = 0ull;
         }
         if (stats && steady) { st_prod += wall_clock64() - tb1; ++st_tiles; }
