@@ -320,7 +320,8 @@ struct RingHost {                         // pinned host memory: host writes hea
     unsigned long long head;              // chunks published
     unsigned long long close;             // != 0: consume what is published, then leave
     unsigned long long stopped;           // written by the feeder when the kernel leaves: 1 closed, 2 idle deadline, 3 a wait ran into its deadline
-    unsigned long long pad[5];
+    unsigned long long arrived, grid;     // written by the feeder while the kernel starts: workgroups on the chip so far, of how many (ring_launch)
+    unsigned long long pad[3];
     unsigned long long done[kRingDepth];  // done[seq % depth] = seq + 1 once chunk seq is complete (outputs written through)
     RingDesc desc[kRingDepth];
 };
@@ -347,9 +348,11 @@ struct RingDev {                          // device memory
     // grab's stores are in its XCD's L2 by then) files REQUEST r = ++flush_req with the chunk's number; every loader wave looks at flush_req once
     // per tile, and the first of an XCD to see a request its XCD has not taken on (flush_claim) writes that XCD's L2 back (buffer_wbl2) and
     // raises flush_done; whoever then finds every XCD past requests (flush_pub, F] raises the host's flags of those chunks, in request order.
+    unsigned long long arrived;             // workgroups of the resident kernel that have started (the host checks that ALL did: ring_launch)
+    unsigned long long grid;                // ... of how many (written by the feeder)
     unsigned long long flush_req;
     unsigned long long flush_pub;
-    unsigned long long flush_pad[14];
+    unsigned long long flush_pad[12];
     unsigned long long flush_ent[kRingDepth][2];       // request r at [r % depth]: (r, chunk number), one 16-byte store
     unsigned long long flush_claim[8][16];             // per XCD, a line of its own
     unsigned long long flush_done[8][16];
@@ -451,6 +454,7 @@ struct PairArgs {            // tiling of the pair-per-lane rational kernel (ker
     unsigned total_steps;         // steps_per_channel * channels
     unsigned steps_per_group;     // ceil(total_steps / ngroups): group g owns steps [g*S, (g+1)*S)
     int ngroups;                  // scheduling groups; workgroup b draws grabs of J steps from group b % ngroups
+    int grid_cap;                 // ring mode: at most that many workgroups (0: as many as the occupancy query says the chip holds)
     int flags_off;                // LDS byte offset of the per-stage tile descriptors
     int pad_every;                // > 0: one 16-byte pad chunk after every pad_every data chunks of a staged tile (pair_loader.h)
     int bank_off;                 // LDS byte offset of the tap bank staged by the compute waves before the first tile (-1: none;

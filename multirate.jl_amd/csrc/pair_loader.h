@@ -343,7 +343,13 @@ __device__ __forceinline__ void ring_feeder(RingDev *rd, RingHost *rh, int lane)
     const unsigned long long idle = ld_sc1(&rd->idle_ticks);
     const int du = lane & 7, dk = lane >> 3;                // 16-byte unit of the descriptor, descriptor of the round (two rounds: dk, dk + 8)
     constexpr int KU = kRingKeyQword / 2;                   // the key's unit
+    bool whole = false;                                     // every workgroup of the grid has started (told to the host: ring_launch)
     for (;;) {
+        if (!whole) {
+            const unsigned long long arr = ld_sc1(&rd->arrived);
+            if (lane == 0) { st_sys(&rh->grid, static_cast<unsigned long long>(gridDim.x)); st_sys(&rh->arrived, arr); }
+            whole = arr >= gridDim.x;
+        }
         const unsigned long long h = ld_sys(&rh->head);
         const unsigned long long tseen = wall_clock64();
         if (h > last) {
@@ -501,7 +507,8 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
 {
     RingDev *const rd = a.ring_dev;
     RingHost *const rh = a.ring_host;
-    if (blockIdx.x == 0) { ring_feeder(rd, rh, lane); return; }
+    if (lane == 0) (void)__hip_atomic_fetch_add(&rd->arrived, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ring_launch counts the workgroups that started)
+    if (blockIdx.x == 0) { if (lane == 0) st_sc1(&rd->grid, static_cast<unsigned long long>(gridDim.x)); ring_feeder(rd, rh, lane); return; }
     volatile unsigned *const td = reinterpret_cast<volatile unsigned *>(smem + pa.flags_off);   // [ns][kRingTileWords]
     // (what every lane loads alike goes to scalar registers at once: the compiler takes a vector load's result for divergent, and with it every
     //  branch on it and every value assigned under such a branch -- the chunk context, the scan position -- which then live in VGPRs)
@@ -554,7 +561,10 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
     auto wait_hist = [&](unsigned long long s) -> bool {
         const unsigned long long t0 = wall_clock64();
         while (uni(ld_sc1(&rd->hist_seq[s % kRingDepth])) != s + 1ull) {
-            if (wall_clock64() - t0 > idle) { if (lane == 0) st_sc1(&rd->closed, 3ull); vm_drain(); aborted = true; return false; }
+            if (wall_clock64() - t0 > idle) {
+                if (lane == 0) { st_sc1(&rd->stats[12], (1ull << 60) | s); st_sc1(&rd->stats[22], (static_cast<unsigned long long>(blockIdx.x) << 40) | ticket); st_sc1(&rd->closed, 3ull); }   // (what gave up: RingDev::stats[12], [22])
+                vm_drain(); aborted = true; return false;
+            }
             __builtin_amdgcn_s_sleep(8);
         }
         st_hist += wall_clock64() - t0;
@@ -613,7 +623,7 @@ __device__ __forceinline__ void pair_ring_loader_wave(const PolyArgs &a, const P
                 c_spc = rl(un.x, 5); c_total = rl(un.y, 5); c_magic = rl(un.z, 5); c_wt = (rl(un.w, 5) & 1u) != 0u;
                 c_seq = cur;
                 if (c_total > 0u && (c_x == 0ull || c_y == 0ull || c_spc == 0u)) {   // (never: a descriptor that cannot be one -- leave rather than fault)
-                    if (lane == 0) st_sc1(&rd->closed, 3ull);
+                    if (lane == 0) { st_sc1(&rd->stats[12], (2ull << 60) | cur); st_sc1(&rd->stats[22], (static_cast<unsigned long long>(blockIdx.x) << 40) | ticket); st_sc1(&rd->closed, 3ull); }
                     vm_drain();
                     aborted = true;
                     return kClosed;

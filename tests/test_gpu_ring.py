@@ -62,6 +62,10 @@ CASES = [
     (Fraction(147, 160), 24, np.float64, np.float32, 2, 120_000, [20_011, 33_000]),               # the README's mixed case
     (Fraction(147, 160), 24, np.float64, np.float64, 1, 120_000, [20_011, 33_000]),
     (Fraction(3, 2), 32, np.float64, np.complex128, 1, 60_000, [9_001, 15_000]),
+    # found by scripts/stress_ring.py: the Float64 instantiation's grid (two workgroups per CU by the occupancy query) did not all fit the
+    # chip -- 509 of 512 started -- and tickets dealt to the others were never served; ring_launch now checks the launch and shrinks it
+    (Fraction(5, 3), 24, np.float64, np.float64, 5, 567_712, [15567, 23797, 17, 37742, 33328, 37889, 26609, 13129, 20436, 37278, 40601, 47597, 5894,
+                                                                51521, 15, 1554, 31927, 30770, 58479, 53535, 27]),
 ]
 
 
