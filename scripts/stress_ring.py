@@ -13,7 +13,7 @@ from oracle import oracle as O
 pkg = ge.load_package()
 TD = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64, np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}
 ap = argparse.ArgumentParser()
-ap.add_argument("--cases", type=int, default=60); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--seconds", type=float, default=200.0)
+ap.add_argument("--cases", type=int, default=60); ap.add_argument("--many", action="store_true", help="80-200 small chunks per case (more chunks than ring slots) and now and then a pause longer than the idle deadline (set MRHIP_RING_IDLE_MS=30)"); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--seconds", type=float, default=200.0)
 a = ap.parse_args()
 os.environ.setdefault("MRHIP_RING_IDLE_MS", "500")
 rng = np.random.default_rng(a.seed)
@@ -25,9 +25,9 @@ for case in range(a.cases):
     T = int(rng.choice([24, 32])); L = ratio.numerator
     th, tx = [(np.float32, np.float32), (np.float32, np.complex64), (np.float64, np.float32), (np.float64, np.float64)][rng.integers(4)]
     nch = int(rng.choice([1, 1, 2, 3, 5, 8, 17]))
-    nchunks = int(rng.integers(3, 40))
-    big = rng.random() < 0.2
-    sizes = [int(rng.integers(1, 400_000 if big else 60_000)) if rng.random() > 0.15 else int(rng.integers(1, 40)) for _ in range(nchunks)]
+    nchunks = int(rng.integers(80, 200)) if a.many else int(rng.integers(3, 40))
+    big = rng.random() < 0.2 and not a.many
+    sizes = [int(rng.integers(1, 400_000 if big else (12_000 if a.many else 60_000))) if rng.random() > 0.15 else int(rng.integers(1, 40)) for _ in range(nchunks)]
     n = sum(sizes)
     h = (pkg.firdes(T * L, 0.45 / max(L, ratio.denominator), beta=7.0) * L).astype(th)
     x = rng.standard_normal((nch, n)).astype(np.float32)
@@ -46,6 +46,7 @@ for case in range(a.cases):
         resident += int(ring.info()["resident"])
         for i in range(nchunks):
             cnt, seq = ring.push(ys[i], xd[:, cuts[i]:cuts[i + 1]]); counts.append(cnt)
+            if a.many and rng.random() < 0.01: time.sleep(0.08)        # longer than MRHIP_RING_IDLE_MS=30: the kernel leaves and is restarted by the next push
         ring.drain()
     got = ys.cpu().numpy()
     ok = True
