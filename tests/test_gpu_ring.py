@@ -278,3 +278,16 @@ def test_ring_errors(pkg, torch_cuda):
     ring.close()
     assert f.filt(x).shape[-1] == 9188                      # the refused push left the stream where it was
     f.close()
+
+
+def test_ring_randomised_stress_short():
+    """scripts/stress_ring.py (random eligible shapes, types, channel counts, ragged chunkings against the oracle's chunk loop) for a few
+    seconds, under both completion protocols -- the script that found the launch that did not fit the chip (profiles/r05/experiments.md S)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({}, {"MRHIP_RING_FLUSH_MIN_MB": "0"}):
+        env = dict(os.environ, MRHIP_RING_IDLE_MS="500", **extra)
+        p = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_ring.py"), "--cases", "30", "--seconds", "40", "--seed", "101"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, (extra, p.stdout[-800:], p.stderr[-800:])
+        assert "mismatches 0" in p.stdout, p.stdout[-400:]
