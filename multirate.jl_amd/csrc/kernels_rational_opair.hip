@@ -120,6 +120,10 @@ bool plan_rational_opair(const TypeKey &tk, bool fused, const PolyArgs &a, int n
     const int waves_per_cu = tk.r_f64 ? 12 : 4 * std::min(8, 512 / vgpr_est);
     int wg_per_cu = std::max(1, std::min(4, waves_per_cu / (nwaves + 1)));
     if (nwaves + 1 == 6 && !tk.r_f64) wg_per_cu = 3;
+    // (Float64 arithmetic: 12 waves per CU are TWO six-wave workgroups on paper only -- 2,2,1,1 waves per SIMD each, and three per SIMD is the
+    //  limit: the ring's launch check found 257 of 512 on the chip.  Planned as what runs: one per CU, three stages of larger tiles:
+    //  147//160 Float64 51.8 -> 54.3 %, the README's mixed case 40.0 -> 41.0 %; profiles/r05/experiments.md T)
+    if (nwaves + 1 == 6 && tk.r_f64) wg_per_cu = 1;
     if (force_wgpc > 0) wg_per_cu = force_wgpc;   // (the ring's RING instantiation holds 128 VGPRs: two workgroups per CU, larger tiles)
     if (const int env_w = opair_env_int("MRHIP_OPAIR_WGPC", 0); env_w > 0) wg_per_cu = env_w;   // experiments
     // TWO pipeline stages of tiles as large as the LDS allows (the DMA runs one tile ahead, far more than the HBM
