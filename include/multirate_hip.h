@@ -352,7 +352,11 @@ int mrhip_cascade_reset(mrhip_cascade *c);
  *     starts a new one;
  *   - FIRRational / FIRInterpolator with 24 or 32 taps per phase and M < 2L (the BASELINE shapes; STRICT numerics) run on the
  *     resident kernel; every other filter takes the same interface as stream-ordered launches, one per chunk, on the ring's
- *     stream (mrhip_ring_info tells which). */
+ *     stream (mrhip_ring_info tells which);
+ *   - a chunk is "complete" when a later kernel on any stream of the device, or a copy, reads its outputs: small chunks are stored
+ *     write-through, chunks of at least MRHIP_RING_FLUSH_MIN_MB (32) of outputs plainly with one L2 write-back per XCD in front of the flag;
+ *   - the resident kernel's launch is checked: if not all of its workgroups are on the chip within 3 ms (the dealing of the work needs
+ *     every one of them) it is launched again with as many as were. */
 typedef struct mrhip_ring mrhip_ring;
 int mrhip_ring_open(mrhip_filter *f, mrhip_ring **out);
 /* filt!(y, self, x) for the next arriving chunk (same argument meaning and errors as mrhip_filt_device); *seq (optional)
