@@ -1119,6 +1119,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 }
                 else if (!f->force_generic && plan_farrow_tiled(tk, fa, n_host, sched_spans, f->num_cus, &fta, &flds)) {
                     fta.counters = MRHIP_ENV_INT("MRHIP_PIPE_DYNAMIC", 1) != 0 ? f->d_counters : nullptr;   // (as for FIRArbitrary below)
+                    if (sf.hist_new) { fa.fold = sf; did_shiftin = true; hist_in_place = in_place; }
                     MRHIP_CHECK_HIP(launch_farrow_tiled(tk, fused, fa, fta, flds, stream, &f->last_kernel, f->num_cus));
                 }
                 else
@@ -1139,7 +1140,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 // the pipe kernel's tiles are handed out from a counter of the filter (its launches are stream-ordered: one at a
                 // time); MRHIP_PIPE_DYNAMIC=0: every workgroup takes every gridDim-th tile
                 ta.counters = MRHIP_ENV_INT("MRHIP_PIPE_DYNAMIC", 1) != 0 ? f->d_counters : nullptr;
-                if (ta.pipe && sf.hist_new) { a.fold = sf; did_shiftin = true; hist_in_place = in_place; }
+                if (sf.hist_new) { a.fold = sf; did_shiftin = true; hist_in_place = in_place; }
                 MRHIP_CHECK_HIP(launch_arb_tiled(tk, fused, a, ta, lds, stream, &f->last_kernel, f->num_cus));
             }
             else

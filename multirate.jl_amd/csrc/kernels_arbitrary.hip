@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "mrhip_internal.h"
+#include "pair_device.h"
 
 #pragma clang fp contract(off)
 
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kArbThreads, 4) void arb_tiled_kernel(ArbArgs a, Ar
     __shared__ unsigned s_grab[2];
     TileHandout th;
     long long tile = th.first(ta.counters, ta.run_tiles, s_grab, tid);
-    if (tile >= ta.total_tiles) { th.leave(tid); return; }
+    if (tile >= ta.total_tiles) { th.leave(tid); dev::shiftin_by_last_workgroup<TX, NC>(a.fold, a.x, a.hist, a.x_stride, a.x_len, a.H, a.nch); return; }
     unsigned it = 0;
     bool asked_prev = false;
     TileInfo cur = tile_info(tile);
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(kArbThreads, 4) void arb_tiled_kernel(ArbArgs a, Ar
         cur = PREFETCH ? nxt : tile_info(next);
     }
     th.leave(tid);
+    dev::shiftin_by_last_workgroup<TX, NC>(a.fold, a.x, a.hist, a.x_stride, a.x_len, a.H, a.nch);
 }
 
 template <typename TX, typename R, int NC>
@@ -537,6 +539,7 @@ __global__ __launch_bounds__(kArbThreads, 3) void farrow_tiled_kernel(FarrowArgs
         tile = tile_after;
     }
     th.leave(tid);
+    dev::shiftin_by_last_workgroup<TX, NC>(a.fold, a.x, a.hist, a.x_stride, a.x_len, a.H, a.nch);
 }
 
 template <typename TX, typename R, int NC>

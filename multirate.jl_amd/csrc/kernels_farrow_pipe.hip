@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
         }
     };
     long long tau = blockIdx.x;
-    if (tau >= ntiles) { leave(); return; }
+    if (tau >= ntiles) { leave(); dev::shiftin_by_last_workgroup<TX, NC>(a.fold, a.x, a.hist, a.x_stride, a.x_len, a.H, a.nch); return; }
     long long t1 = 0, t2 = 0;                                   // handed out: this workgroup's next tile and the one after it
     if (ctr) {
         if (tid == 0) { const unsigned b = atomicAdd(ctr, 2u); s_grab[0] = b; s_grab[1] = b + 1u; }
@@ -429,6 +429,7 @@ __global__ __launch_bounds__(kFpThreads, 3) void farrow_pipe_kernel(FarrowArgs a
         }
     }
     leave();
+    dev::shiftin_by_last_workgroup<TX, NC>(a.fold, a.x, a.hist, a.x_stride, a.x_len, a.H, a.nch);
 }
 
 template <typename TX, typename R, int NC>

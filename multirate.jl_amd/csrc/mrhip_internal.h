@@ -389,7 +389,7 @@ struct ArbArgs {             // FIRArbitrary
     int T, H, Nphi;
     int nch;
     const DevCall *dyn;      // != NULL: n_out is read from it (a device-planned call; the value above is an upper bound)
-    ShiftFold fold;          // arb_pipe_kernel only
+    ShiftFold fold;          // arb_pipe_kernel, arb_tiled_kernel
 };
 
 struct FarrowArgs {          // FIRFarrow
@@ -408,7 +408,7 @@ struct FarrowArgs {          // FIRFarrow
     int seam_below;          // outputs whose 1-based input index n < this start from +0 (support.jl:46): T, or 0 for a
                              // piece that continues a call (mrhip_filt_device splits long calls)
     const DevCall *dyn;      // != NULL: n_out is read from it
-    ShiftFold fold;          // farrow_wave_kernel only
+    ShiftFold fold;          // farrow_wave_kernel, farrow_pipe_kernel, farrow_tiled_kernel
 };
 
 struct HistArgs {            // shiftin! (src/support.jl:61-80) for every channel
