@@ -11,6 +11,7 @@
 // R = promote_type(Th, Tx) -- the order the reference source states (src/support.jl:5-55).
 // This file is compiled with -ffp-contract=off; FUSED mode calls fma explicitly.
 #include "mrhip_internal.h"
+#include "pair_device.h"
 
 #pragma clang fp contract(off)
 
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void arb_generic_kernel(ArbArgs a)
 {
     const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (a.dyn) a.n_out = a.dyn->n_out;              // a device-planned call: the count the schedule's FINISH kernel left
-    if (k >= a.n_out) return;
+    if (k < a.n_out) {                               // (no early return: every thread takes part in the history epilogue below)
     const long long n = a.n_idx[k];
     const double pacc = a.acc[k];
     const double phif = __builtin_floor(pacc);
@@ -136,6 +137,8 @@ __global__ __launch_bounds__(256) void arb_generic_kernel(ArbArgs a)
             yc[k * NC + c] = static_cast<R>(sum);
         }
     }
+    }
+    dev::shiftin_by_last_workgroup<TX, NC>(a.fold, a.x, a.hist, a.x_stride, a.x_len, a.H, a.nch);
 }
 
 // FIRFarrow (src/Filters.jl:123-147, 764-839): the taps of every output are polynomials in the Float64

@@ -389,7 +389,7 @@ struct ArbArgs {             // FIRArbitrary
     int T, H, Nphi;
     int nch;
     const DevCall *dyn;      // != NULL: n_out is read from it (a device-planned call; the value above is an upper bound)
-    ShiftFold fold;          // arb_pipe_kernel, arb_tiled_kernel
+    ShiftFold fold;          // arb_pipe_kernel, arb_tiled_kernel, arb_generic_kernel
 };
 
 struct FarrowArgs {          // FIRFarrow

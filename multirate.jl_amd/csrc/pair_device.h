@@ -105,7 +105,7 @@ __device__ __forceinline__ void shiftin_by_last_workgroup(const ShiftFold &sf, c
     if (!sf.done) {
         // into the OTHER history buffer (not a captured call): nobody in this launch reads what is written -- no counting, no waiting: the
         // last workgroup of the grid copies when it gets here
-        if (blockIdx.x + 1u != gridDim.x) return;
+        if (blockIdx.x + 1u != gridDim.x || blockIdx.y != 0u || blockIdx.z != 0u) return;   // (one of them, on a grid of more dimensions too)
         s_last = 1;
     } else {
     __syncthreads();

@@ -9,6 +9,9 @@ import pytest
 # the library reads its tuning / test knobs (MRHIP_OPAIR, MRHIP_STREAM, ...) once per process unless told otherwise; tests
 # switch kernels between calls with monkeypatch.setenv, so they ask for a fresh read every time
 os.environ.setdefault("MRHIP_ENV_DYNAMIC", "1")
+# the tuned FIRArbitrary kernels are tested at small sizes: keep small calls off the universal kernel here (api.hip: MRHIP_ARB_SMALL_MAX; the
+# dispatch itself: test_small_arbitrary_calls_take_the_universal_kernel and the stress scripts, which run with the defaults)
+os.environ.setdefault("MRHIP_ARB_SMALL_MAX", "0")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

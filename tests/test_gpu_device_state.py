@@ -258,6 +258,38 @@ def test_small_and_long_asynchronous_calls_share_the_record(pkg, O, torch_cuda, 
     f.close()
 
 
+def test_small_arbitrary_calls_take_the_universal_kernel(pkg, O, torch_cuda, monkeypatch):
+    """A FIRArbitrary call of at most MRHIP_ARB_SMALL_MAX outputs x channels runs on arb_generic_kernel (faster there: nothing to set up), which
+    then also writes the next call's history (ShiftFold) -- plain, asynchronous and captured calls against the oracle; a larger call of the same
+    filter goes back to the tuned kernel."""
+    torch = torch_cuda
+    monkeypatch.setenv("MRHIP_ARB_SMALL_MAX", "150000")
+    rng = np.random.default_rng(41)
+    h = (pkg.firdes(32 * 10, 0.45 / 32, beta=7.8562) * 32)
+    rate, chunk, nrep = 1 / 2.123456789, 50_021, 8
+    xh = rng.standard_normal((1, chunk * (nrep + 3))).astype(np.float32)
+    x = torch.from_numpy(xh).cuda()
+    f = pkg.FIRFilter(h, rate, 32).bind(np.float32, 1)
+    fo = O.FIRFilter(h, rate, 32, tx=np.float32)
+    y0 = f.filt(x[:, :chunk])
+    assert f.last_kernel_name() == "arb_generic_kernel"
+    assert_bit_equal(y0.cpu().numpy()[0], fo.filt(xh[0, :chunk]), "plain small call")
+    yb = torch.empty((1, f.outputlength_bound(chunk)), dtype=torch.float64, device="cuda")
+    f.filt_into_async(yb, x[:, chunk:2 * chunk])
+    n1 = f.sync_state()
+    assert_bit_equal(yb[0, :n1].cpu().numpy(), fo.filt(xh[0, chunk:2 * chunk]), "asynchronous small call")
+    outs, counts = _graph_stream(torch, f, x[:, 2 * chunk:], chunk, nrep)
+    yo = _oracle_chunks(fo, xh[0, 2 * chunk:], chunk, nrep)
+    assert counts == [len(v) for v in yo]
+    assert_bit_equal(np.concatenate([o[0] for o in outs]), np.concatenate(yo), "captured small calls")
+    assert_bit_equal(np.atleast_2d(f.history)[0], fo.history, "history behind the replays")
+    big = rng.standard_normal((1, 600_000)).astype(np.float32)
+    yb2 = f.filt(torch.from_numpy(big).cuda())
+    assert f.last_kernel_name() == "arb_pipe_kernel"
+    assert_bit_equal(yb2.cpu().numpy()[0], fo.filt(big[0]), "a larger call on the tuned kernel")
+    f.close()
+
+
 def test_async_call_needs_room_for_the_bound(pkg, torch_cuda):
     torch = torch_cuda
     h = np.ones(24 * 3, dtype=np.float32)
