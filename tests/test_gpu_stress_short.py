@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("stress_sharded.py", ["--cases", "150", "--seconds", "40", "--seed", "202"]),       # mrhip_sharded_*
     ("stress_cascade.py", ["--cases", "150", "--seconds", "40", "--seed", "203"]),       # chained device-planned calls
     ("stress_graph.py", ["--cases", "150", "--seconds", "40", "--seed", "204"]),         # captured calls, history written in place
+    ("stress_multi.py", ["--cases", "80", "--seconds", "40", "--seed", "205"]),          # mrhip_filt_device_multi
 ])
 def test_randomised_stress_short(script, args):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)] + args, capture_output=True, text=True, timeout=400)
