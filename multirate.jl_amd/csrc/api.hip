@@ -565,11 +565,26 @@ void mrhip_destroy(mrhip_filter *f)
 // its last call; when that stream no longer exists -- torch side streams come and go -- behind the whole device, on the
 // filter's own stream).
 // the filter's schedule stream behind a chained call's schedule, which ran on the caller's stream (filt_device_one)
+// The schedule stream behind what ran on a caller's stream (chain_pending / chain_stream): the event is recorded NOW -- it then covers at least
+// what it has to -- and not by every small call (one host call each: profiles/r05/experiments.md O).  A stream that no longer exists has
+// nothing pending the device could still be running for long: the device is waited for instead.
+static int chain_event_now(mrhip_filter *f)
+{
+    if (!f->ev_chain) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_chain, hipEventDisableTiming));
+    if (hipEventRecord(f->ev_chain, f->chain_stream) == hipSuccess) {
+        MRHIP_CHECK_HIP(hipStreamWaitEvent(f->s_sched, f->ev_chain, 0));
+    } else {
+        (void)hipGetLastError();
+        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+    }
+    f->chain_pending = false;
+    return MRHIP_OK;
+}
+
 static int sched_stream_behind_chain(mrhip_filter *f)
 {
     if (f->s_sched && f->chain_pending) {
-        MRHIP_CHECK_HIP(hipStreamWaitEvent(f->s_sched, f->ev_chain, 0));
-        f->chain_pending = false;
+        if (int rc = chain_event_now(f)) return rc;
     }
     return MRHIP_OK;
 }
@@ -1178,10 +1193,8 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             hipStream_t ss = capturing || !f->s_sched || x_from || inline_sched ? stream : f->s_sched;
             // a chained call's schedule ran on the CALLER's stream (it reads the previous stage's call record there) and wrote the record,
             // the piece states and the path tables: a schedule on the filter's own schedule stream must come behind it
-            if (ss == f->s_sched && f->chain_pending) {
-                MRHIP_CHECK_HIP(hipStreamWaitEvent(ss, f->ev_chain, 0));
-                f->chain_pending = false;
-            }
+            if (ss == f->s_sched && f->chain_pending)
+                if (int rc = chain_event_now(f)) return rc;
             if (ss == f->s_sched) f->sched_dirty = true;
             else if (!capturing && f->s_sched && f->sched_dirty) {        // (mrhip_filter.h: sched_dirty)
                 MRHIP_CHECK_HIP(hipEventRecord(f->ev_sdirty, f->s_sched));
@@ -1268,8 +1281,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
                 MRHIP_CHECK_HIP(hipEventRecord(f->ev_filt[b], stream));
                 f->ev_filt_valid[b] = true;
             } else if (!capturing && f->s_sched) {                       // (see chain_pending above; also orders buffer b's next writer)
-                if (!f->ev_chain) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_chain, hipEventDisableTiming));
-                MRHIP_CHECK_HIP(hipEventRecord(f->ev_chain, stream));
+                f->chain_stream = stream;
                 f->chain_pending = true;
             }
         } else if (!cached && est > 2 * piece && y && y_capacity >= est && (f->nch == 1 || y_stride >= est) && est < 0x7fffffffLL) {
@@ -1424,8 +1436,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
         if (int rc = rec_push(f, on_sched ? f->s_sched : stream, -1, std::max<int64_t>(n_out, 0))) return rc;
         if (on_sched) f->async_pending = true;       // (nobody waits for that push: a capture must not start before it has run)
         if (sched_inline) {
-            if (!f->ev_chain) MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_chain, hipEventDisableTiming));
-            MRHIP_CHECK_HIP(hipEventRecord(f->ev_chain, stream));
+            f->chain_stream = stream;
             f->chain_pending = true;
             f->async_pending = true;
         }

@@ -375,7 +375,9 @@ static int enqueue_tables(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y
         MRHIP_CHECK_HIP(launch_schedule_piece(c, a, s, fuse ? &fu : nullptr));
     }
     if (!fuse) MRHIP_CHECK_HIP(launch_sched_finish(c, fa, s));
-    MRHIP_CHECK_HIP(hipEventRecord(f->ev_rec, s));
+    // (the event is what sched_collect waits for: a call nobody collects -- asynchronous, captured: serial_fallback -- does without it, i.e.
+    //  without one host call per small call and one node per call of a captured graph)
+    if (!serial_fallback) MRHIP_CHECK_HIP(hipEventRecord(f->ev_rec, s));
     out->pending = true;
     return MRHIP_OK;
 }
@@ -414,8 +416,7 @@ int sched_enqueue(mrhip_filter *f, int64_t x_len, int64_t est, int64_t y_capacit
                                static_cast<long long>(f->per_Q), static_cast<long long>(f->per_XQ), 0LL, 0LL, 0LL,
                                static_cast<int *>(f->ds_n[b]), static_cast<double *>(f->ds_acc[b]), static_cast<const DevCall *>(f->d_calls[b]));
             MRHIP_CHECK_HIP(hipGetLastError());
-            MRHIP_CHECK_HIP(hipEventRecord(f->ev_rec, s));
-            out->pending = true;
+            out->pending = true;                 // (nobody collects a call planned from the device record: no event)
             out->periodic = true;
             return MRHIP_OK;
         }

@@ -86,6 +86,7 @@ struct mrhip_filter {
     int flip = 0;
     hipEvent_t ev_chain = nullptr;          // recorded behind a schedule that ran on the CALLER's stream (a chained call): the schedule stream's next use waits for it
     bool chain_pending = false;
+    hipStream_t chain_stream = nullptr;     // ... that stream: the event is recorded only when the schedule stream is next used (a stream of small calls never does)
     // memo: the schedule is a pure function of (accumulator, inputDeficit, x_len): a call that repeats the call whose
     // entries buffer memo_buf still holds reuses them (reset + the same block again: benchmarks, batches of equal files)
     bool memo_valid = false;
