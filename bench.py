@@ -27,7 +27,9 @@ filters its own 64-channel shard -- channels are independent, so there is no dat
 and the reported value is all ranks' input samples / max-over-ranks time ("scaling": "weak").  `n_gpus` is the
 world size the process group actually formed (asserted equal to the all-reduced rank count).
 
-One JSON line is printed by rank 0.  `roofline.achieved` = algorithmic bytes per launch
+Rank 0 prints ONE compact JSON line (< 4 KB: the contract keys, `roofline` with the BASELINE rows as
+name -> {kernel_ms, frac, frac_wall}, `cpu_baseline`) as the only line on stdout; the long record (every config row, the
+FUSED rows, the parity object) goes to --full-out (default gpurun_out/bench_full.json).  `roofline.achieved` = algorithmic bytes per launch
 (7.675 B per input sample per channel = 4 B read + 0.91875 * 4 B written; 15.35 B for ComplexF32) x
 samples per launch / average launch duration of the dominant kernel, measured with HIP events recorded on the
 launch stream around the compute-kernel launches of the timed region (mrhip_set_timing / mrhip_timing_read; every
@@ -101,9 +103,9 @@ def cpu_baseline(h, seconds_budget=25.0):
     med = times[len(times) // 2]
     one = {"value": round(n / med / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
            "cpu_model": host["cpu_model"], "host_logical_cores": host["logical_cores"], "runs": len(times),
-           "sample": f"1 channel x {n} Float32 samples, 147//160, 3528 taps, median of {len(times)} runs of "
-                     "oracle/multirate_oracle.c (gcc -O3, strict order, no FMA) on one core; reference is Julia 0.3 and "
-                     "cannot run; README.md:172-193 quotes 17.56 Msamples/s (Float64 taps) on unnamed 2014 hardware"}
+           "sample": f"1 ch x {n:.3g} f32 samples, C1 filter; median of {len(times)} runs of oracle/multirate_oracle.c, gcc -O3, 1 core",
+           "note": "strict order, no FMA; the reference is Julia 0.3 and cannot run; README.md:172-193 quotes 17.56 Msamples/s (Float64 taps) "
+                   "on unnamed 2014 hardware"}
 
     # all cores: one channel per usable core, one thread each (ctypes releases the GIL inside the C call)
     cores = max(1, host["usable_cores"])
@@ -346,7 +348,7 @@ def config_rows(fused=False):
             out[-1]["wall_ms_continuing_stream"] = r["wall_ms_per_call_continuing_stream"]
             out[-1]["wall_ms_with_schedule_memo"] = r.get("wall_ms_with_schedule_memo")
         for k in ("us_per_chunk", "chunks_per_pass", "note"):
-            if k in r and r["config"][:3] in ("C2r", "C2s", "C1 "):
+            if k in r and r["config"].split()[0] in ("C2r", "C2rp", "C2rd", "C2s", "C1"):
                 out[-1][k] = r[k]
     return out
 
@@ -483,9 +485,8 @@ def run_headline(args, R):
             "n_gpus": R.formed, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"FIRRational 147//160, 3528 taps, Float32, {nch} channels x {n} samples per GPU, "
-                                   + ("one filt! call per pass" if chunk == n else f"streamed in {chunk}-sample chunks through one stateful FIRFilter")
-                                   + " (inputs and outputs resident in HBM)",
+            "config": {"workload": f"FIRRational 147//160 3528 taps f32, {nch} ch x {n:.3g} samples/GPU, "
+                                   + ("one filt! per pass" if chunk == n else f"{chunk}-sample chunks, one stateful FIRFilter") + ", HBM-resident",
                        "channels_per_gpu": nch, "samples_per_channel": n, "chunk": chunk,
                        "numerics": args.numerics, "parallelism": f"channel-shard x{world}, no collective",
                        "backend": R.backend if world > 1 else None},
@@ -519,7 +520,7 @@ def run_headline(args, R):
             base = {}
             for r in configs:
                 nm = r.get("name", "")
-                if nm[:3] in ("C1 ", "C2 ", "C2s", "C2r", "C3a", "C3b", "C4 ", "C4f", "C5 "):
+                if nm.split()[0] in BASELINE_ROW_TAGS:
                     base[nm.split()[0]] = {"kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "wall_ms": r["wall_ms"], "frac": r["frac"],
                                            "frac_wall": r["frac_wall"]}
                     if "wall_ms_continuing_stream" in r:
@@ -609,9 +610,8 @@ def run_c5(args, R):
             "n_gpus": R.formed, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(per_step * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C5: FIRRational 147//160, 3528 taps, ComplexF32 samples x Float32 taps, {nch_total} channels x {n} "
-                                   f"samples in all, sharded by channel over {world} GPU(s); one filt! call per pass "
-                                   "(inputs and outputs resident in HBM)",
+            "config": {"workload": f"C5: FIRRational 147//160 3528 taps c64 x f32 taps, {nch_total} ch x {n:.3g} samples in all, "
+                                   f"channel-sharded over {world} GPU(s), HBM-resident",
                        "channels_total": nch_total, "channels_per_gpu": sh.count, "samples_per_channel": n,
                        "parallelism": f"channel-shard x{world}, no data-path collective; final gather timed separately",
                        "backend": R.backend if world > 1 else None},
@@ -627,6 +627,109 @@ def run_c5(args, R):
         }
         return line
     return None
+
+
+
+# ---------------------------------------------------------------------------------------------
+# what is printed: ONE compact JSON line (< 4 KB) on stdout; the long record goes to a file
+# ---------------------------------------------------------------------------------------------
+COMPACT_MAX = 4000
+BASELINE_ROW_TAGS = ("C1", "C2", "C2s", "C2r", "C2rp", "C3a", "C3b", "C4", "C4f", "C5", "C2rd")
+
+
+def _short(s, n=110):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1] + "~"
+
+
+def compact_line(full, full_path=None):
+    """The contract line the driver parses (bench contract keys + `roofline` + `cpu_baseline`), built from the full record:
+    short strings, the BASELINE rows as name -> {kernel_ms, frac, frac_wall} inside `roofline`, nothing else.  Always
+    shorter than COMPACT_MAX bytes: optional keys are dropped, last first, until it fits (round 5's 25.8 KB line left the
+    driver's record unparsed)."""
+    rf = full.get("roofline", {})
+    cfg = full.get("config", {})
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    out["unit"] = _short(out["unit"], 60)
+    out["config"] = {k: (_short(v) if isinstance(v, str) else v) for k, v in cfg.items() if v is not None}
+    out["kernel"] = _short(full.get("kernel"), 90)
+    out["parity_pin"] = full.get("parity_pin")
+    out["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                               "avg_launch_ms", "launches_timed") if k in rf}
+    if rf.get("traffic_source"):
+        out["roofline"]["traffic_source"] = "recorded: " + _short(rf["traffic_source"].get("file"), 50)
+    if rf.get("note"):
+        out["roofline"]["note"] = _short(rf["note"], 100)
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: (_short(v, 100) if isinstance(v, str) else v) for k, v in cb.items()
+                               if k in ("value", "unit", "cores", "kind", "sample", "cpu_model", "runs")}
+    optional = []        # (key path, value), most dispensable LAST
+    base = rf.get("baseline_configs")
+    if base:             # [kernel_ms, frac of 8 TB/s (kernel), frac (wall)] per BASELINE row, both from the same passes
+        optional.append((("roofline", "baseline_configs"),
+                         {k: {"kernel_ms": v.get("kernel_ms"), "frac": v.get("frac"), "frac_wall": v.get("frac_wall")} for k, v in base.items()}))
+    if full.get("c5"):
+        c5 = full["c5"]
+        optional.append((("c5",), {"value": c5.get("value"), "unit": _short(c5.get("unit"), 40), "scaling": c5.get("scaling"), "ms_per_step": c5.get("ms_per_step"),
+                                   "n_gpus": c5.get("n_gpus"), "channels_total": c5.get("channels_total"), "channels_per_gpu": c5.get("channels_per_gpu"),
+                                   "samples_per_channel": c5.get("samples_per_channel"), "kernel": _short(c5.get("kernel"), 60),
+                                   "roofline": {k: (c5.get("roofline") or {}).get(k) for k in ("achieved", "frac", "avg_launch_ms")},
+                                   "gather": {k: {"ms": v.get("ms"), "GBps_into_one_gpu": v.get("GBps_into_one_gpu")} for k, v in (c5.get("gather") or {}).items()}}))
+    if full.get("gather"):
+        optional.append((("gather",), {k: {"ms": v.get("ms"), "GBps_into_one_gpu": v.get("GBps_into_one_gpu")} for k, v in full["gather"].items()}))
+    if full.get("cpu_baseline_simd") and "value" in full["cpu_baseline_simd"]:
+        optional.append((("cpu_baseline_simd",), {"value": full["cpu_baseline_simd"]["value"], "cores": 1}))
+    if full.get("cpu_baseline_all_cores"):
+        optional.append((("cpu_baseline_all_cores",), {"value": full["cpu_baseline_all_cores"]["value"], "cores": full["cpu_baseline_all_cores"]["cores"]}))
+    if full.get("streamed_1e6_chunks"):
+        st = full["streamed_1e6_chunks"]
+        optional.append((("streamed_1e6_chunks",), {"Msamples_per_s": st.get("Msamples_per_s"), "frac": st.get("frac")}))
+    if full.get("fused"):
+        optional.append((("fused",), {k: v.get("frac") for k, v in full["fused"].items() if isinstance(v, dict)}))
+    if full.get("output_msamples_s") is not None:
+        optional.append((("output_msamples_s",), full["output_msamples_s"]))
+    if full_path:
+        optional.append((("full_record",), full_path))
+
+    def put(d, path, v):
+        for k in path[:-1]:
+            d = d.setdefault(k, {})
+        d[path[-1]] = v
+
+    def drop(d, path):
+        for k in path[:-1]:
+            d = d[k]
+        d.pop(path[-1], None)
+
+    for path, v in optional:
+        put(out, path, v)
+    text = json.dumps(out, separators=(",", ":"))
+    while len(text) >= COMPACT_MAX and optional:
+        path, _ = optional.pop()
+        drop(out, path)
+        text = json.dumps(out, separators=(",", ":"))
+    assert len(text) < COMPACT_MAX, len(text)
+    return text
+
+
+def emit(full, args):
+    """Write the long record to a file (and to stderr with --full-stderr), print the compact line as the ONLY line on stdout."""
+    path = args.full_out
+    rel = None
+    if path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, "w") as fh:
+                json.dump(full, fh)
+                fh.write("\n")
+            rel = os.path.relpath(os.path.abspath(path), ROOT)
+        except OSError as e:
+            print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    if args.full_stderr:
+        print(json.dumps(full), file=sys.stderr, flush=True)
+    print(compact_line(full, rel), flush=True)
 
 
 def main():
@@ -646,6 +749,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs reported as `configs` (N = 1 only)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check (timing experiments)")
     ap.add_argument("--no-gather", action="store_true", help="c5: skip the gather timings")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="file that receives the long record (every config row, fused rows, parity object); '' = none")
+    ap.add_argument("--full-stderr", action="store_true", help="also print the long record on stderr")
     ap.add_argument("--no-c5", action="store_true", help="multi-GPU headline: skip the config-5 pass appended as `c5`")
     ap.add_argument("--c5-channels", type=int, default=0, help="multi-GPU headline: channels in all of the appended config-5 pass (default 4096)")
     ap.add_argument("--c5-samples", type=int, default=0, help="... and its samples per channel (default 1e6)")
@@ -676,10 +782,7 @@ def main():
                               "roofline": {k: c5["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_timed", "note")},
                               "workload": c5["config"]["workload"]}
     if line is not None:
-        # `configs` (long) goes LAST so that its BASELINE rows -- the last of it -- end the line
-        if "configs" in line:
-            line["configs"] = line.pop("configs")
-        print(json.dumps(line), flush=True)
+        emit(line, args)
     R.finish()      # only on success: a rank that raised must not wait for the others at a barrier (the launcher ends them)
 
 
