@@ -132,7 +132,8 @@ def _bench(args, backend, timeout=900):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout     # ONE line on stdout, and it is the compact record
+    # ONE JSON line on stdout, and it is the LAST line (the gloo backend of the plumbing runs prints its own "[Gloo] Rank ..." lines first)
+    assert len([ln for ln in lines if ln.startswith("{")]) == 1 and lines[-1].startswith("{"), p.stdout
     assert len(lines[-1]) < 4096, len(lines[-1])                       # (round 5's 25.8 KB line left the driver's record unparsed)
     return json.loads(lines[-1])
 
