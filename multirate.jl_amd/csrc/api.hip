@@ -1154,7 +1154,14 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             // (a small call -- at most MRHIP_ARB_SMALL_MAX (150 000) outputs x channels -- runs faster on the universal kernel, one lane per output and
             //  nothing to set up: 1 ch x 1e5 samples 6.7 against 8.6 us, the crossover at 1 ch x 3e5 / 2 ch x 1.5e5; profiles/r05/experiments.md O)
             const bool small_call = cnt * f->nch <= static_cast<int64_t>(MRHIP_ENV_INT("MRHIP_ARB_SMALL_MAX", 150000));
-            if (!f->force_generic && !small_call && plan_arb_tiled(tk, a, n_host, sched_spans, f->num_cus, &ta, &lds)) {
+            ArbLaneArgs la;
+            if (!f->force_generic && !small_call && MRHIP_ENV_INT("MRHIP_PIPE_DYNAMIC", 1) != 0 && plan_arb_lane(tk, a, f->rate, &la, &lds)) {
+                // (64 channels or more, Float64, a rate >= 1: a lane per channel, the taps in scalar registers -- kernels_arb_lane.hip)
+                la.counters = f->d_counters;
+                if (sf.hist_new) { a.fold = sf; did_shiftin = true; hist_in_place = in_place; }
+                MRHIP_CHECK_HIP(launch_arb_lane(fused, a, la, lds, stream, &f->last_kernel, f->num_cus));
+            }
+            else if (!f->force_generic && !small_call && plan_arb_tiled(tk, a, n_host, sched_spans, f->num_cus, &ta, &lds)) {
                 // the pipe kernel's tiles are handed out from a counter of the filter (its launches are stream-ordered: one at a
                 // time); MRHIP_PIPE_DYNAMIC=0: every workgroup takes every gridDim-th tile
                 ta.counters = MRHIP_ENV_INT("MRHIP_PIPE_DYNAMIC", 1) != 0 ? f->d_counters : nullptr;

@@ -583,6 +583,17 @@ bool plan_arb_tiled(const TypeKey &tk, const ArbArgs &a, const int32_t *n_idx_ho
 bool plan_arb_pipe(const TypeKey &tk, const ArbArgs &a, long long span256, ArbTileArgs *out, size_t *lds);
 hipError_t launch_arb_pipe(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
                            const char **kname, int num_cus);
+// arb_lane_kernel (kernels_arb_lane.hip): FIRArbitrary, Float64 x Float64, a lane per channel
+struct ArbLaneArgs {
+    int ring;                // samples per channel in the ring (a multiple of 16, >= the history length)
+    int pitch8;              // 8-byte units between the channel rows of the ring: ring + mirror, odd
+    int stretch;             // outputs per stretch (a multiple of 16)
+    int ngroups;             // groups of 64 channels
+    int y16;                 // 16-byte stores into y are aligned
+    unsigned *counters;      // [0] stretches handed out beyond the first grid-full, [64] workgroups through (zero between launches)
+};
+bool plan_arb_lane(const TypeKey &tk, const ArbArgs &a, double rate, ArbLaneArgs *out, size_t *lds);
+hipError_t launch_arb_lane(bool fused, const ArbArgs &a, const ArbLaneArgs &la, size_t lds, hipStream_t s, const char **kname, int num_cus);
 hipError_t launch_arb_tiled(const TypeKey &tk, bool fused, const ArbArgs &a, const ArbTileArgs &ta, size_t lds, hipStream_t s,
                             const char **kname, int num_cus);
 bool plan_poly_tiled(const TypeKey &tk, const PolyArgs &a, int num_cus, ArbTileArgs *out, size_t *lds);

@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- pyt
 P=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
            "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
+           "FETCH_SIZE" "WRITE_SIZE" ${EXTRA_PMC:+"$EXTRA_PMC"}; do
   rocprofv3 --output-format csv --pmc $set -d "$OUT/pmc_$P" -o c -- python3 "$R/scripts/bench_configs.py" "$@" > "$OUT/pmc_$P.log" 2>&1
   P=$((P+1))
 done
