@@ -35,11 +35,22 @@ namespace {
 using dev::v2u_t;
 
 constexpr int kLaneWaves = 8;
-constexpr int kLaneThreads = 64 * (kLaneWaves + 1);   // eight compute waves and the loader wave
+constexpr int kLaneThreads = 64 * kLaneWaves;
 constexpr int kLaneStep = 2 * kLaneWaves;        // outputs per step: one pair per wave
 constexpr int kLaneBlock = 16;                   // samples per staging block and channel (128 bytes)
 constexpr int kLaneOutRow = 144;                 // bytes per channel row of an output tile: 16 outputs + 16 bytes (bank stagger of the 16-byte writes)
 constexpr int kLaneMirror = 32;                  // ring positions repeated behind the ring (T <= 32: a window reads T + 1 samples)
+
+#ifdef MRHIP_LANE_TRACE
+// debug builds (make EXP=1 EXPFLAGS=-DMRHIP_LANE_TRACE): clock sums per wave of the LAST launch, printed at process exit:
+// [0] pair statement [1] barrier [2] everything else [3] steps
+__device__ unsigned long long g_lane_prof[8192][8];
+#define LANE_T0() unsigned long long lt_ = __builtin_amdgcn_s_memtime()
+#define LANE_TICK(acc) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (acc) += n_ - lt_; lt_ = n_; } while (0)
+#else
+#define LANE_T0() do {} while (0)
+#define LANE_TICK(acc) do {} while (0)
+#endif
 
 typedef const __attribute__((address_space(4))) double *cdouble_t;   // wave-uniform reads: scalar loads
 typedef const __attribute__((address_space(4))) int *cint_t;
@@ -74,22 +85,20 @@ __device__ __forceinline__ gptr_t<P> lane_uniform_ptr(P *p)
     asm volatile("" : "+s"(lo), "+s"(hi));
     return reinterpret_cast<gptr_t<P>>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
-// the lane's number, derived afresh (opaque to the compiler: a lane constant kept live across the loader's loop is spilled to scratch, and
-// a scratch reload waits for EVERY vector memory operation -- the blocks in flight included)
-__device__ __forceinline__ unsigned lane_id_fresh()
-{
-    unsigned l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-}
 
-// The workgroup's barrier WITHOUT __syncthreads()'s wait for the vector memory counter: the loader wave keeps global loads in flight
+// The workgroup's barrier WITHOUT __syncthreads()'s wait for the vector memory counter: every wave keeps the global loads of its rows in flight
 // across steps (two blocks ahead), and a vmcnt(0) in front of every barrier would make every step as long as a trip to HBM.  LDS
 // operations are complete (lgkmcnt) before the barrier; "memory": the compiler moves no access across it.
 __device__ __forceinline__ void lane_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+
+// The ring: a step reads [first window's oldest, last output's newest) = at most 15 + T samples, and the block written behind it ends
+// at most 16 + 15 samples later: ring >= T + 46, a multiple of 16; rows ring + mirror + 1 eight-byte units apart, odd (the 64 lanes of a
+// window read then fall into 64 different bank pairs).
+constexpr int lane_ring(int T) { return (T + 46 + 15) / 16 * 16; }
+constexpr int lane_pitch8(int T) { return (lane_ring(T) + kLaneMirror + 1) | 1; }
 
 // A pair of outputs whose windows start D samples apart, for this lane's channel: the window is read in two halves of T/2 + 1
 // samples (half the registers; the second output's taps i use the samples i + D).  ONE hand-scheduled statement per pair
@@ -104,197 +113,208 @@ __device__ __forceinline__ void lane_pair(unsigned addr, cdouble_t tl0, cdouble_
     (void)t0; (void)t1;
 }
 
-// the eight compute waves of a stretch: wave wv owns outputs kb + 2 wv, + 1 of every step
+// One stretch of outputs [k0, k1) of one group of 64 channels.  Every wave does three things per step:
+//   * its pair of outputs (kb + 2 wv, + 1) for the 64 channels of its lanes: lane_pair;
+//   * staging for EIGHT channel rows (8 wv ... + 7; lane l: row l / 8, samples l % 8 and l % 8 + 8 of the block): the block step s + 2
+//     needs is requested at step s (global -> registers), goes into the ring during step s + 1 -- behind the wave's own arithmetic, while
+//     other waves still read step s + 1's windows: its places hold samples older than any of them (plan_arb_lane: the ring's length) --
+//     and is read from step s + 2 on: nobody waits for HBM;
+//   * the outputs of the step before for the same eight rows: LDS tile -> whole 128-byte lines of y.
+// (An earlier form gave staging and stores to a ninth wave: its dependent waits -- schedule entry, LDS tile, vector memory -- made it
+//  the last at every barrier, 5 400 cycles a step against the compute waves' 2 400; profiles/r06/experiments.md.)
 template <bool FUSED, int T>
-__device__ __forceinline__ void lane_compute(const ArbArgs &a, const ArbLaneArgs &la, unsigned char *smem, int lane, int wv, long long k0, long long k1, int nsteps)
+__device__ __forceinline__ void lane_stretch(const ArbArgs &a, const ArbLaneArgs &la, unsigned char *smem, int lane, int wv, int ch0, long long k0, long long k1)
 {
     const cint_t n_idx = (cint_t)(a.n_idx);
-    const cdouble_t acc_tab = (cdouble_t)(a.acc);
     const cdouble_t pfb = (cdouble_t)(a.taps), dpfb = (cdouble_t)(a.dtaps);
-    const unsigned RING = static_cast<unsigned>(la.ring);
-    const unsigned ring_row = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem)) + static_cast<unsigned>(lane) * static_cast<unsigned>(la.pitch8) * 8u;
-    unsigned char *const out_lane = smem + static_cast<size_t>(64) * la.pitch8 * 8 + lane * kLaneOutRow + wv * 16;
-#pragma clang loop unroll(disable)
-    for (int s = 0; s < nsteps; ++s) {
-        const long long kp = k0 + static_cast<long long>(s) * kLaneStep + 2 * wv;
-        if (kp < k1) {                                          // (uniform)
-            const long long kq = kp + 1 < k1 ? kp + 1 : kp;
-            const int n0 = n_idx[kp], n1 = n_idx[kq];
-            const double acc0 = acc_tab[kp], acc1 = acc_tab[kq];
-            const double phif0 = __builtin_floor(acc0), phif1 = __builtin_floor(acc1);
-            const double alpha0 = acc0 - phif0, alpha1 = acc1 - phif1;                          // src/Filters.jl:671-672
-            const int phi0 = __builtin_amdgcn_readfirstlane(static_cast<int>(phif0) - 1);       // 0-based column
-            const int phi1 = __builtin_amdgcn_readfirstlane(static_cast<int>(phif1) - 1);
-            const unsigned r0 = (static_cast<unsigned>(n0 - T) + RING) % RING;                // (ring coordinate = sample index + RING)
-            const unsigned addr = ring_row + r0 * 8u;
-            double lo0, up0, lo1, up1;
-            if (n1 != n0) lane_pair<FUSED, T, 1>(addr, pfb + phi0 * T, dpfb + phi0 * T, pfb + phi1 * T, dpfb + phi1 * T, lo0, up0, lo1, up1);
-            else lane_pair<FUSED, T, 0>(addr, pfb + phi0 * T, dpfb + phi0 * T, pfb + phi1 * T, dpfb + phi1 * T, lo0, up0, lo1, up1);
-            const double prod0 = up0 * alpha0, prod1 = up1 * alpha1;                            // Filters.jl:730, rounded once each
-            const v2d_t res = {lo0 + prod0, lo1 + prod1};
-            *reinterpret_cast<v2d_t *>(out_lane + static_cast<size_t>(s & 1) * (64 * kLaneOutRow)) = res;
-        }
-        asm volatile("" ::: "memory");
-        lane_barrier();
-    }
-}
-
-// The loader wave of a stretch: stages the samples (global -> registers -> ring, one block of 16 per channel and step, requested TWO
-// steps before the step that needs it and written to the ring one step before: the wave never waits for HBM) and stores the outputs of
-// the step before (LDS tile -> whole 128-byte lines of y).  Lane l serves piece l % 8 of the rows of channels l / 8 + 8 j.
-__device__ __forceinline__ void lane_loader(const ArbArgs &a, const ArbLaneArgs &la, unsigned char *smem, int lane, int ch0, long long k0, long long k1, int nsteps, int T)
-{
-    const cint_t n_idx = (cint_t)(a.n_idx);
-    const int RING = la.ring, P8 = la.pitch8, H = a.H;
-    const int sq = lane & 7, scl = lane >> 3;
-    unsigned long long *const ring64 = reinterpret_cast<unsigned long long *>(smem);
-    const unsigned char *const out0 = smem + static_cast<size_t>(64) * P8 * 8;
+    // (the ring's length and pitch follow from T alone -- plan_arb_lane computes the same values for the launch: compile-time
+    //  divisors, and two scalars less to keep across the pair's statement, which leaves the compiler 36 SGPRs)
+    constexpr int RING = lane_ring(T), P8 = lane_pitch8(T);
+    const int H = a.H;
+    const int nsteps = static_cast<int>((k1 - k0 + kLaneStep - 1) / kLaneStep);
+    const int kr = static_cast<int>(k1 - k0);                  // outputs of this stretch
+    constexpr unsigned URING = static_cast<unsigned>(RING);
+    const unsigned ring_row = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem)) + static_cast<unsigned>(lane) * static_cast<unsigned>(P8) * 8u;
+    unsigned char *const out0 = smem + static_cast<size_t>(64) * P8 * 8;
+    unsigned char *const out_lane = out0 + lane * kLaneOutRow + wv * 16;                       // this lane's pair in a tile
+    // staging and stores: this lane's row of the group and its piece of the row
+    const int srow = 8 * wv + (lane >> 3), sq = lane & 7;
+    const bool grp_full = ch0 + 64 <= a.nch;                    // (uniform)
+    const bool row_ok = ch0 + srow < a.nch;
+    unsigned long long *const ring_lane = reinterpret_cast<unsigned long long *>(smem) + static_cast<unsigned>(srow) * static_cast<unsigned>(P8) + sq;
+    const unsigned char *const tile_lane = out0 + srow * kLaneOutRow + sq * 16;
     const unsigned long long *const xg = static_cast<const unsigned long long *>(a.x);
     const unsigned long long *const hg = static_cast<const unsigned long long *>(a.hist);
-    const bool grp_full = ch0 + 64 <= a.nch;                    // (uniform)
-    // Addresses are a wave-uniform 64-bit base per row group j plus ONE 32-bit lane offset (the lane's row within the group of 8, its
-    // piece): the scalar-base form of global_load / global_store, no 64-bit vector arithmetic.  (8 rows fit 32 bits: plan_arb_lane)
+    // addresses = a wave-uniform base (the wave's first row) + ONE 32-bit lane offset: the scalar-base form of global_load / global_store
+    const unsigned xoff = (static_cast<unsigned>(lane >> 3) * static_cast<unsigned>(a.x_stride) + static_cast<unsigned>(sq)) * 8u;
+    const unsigned yoff = (static_cast<unsigned>(lane >> 3) * static_cast<unsigned>(a.y_stride) + 2u * static_cast<unsigned>(sq)) * 8u;
+    const unsigned long long *const xw = xg + static_cast<long long>(ch0 + 8 * wv) * a.x_stride;      // (uniform) the wave's first row of x
+    double *const yw = static_cast<double *>(a.y) + static_cast<long long>(ch0 + 8 * wv) * a.y_stride + k0;
 
-    // block u of the ring coordinate = samples 16 u - RING ... + 15; this lane's two of channel row j: sq and sq + 8
-    auto interior = [&](int u) {                                // (uniform) inside the signal, a full group: no per-lane checks
-        const long long s0 = static_cast<long long>(u) * kLaneBlock - RING;
-        return grp_full && s0 >= 0 && s0 + kLaneBlock <= a.x_len;
-    };
-    // 16 loads, nothing waited for -- ALWAYS (an edge block or no block at all: the same loads from a place inside the signal, their
+    // block u of the ring coordinate = samples 16 u - RING ... + 15 of every row; this lane's two: sq and sq + 8.  Blocks u_lo <= u < u_hi
+    // lie inside the signal for every row of a full group: no per-lane checks.
+    const int u_lo = RING / kLaneBlock;
+    const int u_hi = grp_full ? static_cast<int>((a.x_len + RING) / kLaneBlock) : u_lo;
+    auto interior = [&](int u) { return u >= u_lo && u < u_hi; };   // (uniform)
+    // what the dummy loads read (below): a block inside the signal, rows that exist
+    const int u_safe_hi = static_cast<int>((a.x_len + RING) / kLaneBlock) - 1;     // (x_len >= 64: plan_arb_lane)
+    const unsigned long long *const xw_eff = grp_full || ch0 + 8 * wv + 8 <= a.nch ? xw : xg + static_cast<long long>(ch0) * a.x_stride;
+    // two loads, nothing waited for -- ALWAYS (an edge block or no block at all: the same loads from a place inside the signal, their
     // values unused): with the loads behind a condition the compiler's wait for the OLDER block in flight must also cover the path
     // without them, on which that block's loads are the youngest: s_waitcnt vmcnt(0), i.e. a wait for HBM in every step
-    auto issue = [&](int u, unsigned long long (&v)[16]) {
-        long long s0 = static_cast<long long>(u) * kLaneBlock - RING;
-        const bool in = interior(u);
-        if (!in) s0 = s0 < 0 ? 0 : (s0 + kLaneBlock <= a.x_len ? s0 : a.x_len - kLaneBlock);     // (x_len >= 16: plan_arb_lane)
-        const unsigned char *const b0 = reinterpret_cast<const unsigned char *>(xg + static_cast<long long>(ch0) * a.x_stride + s0);
-        const long long rs = in ? a.x_stride * 64 : 0;          // bytes between the row groups (an edge block: rows ch0 ... ch0 + 7 eight times)
-        const unsigned l = lane_id_fresh();
-        const unsigned xo = ((l >> 3) * static_cast<unsigned>(a.x_stride) + (l & 7u)) * 8u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const gptr_t<const unsigned char> bj = lane_uniform_ptr(b0 + j * rs);
-            v[2 * j] = *reinterpret_cast<gptr_t<const unsigned long long>>(bj + xo);
-            v[2 * j + 1] = *reinterpret_cast<gptr_t<const unsigned long long>>(bj + xo + 64u);
+    auto issue = [&](int u, unsigned long long &v0, unsigned long long &v1) {
+        const int uc = u < u_lo ? u_lo : (u > u_safe_hi ? u_safe_hi : u);
+        const gptr_t<const unsigned char> b = lane_uniform_ptr(reinterpret_cast<const unsigned char *>(xw_eff + (static_cast<long long>(uc) * kLaneBlock - RING)));
+        v0 = *reinterpret_cast<gptr_t<const unsigned long long>>(b + xoff);
+        v1 = *reinterpret_cast<gptr_t<const unsigned long long>>(b + xoff + 64u);
+    };
+    auto ring_put = [&](int u, unsigned long long v0, unsigned long long v1) {
+        const unsigned pos = static_cast<unsigned>(u % (RING / kLaneBlock)) * kLaneBlock;       // (uniform) the block's place in the ring
+        unsigned long long *const p = ring_lane + pos;
+        p[0] = v0;
+        p[8] = v1;
+        if (pos < static_cast<unsigned>(kLaneMirror)) {         // (uniform) the ring's first samples once more behind its end
+            p[RING] = v0;
+            p[RING + 8] = v1;
         }
     };
-    auto ring_at = [&](int u, int j) -> unsigned long long * {  // this lane's place for row j of block u
-        const unsigned pos = static_cast<unsigned>(u % (RING / kLaneBlock)) * kLaneBlock;       // (uniform)
-        const unsigned l = lane_id_fresh();
-        return ring64 + ((l >> 3) + static_cast<unsigned>(8 * j)) * static_cast<unsigned>(P8) + (l & 7u) + pos;
-    };
-    auto put = [&](int u, const unsigned long long (&v)[16]) {
-        const bool mirror = static_cast<unsigned>(u % (RING / kLaneBlock)) * kLaneBlock < static_cast<unsigned>(kLaneMirror);   // (uniform)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            unsigned long long *const p = ring_at(u, j);
-            p[0] = v[2 * j];
-            p[8] = v[2 * j + 1];
-            if (mirror) {                                       // the ring's first samples once more behind its end
-                p[RING] = v[2 * j];
-                p[RING + 8] = v[2 * j + 1];
-            }
-        }
-    };
-    auto put_edge = [&](int u) {                                // history, the end of the signal, a partial channel group: row by row, waited for
+    auto put_edge = [&](int u) {                                // history, the end of the signal, a partial channel group: loaded here, waited for
         const long long s0 = static_cast<long long>(u) * kLaneBlock - RING;
-        const bool mirror = static_cast<unsigned>(u % (RING / kLaneBlock)) * kLaneBlock < static_cast<unsigned>(kLaneMirror);
-#pragma unroll 1
-        for (int j = 0; j < 8; ++j) {
-            const int c = ch0 + scl + 8 * j;
-            const bool c_ok = c < a.nch;
-            const unsigned long long *const xrow = xg + static_cast<long long>(c_ok ? c : ch0) * a.x_stride;
-            const unsigned long long *const hrow = hg + static_cast<long long>(c_ok ? c : ch0) * H;
-            unsigned long long t2[2];
+        const unsigned long long *const xrow = xg + static_cast<long long>(row_ok ? ch0 + srow : ch0) * a.x_stride;
+        const unsigned long long *const hrow = hg + static_cast<long long>(row_ok ? ch0 + srow : ch0) * H;
+        unsigned long long t2[2];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const long long sidx = s0 + sq + 8 * e;
-                const bool ok = c_ok && sidx < a.x_len && sidx >= -static_cast<long long>(H);
-                const unsigned long long *p = sidx >= 0 ? xrow + sidx : hrow + (H + sidx);
-                const unsigned long long t = *(ok ? p : static_cast<const unsigned long long *>(a.taps));
-                t2[e] = ok ? t : 0ull;
-            }
-            unsigned long long *const p = ring_at(u, j);
-            p[0] = t2[0];
-            p[8] = t2[1];
-            if (mirror) {
-                p[RING] = t2[0];
-                p[RING + 8] = t2[1];
-            }
+        for (int e = 0; e < 2; ++e) {
+            const long long sidx = s0 + sq + 8 * e;
+            const bool ok = row_ok && sidx < a.x_len && sidx >= -static_cast<long long>(H);
+            const unsigned long long *p = sidx >= 0 ? xrow + sidx : hrow + (H + sidx);
+            const unsigned long long t = *(ok ? p : static_cast<const unsigned long long *>(a.taps));
+            t2[e] = ok ? t : 0ull;
+        }
+        ring_put(u, t2[0], t2[1]);
+    };
+    // the outputs 16 step_ + 2 sq, + 1 (of the stretch) of this lane's row: read from the tile in front of the pair's statement (whose first
+    // wait covers the read), stored behind it
+    auto tile_take = [&](int tb) { return *reinterpret_cast<const v2d_t *>(tile_lane + static_cast<size_t>(tb) * (64 * kLaneOutRow)); };
+    auto store = [&](int step_, v2d_t v) {
+        const int ko = step_ * kLaneStep + 2 * sq;
+        if (ko >= kr || !row_ok) return;
+        const gptr_t<unsigned char> yb = lane_uniform_ptr(reinterpret_cast<unsigned char *>(yw + static_cast<long long>(step_) * kLaneStep));
+        if (la.y16 && ko + 1 < kr) *reinterpret_cast<gptr_t<v2d_t>>(yb + yoff) = v;
+        else {
+            *reinterpret_cast<gptr_t<double>>(yb + yoff) = v.x;
+            if (ko + 1 < kr) *reinterpret_cast<gptr_t<double>>(yb + yoff + 8u) = v.y;
         }
     };
-    // (32-bit lane arithmetic only: a 64-bit lane value spilled to scratch is reloaded with a wait for EVERY vector memory operation --
-    //  the blocks in flight included)
-    const int kr = static_cast<int>(k1 - k0);                  // outputs of this stretch
-    auto flush = [&](int step_, int tb) {                       // outputs 16 step_ + 2 sq, + 1 (of the stretch) of the channels scl + 8 j
-        const unsigned l = lane_id_fresh();
-        const int sq = static_cast<int>(l & 7u), scl = static_cast<int>(l >> 3);
-        const unsigned yoff = (static_cast<unsigned>(scl) * static_cast<unsigned>(a.y_stride) + 2u * static_cast<unsigned>(sq)) * 8u;
-        const int ko = step_ * kLaneStep + 2 * sq;
-        if (ko >= kr) return;
-        const unsigned char *const tile = out0 + static_cast<size_t>(tb) * (64 * kLaneOutRow) + scl * kLaneOutRow + sq * 16;
-        unsigned char *const y0 = reinterpret_cast<unsigned char *>(static_cast<double *>(a.y) + static_cast<long long>(ch0) * a.y_stride + k0 + static_cast<long long>(step_) * kLaneStep);   // (uniform)
-        const bool both = ko + 1 < kr;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (grp_full || ch0 + scl + 8 * j < a.nch) {
-                const v2d_t v = *reinterpret_cast<const v2d_t *>(tile + 8 * j * kLaneOutRow);
-                const gptr_t<unsigned char> yj = lane_uniform_ptr(y0 + static_cast<long long>(8 * j) * a.y_stride * 8);
-                if (la.y16 && both) *reinterpret_cast<gptr_t<v2d_t>>(yj + yoff) = v;
-                else {
-                    *reinterpret_cast<gptr_t<double>>(yj + yoff) = v.x;
-                    if (both) *reinterpret_cast<gptr_t<double>>(yj + yoff + 8u) = v.y;
-                }
-            }
-        }
+    // The schedule entries of the stretch, ONE vector load per wave and stretch: lane l holds (n_k, acc_k) of output 16 (l / 2) + 2 wv + l % 2
+    // -- this wave's pair of step l / 2 -- and the input index of step l's LAST output (which blocks the step needs); a step takes them
+    // with v_readlane.  (Read per step by scalar loads they cost a trip to HBM every step: the schedule streams, every step's entries are a
+    // new cache line -- 3 100 cycles a step outside the pair's statement; profiles/r06/experiments.md.)
+    int ent_n, ent_last;
+    double ent_acc;
+    {
+        long long kk = k0 + kLaneStep * (lane >> 1) + 2 * wv + (lane & 1);
+        if (kk >= k1) kk = k1 - 1;
+        long long kl = k0 + static_cast<long long>(kLaneStep) * lane + kLaneStep - 1;
+        if (kl >= k1) kl = k1 - 1;
+        ent_n = a.n_idx[kk];
+        ent_acc = a.acc[kk];
+        ent_last = a.n_idx[kl];
+    }
+    auto lane_i = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
+    auto lane_d = [](double v, int l) {
+        const v2u_t b = __builtin_bit_cast(v2u_t, v);
+        const v2u_t r = {static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(b.x), l)), static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(b.y), l))};
+        return __builtin_bit_cast(double, r);
     };
     // E(t): the ring must hold every block below E(t) before step t's windows are read
-    auto E = [&](int t) {
-        const long long kl = k0 + static_cast<long long>(t + 1) * kLaneStep - 1;
-        return (n_idx[kl < k1 ? kl : k1 - 1] + RING + kLaneBlock - 1) / kLaneBlock;
+    auto E = [&](int t) { return (lane_i(ent_last, t) + RING + kLaneBlock - 1) / kLaneBlock; };
+    auto entries = [&](int s_, int &n0_, int &n1_, double &a0_, double &a1_) {
+        n0_ = lane_i(ent_n, 2 * s_); n1_ = lane_i(ent_n, 2 * s_ + 1);
+        a0_ = lane_d(ent_acc, 2 * s_); a1_ = lane_d(ent_acc, 2 * s_ + 1);
     };
+
     // the stretch's first windows: every block from the first output's oldest sample to the last sample of step 0, waited for
     int e_iss = E(0);                                           // blocks below e_iss are in the ring or requested
-    unsigned long long va[16], vb[16];                          // the two blocks in flight: va for odd steps, vb for even ones
-    for (int u = (n_idx[k0] - T + RING) / kLaneBlock; u < e_iss; ++u) {
+    unsigned long long va0 = 0, va1 = 0, vb0 = 0, vb1 = 0;      // the two blocks in flight: va for odd steps, vb for even ones
+    for (int u = (n_idx[k0] - T + RING) / kLaneBlock; u < e_iss; ++u) {     // (n_idx[k0]: one scalar load a stretch)
         if (interior(u)) {
-            issue(u, va);
-            put(u, va);
+            issue(u, va0, va1);
+            ring_put(u, va0, va1);
         } else {
             put_edge(u);
         }
     }
-    // At a rate >= 1 sixteen outputs advance by at most sixteen samples: a step needs at most ONE new block.  The block step t needs is
-    // requested during step t - 2 (here: step 1's) and goes into the ring during step t - 1, while the compute waves read step t - 1's
-    // windows: its places hold samples older than any of them (plan_arb_lane: the ring's length).
-    int ua = -1, ub = -1;                                       // the block va / vb holds (-1: none; edge blocks are not requested: staged at their turn)
+    // At a rate >= 1 sixteen outputs advance by at most sixteen samples: a step needs at most ONE new block.
+    int ua = -1, ub = -1;                                       // the block va / vb holds (-1: none; an edge block is loaded at its turn)
     if (nsteps > 1 && E(1) > e_iss) ua = e_iss++;
-    issue(ua >= 0 ? ua : e_iss - 1, va);
+    issue(ua >= 0 ? ua : e_iss - 1, va0, va1);
+    int n0, n1;
+    double acc0, acc1;
+    entries(0, n0, n1, acc0, acc1);
     lane_barrier();
-    auto step = [&](int s, unsigned long long (&vnew)[16], int &unew, unsigned long long (&vold)[16], int &uold) {
-        // vnew: free (its block went into the ring during the step before); vold: the block step s + 1 needs, if any
+#ifdef MRHIP_LANE_TRACE
+    unsigned long long p_asm = 0, p_bar = 0, p_rest = 0;
+#endif
+    LANE_T0();
+    auto step = [&](int s, unsigned long long &vn0, unsigned long long &vn1, int &unew, unsigned long long &vo0, unsigned long long &vo1, int &uold) {
+        // vn: free (its block went into the ring during the step before); vo: the block step s + 1 needs, if any
         if (s + 2 < nsteps && E(s + 2) > e_iss) unew = e_iss++;
-        issue(unew >= 0 ? unew : e_iss - 1, vnew);
-        if (s > 0) flush(s - 1, (s - 1) & 1);
+        issue(unew >= 0 ? unew : e_iss - 1, vn0, vn1);
+        const v2d_t done = tile_take((s + 1) & 1);              // the step before's outputs (step 0: whatever the tile holds, not stored)
+        const int kp = s * kLaneStep + 2 * wv;
+        int n0n = 0, n1n = 0;
+        double acc0n = 0.0, acc1n = 0.0;
+        if (kp < kr) {                                          // (uniform)
+            const double phif0 = __builtin_floor(acc0), phif1 = __builtin_floor(acc1);
+            const double alpha0 = acc0 - phif0, alpha1 = acc1 - phif1;                          // src/Filters.jl:671-672
+            const int phi0 = __builtin_amdgcn_readfirstlane(static_cast<int>(phif0) - 1);       // 0-based column
+            const int phi1 = __builtin_amdgcn_readfirstlane(static_cast<int>(phif1) - 1);
+            const unsigned r0 = (static_cast<unsigned>(n0 - T) + URING) % URING;              // (ring coordinate = sample index + RING)
+            const unsigned addr = ring_row + r0 * 8u;
+            const bool apart = n1 != n0;
+            if (s + 1 < nsteps) entries(s + 1, n0n, n1n, acc0n, acc1n);
+            double lo0, up0, lo1, up1;
+            LANE_TICK(p_rest);
+            if (apart) lane_pair<FUSED, T, 1>(addr, pfb + phi0 * T, dpfb + phi0 * T, pfb + phi1 * T, dpfb + phi1 * T, lo0, up0, lo1, up1);
+            else lane_pair<FUSED, T, 0>(addr, pfb + phi0 * T, dpfb + phi0 * T, pfb + phi1 * T, dpfb + phi1 * T, lo0, up0, lo1, up1);
+            LANE_TICK(p_asm);
+            const double prod0 = up0 * alpha0, prod1 = up1 * alpha1;                            // Filters.jl:730, rounded once each
+            const v2d_t res = {lo0 + prod0, lo1 + prod1};
+            *reinterpret_cast<v2d_t *>(out_lane + static_cast<size_t>(s & 1) * (64 * kLaneOutRow)) = res;
+        }
+        n0 = n0n; n1 = n1n; acc0 = acc0n; acc1 = acc1n;
+        asm volatile("" ::: "memory");                          // (the ring writes below stay below the statement's reads above)
+        // (the ring write first: its wait lets the two loads requested at the top of this step stay in flight -- with the store in front of
+        //  it the compiler's count, the minimum over the paths with and without a store, makes it wait for the first of them)
         if (uold >= 0) {
-            if (interior(uold)) put(uold, vold);
+            if (interior(uold)) ring_put(uold, vo0, vo1);
             else put_edge(uold);
             uold = -1;
         }
+        if (s > 0) store(s - 1, done);
+        LANE_TICK(p_rest);
         lane_barrier();
+        LANE_TICK(p_bar);
     };
     int s = 0;
 #pragma clang loop unroll(disable)
     for (; s + 1 < nsteps; s += 2) {
-        step(s, vb, ub, va, ua);
-        step(s + 1, va, ua, vb, ub);
+        step(s, vb0, vb1, ub, va0, va1, ua);
+        step(s + 1, va0, va1, ua, vb0, vb1, ub);
     }
-    if (s < nsteps) step(s, vb, ub, va, ua);
-    flush(nsteps - 1, (nsteps - 1) & 1);
+    if (s < nsteps) step(s, vb0, vb1, ub, va0, va1, ua);
+    store(nsteps - 1, tile_take((nsteps - 1) & 1));
+#ifdef MRHIP_LANE_TRACE
+    if (lane == 0) {
+        unsigned long long *const g = g_lane_prof[(blockIdx.x * kLaneWaves + wv) & 8191];
+        g[0] += p_asm; g[1] += p_bar; g[2] += p_rest; g[3] += nsteps;
+    }
+#endif
 }
 
 template <bool FUSED, int T>
-__global__ __launch_bounds__(kLaneThreads, 6) void arb_lane_kernel(ArbArgs a, ArbLaneArgs la)
+__global__ __launch_bounds__(kLaneThreads, 4) void arb_lane_kernel(ArbArgs a, ArbLaneArgs la)
 {
     static_assert(T >= 2 && T <= kLaneMirror, "a window of T + 1 samples lies inside ring + mirror");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -308,29 +328,15 @@ __global__ __launch_bounds__(kLaneThreads, 6) void arb_lane_kernel(ArbArgs a, Ar
     unsigned *const ctr = la.counters;
     const long long G = gridDim.x;
 
-    // (the two roles run the item loop apart: what only the loader needs -- the signal's and the outputs' addresses and strides -- is then
-    //  not live across the compute waves' statement, whose fixed scalar registers leave the compiler 36 SGPRs)
-    if (wv == kLaneWaves) {
-        for (long long item = blockIdx.x; item < items;) {
-            const long long sigma = item / la.ngroups;
-            const int grp = static_cast<int>(item - sigma * la.ngroups);
-            const long long k0 = sigma * STRETCH;
-            const long long k1 = k0 + STRETCH < n_out ? k0 + STRETCH : n_out;
-            lane_loader(a, la, smem, lane, grp * 64, k0, k1, static_cast<int>((k1 - k0 + kLaneStep - 1) / kLaneStep), T);
-            if (lane == 0) s_item = atomicAdd(ctr, 1u);
-            lane_barrier();                                    // every window of this stretch is read, its last tile stored; the next item
-            item = G + uniform_ll(static_cast<long long>(s_item));
-        }
-    } else {
-        for (long long item = blockIdx.x; item < items;) {
-            const long long sigma = item / la.ngroups;
-            const long long k0 = sigma * STRETCH;
-            const long long k1 = k0 + STRETCH < n_out ? k0 + STRETCH : n_out;
-            lane_barrier();                                    // (the loader's first blocks are in the ring)
-            lane_compute<FUSED, T>(a, la, smem, lane, wv, k0, k1, static_cast<int>((k1 - k0 + kLaneStep - 1) / kLaneStep));
-            lane_barrier();
-            item = G + uniform_ll(static_cast<long long>(s_item));
-        }
+    for (long long item = blockIdx.x; item < items;) {
+        const long long sigma = item / la.ngroups;
+        const int grp = static_cast<int>(item - sigma * la.ngroups);
+        const long long k0 = sigma * STRETCH;
+        const long long k1 = k0 + STRETCH < n_out ? k0 + STRETCH : n_out;
+        lane_stretch<FUSED, T>(a, la, smem, lane, wv, grp * 64, k0, k1);
+        if (tid == 0) s_item = atomicAdd(ctr, 1u);
+        lane_barrier();                                        // every window of this stretch is read, every tile stored from; the next item
+        item = G + uniform_ll(static_cast<long long>(s_item));
     }
     // every workgroup counts itself off; the last one re-arms the counters for the next launch (stream order makes it visible)
     if (tid == 0) {
@@ -364,6 +370,31 @@ hipError_t launch_lane_t(bool fused, const ArbArgs &a, const ArbLaneArgs &la, si
             std::fprintf(stderr, "[mrhip] arb_lane T=%d Nphi=%d grid=%lld lds=%zu occ/CU=%d regs=%d ring=%d stretch=%d items=%lld\n",
                          a.T, a.Nphi, g, lds, per_cu, fa.numRegs, la.ring, la.stretch, items);
         }
+#ifdef MRHIP_LANE_TRACE
+        {
+            static bool armed = false;
+            static long long last_grid = 0;
+            last_grid = g;
+            (void)hipStreamSynchronize(s);
+            static unsigned long long zeros[8192][8];
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lane_prof), zeros, sizeof(zeros));
+            if (!armed) {
+                armed = true;
+                std::atexit([] {
+                    (void)hipDeviceSynchronize();
+                    static unsigned long long h[8192][8];
+                    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lane_prof), sizeof(h)) != hipSuccess) return;
+                    double c[4] = {0, 0, 0, 0};
+                    long long nc = 0;
+                    for (long long b = 0; b < last_grid && (b + 1) * kLaneWaves <= 8192; ++b)
+                        for (int w = 0; w < kLaneWaves; ++w) { for (int i = 0; i < 4; ++i) c[i] += h[b * kLaneWaves + w][i]; ++nc; }
+                    if (c[3] > 0)
+                        std::fprintf(stderr, "[lane_trace] grid=%lld  shader cycles per wave and step: pair statement %.1f barrier %.1f everything else %.1f (steps per wave %.0f)\n",
+                                     last_grid, c[0] / c[3], c[1] / c[3], c[2] / c[3], c[3] / nc);
+                });
+            }
+        }
+#endif
         launch_kernel(kfn, dim3(static_cast<unsigned>(g)), dim3(kLaneThreads), lds, s, a, la);
         return hipGetLastError();
     };
@@ -381,17 +412,15 @@ bool plan_arb_lane(const TypeKey &tk, const ArbArgs &a, double rate, ArbLaneArgs
     if (!tk.x_f64 || !tk.r_f64 || tk.complex_x) return false;     // (the tap banks are kept in the arithmetic type: Float64)
     if (a.T != 32 && a.T != 16) return false;
     if (!(rate >= 1.0) || a.n_out < 1 || a.H > kLaneMirror || a.x_len < 64) return false;
-    if (static_cast<double>(a.x_stride) * 8.0 * 8.0 >= 4294967296.0 || static_cast<double>(a.y_stride) * 8.0 * 8.0 >= 4294967296.0) return false;   // (the loader's 32-bit lane offsets span 8 rows)
+    if (static_cast<double>(a.x_stride) * 8.0 * 8.0 >= 4294967296.0 || static_cast<double>(a.y_stride) * 8.0 * 8.0 >= 4294967296.0) return false;   // (the 32-bit lane offsets of staging and stores span 8 rows)
     const int min_ch = MRHIP_ENV_INT("MRHIP_LANE_MIN_CH", 48);
     if (a.nch < min_ch || (a.nch % 64 != 0 && a.nch % 64 < min_ch)) return false;          // (a last group with few channels wastes its lanes)
     ArbLaneArgs la{};
-    // the ring: a step reads [first window's oldest, last output's newest) = at most 15 + T samples and the block written behind it
-    // ends at most 16 + 15 samples later: ring >= T + 46, a multiple of 16
-    la.ring = ((a.T + 46 + 15) / 16) * 16;
-    la.pitch8 = la.ring + kLaneMirror + 1;
-    if ((la.pitch8 & 1) == 0) ++la.pitch8;
+    la.ring = lane_ring(a.T);
+    la.pitch8 = lane_pitch8(a.T);
     int stretch = MRHIP_ENV_INT("MRHIP_LANE_STRETCH", 512);
     if (stretch < kLaneStep) stretch = kLaneStep;
+    if (stretch > 32 * kLaneStep) stretch = 32 * kLaneStep;    // (a wave holds its 64 schedule entries of a stretch in one register)
     la.stretch = stretch / kLaneStep * kLaneStep;
     la.ngroups = (a.nch + 63) / 64;
     la.y16 = (reinterpret_cast<uintptr_t>(a.y) % 16 == 0) && (a.y_stride % 2 == 0);

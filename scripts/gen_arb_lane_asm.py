@@ -26,8 +26,14 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "multirate.jl_amd", "csrc", "arb_lane_pair.inc")
 
-BUF = {"A": (36, 52), "B": (68, 84)}       # first SGPR of the yLower / yUpper block of eight taps
-CLOBBER_LO, CLOBBER_HI = 36, 99
+import sys
+NB = int(os.environ.get("LANE_BLOCK_TAPS", "4"))       # taps per block: 8 (s_load_dwordx16, 64 fixed SGPRs) or 4 (s_load_dwordx8, 32)
+if NB == 8:
+    BUF = {"A": (36, 52), "B": (68, 84)}   # first SGPR of the yLower / yUpper block of taps
+    CLOBBER_LO, CLOBBER_HI = 36, 99
+else:
+    BUF = {"A": (68, 76), "B": (84, 92)}
+    CLOBBER_LO, CLOBBER_HI = 68, 99
 
 
 def sreg(first, j):
@@ -36,7 +42,7 @@ def sreg(first, j):
 
 def gen(T, D, fused):
     HT = T // 2
-    nblk = HT // 8                          # blocks of eight taps per output and half
+    nblk = HT // NB                         # blocks of NB taps per output and half
     lines = []
     emit = lines.append
     # the blocks of a pair in the order they are computed: (half, output, block within the half)
@@ -44,10 +50,10 @@ def gen(T, D, fused):
 
     def load(buf, blk):
         h, o, b = blk
-        off = (h * HT + b * 8) * 8
+        off = (h * HT + b * NB) * 8
         lo, up = BUF[buf]
-        emit(f"s_load_dwordx16 s[{lo}:{lo + 15}], %[p{o}l], 0x{off:x}")
-        emit(f"s_load_dwordx16 s[{up}:{up + 15}], %[p{o}u], 0x{off:x}")
+        emit(f"s_load_dwordx{2 * NB} s[{lo}:{lo + 2 * NB - 1}], %[p{o}l], 0x{off:x}")
+        emit(f"s_load_dwordx{2 * NB} s[{up}:{up + 2 * NB - 1}], %[p{o}u], 0x{off:x}")
 
     def reads(h):
         for i in range(HT + 1):
@@ -57,8 +63,8 @@ def gen(T, D, fused):
         h, o, b = blk
         lo, up = BUF[buf]
         d = D if o == 1 else 0
-        for j in range(8):
-            x = f"%[x{b * 8 + j + d}]"
+        for j in range(NB):
+            x = f"%[x{b * NB + j + d}]"
             L, U = f"%[l{o}]", f"%[u{o}]"
             if first_of_output and j == 0:                    # the first product initialises (no add, no fma)
                 emit(f"v_mul_f64 {L}, {sreg(lo, j)}, {x}")
