@@ -126,7 +126,6 @@ template <bool FUSED, int T>
 __device__ __forceinline__ void lane_stretch(const ArbArgs &a, const ArbLaneArgs &la, unsigned char *smem, int lane, int wv, int ch0, long long k0, long long k1)
 {
     const cint_t n_idx = (cint_t)(a.n_idx);
-    const cdouble_t pfb = (cdouble_t)(a.taps), dpfb = (cdouble_t)(a.dtaps);
     // (the ring's length and pitch follow from T alone -- plan_arb_lane computes the same values for the launch: compile-time
     //  divisors, and two scalars less to keep across the pair's statement, which leaves the compiler 36 SGPRs)
     constexpr int RING = lane_ring(T), P8 = lane_pitch8(T);
@@ -221,6 +220,10 @@ __device__ __forceinline__ void lane_stretch(const ArbArgs &a, const ArbLaneArgs
         ent_acc = a.acc[kk];
         ent_last = a.n_idx[kl];
     }
+    // phase (0-based PFB column) and alpha of the lane's output, once per stretch (src/Filters.jl:671-672)
+    const double ent_phif = __builtin_floor(ent_acc);
+    const int ent_phi = static_cast<int>(ent_phif) - 1;
+    const double ent_alpha = ent_acc - ent_phif;
     auto lane_i = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
     auto lane_d = [](double v, int l) {
         const v2u_t b = __builtin_bit_cast(v2u_t, v);
@@ -229,9 +232,21 @@ __device__ __forceinline__ void lane_stretch(const ArbArgs &a, const ArbLaneArgs
     };
     // E(t): the ring must hold every block below E(t) before step t's windows are read
     auto E = [&](int t) { return (lane_i(ent_last, t) + RING + kLaneBlock - 1) / kLaneBlock; };
-    auto entries = [&](int s_, int &n0_, int &n1_, double &a0_, double &a1_) {
-        n0_ = lane_i(ent_n, 2 * s_); n1_ = lane_i(ent_n, 2 * s_ + 1);
-        a0_ = lane_d(ent_acc, 2 * s_); a1_ = lane_d(ent_acc, 2 * s_ + 1);
+    // what the pair's statement of step s_ takes: the window's LDS address, the four tap columns, alpha of both outputs, and whether the
+    // second window starts a sample later.  Prepared BEHIND the statement of the step before, in front of the barrier: a wave that
+    // leaves the barrier goes straight into its statement.
+    const cdouble_t pfb = (cdouble_t)(a.taps), dpfb = (cdouble_t)(a.dtaps);
+    struct PairIn { unsigned addr; cdouble_t tl0, tu0, tl1, tu1; double alpha0, alpha1; bool apart; };
+    auto prepare = [&](int s_) {
+        PairIn q;
+        const int n0 = lane_i(ent_n, 2 * s_), n1 = lane_i(ent_n, 2 * s_ + 1);
+        const int phi0 = lane_i(ent_phi, 2 * s_), phi1 = lane_i(ent_phi, 2 * s_ + 1);
+        q.alpha0 = lane_d(ent_alpha, 2 * s_); q.alpha1 = lane_d(ent_alpha, 2 * s_ + 1);
+        const unsigned r0 = (static_cast<unsigned>(n0 - T) + URING) % URING;                  // (ring coordinate = sample index + RING)
+        q.addr = ring_row + r0 * 8u;
+        q.tl0 = pfb + phi0 * T; q.tu0 = dpfb + phi0 * T; q.tl1 = pfb + phi1 * T; q.tu1 = dpfb + phi1 * T;
+        q.apart = n1 != n0;
+        return q;
     };
 
     // the stretch's first windows: every block from the first output's oldest sample to the last sample of step 0, waited for
@@ -249,9 +264,7 @@ __device__ __forceinline__ void lane_stretch(const ArbArgs &a, const ArbLaneArgs
     int ua = -1, ub = -1;                                       // the block va / vb holds (-1: none; an edge block is loaded at its turn)
     if (nsteps > 1 && E(1) > e_iss) ua = e_iss++;
     issue(ua >= 0 ? ua : e_iss - 1, va0, va1);
-    int n0, n1;
-    double acc0, acc1;
-    entries(0, n0, n1, acc0, acc1);
+    PairIn cur = prepare(0);
     lane_barrier();
 #ifdef MRHIP_LANE_TRACE
     unsigned long long p_asm = 0, p_bar = 0, p_rest = 0;
@@ -263,27 +276,17 @@ __device__ __forceinline__ void lane_stretch(const ArbArgs &a, const ArbLaneArgs
         issue(unew >= 0 ? unew : e_iss - 1, vn0, vn1);
         const v2d_t done = tile_take((s + 1) & 1);              // the step before's outputs (step 0: whatever the tile holds, not stored)
         const int kp = s * kLaneStep + 2 * wv;
-        int n0n = 0, n1n = 0;
-        double acc0n = 0.0, acc1n = 0.0;
         if (kp < kr) {                                          // (uniform)
-            const double phif0 = __builtin_floor(acc0), phif1 = __builtin_floor(acc1);
-            const double alpha0 = acc0 - phif0, alpha1 = acc1 - phif1;                          // src/Filters.jl:671-672
-            const int phi0 = __builtin_amdgcn_readfirstlane(static_cast<int>(phif0) - 1);       // 0-based column
-            const int phi1 = __builtin_amdgcn_readfirstlane(static_cast<int>(phif1) - 1);
-            const unsigned r0 = (static_cast<unsigned>(n0 - T) + URING) % URING;              // (ring coordinate = sample index + RING)
-            const unsigned addr = ring_row + r0 * 8u;
-            const bool apart = n1 != n0;
-            if (s + 1 < nsteps) entries(s + 1, n0n, n1n, acc0n, acc1n);
             double lo0, up0, lo1, up1;
             LANE_TICK(p_rest);
-            if (apart) lane_pair<FUSED, T, 1>(addr, pfb + phi0 * T, dpfb + phi0 * T, pfb + phi1 * T, dpfb + phi1 * T, lo0, up0, lo1, up1);
-            else lane_pair<FUSED, T, 0>(addr, pfb + phi0 * T, dpfb + phi0 * T, pfb + phi1 * T, dpfb + phi1 * T, lo0, up0, lo1, up1);
+            if (cur.apart) lane_pair<FUSED, T, 1>(cur.addr, cur.tl0, cur.tu0, cur.tl1, cur.tu1, lo0, up0, lo1, up1);
+            else lane_pair<FUSED, T, 0>(cur.addr, cur.tl0, cur.tu0, cur.tl1, cur.tu1, lo0, up0, lo1, up1);
             LANE_TICK(p_asm);
-            const double prod0 = up0 * alpha0, prod1 = up1 * alpha1;                            // Filters.jl:730, rounded once each
+            const double prod0 = up0 * cur.alpha0, prod1 = up1 * cur.alpha1;                    // Filters.jl:730, rounded once each
             const v2d_t res = {lo0 + prod0, lo1 + prod1};
             *reinterpret_cast<v2d_t *>(out_lane + static_cast<size_t>(s & 1) * (64 * kLaneOutRow)) = res;
         }
-        n0 = n0n; n1 = n1n; acc0 = acc0n; acc1 = acc1n;
+        if (s + 1 < nsteps) cur = prepare(s + 1);
         asm volatile("" ::: "memory");                          // (the ring writes below stay below the statement's reads above)
         // (the ring write first: its wait lets the two loads requested at the top of this step stay in flight -- with the store in front of
         //  it the compiler's count, the minimum over the paths with and without a store, makes it wait for the first of them)
