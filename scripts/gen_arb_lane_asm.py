@@ -7,7 +7,7 @@ the compiler the loads of a whole output are hoisted in front of its arithmetic 
 waited for block by block from separate statements every block pays the scalar cache's latency (measured: the kernel ran at 31 %
 VALU utilisation).  A load that is still in flight when a statement ends is not expressible (the compiler takes an asm output for
 valid at once and may move or re-use it), so the whole pair is one statement with its own double buffer of tap blocks in fixed
-scalar registers s[36:99] (declared clobbered): the loads of block b + 1 are issued in front of the arithmetic of block b and
+scalar registers (declared clobbered: s[68:99] with blocks of four taps, the default; s[36:99] with blocks of eight): the loads of block b + 1 are issued in front of the arithmetic of block b and
 waited for behind it.
 
 What a statement does (T taps per phase, halves of HT = T/2 taps so that a window costs HT + 1 registers, not T + 1):
@@ -26,7 +26,6 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "multirate.jl_amd", "csrc", "arb_lane_pair.inc")
 
-import sys
 NB = int(os.environ.get("LANE_BLOCK_TAPS", "4"))       # taps per block: 8 (s_load_dwordx16, 64 fixed SGPRs) or 4 (s_load_dwordx8, 32)
 if NB == 8:
     BUF = {"A": (36, 52), "B": (68, 84)}   # first SGPR of the yLower / yUpper block of taps
@@ -104,16 +103,21 @@ def gen(T, D, fused):
             f"    }}\n")
 
 
-def main():
+def render():
     parts = ["// GENERATED by scripts/gen_arb_lane_asm.py -- do not edit; see that script for what the statements do and why they are assembly.\n"
              "// Included inside lane_pair<FUSED, T, D>(addr, tl0, tu0, tl1, tu1, lo0, up0, lo1, up1) with `double t0, t1;` declared.\n"]
     for T in (32, 16):
         for D in (0, 1):
             for fused in (False, True):
                 parts.append(gen(T, D, fused))
+    return "".join(parts)
+
+
+def main():
+    text = render()
     with open(OUT, "w") as fh:
-        fh.write("".join(parts))
-    print("wrote", OUT, sum(p.count("\n") for p in parts), "lines")
+        fh.write(text)
+    print("wrote", OUT, text.count("\n"), "lines")
 
 
 if __name__ == "__main__":

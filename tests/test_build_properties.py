@@ -53,6 +53,26 @@ def test_pipe_kernels_use_no_scratch(pkg, src, kernel):
     assert not spilling, f"{kernel}: instantiations with scratch or AccVGPRs (registers parked next to hand-issued LDS reads): {list(spilling.items())[:6]}"
 
 
+def test_lane_kernel_uses_no_scratch_and_its_statements_are_the_generators(pkg):
+    """arb_lane_kernel (kernels_arb_lane.hip): its pair statements keep tap blocks in fixed scalar registers and samples in registers
+    whose reads are in flight inside the statement only; staging keeps global loads in flight across steps -- a scratch reload waits
+    for every one of them (s_waitcnt vmcnt(0)): no instantiation may use scratch.  The statements (arb_lane_pair.inc) are generated:
+    the committed file must be what scripts/gen_arb_lane_asm.py writes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_arb_lane_asm", os.path.join(ROOT, "scripts", "gen_arb_lane_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(os.path.join(CSRC, "arb_lane_pair.inc")).read() == gen.render(), "arb_lane_pair.inc is stale: run scripts/gen_arb_lane_asm.py"
+    obj = os.path.join(CSRC, "build", "kernels_arb_lane.hip.o")
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("no built object (the library came prebuilt) or no llvm tools")
+    if os.path.getmtime(obj) < max(os.path.getmtime(os.path.join(CSRC, f)) for f in ("kernels_arb_lane.hip", "arb_lane_pair.inc")):
+        pytest.skip("object older than its source")
+    sizes = {k: v for k, v in _kernel_scratch(obj).items() if "arb_lane_kernel" in k}
+    assert len(sizes) == 4, f"expected STRICT / FUSED x 32 / 16 taps per phase, found {sorted(sizes)}"
+    assert not {k: v for k, v in sizes.items() if v != 0}, sizes
+
+
 @pytest.mark.gpu
 def test_instantiations_with_scratch_are_bit_exact_on_the_gpu():
     """The older hand-scheduled kernels (output-pair, streaming) have instantiations that do use scratch memory: each one, read

@@ -1322,6 +1322,54 @@ def test_arb_pipe_exact_32_taps(pkg, O, torch_cuda, monkeypatch):
                     assert_bit_equal(ys["exact"][0][nch - 1], yo, "unrolled vs oracle " + tag)
 
 
+def test_arb_lane_kernel_float64_lane_per_channel(pkg, O, torch_cuda, monkeypatch):
+    """arb_lane_kernel (kernels_arb_lane.hip; BASELINE config 4's shape: Float64 samples, 32 taps per phase, 64 channels, rate >= 1): a lane
+    per channel, taps by scalar loads into SGPR operands, two outputs per window, samples through an LDS ring.  Outputs, end state and
+    history bit for bit those of arb_pipe_kernel, of the universal kernel and of the oracle: STRICT and FUSED, Float64 and Float32 taps,
+    16 and 32 taps per phase, full, several and partial channel groups, rates whose consecutive windows coincide (10.3) or never do (1.0),
+    chunkings with a one-sample and a 17-sample call (first / last blocks come from the history), -0.0 / +-Inf / NaN samples."""
+    torch = torch_cuda
+    rng = np.random.default_rng(606)
+    monkeypatch.setenv("MRHIP_ARB_SMALL_MAX", "0")           # (small calls go to the universal kernel: not here)
+    cases = [(32, 32, 64, math.pi / 3, 40_000), (32, 32, 64, 1.0, 24_000), (32, 32, 128, 1.5, 21_000), (32, 32, 50, 2.7, 21_000),
+             (32, 16, 64, 10.3, 12_000), (8, 32, 64, 1.9, 21_000), (10, 16, 113, math.e / 2, 21_000)]
+    for (nphi, T, nch, rate, n) in cases:
+        for th in (np.float64, np.float32):
+            h = rng.standard_normal(nphi * T).astype(th)
+            x = rng.random((nch, n)) - 0.5
+            x[0, 5] = -0.0; x[0, 1000] = np.inf; x[1, 1001] = -np.inf; x[2, 7_000] = np.nan
+            xd = torch.from_numpy(x).cuda()
+            sizes = [5_000, 1, 17, n - 5_018 - 3_003, 3_003]
+            for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
+                got = {}
+                for mode, env in (("lane", {}), ("pipe", {"MRHIP_ARB_LANE": "0"}), ("generic", {"MRHIP_FORCE_GENERIC": "1"})):
+                    for k, v in env.items():
+                        monkeypatch.setenv(k, v)
+                    f = pkg.FIRFilter(h, float(rate), nphi, numerics=numerics)
+                    y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+                    st = f.state
+                    got[mode] = (y, f.last_kernel_name(), (st.phiIdx, st.inputDeficit, st.phiAccumulator, st.alpha), np.array(f.history))
+                    f.close()
+                    for k in env:
+                        monkeypatch.delenv(k)
+                tag = f"Nphi={nphi} T={T} nch={nch} rate={rate:.4f} taps={np.dtype(th)} numerics={numerics}"
+                assert got["lane"][1] == "arb_lane_kernel" and got["pipe"][1] != "arb_lane_kernel" and got["generic"][1] == "arb_generic_kernel", (tag, got["lane"][1], got["pipe"][1])
+                assert_bit_equal(got["lane"][0], got["generic"][0], "lane vs universal " + tag)
+                assert_bit_equal(got["lane"][0], got["pipe"][0], "lane vs pipe " + tag)
+                assert got["lane"][2] == got["generic"][2], tag
+                assert_bit_equal(got["lane"][3], got["generic"][3], "history " + tag)
+                if numerics == pkg.NUMERICS_STRICT:
+                    for c in (0, 1, 2, nch - 1):
+                        fo = O.FIRFilter(h, float(rate), nphi, tx=np.float64)
+                        assert_bit_equal(got["lane"][0][c], np.concatenate(_run_chunks(fo, x[c], sizes)), f"lane vs oracle ch {c} " + tag)
+    # what the kernel does not serve stays where it was: a decimating rate, few channels, Float32 samples
+    for (nch, rate, tx) in ((64, 0.71, np.float64), (16, math.pi / 3, np.float64), (64, math.pi / 3, np.float32)):
+        f = pkg.FIRFilter(rng.standard_normal(32 * 32), float(rate), 32)
+        f.filt(torch.from_numpy(rng.random((nch, 20_000)).astype(tx)).cuda())
+        assert f.last_kernel_name() != "arb_lane_kernel", (nch, rate, tx)
+        f.close()
+
+
 def test_large_L_runs_on_the_output_pair_kernel_in_period_blocks(pkg, O, torch_cuda, monkeypatch):
     """L > 512 (625//512, 1000//999, 640//441: ordinary clock-trim ratios) used to fall off the tuned kernels onto poly_tiled /
     poly_generic at 1-9 % of the HBM roofline.  The output-pair kernel now cuts the period of 2L outputs into BLOCKS, one workgroup
