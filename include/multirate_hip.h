@@ -372,10 +372,13 @@ int mrhip_ring_wait(mrhip_ring *r, uint64_t seq);
 /* block until every pushed chunk is complete */
 int mrhip_ring_drain(mrhip_ring *r);
 /* drain, end the resident kernel, hand the stream (state behind the last chunk, history, device record) back to the filter,
- * free the ring */
+ * free the ring.  (A filter destroyed while it still feeds a ring -- finalizers run in any order -- shuts the ring down itself;
+ * the ring's entry points then fail and mrhip_ring_close only frees the handle.) */
 int mrhip_ring_close(mrhip_ring *r);
 /* info[0..n): [0] 1 = resident kernel, 0 = one launch per chunk; [1] ring depth; [2] chunks pushed; [3] kernels restarted after an
- * idle deadline; [4] steps per grab; [5] outputs per step */
+ * idle deadline; [4] steps per grab; [5] outputs per step; [6] launches repeated with fewer workgroups (not all started in time: a
+ * co-tenant kernel held part of the chip); [7] workgroups of the resident kernel (0: as many as the chip holds); [8] XCDs of the
+ * device (other than 8: every chunk completes by write-through stores) */
 int mrhip_ring_info(const mrhip_ring *r, int64_t *info, int n);
 
 /* ---- one FIRFilter whose channels are split over several GPUs (BASELINE.json config 5) ------------------------ */
@@ -412,6 +415,12 @@ int mrhip_sharded_filt_host(mrhip_sharded *s, const void *x, int64_t x_len, int6
 /* the final gather: rows [start_i, start_i + count_i) of a (nchannels x n_out) result at `dst` on `dst_device` (row stride dst_stride
  * samples) from y[i] on shard i's device, asynchronous on the shards' streams behind their filter kernels */
 int mrhip_sharded_gather(mrhip_sharded *s, const void *const *y, int64_t n_out, const int64_t *y_stride, void *dst, int64_t dst_stride, int dst_device);
+/* ordering against a CALLER's stream on shard i's device (the shards run on private streams): _wait_stream puts the shard's stream
+ * behind what `stream` holds so far (inputs the caller's kernels still write, buffers its allocator handed out in stream order),
+ * _signal_stream puts `stream` behind what the shard's stream holds so far (the caller's later kernels see the outputs).  No
+ * reference counterpart: the reference is synchronous (src/Filters.jl:577-587). */
+int mrhip_sharded_wait_stream(mrhip_sharded *s, int shard, void *stream);
+int mrhip_sharded_signal_stream(mrhip_sharded *s, int shard, void *stream);
 int mrhip_sharded_synchronize(mrhip_sharded *s);
 
 /* replaces the stateless filt(h, x, ratio), src/Filters.jl:858-861, and

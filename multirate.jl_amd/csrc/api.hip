@@ -536,6 +536,9 @@ int mrhip_farrow_tapsforphase(const mrhip_filter *f, double phase, void *host_ou
 void mrhip_destroy(mrhip_filter *f)
 {
     if (!f) return;
+    // a ring the filter still feeds: its resident kernel reads the taps and the history freed below (and hipFree would first wait for the
+    // kernel's idle deadline), its close would write into the freed object.  Shut it down; the handle stays valid for mrhip_ring_close.
+    if (f->ring) (void)ring_shutdown(f->ring);
     DeviceGuard guard(f->device);
     if (f->captured) (void)hipDeviceSynchronize();   // replays of a graph that holds this filter's calls ran on streams the library never saw
     (void)drain_filter(f);                       // this filter's work only; other streams of the process keep running

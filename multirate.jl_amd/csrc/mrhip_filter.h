@@ -146,6 +146,7 @@ struct mrhip_filter {
 
     int mod_form = 0;                  // FIRArbitrary / FIRFarrow: 1 = update()'s mod() as Julia Base before 0.4 computed it (mrhip_set_mod_form)
     bool ring_open = false;            // the filter feeds a ring of arriving chunks (ring_api.inc): its own entry points refuse calls meanwhile
+    struct mrhip_ring *ring = nullptr; // ... that ring (mrhip_destroy shuts it down first)
 
     // measurement
     bool timing = false;
@@ -198,3 +199,6 @@ int rec_push(mrhip_filter *f, hipStream_t s, long long call_n_out = -1, long lon
 int rec_pull(mrhip_filter *f);
 hipError_t launch_poly_plan(mrhip_filter *f, int64_t x_len, long long P, long long y_capacity, long long *count_out, hipStream_t s, const DevCall *x_from = nullptr);
 }  // namespace mrhip
+// ring_api.inc: everything mrhip_ring_close does except freeing the handle (mrhip_destroy: a filter that still feeds a ring)
+namespace mrhip { int ring_shutdown(struct mrhip_ring *r); }
+

@@ -18,6 +18,7 @@ struct mrhip_sharded {
     std::vector<int> device;
     std::vector<int64_t> start, count;
     std::vector<hipStream_t> stream;
+    std::vector<hipEvent_t> ev;            // orders a shard's stream against a caller's stream (mrhip_sharded_wait_stream / _signal_stream)
     int64_t nch = 0;
     int tx = 0, ty = 0;
 };
@@ -52,6 +53,7 @@ int mrhip_sharded_create(int ctor, const void *h, int64_t hLen, int tap_dtype, i
         s->count.push_back(cnt);
         s->shard.push_back(nullptr);
         s->stream.push_back(nullptr);
+        s->ev.push_back(nullptr);
         if (cnt == 0) continue;
         mrhip_filter *f = nullptr;
         int rc = ctor == 0 ? mrhip_create_rational(h, hLen, tap_dtype, num, den, sample_dtype, cnt, devices[i], &f)
@@ -60,6 +62,7 @@ int mrhip_sharded_create(int ctor, const void *h, int64_t hLen, int tap_dtype, i
         if (rc == MRHIP_OK) {
             DevGuard g(devices[i]);
             if (hipStreamCreateWithFlags(&s->stream[static_cast<size_t>(i)], hipStreamNonBlocking) != hipSuccess) rc = fail(MRHIP_ERR_HIP, "hipStreamCreate failed");
+            else if (hipEventCreateWithFlags(&s->ev[static_cast<size_t>(i)], hipEventDisableTiming) != hipSuccess) rc = fail(MRHIP_ERR_HIP, "hipEventCreate failed");
         }
         if (rc != MRHIP_OK) {
             const std::string msg = mrhip_last_error();
@@ -77,8 +80,11 @@ void mrhip_sharded_destroy(mrhip_sharded *s)
 {
     if (!s) return;
     for (size_t i = 0; i < s->shard.size(); ++i) {
+        // (the shard's kernels run on its stream: they are through before the filter they read is freed)
+        if (s->stream[i]) { DevGuard g(s->device[i]); (void)hipStreamSynchronize(s->stream[i]); }
         if (s->shard[i]) mrhip_destroy(s->shard[i]);
-        if (s->stream[i]) { DevGuard g(s->device[i]); (void)hipStreamSynchronize(s->stream[i]); (void)hipStreamDestroy(s->stream[i]); }
+        if (s->ev[i]) { DevGuard g(s->device[i]); (void)hipEventDestroy(s->ev[i]); }
+        if (s->stream[i]) { DevGuard g(s->device[i]); (void)hipStreamDestroy(s->stream[i]); }
     }
     delete s;
 }
@@ -128,6 +134,17 @@ int mrhip_sharded_filt_device(mrhip_sharded *s, const void *const *x, int64_t x_
     const int64_t want = mrhip_sharded_next_output_count(s, x_len);
     const bool estimate = !s->shard.empty() && [&] { for (mrhip_filter *f : s->shard) if (f) return f->kind == MRHIP_FIR_ARBITRARY || f->kind == MRHIP_FIR_FARROW; return false; }();
     if (!estimate && want > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
+    // every shard's arguments before anything is enqueued on any: a call that fails half way leaves the shards at different stream
+    // positions (FIRArbitrary / FIRFarrow: the count is an estimate, the room is checked against the reference's outputlength)
+    for (size_t i = 0; i < s->shard.size(); ++i) {
+        mrhip_filter *f = s->shard[i];
+        if (!f) continue;
+        const int64_t xs = x_stride ? x_stride[i] : x_len, ys = y_stride ? y_stride[i] : y_capacity;
+        if (x_len < 0 || y_capacity < 0) return fail(MRHIP_ERR_INVALID_ARG, "negative length");
+        if (x_len > 0 && (!x[i] || !y[i])) return fail(MRHIP_ERR_INVALID_ARG, "a shard's x or y is NULL");
+        if (s->count[i] > 1 && (xs < x_len || ys < std::min<int64_t>(want, y_capacity))) return fail(MRHIP_ERR_INVALID_ARG, "a shard's stride is shorter than its rows");
+        if (estimate && mrhip_outputlength(f, x_len) > y_capacity) return fail(MRHIP_ERR_BUFFER_TOO_SMALL, "buffer is too small");
+    }
     int64_t got_all = -1;
     for (size_t i = 0; i < s->shard.size(); ++i) {
         mrhip_filter *f = s->shard[i];
@@ -196,6 +213,30 @@ int mrhip_sharded_gather(mrhip_sharded *s, const void *const *y, int64_t n_out, 
                                              static_cast<size_t>(s->count[i]), hipMemcpyDefault, s->stream[i]));
         }
     }
+    return MRHIP_OK;
+}
+
+// shard i's stream behind what `stream` (a stream of the shard's device; NULL: the default stream) holds so far: inputs a caller's
+// kernels are still writing, buffers its allocator has handed out in stream order
+int mrhip_sharded_wait_stream(mrhip_sharded *s, int i, void *stream)
+{
+    if (!s || i < 0 || i >= static_cast<int>(s->shard.size())) return fail(MRHIP_ERR_INVALID_ARG, "no such shard");
+    if (!s->stream[static_cast<size_t>(i)]) return MRHIP_OK;
+    DevGuard g(s->device[static_cast<size_t>(i)]);
+    MRHIP_CHECK_HIP(hipEventRecord(s->ev[static_cast<size_t>(i)], static_cast<hipStream_t>(stream)));
+    MRHIP_CHECK_HIP(hipStreamWaitEvent(s->stream[static_cast<size_t>(i)], s->ev[static_cast<size_t>(i)], 0));
+    return MRHIP_OK;
+}
+
+// ... and `stream` behind what shard i's stream holds so far: the caller's later kernels see the shard's outputs, its allocator may
+// re-use their memory in stream order
+int mrhip_sharded_signal_stream(mrhip_sharded *s, int i, void *stream)
+{
+    if (!s || i < 0 || i >= static_cast<int>(s->shard.size())) return fail(MRHIP_ERR_INVALID_ARG, "no such shard");
+    if (!s->stream[static_cast<size_t>(i)]) return MRHIP_OK;
+    DevGuard g(s->device[static_cast<size_t>(i)]);
+    MRHIP_CHECK_HIP(hipEventRecord(s->ev[static_cast<size_t>(i)], s->stream[static_cast<size_t>(i)]));
+    MRHIP_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), s->ev[static_cast<size_t>(i)], 0));
     return MRHIP_OK;
 }
 

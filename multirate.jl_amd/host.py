@@ -127,6 +127,8 @@ ABI = [
     ("mrhip_sharded_filt_device", _i, [_vp, C.POINTER(_vp), _i64, _pi64, C.POINTER(_vp), _i64, _pi64, _pi64]),
     ("mrhip_sharded_filt_host", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64]),
     ("mrhip_sharded_gather", _i, [_vp, C.POINTER(_vp), _i64, _pi64, _vp, _i64, _i]),
+    ("mrhip_sharded_wait_stream", _i, [_vp, _i, _vp]),
+    ("mrhip_sharded_signal_stream", _i, [_vp, _i, _vp]),
     ("mrhip_sharded_synchronize", _i, [_vp]),
     ("mrhip_ring_open", _i, [_vp, C.POINTER(_vp)]),
     ("mrhip_ring_push", _i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _pi64, C.POINTER(C.c_uint64)]),
@@ -695,9 +697,10 @@ class ChunkRing:
             pass
 
     def info(self) -> dict:
-        v = (C.c_int64 * 6)()
-        _check(self._lib.mrhip_ring_info(self._h, v, 6))
-        return {"resident": bool(v[0]), "depth": v[1], "pushed": v[2], "restarts": v[3], "steps_per_grab": v[4], "outputs_per_step": v[5]}
+        v = (C.c_int64 * 9)()
+        _check(self._lib.mrhip_ring_info(self._h, v, 9))
+        return {"resident": bool(v[0]), "depth": v[1], "pushed": v[2], "restarts": v[3], "steps_per_grab": v[4], "outputs_per_step": v[5],
+                "shrunk": v[6], "workgroups": v[7], "xcds": v[8]}
 
     def _args(self, buffer, x):
         f = self.filter
@@ -832,8 +835,18 @@ class ShardedFIRFilter:
         xst = (C.c_int64 * k)(*[x.stride(0) if cnt else 0 for (st, cnt, dev), x in zip(self.shards, xs)])
         yst = (C.c_int64 * k)(*[cap] * k)
         nw = C.c_int64(0)
+        # the shards run on private streams: each behind torch's current stream on its device (xs[i] may still be written there, ys[i]
+        # came from the caching allocator in that stream's order) ...
+        self._order(self._lib.mrhip_sharded_wait_stream)
         _check(self._lib.mrhip_sharded_filt_device(self._h, xp, n, xst, yp, cap, yst, C.byref(nw)))
+        # ... and torch's stream behind them: later torch kernels see the outputs, the allocator may re-use ys[i] in stream order
+        self._order(self._lib.mrhip_sharded_signal_stream)
         return [y[:, :nw.value] if y is not None else None for y in ys]
+
+    def _order(self, fn):
+        for i, (st, cnt, dev) in enumerate(self.shards):
+            if cnt:
+                _check(fn(self._h, i, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
     def gather(self, ys, device: int):
         """(nchannels, n_out) on ``device`` from the per-shard outputs (views as ``filt_shards`` returns them)"""
@@ -842,7 +855,24 @@ class ShardedFIRFilter:
         k = len(self.shards)
         yp = (C.c_void_p * k)(*[C.c_void_p(y.data_ptr()) if y is not None else None for y in ys])
         yst = (C.c_int64 * k)(*[y.stride(0) if y is not None else 0 for y in ys])
+        self._order(self._lib.mrhip_sharded_wait_stream)         # (ys may come from torch kernels; `out` from the allocator of its device:)
+        for i, (st, cnt, dev) in enumerate(self.shards):
+            if cnt and dev != int(device):
+                # a shard on another device writes into `out`: behind the destination device's current stream too (an event recorded
+                # there, waited for by the shard's stream -- HIP events order streams across devices)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(int(device)))
+                with torch.cuda.device(dev):
+                    torch.cuda.current_stream(dev).wait_event(ev)
+                _check(self._lib.mrhip_sharded_wait_stream(self._h, i, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         _check(self._lib.mrhip_sharded_gather(self._h, yp, n_out, yst, C.c_void_p(out.data_ptr()), n_out, int(device)))
+        self._order(self._lib.mrhip_sharded_signal_stream)
+        for i, (st, cnt, dev) in enumerate(self.shards):         # the destination's stream behind every shard's copy
+            if cnt and dev != int(device):
+                ev = torch.cuda.Event()
+                with torch.cuda.device(dev):
+                    ev.record(torch.cuda.current_stream(dev))
+                torch.cuda.current_stream(int(device)).wait_event(ev)
         return out
 
     def synchronize(self):

@@ -479,9 +479,10 @@ function Base.close(r::ChunkRing)
     nothing
 end
 function ringinfo(r::ChunkRing)
-    v = zeros(Int64, 6)
-    check(ccall((:mrhip_ring_info, libmr), Cint, (Ptr{Cvoid}, Ptr{Int64}, Cint), r.handle, v, 6))
-    (resident = v[1] != 0, depth = v[2], pushed = v[3], restarts = v[4], steps_per_grab = v[5], outputs_per_step = v[6])
+    v = zeros(Int64, 9)
+    check(ccall((:mrhip_ring_info, libmr), Cint, (Ptr{Cvoid}, Ptr{Int64}, Cint), r.handle, v, 9))
+    (resident = v[1] != 0, depth = v[2], pushed = v[3], restarts = v[4], steps_per_grab = v[5], outputs_per_step = v[6],
+     shrunk = v[7], workgroups = v[8], xcds = v[9])
 end
 
 # ---- one FIRFilter whose channels are split over several GPUs (mrhip_sharded_*; BASELINE config 5 from Julia) ----------------------

@@ -277,6 +277,30 @@ def test_headline_c2_streaming_1e8_vs_oracle(pkg, O, torch_cuda):
         assert (f.state.phiIdx, f.state.inputDeficit) == st
         assert_bit_equal(f.history, hist, "history after the chunked entry")
         f.close()
+        # config 2 AS STATED -- the chunks arrive one after the other -- through the ring of arriving chunks (mrhip_ring_*: one descriptor
+        # per chunk into ONE resident kernel): the same 100 (101) chunks pushed one by one, then by the library's push loop; every one
+        # of the 91 875 000 outputs, the end state and the history against the oracle's stream
+        for how in ("push", "push_chunks"):
+            f = pkg.FIRFilter(h, Fraction(147, 160)).bind(np.float32, 1)
+            yd.zero_()
+            torch.cuda.synchronize()
+            ring = f.open_ring()
+            assert ring.info()["resident"]
+            if how == "push":
+                k = 0
+                for a in range(0, n, chunk):
+                    cnt, _ = ring.push(yd[k:], xd[a:a + chunk])
+                    k += cnt
+            else:
+                k, _ = ring.push_chunks(yd, xd, chunk)
+            assert k == len(yo)
+            ring.drain()
+            ring.close()
+            assert_bit_equal(yd[:len(yo)].cpu().numpy(), yo, f"ring ({how}), chunk {chunk}")
+            assert (f.state.phiIdx, f.state.inputDeficit) == st
+            assert_bit_equal(f.history, hist, f"history after the ring ({how})")
+            # ... and the stream goes on in the filter behind the ring: one more call equals the oracle's next call
+            f.close()
         del yd
 
 

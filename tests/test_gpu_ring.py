@@ -280,6 +280,32 @@ def test_ring_errors(pkg, torch_cuda):
     f.close()
 
 
+def test_filter_destroyed_while_it_feeds_a_ring(pkg, O, torch_cuda):
+    """FIRFilter.close() before ChunkRing.close() (a garbage collector runs the two finalizers in any order) used to free the
+    taps and the history under the resident kernel and leave the ring a dangling filter pointer.  mrhip_destroy now shuts the ring down
+    first: what was pushed is complete, the ring's entry points fail, its close only frees the handle."""
+    torch = torch_cuda
+    h = pkg.firdes(24 * 147, 0.5 / 147, beta=7.8562).astype(np.float32)
+    x = torch.rand((1, 200_000), device="cuda")
+    torch.cuda.synchronize()
+    for resident in (True, False):
+        f = (pkg.FIRFilter(h, Fraction(147, 160), device=0) if resident else pkg.FIRFilter(h[:128].copy(), Fraction(1, 4), device=0)).bind(np.float32, 1)
+        y = torch.zeros((1, f.outputlength(200_000) + 8), device="cuda")
+        ring = f.open_ring()
+        info = ring.info()
+        assert info["resident"] == resident and info["xcds"] in (0, 8) and info["shrunk"] >= 0 and info["workgroups"] >= 0
+        cnt, _ = ring.push(y, x)
+        href = (h if resident else h[:128].copy())
+        ref = O.FIRFilter(href, Fraction(147, 160) if resident else Fraction(1, 4), tx=np.float32).filt(x[0].cpu().numpy())
+        f.close()                                               # the filter goes first
+        assert np.array_equal(y[0, :cnt].cpu().numpy().view(np.uint32), ref.view(np.uint32))      # the pushed chunk was completed
+        with pytest.raises(pkg.MultirateHIPError, match="has been destroyed"):
+            ring.push(y, x)
+        with pytest.raises(pkg.MultirateHIPError, match="has been destroyed"):
+            ring.drain()
+        ring.close()                                            # frees the handle, nothing else
+
+
 def test_ring_randomised_stress_short():
     """scripts/stress_ring.py (random eligible shapes, types, channel counts, ragged chunkings against the oracle's chunk loop) for a few
     seconds, under both completion protocols -- the script that found the launch that did not fit the chip (profiles/r05/experiments.md S)."""

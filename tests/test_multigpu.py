@@ -250,6 +250,31 @@ def test_sharded_filter_behind_the_c_abi(pkg, O):
         for c in range(nch):
             ref = fos[c].filt(x[c])
             assert got[c].shape == ref.shape and np.array_equal(got[c].view(np.uint8), ref.view(np.uint8)), f"{ratio} device path channel {c}"
+        # ... and in STREAM ORDER with the caller's torch work, no host synchronisation in between: the inputs are still
+        # being produced by torch kernels on the current streams when filt_shards is called, the outputs are consumed by torch kernels
+        # right behind it (mrhip_sharded_wait_stream / mrhip_sharded_signal_stream)
+        sf.reset()
+        fos = [O.FIRFilter(h, ratio, 32, tx=tx) if isinstance(ratio, float) else O.FIRFilter(h, ratio, tx=tx) for _ in range(nch)]
+        base = [torch.from_numpy(np.ascontiguousarray(x[s:s + c])).to(f"cuda:{d}") if c else None for s, c, d in sf.shards]
+        xs2 = []
+        for b in base:
+            if b is None:
+                xs2.append(None); continue
+            with torch.cuda.device(b.device):
+                junk = torch.empty((64, 1 << 20), device=b.device).normal_()      # keeps the stream busy in front of the copy below
+                for _ in range(4):
+                    junk = junk * 1.0001
+                xs2.append((b + 0) if not b.is_complex() else (b * 1.0))           # a torch kernel writes the input, asynchronously
+        ys2 = sf.filt_shards(xs2)
+        sums = [(y.clone() if y is not None else None) for y in ys2]                # torch kernels read the outputs, no sync in between
+        full2 = sf.gather(ys2, devices[0])
+        got2 = full2.clone().cpu().numpy()                                          # (.cpu() synchronises torch's stream only)
+        for c in range(nch):
+            ref = fos[c].filt(x[c])
+            assert got2[c].shape == ref.shape and np.array_equal(got2[c].view(np.uint8), ref.view(np.uint8)), f"{ratio} stream-ordered device path channel {c}"
+        for (s0, cnt, d), y in zip(sf.shards, sums):
+            if cnt:
+                assert np.array_equal(y.cpu().numpy().view(np.uint8), got2[s0:s0 + cnt].view(np.uint8))
         sf.close()
     # reference: error() before any work, on every shard (Filters.jl:550)
     sf = pkg.ShardedFIRFilter(h147, Fraction(147, 160), 4, devices, dtype=np.float32)
