@@ -120,7 +120,7 @@ int alloc_common(mrhip_filter *f)
     // Every later launch goes to a non-blocking stream, which the null stream's memsets are not ordered with: zero
     // on the filter's own stream and wait for it here (construction may block; nothing else in the library does).
     MRHIP_CHECK_HIP(hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         MRHIP_CHECK_HIP(hipMalloc(&f->d_hist[i], hbytes));
         MRHIP_CHECK_HIP(hipMemsetAsync(f->d_hist[i], 0, hbytes, f->own_stream));   // history = zeros(historyLen), Filters.jl:177
     }
@@ -544,7 +544,7 @@ void mrhip_destroy(mrhip_filter *f)
     (void)drain_filter(f);                       // this filter's work only; other streams of the process keep running
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
         if (st) (void)hipStreamSynchronize(st);
-    for (void *p : {f->d_taps_alloc, f->d_dtaps_alloc, static_cast<void *>(f->d_pnfb), static_cast<void *>(f->d_pnfb_t), f->d_hist[0], f->d_hist[1], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc,
+    for (void *p : {f->d_taps_alloc, f->d_dtaps_alloc, static_cast<void *>(f->d_pnfb), static_cast<void *>(f->d_pnfb_t), f->d_hist[0], f->d_hist[1], f->d_hist[2], static_cast<void *>(f->d_counters), f->d_sched_n, f->d_sched_acc,
                     f->d_xbuf[0], f->d_xbuf[1], f->d_ybuf[0], f->d_ybuf[1]})
         if (p) (void)hipFree(p);
     if (f->pin_n) (void)hipHostFree(f->pin_n);
@@ -786,6 +786,7 @@ int mrhip_set_history(mrhip_filter *f, const void *host_in)
     hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
     if (stream_is_capturing(s)) return fail(MRHIP_ERR_UNSUPPORTED, "set_history while the filter's stream is being captured");
     const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
+    hist_leave_zeros(f);
     if (bytes && hipMemcpyAsync(f->d_hist[f->hist_cur], host_in, bytes, hipMemcpyHostToDevice, s) != hipSuccess) {
         // the stream of the filter's last call no longer exists (the caller destroyed it): everything it carried has
         // either run or gone with it -- order behind the whole device once and carry on on the filter's own stream
@@ -811,6 +812,7 @@ int mrhip_set_history_device(mrhip_filter *f, const void *dev_in, void *stream_)
     if (stream_is_capturing(stream)) return fail(MRHIP_ERR_UNSUPPORTED, "set_history while the stream is being captured");
     if (int rc = adopt_stream(f, stream)) return rc;          // behind the filter's earlier launches, ahead of its next one
     const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
+    hist_leave_zeros(f);
     if (bytes) MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_hist[f->hist_cur], dev_in, bytes, hipMemcpyDeviceToDevice, stream));
     return MRHIP_OK;
 }
@@ -824,10 +826,19 @@ int mrhip_reset(mrhip_filter *f)
     // the next filt call is on that stream too, or waits for it (adopt_stream).
     hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
     const size_t bytes = static_cast<size_t>(f->nch) * f->H * x_elt(f);
+    // history = zeros(historyLen) (Filters.jl:177): the read-only slot of zeros becomes the current one -- no memset, no launch -- unless a
+    // captured graph has a slot baked in (its replays read THAT slot: zero it).  The hand-out counters are zero between launches by
+    // their own protocol; they are zeroed once more by the kernel that pushes the record below (no launch of their own) when that
+    // kernel runs on the filter's stream.
+    const bool fast = !f->captured && MRHIP_ENV_INT("MRHIP_RESET_FAST", 1) != 0;
+    const bool rec_on_s = !f->s_sched;                 // (FIRArbitrary / FIRFarrow push the record on their schedule stream)
+    if (fast) f->hist_cur = 2;
     auto zero_on = [&](hipStream_t st) -> hipError_t {
-        if (bytes) { hipError_t e = hipMemsetAsync(f->d_hist[f->hist_cur], 0, bytes, st); if (e != hipSuccess) return e; }
+        if (bytes && !fast) { hipError_t e = hipMemsetAsync(f->d_hist[f->hist_cur], 0, bytes, st); if (e != hipSuccess) return e; }
+        if (fast && rec_on_s) return hipSuccess;
         return hipMemsetAsync(f->d_counters, 0, mrhip::kCounterBytes, st);
     };
+    if (stream_is_capturing(s)) return fail(MRHIP_ERR_UNSUPPORTED, "reset while the filter's stream is being captured");
     if (zero_on(s) != hipSuccess) {
         // the stream of the filter's last call no longer exists (torch side streams come and go): like adopt_stream,
         // order behind the whole device once and carry on on the filter's own stream
@@ -851,7 +862,19 @@ int mrhip_reset(mrhip_filter *f)
         if (int rc = sched_stream_behind_chain(f)) return rc;
     }
     if (f->s_sched) f->sched_dirty = true;
-    return f->s_sched ? rec_push(f, f->s_sched) : rec_push(f, s);   // the device record: constructor state, in stream order
+    if (f->s_sched) return rec_push(f, f->s_sched);                   // the device record: constructor state, in stream order
+    if (fast) {
+        // the record's kernel zeroes the counters too; a stream that no longer exists (torch side streams come and go): behind the
+        // whole device once, on the filter's own stream
+        if (rec_push(f, s, -1, -1, f->d_counters) != MRHIP_OK) {
+            (void)hipGetLastError();
+            MRHIP_CHECK_HIP(hipDeviceSynchronize());
+            f->last_stream = f->own_stream;
+            return rec_push(f, f->own_stream, -1, -1, f->d_counters);
+        }
+        return MRHIP_OK;
+    }
+    return rec_push(f, s);
 }
 
 int mrhip_set_numerics(mrhip_filter *f, int numerics)
@@ -1096,7 +1119,7 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
     bool sched_inline = false;         // FIRArbitrary / FIRFarrow: this call's schedule ran on the caller's stream although the filter has a schedule stream
     bool hist_in_place = false;        // ... by a filter kernel inside a capture, straight into the slot the replay reads (ShiftFold)
     bool rec_current = false;          // the device record has (or will have, in stream order) this call's end state
-    const int hist_next = f->hist_cur ^ 1;
+    const int hist_next = hist_other(f);
     if (arb) {
         // one range [k0, k0+cnt) of this call's outputs: schedule entries are already in the device buffers
         const size_t yelt = dtype_scalar_size(f->ty) * static_cast<size_t>(f->nc);
@@ -1606,7 +1629,7 @@ int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *con
     }
     if (n_out_max < 1) return single_calls();                        // (short inputs only: history shifts, no kernel worth sharing)
     PolyArgs a{};
-    a.x = x[0]; a.y = y[0]; a.hist = f0->d_hist[f0->hist_cur]; a.hist_new = f0->d_hist[f0->hist_cur ^ 1]; a.taps = f0->d_taps;
+    a.x = x[0]; a.y = y[0]; a.hist = f0->d_hist[f0->hist_cur]; a.hist_new = f0->d_hist[hist_other(f0)]; a.taps = f0->d_taps;
     a.x_stride = x_len_max; a.y_stride = n_out_max; a.x_len = x_len_max; a.n_out = n_out_max;
     a.u0 = 0; a.d0 = 1;
     a.zero_start_below = f0->kind == MRHIP_FIR_STANDARD ? f0->hLen + 1 : f0->kind == MRHIP_FIR_DECIMATOR ? f0->hLen : 0;   // support.jl:46 (per call: every stream's call starts here)
@@ -1629,7 +1652,7 @@ int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *con
         const int64_t spc = (p.n_out + pa.P - 1) / pa.P;
         if (spc * f->nch >= (1LL << 31)) return fail(MRHIP_ERR_INVALID_ARG, "stream too long for one launch");
         MultiDesc &m = d[i];
-        m.x = x[i]; m.y = y[i]; m.hist = f->d_hist[f->hist_cur]; m.hist_new = f->d_hist[f->hist_cur ^ 1]; m.taps = f->d_taps; m.rec = f->d_rec;
+        m.x = x[i]; m.y = y[i]; m.hist = f->d_hist[f->hist_cur]; m.hist_new = f->d_hist[hist_other(f)]; m.taps = f->d_taps; m.rec = f->d_rec;
         m.x_stride = x_len[i]; m.y_stride = y_capacity[i]; m.x_len = x_len[i]; m.n_out = p.n_out;
         m.u0 = p.phi0 - 1; m.d0 = p.d0; m.phi_end = p.phi_end; m.d_end = p.d_end;
         m.steps_per_channel = static_cast<unsigned>(spc);
@@ -1655,7 +1678,7 @@ int mrhip_filt_device_multi(mrhip_filter *const *filters, int n, const void *con
         if (plans[i].n_out == 0) {
             // (a stream without outputs in this call has no tiles: its workgroups still shift its history and file its state)
         }
-        if (f->H > 0) f->hist_cur ^= 1;
+        if (f->H > 0) f->hist_cur = hist_other(f);
         f->last_kernel = f0->last_kernel;
         if (n_written) n_written[i] = plans[i].n_out;
     }

@@ -30,7 +30,7 @@ struct mrhip_filter {
     double *d_pnfb_t = nullptr;            // ... degree-major and padded to 32 taps, [polyorder+1][32] (farrow_wave_kernel; tapsPerPhi <= 32)
     std::vector<double> h_pnfb;            // ... and on the host, [T][polyorder+1]
     int64_t polyorder = 0;
-    void *d_hist[2] = {nullptr, nullptr};
+    void *d_hist[3] = {nullptr, nullptr, nullptr};   // [0], [1]: ping-pong; [2]: zeros(historyLen), read-only -- what a reset() makes current (hist_other)
     unsigned *d_counters = nullptr;   // pair kernel's dynamic scheduling: 33 counters, 256 bytes apart, zero between launches
     int hist_cur = 0;
     // host copies of the taps in tap dtype (for get_taps)
@@ -194,11 +194,17 @@ int rec_alloc(mrhip_filter *f);
 void rec_free(mrhip_filter *f);
 // write the host's state into the device record (and its mirror), in stream order on `s`; call_n_out >= 0 also arms the
 // DevCall with that output count (a call the host evaluated, whose filter kernel reads the DevCall)
-int rec_push(mrhip_filter *f, hipStream_t s, long long call_n_out = -1, long long n_written = -1);
+int rec_push(mrhip_filter *f, hipStream_t s, long long call_n_out = -1, long long n_written = -1, unsigned *zero_counters = nullptr);
 // wait for everything enqueued on the filter's behalf and take the device record over into the host fields
 int rec_pull(mrhip_filter *f);
 hipError_t launch_poly_plan(mrhip_filter *f, int64_t x_len, long long P, long long y_capacity, long long *count_out, hipStream_t s, const DevCall *x_from = nullptr);
 }  // namespace mrhip
+// The history slot the next call WRITES (the slots 0 and 1 ping-pong; slot 2 holds zeros and is what reset() makes current instead of
+// zeroing a slot: read-only until a captured call adopts it as its in-place slot -- after which reset() zeroes the current slot itself)
+inline int hist_other(const mrhip_filter *f) { return f->hist_cur == 2 ? 0 : f->hist_cur ^ 1; }
+// ... and before the CURRENT slot is written in place (set_history, a ring handing the stream back): never the zeros
+inline void hist_leave_zeros(mrhip_filter *f) { if (f->hist_cur == 2) f->hist_cur = 0; }
+
 // ring_api.inc: everything mrhip_ring_close does except freeing the handle (mrhip_destroy: a filter that still feeds a ring)
 namespace mrhip { int ring_shutdown(struct mrhip_ring *r); }
 

@@ -23,10 +23,13 @@ struct SetArgs {
     DevCall *call;
     DevStream v;
     long long call_n_out;         // >= 0: arm the DevCall with this output count
+    unsigned *zero;               // != NULL: kCounterBytes of hand-out counters to zero (reset(): no memset launch of its own)
 };
 
 __global__ __launch_bounds__(64) void stream_set_kernel(SetArgs a)
 {
+    if (a.zero)
+        for (unsigned i = threadIdx.x; i < kCounterBytes / 4; i += 64) a.zero[i] = 0u;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     DevStream v = a.v;
     v.calls = a.rec->calls + (a.v.calls != 0 ? 1 : 0);        // (v.calls is a flag here: this push completes a call)
@@ -143,9 +146,10 @@ static DevStream *mirror_dev(mrhip_filter *f)
     return static_cast<DevStream *>(p);
 }
 
-int rec_push(mrhip_filter *f, hipStream_t s, long long call_n_out, long long n_written)
+int rec_push(mrhip_filter *f, hipStream_t s, long long call_n_out, long long n_written, unsigned *zero_counters)
 {
     SetArgs a{};
+    a.zero = zero_counters;
     a.rec = f->d_rec; a.mirror = mirror_dev(f); a.call = f->d_call;
     a.v.phiIdx = f->phiIdx; a.v.inputDeficit = f->inputDeficit; a.v.acc = f->phiAcc;
     a.v.drift = f->sched_drift; a.v.ksteps = f->sched_ksteps; a.v.per_pos = f->per_pos;
