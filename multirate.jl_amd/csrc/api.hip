@@ -540,6 +540,7 @@ void mrhip_destroy(mrhip_filter *f)
     // kernel's idle deadline), its close would write into the freed object.  Shut it down; the handle stays valid for mrhip_ring_close.
     if (f->ring) (void)ring_shutdown(f->ring);
     DeviceGuard guard(f->device);
+    ring_cache_free(f);
     if (f->captured) (void)hipDeviceSynchronize();   // replays of a graph that holds this filter's calls ran on streams the library never saw
     (void)drain_filter(f);                       // this filter's work only; other streams of the process keep running
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})

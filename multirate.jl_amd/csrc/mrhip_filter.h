@@ -147,6 +147,9 @@ struct mrhip_filter {
     int mod_form = 0;                  // FIRArbitrary / FIRFarrow: 1 = update()'s mod() as Julia Base before 0.4 computed it (mrhip_set_mod_form)
     bool ring_open = false;            // the filter feeds a ring of arriving chunks (ring_api.inc): its own entry points refuse calls meanwhile
     struct mrhip_ring *ring = nullptr; // ... that ring (mrhip_destroy shuts it down first)
+    // what a closed ring leaves behind for the next one of this filter (pinned descriptor ring, device-side ring, history slots, stream):
+    // allocating and freeing them was 0.45 of the 0.6 ms it cost to open and close a ring (hipFree waits for the device)
+    struct RingCache { void *host = nullptr, *host_dev = nullptr, *dev = nullptr, *hist = nullptr; size_t slot_bytes = 0; hipStream_t stream = nullptr; } ring_cache;
 
     // measurement
     bool timing = false;
@@ -206,5 +209,5 @@ inline int hist_other(const mrhip_filter *f) { return f->hist_cur == 2 ? 0 : f->
 inline void hist_leave_zeros(mrhip_filter *f) { if (f->hist_cur == 2) f->hist_cur = 0; }
 
 // ring_api.inc: everything mrhip_ring_close does except freeing the handle (mrhip_destroy: a filter that still feeds a ring)
-namespace mrhip { int ring_shutdown(struct mrhip_ring *r); }
+namespace mrhip { int ring_shutdown(struct mrhip_ring *r); void ring_cache_free(mrhip_filter *f); }
 
