@@ -348,7 +348,7 @@ def config_rows(fused=False):
             out[-1]["wall_ms_continuing_stream"] = r["wall_ms_per_call_continuing_stream"]
             out[-1]["wall_ms_with_schedule_memo"] = r.get("wall_ms_with_schedule_memo")
         for k in ("us_per_chunk", "chunks_per_pass", "note"):
-            if k in r and r["config"].split()[0] in ("C2r", "C2rp", "C2rd", "C2s", "C1"):
+            if k in r and r["config"].split()[0] in ("C2r", "C2rp", "C2rq", "C2rd", "C2s", "C1"):
                 out[-1][k] = r[k]
     return out
 
@@ -634,7 +634,7 @@ def run_c5(args, R):
 # what is printed: ONE compact JSON line (< 4 KB) on stdout; the long record goes to a file
 # ---------------------------------------------------------------------------------------------
 COMPACT_MAX = 4000
-BASELINE_ROW_TAGS = ("C1", "C2", "C2s", "C2r", "C2rp", "C3a", "C3b", "C4", "C4f", "C5", "C2rd")
+BASELINE_ROW_TAGS = ("C1", "C2", "C2s", "C2r", "C2rp", "C2rq", "C3a", "C3b", "C4", "C4f", "C5", "C2rd")
 
 
 def _short(s, n=110):

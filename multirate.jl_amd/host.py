@@ -682,6 +682,8 @@ class ChunkRing:
         h = C.c_void_p()
         _check(self._lib.mrhip_ring_open(f._handle, C.byref(h)))
         self._h = h
+        self._push = self._lib.mrhip_ring_push                   # (push_raw: no attribute look-ups, no byref objects per call)
+        self._nw, self._seq = C.byref(C.c_int64(0)), C.byref(C.c_uint64(0))
 
     def __enter__(self):
         return self
@@ -728,6 +730,13 @@ class ChunkRing:
         nw, seq = C.c_int64(0), C.c_uint64(0)
         _check(self._lib.mrhip_ring_push(self._h, C.c_void_p(x.data_ptr()), n, xs, C.c_void_p(buffer.data_ptr()), cap, ys, C.byref(nw), C.byref(seq)))
         return nw.value, seq.value
+
+    def push_raw(self, x_ptr: int, n: int, x_stride: int, y_ptr: int, y_capacity: int, y_stride: int):
+        """``push`` for a caller that already holds device addresses (a loop in another language, a preplanned stream): one
+        ``mrhip_ring_push`` and nothing else -- no tensor checks; the same contract, unchecked: (count, chunk number)"""
+        nw, seq = self._nw, self._seq
+        _check(self._push(self._h, x_ptr, n, x_stride, y_ptr, y_capacity, y_stride, nw, seq))
+        return nw._obj.value, seq._obj.value
 
     def push_chunks(self, buffer, x, chunk: int):
         """the library's loop of ``push`` over consecutive ``chunk``-sample pieces of a resident signal, outputs back to back in

@@ -161,7 +161,8 @@ def rows(which):
         f = pkg.FIRFilter(h147, Fraction(147, 160), device=dev.index or 0).bind(np.float32, 1)
         y = torch.empty((1, f.outputlength(n) + 8), dtype=torch.float32, device=dev)
         gb = n * 7.675 / 1e9
-        for tag, label, how in (("C2r", "pushed by the library's chunk loop (mrhip_ring_push_chunks)", "lib"), ("C2rp", "pushed one by one from Python (mrhip_ring_push)", "py")):
+        for tag, label, how in (("C2r", "pushed by the library's chunk loop (mrhip_ring_push_chunks)", "lib"), ("C2rp", "pushed one by one from Python (mrhip_ring_push, tensor checks per push)", "py"),
+                                ("C2rq", "one mrhip_ring_push per chunk on precomputed addresses (what a loop in another language pays, plus ctypes)", "raw")):
             t_push, t_all = [], []
             for rep in range(reps + 1):
                 f.reset()
@@ -171,6 +172,11 @@ def rows(which):
                 t1 = time.perf_counter()
                 if how == "lib":
                     total, _ = ring.push_chunks(y, x, chunk)
+                elif how == "raw":
+                    xp, yp, k, cap = x.data_ptr(), y.data_ptr(), 0, y.shape[-1]
+                    for a in range(0, n, chunk):
+                        cnt, _ = ring.push_raw(xp + 4 * a, chunk, chunk, yp + 4 * k, cap - k, cap - k)
+                        k += cnt
                 else:
                     k = 0
                     for a in range(0, n, chunk):
