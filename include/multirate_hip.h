@@ -287,7 +287,10 @@ int64_t mrhip_outputlength_bound(const mrhip_filter *f, int64_t inputlength);
 /* wait for everything the filter has enqueued (after a HIP-graph capture of one of its calls: for the device -- replays run
  * on streams the library never saw) and take the device-resident stream state over into the host object;
  * *last_n_written (optional) receives the per-channel count of the last call.  Returns the status of a device-planned call
- * that failed since the last mrhip_sync_state, once. */
+ * that failed since the last mrhip_sync_state, once.  A device-wide wait invalidates a HIP-graph capture that is going on on
+ * another stream: while a stream the library has been called on is still capturing, the wait of a filter whose calls were captured
+ * once -- here and in every entry point that needs the host-side state (mrhip_next_output_count, mrhip_outputlength,
+ * mrhip_get_state, a synchronous mrhip_filt_*) -- is refused with MRHIP_ERR_UNSUPPORTED (-1 from the counting functions). */
 int mrhip_sync_state(mrhip_filter *f, int64_t *last_n_written);
 /* Streaming helper: exactly the sequence of filt!(buffer, self, x[a:a+chunk]) calls a caller would make
  * over consecutive `chunk`-sample pieces of a device-resident signal, issued back to back by the library (one host

@@ -141,12 +141,36 @@ int alloc_common(mrhip_filter *f)
 
 // Is `stream` being captured into a HIP graph?  (The legacy null stream cannot be; while another stream captures in
 // global mode the query itself fails for it, which means "no".)
+// (the streams the library has seen capturing are remembered: any_capture_active)
+static std::mutex g_capture_mutex;
+static std::vector<hipStream_t> g_capture_streams;
+
 bool stream_is_capturing(hipStream_t stream)
 {
     if (!stream) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return cs == hipStreamCaptureStatusActive;
+    if (cs != hipStreamCaptureStatusActive) return false;
+    std::lock_guard<std::mutex> g(g_capture_mutex);
+    if (std::find(g_capture_streams.begin(), g_capture_streams.end(), stream) == g_capture_streams.end()) g_capture_streams.push_back(stream);
+    return true;
+}
+
+// Is a stream the library has been called on still being captured?  A device-wide wait (what the host-side view of a filter whose calls
+// were captured once needs: its replays run on streams the library never saw) would invalidate that capture -- in the relaxed capture
+// mode too, as measured: rec_pull refuses instead.
+bool any_capture_active_impl()
+{
+    std::lock_guard<std::mutex> g(g_capture_mutex);
+    bool active = false;
+    for (size_t i = 0; i < g_capture_streams.size();) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool ok = hipStreamIsCapturing(g_capture_streams[i], &cs) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        if (ok && cs == hipStreamCaptureStatusActive) { active = true; ++i; }
+        else g_capture_streams.erase(g_capture_streams.begin() + static_cast<long>(i));    // (ended, or the stream is gone)
+    }
+    return active;
 }
 
 // Order this call after whatever the filter enqueued before on another stream (see mrhip_filter::last_stream).
@@ -157,7 +181,7 @@ int adopt_stream(mrhip_filter *f, hipStream_t stream)
             MRHIP_CHECK_HIP(hipStreamWaitEvent(stream, f->xs_event, 0));
         } else {                       // the earlier stream no longer exists: everything on the device is older
             (void)hipGetLastError();
-            MRHIP_CHECK_HIP(hipDeviceSynchronize());
+            MRHIP_CHECK_HIP(device_sync_relaxed());
         }
     }
     f->last_stream = stream;
@@ -170,7 +194,7 @@ int drain_filter(mrhip_filter *f)
 {
     if (f->last_stream_valid && hipStreamSynchronize(f->last_stream) != hipSuccess) {
         (void)hipGetLastError();
-        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        MRHIP_CHECK_HIP(device_sync_relaxed());
     }
     return MRHIP_OK;
 }
@@ -308,6 +332,8 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
 }
 
 }  // namespace
+
+bool any_capture_active() { return any_capture_active_impl(); }
 }  // namespace mrhip
 
 using namespace mrhip;
@@ -541,7 +567,7 @@ void mrhip_destroy(mrhip_filter *f)
     if (f->ring) (void)ring_shutdown(f->ring);
     DeviceGuard guard(f->device);
     ring_cache_free(f);
-    if (f->captured) (void)hipDeviceSynchronize();   // replays of a graph that holds this filter's calls ran on streams the library never saw
+    if (f->captured) (void)device_sync_relaxed();   // replays of a graph that holds this filter's calls ran on streams the library never saw
     (void)drain_filter(f);                       // this filter's work only; other streams of the process keep running
     for (hipStream_t st : {f->own_stream, f->s_in, f->s_out})
         if (st) (void)hipStreamSynchronize(st);
@@ -579,7 +605,7 @@ static int chain_event_now(mrhip_filter *f)
         MRHIP_CHECK_HIP(hipStreamWaitEvent(f->s_sched, f->ev_chain, 0));
     } else {
         (void)hipGetLastError();
-        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        MRHIP_CHECK_HIP(device_sync_relaxed());
     }
     f->chain_pending = false;
     return MRHIP_OK;
@@ -604,7 +630,7 @@ static int push_state(mrhip_filter *f)
     hipStream_t s = f->last_stream_valid ? f->last_stream : f->own_stream;
     if (rec_push(f, s) != MRHIP_OK) {
         (void)hipGetLastError();
-        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        MRHIP_CHECK_HIP(device_sync_relaxed());
         s = f->own_stream;
         if (int rc = rec_push(f, s)) return rc;
     }
@@ -792,13 +818,13 @@ int mrhip_set_history(mrhip_filter *f, const void *host_in)
         // the stream of the filter's last call no longer exists (the caller destroyed it): everything it carried has
         // either run or gone with it -- order behind the whole device once and carry on on the filter's own stream
         (void)hipGetLastError();
-        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        MRHIP_CHECK_HIP(device_sync_relaxed());
         s = f->own_stream;
         MRHIP_CHECK_HIP(hipMemcpyAsync(f->d_hist[f->hist_cur], host_in, bytes, hipMemcpyHostToDevice, s));
     }
     if (hipStreamSynchronize(s) != hipSuccess) {
         (void)hipGetLastError();
-        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        MRHIP_CHECK_HIP(device_sync_relaxed());
         s = f->own_stream;
     }
     f->last_stream = s; f->last_stream_valid = true;
@@ -844,7 +870,7 @@ int mrhip_reset(mrhip_filter *f)
         // the stream of the filter's last call no longer exists (torch side streams come and go): like adopt_stream,
         // order behind the whole device once and carry on on the filter's own stream
         (void)hipGetLastError();
-        MRHIP_CHECK_HIP(hipDeviceSynchronize());
+        MRHIP_CHECK_HIP(device_sync_relaxed());
         s = f->own_stream;
         MRHIP_CHECK_HIP(zero_on(s));
     }
@@ -869,7 +895,7 @@ int mrhip_reset(mrhip_filter *f)
         // whole device once, on the filter's own stream
         if (rec_push(f, s, -1, -1, f->d_counters) != MRHIP_OK) {
             (void)hipGetLastError();
-            MRHIP_CHECK_HIP(hipDeviceSynchronize());
+            MRHIP_CHECK_HIP(device_sync_relaxed());
             f->last_stream = f->own_stream;
             return rec_push(f, f->own_stream, -1, -1, f->d_counters);
         }

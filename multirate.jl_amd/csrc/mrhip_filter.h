@@ -200,8 +200,24 @@ void rec_free(mrhip_filter *f);
 int rec_push(mrhip_filter *f, hipStream_t s, long long call_n_out = -1, long long n_written = -1, unsigned *zero_counters = nullptr);
 // wait for everything enqueued on the filter's behalf and take the device record over into the host fields
 int rec_pull(mrhip_filter *f);
+// api.hip: is a stream the library has been called on still being captured into a graph?
+bool any_capture_active();
 hipError_t launch_poly_plan(mrhip_filter *f, int64_t x_len, long long P, long long y_capacity, long long *count_out, hipStream_t s, const DevCall *x_from = nullptr);
 }  // namespace mrhip
+// hipDeviceSynchronize as the library uses it: the wait for work on streams it never saw (replays of a graph that holds a filter's
+// calls; whatever ran on a stream that no longer exists).  While ANOTHER stream of the process is being captured in the global mode
+// (torch.cuda.graph's default) a plain hipDeviceSynchronize from any thread is an "unsafe call" and invalidates that capture: the
+// calling thread switches to the relaxed mode for the one call (mrhip_next_output_count on a filter that was once captured,
+// issued while another filter's stream was being captured, killed the capture).
+inline hipError_t device_sync_relaxed()
+{
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+    const hipError_t e = hipDeviceSynchronize();
+    if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
+    return e;
+}
+
 // The history slot the next call WRITES (the slots 0 and 1 ping-pong; slot 2 holds zeros and is what reset() makes current instead of
 // zeroing a slot: read-only until a captured call adopts it as its in-place slot -- after which reset() zeroes the current slot itself)
 inline int hist_other(const mrhip_filter *f) { return f->hist_cur == 2 ? 0 : f->hist_cur ^ 1; }

@@ -166,11 +166,16 @@ int rec_push(mrhip_filter *f, hipStream_t s, long long call_n_out, long long n_w
 int rec_pull(mrhip_filter *f)
 {
     // graph replays run on streams the library never saw: after a capture only the whole device is a safe wait
-    if (f->captured) MRHIP_CHECK_HIP(hipDeviceSynchronize());
+    if (f->captured) {
+        if (any_capture_active())
+            return fail(MRHIP_ERR_UNSUPPORTED, "a stream is being captured: the host-side state of a filter whose calls were captured once needs a device-wide wait (its "
+                                               "replays run on streams the library never saw), which would invalidate that capture -- ask before the capture begins or after it ends");
+        MRHIP_CHECK_HIP(device_sync_relaxed());
+    }
     else {
         if (f->last_stream_valid && hipStreamSynchronize(f->last_stream) != hipSuccess) {
             (void)hipGetLastError();
-            MRHIP_CHECK_HIP(hipDeviceSynchronize());
+            MRHIP_CHECK_HIP(device_sync_relaxed());
         }
         if (f->s_sched) MRHIP_CHECK_HIP(hipStreamSynchronize(f->s_sched));
     }

@@ -91,6 +91,58 @@ def test_graph_capture_rational_chunk_that_advances_the_state(pkg, O, torch_cuda
     f.close()
 
 
+def test_once_captured_filter_does_not_break_another_filters_capture(pkg, O, torch_cuda):
+    """ADVICE r4 / VERDICT r5 item 7: a filter whose calls were captured once waits for the whole DEVICE whenever the host needs its state
+    (replays run on streams the library never saw) -- and a plain hipDeviceSynchronize issued while ANOTHER stream is being captured in
+    the global mode (torch.cuda.graph's default) is an unsafe call that invalidates that capture.  The library's device waits now run in
+    the relaxed capture mode of the calling thread where they must happen, and -- measured: hipDeviceSynchronize invalidates a capture
+    in that mode too -- are REFUSED while a stream the library has been called on is still capturing: filter B (captured and replayed
+    earlier) is asked for its state while filter A's stream is capturing: MRHIP_ERR_UNSUPPORTED, A's capture survives and replays
+    correctly, B answers once the capture is over."""
+    torch = torch_cuda
+    L, M, chunk, nch = 147, 160, 50_003, 2
+    h = pkg.firdes(24 * L, 0.5 / L, beta=7.8562).astype(np.float32)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.rand((nch, chunk * 6), generator=gen, device="cuda", dtype=torch.float32) - 0.5
+    xh = x.cpu().numpy()
+    # B: captured and replayed first (its `captured` flag is set for good)
+    fb = pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nch)
+    outs_b, counts_b = _graph_stream(torch, fb, x, chunk, 3)
+    # A: captured now; in the middle of the capture B is used from the host
+    fa = pkg.FIRFilter(h, Fraction(L, M)).bind(np.float32, nch)
+    bound = fa.outputlength_bound(chunk)
+    xs = torch.zeros((nch, chunk), dtype=torch.float32, device="cuda")
+    ys = torch.zeros((nch, bound), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=s):                                  # (capture_error_mode: the default, "global")
+        fa.filt_into_async(ys, xs, cnt)
+        # -> fresh() -> the device-wide wait of a once-captured filter: refused while a capture is active (nothing unsafe is issued)
+        with pytest.raises(pkg.MultirateHIPError, match="being captured"):
+            fb.sync_state()
+        assert fb.next_output_count(chunk) == -1
+    nb = fb.next_output_count(chunk)                                     # (the capture is over)
+    fo_b = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
+    ref_b = _oracle_chunks(fo_b, xh[0], chunk, 4)
+    assert counts_b == [len(v) for v in ref_b[:3]] and nb == len(ref_b[3])
+    # A's graph is intact: replays == the oracle's chunk loop
+    fo_a = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
+    for rep in range(4):
+        xs.copy_(x[:, rep * chunk:(rep + 1) * chunk])
+        g.replay()
+        torch.cuda.synchronize()
+        ref = fo_a.filt(xh[nch - 1, rep * chunk:(rep + 1) * chunk])
+        c = int(cnt.item())
+        assert c == len(ref)
+        assert_bit_equal(ys[nch - 1, :c].cpu().numpy(), ref, f"replay {rep} of the graph captured while another filter was used")
+    # and B goes on where its replays left it
+    yb = fb.filt(x[:, 3 * chunk:4 * chunk]).cpu().numpy()
+    assert_bit_equal(yb[0], ref_b[3], "the once-captured filter's next plain call")
+    fa.close(); fb.close()
+
+
 @pytest.mark.parametrize("L,M,tx,chunk,ncalls", [(1, 4, np.complex64, 10_007, 3), (3, 17, np.float64, 4_099, 2), (1, 1, np.float32, 5_001, 2),
                                                  (4, 1, np.float32, 3_001, 2), (2, 13, np.float32, 7_919, 1),
                                                  (1, 20, np.float32, 10_007, 3), (1, 37, np.complex64, 9_001, 2)])
