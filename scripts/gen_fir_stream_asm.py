@@ -29,7 +29,10 @@ M, BS, T = 4, 8, 128
 NB = T // BS
 XBUF = (32, 48)                 # first VGPR of the two sample buffers (16 registers each: 8 complex samples)
 TBUF = (68, 76, 84)             # first SGPR of the three tap buffers (8 taps each)
-V_CLOB = range(32, 64)
+ACC = {0: (64, 66), 1: (68, 70)}   # (sum, product) of output 0 / 1, in fixed registers of DIFFERENT banks (register number mod 4): left
+                                     # to the allocator, sum and product of an output landed on the same two banks and every
+                                     # v_pk_add_f32 read both operands from them -- the statement ran 11 % slower than the compiler's loop
+V_CLOB = range(32, 72)
 S_CLOB = range(68, 92)
 
 
@@ -64,7 +67,7 @@ def gen(fused):
     def mac(out, xbuf, e, tbuf, tidx):
         x = f"v[{XBUF[xbuf] + 2 * e}:{XBUF[xbuf] + 2 * e + 1}]"
         pair, mod = tap_operand(tbuf, tidx, fused and started[out])
-        acc, tmp = f"%[a{out}]", f"%[t{out}]"
+        acc, tmp = f"v[{ACC[out][0]}:{ACC[out][0] + 1}]", f"v[{ACC[out][1]}:{ACC[out][1] + 1}]"
         if not started[out]:                                  # the first product initialises
             emit(f"v_pk_mul_f32 {acc}, {x}, {pair} {tap_operand(tbuf, tidx, False)[1]}")
             started[out] = True
@@ -102,11 +105,13 @@ def gen(fused):
     for e in range(M):
         for a in mac(1, xb, e, (NB - 1) % 3, e + M):
             emit(a)
+    emit(f"v_mov_b64 %[a0], v[{ACC[0][0]}:{ACC[0][0] + 1}]")
+    emit(f"v_mov_b64 %[a1], v[{ACC[1][0]}:{ACC[1][0] + 1}]")
     body = "\n".join(f'        "{ln}\\n\\t"' for ln in lines)
     clob = ", ".join([f'"v{i}"' for i in V_CLOB] + [f'"s{i}"' for i in S_CLOB])
     return (f"    if constexpr (FUSED_ == {'true' if fused else 'false'}) {{\n"
             f"        asm volatile(\n{body}\n"
-            f'        : [a0] "=&v"(a0), [a1] "=&v"(a1), [t0] "=&v"(t0), [t1] "=&v"(t1)\n'
+            f'        : [a0] "=&v"(a0), [a1] "=&v"(a1)\n'
             f'        : [ad] "v"(lds_addr), [tp] "s"(taps)\n'
             f'        : {clob}, "memory");\n'
             f"    }}\n")
@@ -114,7 +119,7 @@ def gen(fused):
 
 def render():
     return ("// GENERATED by scripts/gen_fir_stream_asm.py -- do not edit; see that script for what the statements do and why they are assembly.\n"
-            "// Included inside stream_pair_c64_m4_t128<FUSED_>(lds_addr, taps, a0, a1) with `v2f_t t0, t1;` declared.\n"
+            "// Included inside stream_pair_c64_m4_t128<FUSED_>(lds_addr, taps, a0, a1).\n"
             + gen(False) + gen(True))
 
 

@@ -73,6 +73,17 @@ def test_lane_kernel_uses_no_scratch_and_its_statements_are_the_generators(pkg):
     assert not {k: v for k, v in sizes.items() if v != 0}, sizes
 
 
+def test_stream_pair_statements_are_the_generators(pkg):
+    """fir_stream_kernel's hand-scheduled pair for config 3b's shape (fir_stream_pair_c64_m4.inc) is generated: the committed file must be
+    what scripts/gen_fir_stream_asm.py writes; its sample buffers and sums live in fixed VGPRs below 72 (the kernel keeps 7 waves per SIMD)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_fir_stream_asm", os.path.join(ROOT, "scripts", "gen_fir_stream_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(os.path.join(CSRC, "fir_stream_pair_c64_m4.inc")).read() == gen.render(), "fir_stream_pair_c64_m4.inc is stale: run scripts/gen_fir_stream_asm.py"
+    assert max(gen.V_CLOB) < 72 and len(set(a % 4 for pair in gen.ACC.values() for a in pair)) == 2     # sums and products on different banks
+
+
 @pytest.mark.gpu
 def test_instantiations_with_scratch_are_bit_exact_on_the_gpu():
     """The older hand-scheduled kernels (output-pair, streaming) have instantiations that do use scratch memory: each one, read

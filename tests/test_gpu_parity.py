@@ -1346,6 +1346,41 @@ def test_arb_pipe_exact_32_taps(pkg, O, torch_cuda, monkeypatch):
                     assert_bit_equal(ys["exact"][0][nch - 1], yo, "unrolled vs oracle " + tag)
 
 
+def test_stream_kernel_hand_scheduled_pair_config3b(pkg, O, torch_cuda, monkeypatch):
+    """fir_stream_kernel's hand-scheduled pair of outputs for BASELINE config 3b's shape (FIRDecimator 1//4, 128 Float32 taps, ComplexF32
+    samples; fir_stream_pair_c64_m4.inc): STRICT and FUSED, several channels, chunkings that put the start-from-zero seam (support.jl:46,
+    the C++ path) and the hand-scheduled tiles into one stream, -0.0 / +-Inf / NaN samples -- bit for bit the universal kernel's and
+    (STRICT) the oracle's outputs, end state and history."""
+    torch = torch_cuda
+    rng = np.random.default_rng(3404)
+    h = (rng.standard_normal(128) / 8).astype(np.float32)
+    nch, n = 5, 300_000
+    x = (rng.standard_normal((nch, n)) + 1j * rng.standard_normal((nch, n))).astype(np.complex64)
+    flat = x.view(np.float32)
+    flat[0, 10] = -0.0; flat[0, 2001] = np.inf; flat[1, 2003] = -np.inf; flat[2, 150_001] = np.nan
+    xd = torch.from_numpy(x).cuda()
+    sizes = [3, 100_001, 1, 126, 131, n - 100_262]
+    for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
+        got = {}
+        for mode, env in (("hand", {}), ("generic", {"MRHIP_FORCE_GENERIC": "1"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            f = pkg.FIRFilter(h, Fraction(1, 4), numerics=numerics)
+            y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+            got[mode] = (y, f.last_kernel_name(), (f.state.phiIdx, f.state.inputDeficit), np.array(f.history))
+            f.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        assert got["hand"][1] == "fir_stream_kernel" and got["generic"][1] != "fir_stream_kernel", (got["hand"][1], got["generic"][1])
+        assert_bit_equal(got["hand"][0], got["generic"][0], f"hand-scheduled pair vs universal kernel, numerics {numerics}")
+        assert got["hand"][2] == got["generic"][2]
+        assert_bit_equal(got["hand"][3], got["generic"][3], "history")
+        if numerics == pkg.NUMERICS_STRICT:
+            for c in (0, 2, nch - 1):
+                fo = O.FIRFilter(h, Fraction(1, 4), tx=np.complex64)
+                assert_bit_equal(got["hand"][0][c], np.concatenate(_run_chunks(fo, x[c], sizes)), f"hand-scheduled pair vs oracle, channel {c}")
+
+
 def test_arb_lane_kernel_float64_lane_per_channel(pkg, O, torch_cuda, monkeypatch):
     """arb_lane_kernel (kernels_arb_lane.hip; BASELINE config 4's shape: Float64 samples, 32 taps per phase, 64 channels, rate >= 1): a lane
     per channel, taps by scalar loads into SGPR operands, two outputs per window, samples through an LDS ring.  Outputs, end state and
