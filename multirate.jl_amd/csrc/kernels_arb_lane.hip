@@ -209,29 +209,52 @@ __device__ __forceinline__ void lane_stretch(const ArbArgs &a, const ArbLaneArgs
     // -- this wave's pair of step l / 2 -- and the input index of step l's LAST output (which blocks the step needs); a step takes them
     // with v_readlane.  (Read per step by scalar loads they cost a trip to HBM every step: the schedule streams, every step's entries are a
     // new cache line -- 3 100 cycles a step outside the pair's statement; profiles/r06/experiments.md.)
-    int ent_n, ent_last;
-    double ent_acc;
-    {
-        long long kk = k0 + kLaneStep * (lane >> 1) + 2 * wv + (lane & 1);
+    // A stretch may be a CHUNK of several consecutive 512-output stretches (the hand-out gives out runs of them: the ring carries on, no
+    // window is staged twice, and the next run's entries are requested 28 steps before they are needed -- starting a stretch from
+    // nothing costs ~4 us of dependent trips to HBM, 2.7 % of a 512-output stretch): entries of the run of 32 steps in hand (`ent_*`)
+    // and of the next one (`nxt_*`).
+    struct Entries { int n, last, phi; double alpha; };
+    auto load_entries = [&](int run, int &n_, double &acc_, int &last_) {       // (plain vector loads: waited for at their first use)
+        long long kk = k0 + static_cast<long long>(run) * (32 * kLaneStep) + kLaneStep * (lane >> 1) + 2 * wv + (lane & 1);
         if (kk >= k1) kk = k1 - 1;
-        long long kl = k0 + static_cast<long long>(kLaneStep) * lane + kLaneStep - 1;
+        long long kl = k0 + static_cast<long long>(run) * (32 * kLaneStep) + static_cast<long long>(kLaneStep) * lane + kLaneStep - 1;
         if (kl >= k1) kl = k1 - 1;
-        ent_n = a.n_idx[kk];
-        ent_acc = a.acc[kk];
-        ent_last = a.n_idx[kl];
-    }
-    // phase (0-based PFB column) and alpha of the lane's output, once per stretch (src/Filters.jl:671-672)
-    const double ent_phif = __builtin_floor(ent_acc);
-    const int ent_phi = static_cast<int>(ent_phif) - 1;
-    const double ent_alpha = ent_acc - ent_phif;
+        n_ = a.n_idx[kk];
+        acc_ = a.acc[kk];
+        last_ = a.n_idx[kl];
+    };
+    auto finish_entries = [](int n_, double acc_, int last_) {                 // phase (0-based PFB column) and alpha, src/Filters.jl:671-672
+        Entries e;
+        const double phif = __builtin_floor(acc_);
+        e.n = n_; e.last = last_; e.phi = static_cast<int>(phif) - 1; e.alpha = acc_ - phif;
+        return e;
+    };
+    Entries ent, nxt;
+    int raw_n = 0, raw_last = 0;
+    double raw_acc = 0.0;
+    load_entries(0, raw_n, raw_acc, raw_last);
+    ent = finish_entries(raw_n, raw_acc, raw_last);
+    nxt = ent;
+    const int nruns = (nsteps + 31) / 32;
+    if (nruns > 1) load_entries(1, raw_n, raw_acc, raw_last);
+    int run_of_ent = 0;                                         // `ent` holds the entries of steps 32 run_of_ent ... + 31, `nxt` (once finished) the run after
+    bool nxt_ready = false;
     auto lane_i = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
     auto lane_d = [](double v, int l) {
         const v2u_t b = __builtin_bit_cast(v2u_t, v);
         const v2u_t r = {static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(b.x), l)), static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(b.y), l))};
         return __builtin_bit_cast(double, r);
     };
+    // entries of (global) step t: t lies in the run in hand or in the next one
+    auto take_next = [&]() { if (!nxt_ready) { nxt = finish_entries(raw_n, raw_acc, raw_last); nxt_ready = true; } };
     // E(t): the ring must hold every block below E(t) before step t's windows are read
-    auto E = [&](int t) { return (lane_i(ent_last, t) + RING + kLaneBlock - 1) / kLaneBlock; };
+    auto E = [&](int t) {
+        const int l = t - 32 * run_of_ent;
+        int last;
+        if (l < 32) last = lane_i(ent.last, l);
+        else { take_next(); last = lane_i(nxt.last, l - 32); }
+        return (last + RING + kLaneBlock - 1) / kLaneBlock;
+    };
     // what the pair's statement of step s_ takes: the window's LDS address, the four tap columns, alpha of both outputs, and whether the
     // second window starts a sample later.  Prepared BEHIND the statement of the step before, in front of the barrier: a wave that
     // leaves the barrier goes straight into its statement.
@@ -239,9 +262,18 @@ __device__ __forceinline__ void lane_stretch(const ArbArgs &a, const ArbLaneArgs
     struct PairIn { unsigned addr; cdouble_t tl0, tu0, tl1, tu1; double alpha0, alpha1; bool apart; };
     auto prepare = [&](int s_) {
         PairIn q;
-        const int n0 = lane_i(ent_n, 2 * s_), n1 = lane_i(ent_n, 2 * s_ + 1);
-        const int phi0 = lane_i(ent_phi, 2 * s_), phi1 = lane_i(ent_phi, 2 * s_ + 1);
-        q.alpha0 = lane_d(ent_alpha, 2 * s_); q.alpha1 = lane_d(ent_alpha, 2 * s_ + 1);
+        int l = s_ - 32 * run_of_ent;
+        if (l >= 32) {                                          // (uniform) the next run begins: its entries become the ones in hand, the run after it is requested
+            take_next();
+            ent = nxt;
+            ++run_of_ent;
+            nxt_ready = false;
+            if (run_of_ent + 1 < nruns) load_entries(run_of_ent + 1, raw_n, raw_acc, raw_last);
+            l -= 32;
+        }
+        const int n0 = lane_i(ent.n, 2 * l), n1 = lane_i(ent.n, 2 * l + 1);
+        const int phi0 = lane_i(ent.phi, 2 * l), phi1 = lane_i(ent.phi, 2 * l + 1);
+        q.alpha0 = lane_d(ent.alpha, 2 * l); q.alpha1 = lane_d(ent.alpha, 2 * l + 1);
         const unsigned r0 = (static_cast<unsigned>(n0 - T) + URING) % URING;                  // (ring coordinate = sample index + RING)
         q.addr = ring_row + r0 * 8u;
         q.tl0 = pfb + phi0 * T; q.tu0 = dpfb + phi0 * T; q.tl1 = pfb + phi1 * T; q.tu1 = dpfb + phi1 * T;
@@ -321,25 +353,44 @@ __global__ __launch_bounds__(kLaneThreads, 4) void arb_lane_kernel(ArbArgs a, Ar
 {
     static_assert(T >= 2 && T <= kLaneMirror, "a window of T + 1 samples lies inside ring + mirror");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned s_item;
+    __shared__ unsigned s_item[2];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long n_out = a.dyn ? a.dyn->n_out : a.n_out;     // (a device-planned call: the count from the call record)
     const long long STRETCH = la.stretch;
-    const long long items = (n_out + STRETCH - 1) / STRETCH * la.ngroups;
+    const long long NS = (n_out + STRETCH - 1) / STRETCH;       // stretches per channel group
+    const long long total = NS * la.ngroups;                    // ... in all, group by group: index i = group i / NS, stretch i % NS
     unsigned *const ctr = la.counters;
     const long long G = gridDim.x;
+    const long long CMAX = la.chunk_max;
 
-    for (long long item = blockIdx.x; item < items;) {
-        const long long sigma = item / la.ngroups;
-        const int grp = static_cast<int>(item - sigma * la.ngroups);
-        const long long k0 = sigma * STRETCH;
-        const long long k1 = k0 + STRETCH < n_out ? k0 + STRETCH : n_out;
-        lane_stretch<FUSED, T>(a, la, smem, lane, wv, grp * 64, k0, k1);
-        if (tid == 0) s_item = atomicAdd(ctr, 1u);
-        lane_barrier();                                        // every window of this stretch is read, every tile stored from; the next item
-        item = G + uniform_ll(static_cast<long long>(s_item));
+    // Chunks of consecutive stretches are handed out from the counter, large first and smaller towards the end (each workgroup asks for
+    // 1/(2 G) of what it believes is left, at most chunk_max, at least one): inside a chunk the ring carries on from stretch to stretch.
+    long long seen = 0;                                         // the counter as this workgroup last saw it
+    for (;;) {
+        if (tid == 0) {
+            long long c = (total - seen) / (2 * G);
+            c = c < 1 ? 1 : (c > CMAX ? CMAX : c);
+            s_item[0] = atomicAdd(ctr, static_cast<unsigned>(c));
+            s_item[1] = static_cast<unsigned>(c);
+        }
+        lane_barrier();                                        // (also: every window of the chunk before is read, every tile stored from)
+        long long first = uniform_ll(static_cast<long long>(s_item[0]));
+        long long count = uniform_ll(static_cast<long long>(s_item[1]));
+        lane_barrier();                                        // (s_item is read by everyone before it is written again)
+        if (first >= total) break;
+        seen = first + count;
+        if (first + count > total) count = total - first;
+        while (count > 0) {                                     // (a chunk that crosses into the next channel group: two pieces)
+            const long long grp = first / NS, sigma = first - grp * NS;
+            const long long here = sigma + count <= NS ? count : NS - sigma;
+            const long long k0 = sigma * STRETCH;
+            const long long k1 = k0 + here * STRETCH < n_out ? k0 + here * STRETCH : n_out;
+            lane_stretch<FUSED, T>(a, la, smem, lane, wv, static_cast<int>(grp) * 64, k0, k1);
+            first += here; count -= here;
+            if (count > 0) lane_barrier();
+        }
     }
     // every workgroup counts itself off; the last one re-arms the counters for the next launch (stream order makes it visible)
     if (tid == 0) {
@@ -365,7 +416,7 @@ hipError_t launch_lane_t(bool fused, const ArbArgs &a, const ArbLaneArgs &la, si
         if (bpc > 0 && bpc < per_cu) per_cu = bpc;
         const long long items = (a.n_out + la.stretch - 1) / la.stretch * la.ngroups;
         long long g = static_cast<long long>(num_cus) * per_cu;
-        if (g > items) g = items;
+        if (g > items) g = items;                               // (workgroups beyond the stretches would only ask the counter and leave)
         if (g < 1) g = 1;
         if (MRHIP_ENV_INT("MRHIP_DEBUG", 0) == 1) {
             hipFuncAttributes fa;
@@ -426,6 +477,7 @@ bool plan_arb_lane(const TypeKey &tk, const ArbArgs &a, double rate, ArbLaneArgs
     if (stretch > 32 * kLaneStep) stretch = 32 * kLaneStep;    // (a wave holds its 64 schedule entries of a stretch in one register)
     la.stretch = stretch / kLaneStep * kLaneStep;
     la.ngroups = (a.nch + 63) / 64;
+    la.chunk_max = std::max(1, std::min(8, MRHIP_ENV_INT("MRHIP_LANE_CHUNK", 8)));       // (8 x 512 outputs: step counts and offsets stay small)
     la.y16 = (reinterpret_cast<uintptr_t>(a.y) % 16 == 0) && (a.y_stride % 2 == 0);
     *out = la;
     *lds = static_cast<size_t>(64) * la.pitch8 * 8 + 2 * 64 * kLaneOutRow;

@@ -588,6 +588,7 @@ struct ArbLaneArgs {
     int ring;                // samples per channel in the ring (a multiple of 16, >= the history length)
     int pitch8;              // 8-byte units between the channel rows of the ring: ring + mirror, odd
     int stretch;             // outputs per stretch (a multiple of 16)
+    int chunk_max;           // most consecutive stretches handed out at once (the ring carries on inside a chunk)
     int ngroups;             // groups of 64 channels
     int y16;                 // 16-byte stores into y are aligned
     unsigned *counters;      // [0] stretches handed out beyond the first grid-full, [64] workgroups through (zero between launches)
