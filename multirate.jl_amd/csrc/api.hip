@@ -283,6 +283,11 @@ hipError_t launch_opair_blocks(mrhip_filter *f, const TypeKey &tk, bool fused, c
     return e;
 }
 
+}  // namespace
+// kernels_interp_lane.hip: FIRInterpolator 4//1, 32 taps per phase, ComplexF32: a lane per channel (plans and launches; false: not its call)
+bool try_launch_interp_lane(const TypeKey &tk, bool fused, const PolyArgs &a, unsigned *counters, hipStream_t s, const char **kname, int num_cus, hipError_t *err);
+namespace {
+
 // Kernel selection for the rational family.  Tuned kernels are tried first; the universal
 // one-thread-per-output kernel accepts everything.
 hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, const PolyArgs &a, hipStream_t s,
@@ -300,6 +305,10 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
                 *did_shiftin = a.H > 0;          // its loader waves write the call-end history themselves
                 return launch_fir_stream(fused, a, spa, sblock, slds, s, kname, f->num_cus, counters);
             }
+        }
+        {
+            hipError_t el = hipSuccess;           // (shiftin! and the record are the caller's: did_shiftin / rec_written stay false)
+            if (try_launch_interp_lane(tk, fused, a, counters, s, kname, f->num_cus, &el)) return el;
         }
         {
             PairArgs pa;

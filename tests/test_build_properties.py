@@ -73,6 +73,29 @@ def test_lane_kernel_uses_no_scratch_and_its_statements_are_the_generators(pkg):
     assert not {k: v for k, v in sizes.items() if v != 0}, sizes
 
 
+def test_interp_lane_kernel_uses_no_scratch_and_its_statements_are_the_generators(pkg):
+    """interp_lane_kernel (kernels_interp_lane.hip) keeps its channels' sliding window in 78 VGPRs next to the unit of samples in flight:
+    at three waves per SIMD (168 VGPRs) nothing may spill (at four, 128, it does: 3.9 ms against 2.85 on config 3a).  Its statements
+    (interp_lane_quad.inc) are generated: the committed file must be what scripts/gen_interp_lane_asm.py writes; a phase's sum and
+    product sit on different VGPR banks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_interp_lane_asm", os.path.join(ROOT, "scripts", "gen_interp_lane_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(os.path.join(CSRC, "interp_lane_quad.inc")).read() == gen.render(), "interp_lane_quad.inc is stale: run scripts/gen_interp_lane_asm.py"
+    for p in range(4):
+        acc, tmp = gen.acc_reg(4, p)
+        assert (acc % 4 < 2) != (tmp % 4 < 2), (p, acc, tmp)
+    obj = os.path.join(CSRC, "build", "kernels_interp_lane.hip.o")
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("no built object (the library came prebuilt) or no llvm tools")
+    if os.path.getmtime(obj) < max(os.path.getmtime(os.path.join(CSRC, f)) for f in ("kernels_interp_lane.hip", "interp_lane_quad.inc")):
+        pytest.skip("object older than its source")
+    sizes = {k: v for k, v in _kernel_scratch(obj).items() if "interp_lane_kernel" in k}
+    assert len(sizes) == 2, f"expected STRICT and FUSED, found {sorted(sizes)}"
+    assert not {k: v for k, v in sizes.items() if v != 0}, sizes
+
+
 def test_stream_pair_statements_are_the_generators(pkg):
     """fir_stream_kernel's hand-scheduled pair for config 3b's shape (fir_stream_pair_c64_m4.inc) is generated: the committed file must be
     what scripts/gen_fir_stream_asm.py writes; its sample buffers and sums live in fixed VGPRs below 72 (the kernel keeps 7 waves per SIMD)."""

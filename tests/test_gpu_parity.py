@@ -1381,6 +1381,79 @@ def test_stream_kernel_hand_scheduled_pair_config3b(pkg, O, torch_cuda, monkeypa
                 assert_bit_equal(got["hand"][0][c], np.concatenate(_run_chunks(fo, x[c], sizes)), f"hand-scheduled pair vs oracle, channel {c}")
 
 
+def test_interp_lane_kernel_config3a_window_in_registers(pkg, O, torch_cuda, monkeypatch):
+    """interp_lane_kernel (kernels_interp_lane.hip; BASELINE config 3a's shape: FIRInterpolator 4//1, 32 taps per phase, ComplexF32 samples x
+    Float32 taps): a lane per channel, one wave per stretch, the sliding window in registers, taps as SGPR operands, samples and outputs
+    transposed through the wave's own LDS patch.  Outputs and history bit for bit those of rational_opair_kernel, of the universal kernel
+    and (STRICT) of the oracle: full, several and partial channel groups, chunkings whose calls are not multiples of 8 inputs (the last
+    block of a stretch is ragged), too short for the kernel (< 64 inputs: the output-pair kernel takes them, the history carries over) or
+    one sample long, x and y given as VIEWS (odd sample offsets: the 8-byte store path; row strides that are not the length), -0.0 /
+    +-Inf / NaN samples.  By default only long calls take the kernel (>= 5e7 channel-samples): checked at config 3a's width."""
+    torch = torch_cuda
+    rng = np.random.default_rng(707)
+    for nch, n in ((64, 30_000), (256, 9_000), (50, 9_000), (113, 9_000)):
+        h = (rng.standard_normal(128) / 4).astype(np.float32)
+        x = (rng.standard_normal((nch, n)) + 1j * rng.standard_normal((nch, n))).astype(np.complex64)
+        flat = x.view(np.float32)
+        flat[0, 10] = -0.0; flat[0, 2001] = np.inf; flat[1, 2003] = -np.inf; flat[2, 5001] = np.nan
+        xbig = torch.zeros((nch, n + 11), dtype=torch.complex64, device="cuda")
+        xbig[:, 3:3 + n] = torch.from_numpy(x).cuda()
+        xd = xbig[:, 3:3 + n]                                   # a view: 8-byte aligned rows, stride n + 11
+        sizes = [3_001, 1, 17, 64, 65, n - 3_148 - 1_003, 1_003]
+        for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
+            got = {}
+            for mode, env in (("lane", {"MRHIP_INTERP_LANE": "2"}), ("opair", {"MRHIP_INTERP_LANE": "0"}), ("generic", {"MRHIP_FORCE_GENERIC": "1"})):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                f = pkg.FIRFilter(h, Fraction(4, 1), numerics=numerics)
+                ybig = torch.zeros((nch, 4 * n + 9), dtype=torch.complex64, device="cuda")
+                pos, names = 0, set()
+                for sz in sizes:
+                    cnt = f.filt_into(ybig[:, 1 + 4 * pos:1 + 4 * (pos + sz)], xd[:, pos:pos + sz])
+                    assert cnt == 4 * sz
+                    names.add(f.last_kernel_name())
+                    pos += sz
+                got[mode] = (ybig.cpu().numpy(), names, np.array(f.history))
+                f.close()
+                for k in env:
+                    monkeypatch.delenv(k)
+            tag = f"nch={nch} numerics={numerics}"
+            assert got["lane"][1] == {"interp_lane_kernel", "rational_opair_kernel"} and got["opair"][1] == {"rational_opair_kernel"}, (tag, got["lane"][1], got["opair"][1])
+            assert_bit_equal(got["lane"][0], got["generic"][0], "lane vs universal " + tag)      # (the guard columns 0 and 4 n + 1 ... stay zero in both)
+            assert_bit_equal(got["lane"][0], got["opair"][0], "lane vs output-pair " + tag)
+            assert_bit_equal(got["lane"][2], got["generic"][2], "history " + tag)
+            if numerics == pkg.NUMERICS_STRICT:
+                for c in (0, 1, 2, nch - 1):
+                    fo = O.FIRFilter(h, Fraction(4, 1), tx=np.complex64)
+                    assert_bit_equal(got["lane"][0][c, 1:1 + 4 * n], np.concatenate(_run_chunks(fo, x[c], sizes)), f"lane vs oracle ch {c} " + tag)
+    # the default choice: long calls only; and on such a call every output against the output-pair kernel
+    h = pkg.firdes(128, 0.5 / 4, beta=7.8562).astype(np.float32)
+    nch, n = 256, 200_000
+    xd = torch.view_as_complex(torch.rand((nch, n, 2), dtype=torch.float32, device="cuda") - 0.5)
+    ys = {}
+    for mode, env in (("default", {}), ("opair", {"MRHIP_INTERP_LANE": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        f = pkg.FIRFilter(h, Fraction(4, 1))
+        f.filt(xd[:, :10_000])
+        assert f.last_kernel_name() == "rational_opair_kernel"
+        y = f.filt(xd)
+        ys[mode] = (y, f.last_kernel_name())
+        f.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    assert ys["default"][1] == "interp_lane_kernel" and ys["opair"][1] == "rational_opair_kernel"
+    assert torch.equal(torch.view_as_real(ys["default"][0]).view(torch.int32), torch.view_as_real(ys["opair"][0]).view(torch.int32))
+    # what the kernel does not serve stays where it was: other ratios, lengths, sample types, few channels
+    for (ratio, taps, tx, nchs) in ((Fraction(2, 1), 64, np.complex64, 64), (Fraction(4, 1), 64, np.complex64, 64), (Fraction(4, 1), 128, np.float32, 64), (Fraction(4, 1), 128, np.complex64, 16)):
+        monkeypatch.setenv("MRHIP_INTERP_LANE", "2")
+        f = pkg.FIRFilter((rng.standard_normal(taps) / 4).astype(np.float32), ratio)
+        f.filt(torch.from_numpy(_rand(rng, (nchs, 5_000), tx)).cuda())
+        assert f.last_kernel_name() != "interp_lane_kernel", (ratio, taps, tx, nchs)
+        f.close()
+        monkeypatch.delenv("MRHIP_INTERP_LANE")
+
+
 def test_arb_lane_kernel_float64_lane_per_channel(pkg, O, torch_cuda, monkeypatch):
     """arb_lane_kernel (kernels_arb_lane.hip; BASELINE config 4's shape: Float64 samples, 32 taps per phase, 64 channels, rate >= 1): a lane
     per channel, taps by scalar loads into SGPR operands, two outputs per window, samples through an LDS ring.  Outputs, end state and
