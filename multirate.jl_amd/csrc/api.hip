@@ -286,6 +286,8 @@ hipError_t launch_opair_blocks(mrhip_filter *f, const TypeKey &tk, bool fused, c
 }  // namespace
 // kernels_interp_lane.hip: FIRInterpolator 4//1, 32 taps per phase, ComplexF32: a lane per channel (plans and launches; false: not its call)
 bool try_launch_interp_lane(const TypeKey &tk, bool fused, const PolyArgs &a, unsigned *counters, hipStream_t s, const char **kname, int num_cus, hipError_t *err);
+// (kernels_arb_window.hip: FIRArbitrary, Float64, 32 taps per phase, long calls -- a lane per channel, the window in registers)
+bool try_launch_arb_window(const TypeKey &tk, bool fused, const ArbArgs &a, double rate, unsigned *counters, hipStream_t s, const char **kname, int num_cus, hipError_t *err);
 namespace {
 
 // Kernel selection for the rational family.  Tuned kernels are tried first; the universal
@@ -1217,7 +1219,15 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             //  nothing to set up: 1 ch x 1e5 samples 6.7 against 8.6 us, the crossover at 1 ch x 3e5 / 2 ch x 1.5e5; profiles/r05/experiments.md O)
             const bool small_call = cnt * f->nch <= static_cast<int64_t>(MRHIP_ENV_INT("MRHIP_ARB_SMALL_MAX", 150000));
             ArbLaneArgs la;
-            if (!f->force_generic && !small_call && MRHIP_ENV_INT("MRHIP_PIPE_DYNAMIC", 1) != 0 && plan_arb_lane(tk, a, f->rate, &la, &lds)) {
+            const bool lane_ok = !f->force_generic && !small_call && MRHIP_ENV_INT("MRHIP_PIPE_DYNAMIC", 1) != 0;
+            hipError_t ew = hipSuccess;
+            if (lane_ok && sf.hist_new) a.fold = sf;            // (every kernel below folds shiftin! into its last workgroup)
+            if (lane_ok && try_launch_arb_window(tk, fused, a, f->rate, f->d_counters, stream, &f->last_kernel, f->num_cus, &ew)) {
+                // (a long call of config 4's shape: one wave per stretch, the window in registers -- kernels_arb_window.hip)
+                if (sf.hist_new) { did_shiftin = true; hist_in_place = in_place; }
+                MRHIP_CHECK_HIP(ew);
+            }
+            else if (lane_ok && plan_arb_lane(tk, a, f->rate, &la, &lds)) {
                 // (64 channels or more, Float64, a rate >= 1: a lane per channel, the taps in scalar registers -- kernels_arb_lane.hip)
                 la.counters = f->d_counters;
                 if (sf.hist_new) { a.fold = sf; did_shiftin = true; hist_in_place = in_place; }

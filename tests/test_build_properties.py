@@ -18,14 +18,16 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def _kernel_scratch(obj):
-    """{kernel name: private_segment_fixed_size + agpr_count} of the gfx950 code object bundled in a host object file."""
+    """{kernel name: private_segment_fixed_size + agpr_count} of the gfx950 code object bundled in a host object file (the bundle is
+    compressed: --offload-compress; clang-offload-bundler unpacks both kinds)."""
     with tempfile.TemporaryDirectory() as tmp:
-        local = os.path.join(tmp, os.path.basename(obj))
-        shutil.copy(obj, local)
-        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], cwd=tmp, capture_output=True, text=True, timeout=300, check=True)
-        cos = [f for f in os.listdir(tmp) if "amdgcn" in f]
-        assert cos, "no device code object bundled in " + obj
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, cos[0])], capture_output=True, text=True, timeout=300, check=True).stdout
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "co.o")
+        got = subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(tmp, "copy.o")], capture_output=True, text=True, timeout=300)
+        assert got.returncode == 0 and os.path.exists(fat), "no device code bundled in " + obj      # (a host-only unit: check_spilling_instantiations.py skips it)
+        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co],
+                       capture_output=True, text=True, timeout=300, check=True)
+        assert os.path.getsize(co) > 0, "no device code object bundled in " + obj
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, timeout=300, check=True).stdout
     out = {}
     for entry in notes.split("\n  - .agpr_count")[1:]:
         name = re.search(r"\n    \.name:\s+(\S+)", entry)
@@ -51,6 +53,16 @@ def test_pipe_kernels_use_no_scratch(pkg, src, kernel):
     assert len(sizes) >= 12, f"expected the instantiations of {kernel} in the object, found {len(sizes)}"
     spilling = {k: v for k, v in sizes.items() if v != 0}
     assert not spilling, f"{kernel}: instantiations with scratch or AccVGPRs (registers parked next to hand-issued LDS reads): {list(spilling.items())[:6]}"
+
+
+def test_library_ships_compressed_device_code(pkg):
+    """The ~700 kernel instantiations are 46 MB of gfx950 code uncompressed; every translation unit is built with --offload-compress
+    (the HIP runtime unpacks a unit's bundle when its first kernel is launched): the library stays under 20 MB."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert re.search(r"^CXXFLAGS\s*=.*--offload-compress", mk, re.M), "Makefile no longer compresses the device code"
+    lib = os.path.join(os.path.dirname(CSRC), "libmultirate_hip.so")
+    assert os.path.exists(lib)
+    assert os.path.getsize(lib) < 20_000_000, os.path.getsize(lib)
 
 
 def test_lane_kernel_uses_no_scratch_and_its_statements_are_the_generators(pkg):
@@ -83,6 +95,10 @@ def test_interp_lane_kernel_uses_no_scratch_and_its_statements_are_the_generator
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     assert open(os.path.join(CSRC, "interp_lane_quad.inc")).read() == gen.render(), "interp_lane_quad.inc is stale: run scripts/gen_interp_lane_asm.py"
+    spec = importlib.util.spec_from_file_location("gen_arb_window_asm", os.path.join(ROOT, "scripts", "gen_arb_window_asm.py"))
+    genw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(genw)
+    assert open(os.path.join(CSRC, "arb_window_one.inc")).read() == genw.render(), "arb_window_one.inc is stale: run scripts/gen_arb_window_asm.py"
     for p in range(4):
         acc, tmp = gen.acc_reg(4, p)
         assert (acc % 4 < 2) != (tmp % 4 < 2), (p, acc, tmp)

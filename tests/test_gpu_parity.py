@@ -1502,6 +1502,46 @@ def test_arb_lane_kernel_float64_lane_per_channel(pkg, O, torch_cuda, monkeypatc
         f.close()
 
 
+def test_arb_window_kernel_behind_its_switch(pkg, O, torch_cuda, monkeypatch):
+    """arb_window_kernel (kernels_arb_window.hip: FIRArbitrary, Float64, 32 taps per phase, one wave per stretch with the window in
+    registers) is NOT the default -- on config 4 it measures slower than arb_lane_kernel (profiles/r06/experiments.md G) -- but stays in the
+    library behind MRHIP_ARB_WINDOW: outputs, end state and history bit for bit those of arb_lane_kernel, of the universal kernel and
+    (STRICT) of the oracle: full, several and partial channel groups, rates whose consecutive windows coincide (10.3) or never do (1.0),
+    chunkings with a one-sample and a 17-sample call, -0.0 / +-Inf / NaN samples."""
+    torch = torch_cuda
+    rng = np.random.default_rng(808)
+    monkeypatch.setenv("MRHIP_ARB_SMALL_MAX", "0")
+    cases = [(32, 64, math.pi / 3, 40_000), (32, 64, 1.0, 24_000), (32, 128, 1.5, 21_000), (32, 50, 2.7, 21_000), (32, 64, 10.3, 12_000), (10, 113, math.e / 2, 21_000)]
+    for (nphi, nch, rate, n) in cases:
+        h = rng.standard_normal(nphi * 32)
+        x = rng.random((nch, n)) - 0.5
+        x[0, 5] = -0.0; x[0, 1000] = np.inf; x[1, 1001] = -np.inf; x[2, 7_000] = np.nan
+        xd = torch.from_numpy(x).cuda()
+        sizes = [5_000, 1, 17, n - 5_018 - 3_003, 3_003]
+        for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
+            got = {}
+            for mode, env in (("window", {"MRHIP_ARB_WINDOW": "2"}), ("lane", {}), ("generic", {"MRHIP_FORCE_GENERIC": "1"})):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                f = pkg.FIRFilter(h, float(rate), nphi, numerics=numerics)
+                y = torch.cat(_run_chunks(f, xd, sizes), dim=-1).cpu().numpy()
+                st = f.state
+                got[mode] = (y, f.last_kernel_name(), (st.phiIdx, st.inputDeficit, st.phiAccumulator, st.alpha), np.array(f.history))
+                f.close()
+                for k in env:
+                    monkeypatch.delenv(k)
+            tag = f"Nphi={nphi} nch={nch} rate={rate:.4f} numerics={numerics}"
+            assert got["window"][1] == "arb_window_kernel" and got["lane"][1] == "arb_lane_kernel" and got["generic"][1] == "arb_generic_kernel", (tag, got["window"][1], got["lane"][1])
+            assert_bit_equal(got["window"][0], got["generic"][0], "window vs universal " + tag)
+            assert_bit_equal(got["window"][0], got["lane"][0], "window vs lane " + tag)
+            assert got["window"][2] == got["generic"][2], tag
+            assert_bit_equal(got["window"][3], got["generic"][3], "history " + tag)
+            if numerics == pkg.NUMERICS_STRICT:
+                for c in (0, 2, nch - 1):
+                    fo = O.FIRFilter(h, float(rate), nphi, tx=np.float64)
+                    assert_bit_equal(got["window"][0][c], np.concatenate(_run_chunks(fo, x[c], sizes)), f"window vs oracle ch {c} " + tag)
+
+
 def test_large_L_runs_on_the_output_pair_kernel_in_period_blocks(pkg, O, torch_cuda, monkeypatch):
     """L > 512 (625//512, 1000//999, 640//441: ordinary clock-trim ratios) used to fall off the tuned kernels onto poly_tiled /
     poly_generic at 1-9 % of the HBM roofline.  The output-pair kernel now cuts the period of 2L outputs into BLOCKS, one workgroup
