@@ -1268,7 +1268,13 @@ static int filt_device_one(mrhip_filter *f, const void *x, int64_t x_len, int64_
             // (a chained call's schedule reads the previous stage's call record, which is written on the caller's stream: it runs there)
             // (a call of one small piece -- at most MRHIP_SCHED_INLINE_MAX outputs, default 65 536 -- is launch-bound: its three kernels go down ONE
             //  queue without the three event operations the second stream costs the host; profiles/r05/experiments.md O)
-            const bool inline_sched = est <= MRHIP_ENV_INT("MRHIP_SCHED_INLINE_MAX", 65536);
+            // (calls arb_lane_kernel will serve: that kernel's persistent workgroups hold every vector register of the chip -- the next call's schedule
+            //  cannot run BESIDE it: its tables / chain workgroups either wait for the kernel's end anyway or, when the race at the start lets
+            //  them in, both run much longer -- config 4 on a continuing stream read 3.9 or 4.5-5.1 ms per call.  Behind it, on the caller's
+            //  stream: 3.93 + 0.2 ms, every call.  profiles/r06/experiments.md I; MRHIP_SCHED_BESIDE_LANE=1: as before)
+            const bool lane_shape = f->kind == MRHIP_FIR_ARBITRARY && tk.x_f64 && tk.r_f64 && !tk.complex_x && (f->T == 32 || f->T == 16) && f->rate >= 1.0 &&
+                                    f->nch >= 48 && MRHIP_ENV_INT("MRHIP_ARB_LANE", 1) != 0 && MRHIP_ENV_INT("MRHIP_SCHED_BESIDE_LANE", 0) == 0;
+            const bool inline_sched = est <= MRHIP_ENV_INT("MRHIP_SCHED_INLINE_MAX", 65536) || lane_shape;
             hipStream_t ss = capturing || !f->s_sched || x_from || inline_sched ? stream : f->s_sched;
             // a chained call's schedule ran on the CALLER's stream (it reads the previous stage's call record there) and wrote the record,
             // the piece states and the path tables: a schedule on the filter's own schedule stream must come behind it

@@ -110,6 +110,7 @@ int rec_alloc(mrhip_filter *f)
         if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = 0; }
         const char *pv = std::getenv("MRHIP_SCHED_PRIO");
         if (pv && *pv == '0') prio_least = 0;
+        if (pv && *pv == 'h') prio_least = prio_greatest;      // ("high")
         MRHIP_CHECK_HIP(hipStreamCreateWithPriority(&f->s_sched, hipStreamNonBlocking, prio_least));
         for (int b = 0; b < 2; ++b) {
             MRHIP_CHECK_HIP(hipEventCreateWithFlags(&f->ev_fin[b], hipEventDisableTiming));
