@@ -95,11 +95,20 @@ size_t y_elt(const mrhip_filter *f) { return dtype_size(f->ty); }
 // what Julia's promotion does on every multiply (Real*Real / Real*Complex methods).
 // The vector sits between two runs of kTapPad zero elements: fir_stream_rt_kernel reads whole blocks of taps around the
 // ends of a window (it discards what the out-of-window ones produce) without a clamp per tap.
+constexpr size_t kDecimTabBytes = 4 * 64 * sizeof(float);
+// decim_lane_kernel (kernels_decim_lane.hip) reads the taps of a FIRDecimator 1//4 x 128 Float32 taps as four doubled, age-ordered columns:
+// they sit behind the tap vector's second pad.  NULL: not that shape.
+const float *decim_tab(const mrhip_filter *f)
+{
+    if (f->kind != MRHIP_FIR_DECIMATOR || f->M != 4 || f->hLen != 128 || f->th != MRHIP_F32 || f->r_f64 || !f->d_taps_alloc) return nullptr;
+    return reinterpret_cast<const float *>(static_cast<const unsigned char *>(f->d_taps_alloc) + 128 * sizeof(float) + 2 * static_cast<size_t>(mrhip::kTapPad) * sizeof(float));
+}
+
 int upload_taps(mrhip_filter *f, const std::vector<unsigned char> &src, void **dptr, void **alloc)
 {
     const size_t n = src.size() / dtype_scalar_size(f->th);
     const size_t pad = static_cast<size_t>(mrhip::kTapPad) * r_size(f);
-    const size_t bytes = std::max<size_t>(n * r_size(f), 16) + 2 * pad;
+    const size_t bytes = std::max<size_t>(n * r_size(f), 16) + 2 * pad + kDecimTabBytes;   // (+ decim_lane_kernel's tap columns: decim_tab)
     MRHIP_CHECK_HIP(hipMalloc(alloc, bytes));
     MRHIP_CHECK_HIP(hipMemset(*alloc, 0, bytes));
     *dptr = static_cast<unsigned char *>(*alloc) + pad;
@@ -286,6 +295,9 @@ hipError_t launch_opair_blocks(mrhip_filter *f, const TypeKey &tk, bool fused, c
 }  // namespace
 // kernels_interp_lane.hip: FIRInterpolator 4//1, 32 taps per phase, ComplexF32: a lane per channel (plans and launches; false: not its call)
 bool try_launch_interp_lane(const TypeKey &tk, bool fused, const PolyArgs &a, unsigned *counters, hipStream_t s, const char **kname, int num_cus, hipError_t *err);
+// (kernels_decim_lane.hip: FIRDecimator 1//4 x 128 taps, ComplexF32, long calls -- a lane per channel, the 32 outputs in flight in registers)
+void decim_lane_table(const float *taps_oldest_first, float *tab);
+bool try_launch_decim_lane(const TypeKey &tk, bool fused, const PolyArgs &a, const float *tab, unsigned *counters, hipStream_t s, const char **kname, int num_cus, hipError_t *err);
 // (kernels_arb_window.hip: FIRArbitrary, Float64, 32 taps per phase, long calls -- a lane per channel, the window in registers)
 bool try_launch_arb_window(const TypeKey &tk, bool fused, const ArbArgs &a, double rate, unsigned *counters, hipStream_t s, const char **kname, int num_cus, hipError_t *err);
 namespace {
@@ -299,6 +311,8 @@ hipError_t launch_poly(const mrhip_filter *f, const TypeKey &tk, bool fused, con
     *rec_written = false;             // the pair kernels and the universal kernel file the call's end state in the device record
     if (!f->force_generic) {
         if (a.L == 1) {
+            hipError_t ed = hipSuccess;           // (shiftin! and the record are the caller's: did_shiftin / rec_written stay false)
+            if (try_launch_decim_lane(tk, fused, a, decim_tab(f), counters, s, kname, f->num_cus, &ed)) return ed;
             PairArgs spa;
             dim3 sblock;
             size_t slds = 0;
@@ -412,6 +426,11 @@ int mrhip_create_rational(const void *h, int64_t hLen, int th, int64_t num, int6
         taps2pfb(h, hLen, th, L, f->h_taps.data());
     }
     int rc = upload_taps(f, f->h_taps, &f->d_taps, &f->d_taps_alloc);
+    if (!rc && decim_tab(f)) {
+        float tab[4 * 64];
+        mrhip::decim_lane_table(reinterpret_cast<const float *>(f->h_taps.data()), tab);
+        if (hipMemcpy(const_cast<float *>(decim_tab(f)), tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess) rc = fail(MRHIP_ERR_HIP, "hipMemcpy failed");
+    }
     if (!rc) rc = alloc_common(f);
     if (rc) { mrhip_destroy(f); return rc; }
     *out = f;

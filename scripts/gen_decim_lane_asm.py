@@ -80,11 +80,31 @@ def gen(fused):
             f"    }}\n")
 
 
+ROT = 2                              # the kernel handles ROT groups per iteration with the slots in place, then moves every accumulator ROT registers down
+
+
+def gen_rotate():
+    """acc[i] = acc[(i + ROT) mod 32], in place (tied operands: written in C++ the compiler builds the rotated set in other registers first)"""
+    lines = [f"v_mov_b64 %[r{k}], %[a{k}]" for k in range(ROT)]
+    lines += [f"v_mov_b64 %[a{i}], %[a{i + ROT}]" for i in range(SLOTS - ROT)]
+    lines += [f"v_mov_b64 %[a{SLOTS - ROT + k}], %[r{k}]" for k in range(ROT)]
+    body = "\n".join(f'        "{ln}\\n\\t"' for ln in lines)
+    outs = ", ".join(f'[a{s}] "+v"(acc[{s}])' for s in range(SLOTS)) + ", " + ", ".join(f'[r{k}] "=&v"(t[{k}])' for k in range(ROT))
+    return (f"    if constexpr (ROTATE) {{\n"
+            f"        asm volatile(\n{body}\n"
+            f"        : {outs});\n"
+            f"    }}\n")
+
+
 def render():
     return ("// GENERATED by scripts/gen_decim_lane_asm.py -- do not edit; see that script for what the statements do and why they are assembly.\n"
-            "// Included inside decim_lane_group<FUSED>(acc, x, tp) with `v2f_t t[4];` declared -- acc[0 .. 31]: the outputs in flight (slot = output index\n"
-            "// modulo 32); x[0 .. 3]: the group's samples; tp: the doubled tap columns + 32 - (group index modulo 32).\n"
-            + gen(False) + gen(True))
+            "// Included inside decim_lane_group<FUSED, ROTATE>(acc, x, tp) with `v2f_t t[4];` declared -- acc[0 .. 31]: the outputs in flight; x[0 .. 3]:\n"
+            "// the group's samples; tp: the doubled tap columns + 32 - (the group's place in the iteration).  ROTATE: no arithmetic, the accumulators\n"
+            f"// move {ROT} registers down.\n"
+            "    if constexpr (!ROTATE) {\n"
+            + gen(False) + gen(True) +
+            "    }\n"
+            + gen_rotate())
 
 
 def main():

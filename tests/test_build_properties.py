@@ -99,6 +99,10 @@ def test_interp_lane_kernel_uses_no_scratch_and_its_statements_are_the_generator
     genw = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(genw)
     assert open(os.path.join(CSRC, "arb_window_one.inc")).read() == genw.render(), "arb_window_one.inc is stale: run scripts/gen_arb_window_asm.py"
+    spec = importlib.util.spec_from_file_location("gen_decim_lane_asm", os.path.join(ROOT, "scripts", "gen_decim_lane_asm.py"))
+    gend = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gend)
+    assert open(os.path.join(CSRC, "decim_lane_group.inc")).read() == gend.render(), "decim_lane_group.inc is stale: run scripts/gen_decim_lane_asm.py"
     for p in range(4):
         acc, tmp = gen.acc_reg(4, p)
         assert (acc % 4 < 2) != (tmp % 4 < 2), (p, acc, tmp)

@@ -1454,6 +1454,52 @@ def test_interp_lane_kernel_config3a_window_in_registers(pkg, O, torch_cuda, mon
         monkeypatch.delenv("MRHIP_INTERP_LANE")
 
 
+def test_decim_lane_kernel_behind_its_switch(pkg, O, torch_cuda, monkeypatch):
+    """decim_lane_kernel (kernels_decim_lane.hip: FIRDecimator 1//4 x 128 taps, ComplexF32, a lane per channel in TRANSPOSED form -- the 32
+    outputs whose windows contain a sample are in flight in registers, every accumulator started from -0.0 or, where the reference's loop
+    does, from +0.0) is NOT the default -- on config 3b it measures slower than fir_stream_kernel (profiles/r06/experiments.md J) -- but
+    stays in the library behind MRHIP_DECIM_LANE: outputs, end state and history bit for bit those of fir_stream_kernel, of the universal
+    kernel and (STRICT) of the oracle: full, several and partial channel groups, every inputDeficit a call can start with (chunks of
+    4 k + 1, + 2, + 3 samples), calls too short for the kernel, -0.0 / +-Inf / NaN samples and an all-negative-zero stretch (the sign of a zero
+    sum is where "-0.0 start" and "first product initialises" could differ)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(909)
+    for nch, n in ((64, 30_000), (256, 9_000), (50, 9_000), (113, 9_000)):
+        h = (rng.standard_normal(128) / 4).astype(np.float32)
+        x = (rng.standard_normal((nch, n)) + 1j * rng.standard_normal((nch, n))).astype(np.complex64)
+        flat = x.view(np.float32)
+        flat[0, 10] = -0.0; flat[0, 2001] = np.inf; flat[1, 2003] = -np.inf; flat[2, 5001] = np.nan
+        flat[3, 2 * 4_000:2 * 4_600] = -0.0                      # 600 samples of (-0.0, -0.0): whole windows of zeros of either sign
+        flat[4, :400] = -0.0                                     # ... and at the very start (the +0.0 starts of support.jl:46)
+        xd = torch.from_numpy(x).cuda()
+        sizes = [3_001, 1, 17, 64, 65, 2, 3, 1_002, n - 5_158 - 1_003, 1_003]
+        for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
+            got = {}
+            for mode, env in (("lane", {"MRHIP_DECIM_LANE": "2"}), ("stream", {}), ("generic", {"MRHIP_FORCE_GENERIC": "1"})):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                f = pkg.FIRFilter(h, Fraction(1, 4), numerics=numerics)
+                outs, names, pos = [], set(), 0
+                for sz in sizes:
+                    outs.append(f.filt(xd[:, pos:pos + sz]))
+                    names.add(f.last_kernel_name())
+                    pos += sz
+                got[mode] = (torch.cat(outs, dim=-1).cpu().numpy(), names, (f.state.phiIdx, f.state.inputDeficit), np.array(f.history))
+                f.close()
+                for k in env:
+                    monkeypatch.delenv(k)
+            tag = f"nch={nch} numerics={numerics}"
+            assert "decim_lane_kernel" in got["lane"][1] and "decim_lane_kernel" not in got["stream"][1], (tag, got["lane"][1], got["stream"][1])
+            assert_bit_equal(got["lane"][0], got["generic"][0], "lane vs universal " + tag)
+            assert_bit_equal(got["lane"][0], got["stream"][0], "lane vs streaming kernel " + tag)
+            assert got["lane"][2] == got["generic"][2], tag
+            assert_bit_equal(got["lane"][3], got["generic"][3], "history " + tag)
+            if numerics == pkg.NUMERICS_STRICT:
+                for c in (0, 3, 4, nch - 1):
+                    fo = O.FIRFilter(h, Fraction(1, 4), tx=np.complex64)
+                    assert_bit_equal(got["lane"][0][c], np.concatenate(_run_chunks(fo, x[c], sizes)), f"lane vs oracle ch {c} " + tag)
+
+
 def test_arb_lane_kernel_float64_lane_per_channel(pkg, O, torch_cuda, monkeypatch):
     """arb_lane_kernel (kernels_arb_lane.hip; BASELINE config 4's shape: Float64 samples, 32 taps per phase, 64 channels, rate >= 1): a lane
     per channel, taps by scalar loads into SGPR operands, two outputs per window, samples through an LDS ring.  Outputs, end state and
