@@ -91,6 +91,15 @@ __device__ __forceinline__ v2u_t lds_read_b64(unsigned byte_addr)
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
     return v;
 }
+// two consecutive 32-bit words from a 4-byte aligned address (the windows of 4-byte samples start at any sample)
+template <int OFF>
+__device__ __forceinline__ v2u_t lds_read2_b32(unsigned byte_addr)
+{
+    static_assert(OFF % 4 == 0 && OFF / 4 + 1 <= 255, "ds_read2_b32 offsets are 8-bit counts of dwords");
+    v2u_t v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(byte_addr), "n"(OFF / 4), "n"(OFF / 4 + 1));
+    return v;
+}
 template <int OFF>
 __device__ __forceinline__ unsigned lds_read_b32(unsigned byte_addr)
 {
@@ -111,10 +120,15 @@ __device__ __forceinline__ void lgkm_wait(V &reg)
 // HBM -> LDS, 16 bytes per lane, no VGPR data: LDS destination = lds_wave_base + lane*16 (the base
 // must be wave-uniform), global source is per lane and only needs 4-byte alignment (verified on
 // gfx950 by scripts/ubench/dma_test.hip).
+//
+// OFF: the instruction's immediate offset, added to BOTH addresses: the DMAs a wave issues for one stage share ONE base (the LDS base
+// travels in M0: one s_mov instead of one per round) and tell their rounds apart by OFF.
+template <int OFF>
 __device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base)
 {
+    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed immediate");
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, OFF, 0);
 }
 
 // One 16-byte chunk = VPS samples of SW 32-bit words each; checked element by element against the
@@ -142,7 +156,10 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
 {
     constexpr int SW = static_cast<int>(sizeof(TX)) * NC / 4;   // 32-bit words per sample: 1, 2 or 4
     constexpr int VPS = 4 / SW;                                  // samples per 16-byte chunk
-    constexpr bool TWO_COPIES = SW == 1;
+    // (rounds 3-5 kept a second copy of a 4-byte-sample stage, shifted by one sample, so that every window could be read by aligned 8-byte reads;
+    //  it needed a second LDS base per stage -- see dma16 -- and is gone: ds_read2_b32 reads a window from any sample)
+    constexpr bool TWO_COPIES = false;
+    constexpr bool READ2 = SW == 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS byte offset of smem[0] (low 32 bits of the flat address of an LDS object are its LDS offset)
@@ -170,7 +187,6 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
     }
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int nwaves = blockDim.x >> 6;
 
     R taps[T];
     {
@@ -198,18 +214,14 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
         // wave-uniform: every byte the DMA touches (copy B reads one sample further) is inside x
         const bool interior = ta.x_aligned16 && g0 >= 0 && g0 + ta.tile_len + (TWO_COPIES ? 1 : 0) <= a.x_len;
         if (interior) {
-            const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + g0 * SW);
-#pragma unroll
-            for (int d = 0; d < kMaxDmaRounds; ++d) {
-                if (d < ta.dma_rounds) {
-                    const int slot = d * nwaves + wave;            // 1 KiB slot of the stage copy
-                    const int ci = slot * 64 + lane;
-                    const int cis = ci < nchunks ? ci : 0;         // padding lanes re-read chunk 0 (lands in LDS padding)
-                    dma16(src + static_cast<size_t>(cis) * 16, stA + static_cast<size_t>(slot) * 1024);
-                    if constexpr (TWO_COPIES)
-                        dma16(src + static_cast<size_t>(cis) * 16 + 4, stB + static_cast<size_t>(slot) * 1024);
-                }
-            }
+            // this wave's chunks: slots wave * rounds ... + rounds - 1 (1 KiB each), i.e. chunks (wave * rounds * 64 + lane) + 64 d, d = 0 ... rounds - 1
+            const int ci0 = wave * ta.dma_rounds * 64 + lane;
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(xc + g0 * SW) + static_cast<size_t>(ci0) * 16;
+            unsigned char *const stw = stA + static_cast<size_t>(wave) * ta.dma_rounds * 1024;
+            static_for<0, kMaxDmaRounds>([&](auto D) {
+                constexpr int d = decltype(D)::value;
+                if (d < ta.dma_rounds && ci0 + 64 * d < nchunks) dma16<d * 1024>(src, stw);     // (lanes beyond the tile: masked off)
+            });
         } else {
             const unsigned *__restrict__ hc = static_cast<const unsigned *>(a.hist) + static_cast<long long>(ch) * a.H * SW;
             unsigned *lA = reinterpret_cast<unsigned *>(stA), *lB = reinterpret_cast<unsigned *>(stB);
@@ -237,9 +249,13 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
         const long long o = a.d0 - T + tau * tile_in;
         const int sh = static_cast<int>(o - (o & ~static_cast<long long>(VPS - 1)));   // origin offset inside chunk 0
 
-        // One barrier per tile: it (a) publishes this tile's staged data -- every wave waits for its
-        // own DMA / LDS writes first (__syncthreads drains vmcnt and lgkmcnt) -- and (b) proves that
-        // every wave has finished reading the other stage, which the next DMA is about to overwrite.
+        // One barrier per tile: it (a) publishes this tile's staged data -- every wave waits for ITS OWN DMA / LDS writes first, EXPLICITLY:
+        // __syncthreads() alone does not (a workgroup-scope release needs no vmcnt wait for ordinary memory, and the LDS reads below are
+        // assembly the compiler's own DMA-to-LDS bookkeeping cannot see).  Rounds 3-5 relied on it: with the signal just uploaded (every
+        // line from HBM) the next tile's samples were still on their way when the barrier opened -- wrong outputs on the FIRST call after an
+        // upload, found by tests/stress_random.py --seed 61 in round 6 (profiles/r06/experiments.md K) -- and (b) proves that every wave
+        // has finished reading the other stage, which the next DMA is about to overwrite.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         if (tile + gridDim.x < ta.total_tiles && !(ta.ablate & 1)) stage_tile(tile + gridDim.x, s ^ 1);
 
@@ -268,14 +284,14 @@ __global__ __launch_bounds__(kMaxThreads) void poly_phase_stationary_kernel(Poly
                         for (int c2 = 0; c2 < NC; ++c2) acc[c2] = mac<R, FUSED>(taps[i], xv[c2], acc[c2]);
                     }
                 };
-                if constexpr (TWO_COPIES) {
-                    // 4-byte samples: T/2 aligned 8-byte reads from whichever copy makes the window start even
+                if constexpr (READ2) {
+                    // 4-byte samples: T/2 reads of two consecutive words each, from wherever the window starts
                     constexpr int NP = T / 2;
                     constexpr int NR = NP + (T & 1);
-                    const unsigned waddr = stage_base + ((start & 1) ? ta.copyB_offset_bytes + (start - 1) * 4 : start * 4);
+                    const unsigned waddr = stage_base + start * 4;
                     v2u_t pr[NP > 0 ? NP : 1];
                     unsigned last = 0;
-                    static_for<0, NP>([&](auto I) { pr[decltype(I)::value] = lds_read_b64<decltype(I)::value * 8>(waddr); });
+                    static_for<0, NP>([&](auto I) { pr[decltype(I)::value] = lds_read2_b32<decltype(I)::value * 8>(waddr); });
                     if constexpr (T & 1) last = lds_read_b32<(T - 1) * 4>(waddr);
                     static_for<0, NP>([&](auto I) {
                         constexpr int i = decltype(I)::value;
@@ -437,7 +453,7 @@ bool plan_phase_stationary(const TypeKey &tk, const PolyArgs &a, int num_cus, Ti
     const int sh0 = static_cast<int>(((o0 % vps) + vps) % vps);
     const bool sh_constant = (J * cM) % vps == 0;
     const size_t copyB_off = copy_bytes + 128 + ((sh_constant && (sh0 & 1)) ? 8 : 0);
-    const size_t stage_bytes = sw == 1 ? (copyB_off + copy_bytes + 127) / 128 * 128 + 128 : copy_bytes;
+    const size_t stage_bytes = copy_bytes;                                        // (one copy: see the kernel's READ2)
     const size_t total = 2 * stage_bytes;
     if (total > 156 * 1024) return false;
 

@@ -6,7 +6,8 @@ dot(pfb[:, phi], window ending at m)), ComplexF32 samples x Float32 taps, a lane
 The 64 lanes of a wave are 64 channels at the same input index: the L phases' tap columns are wave-uniform and come by scalar loads
 (s_load_dwordx4: four taps of one column) into fixed scalar registers, double-buffered: block b + 1's taps are requested in front of
 block b's arithmetic and waited for behind it.  The window's T ComplexF32 samples are REGISTERS of the wave (operands w0 ... w{T-1}: the
-kernel keeps the sliding window of its channels in VGPRs from input to input) -- no LDS read, no barrier.
+kernel keeps the sliding window of its channels in VGPRs from input to input) -- no LDS read, no barrier.  A statement covers FOUR
+consecutive inputs (operands w0 ... w{T+2}): the tap blocks cycle, block 0 of the next input is requested behind block 7 of this one.
 
 Per tap i (oldest sample first) and phase p:  STRICT  t_p = x_i * tap[p][i] (v_pk_mul_f32: (re, im) packed, the tap broadcast);
 acc_p = acc_p + t_p (v_pk_add_f32);  FUSED  acc_p = fma(x_i, tap[p][i], acc_p).  The first product of a phase initialises its sum
@@ -38,6 +39,10 @@ def tap_operand(first_sgpr, idx, fused):
     return pair, mod
 
 
+NIN = 4                           # inputs per statement: the tap blocks cycle (every input uses the same columns), so block 0 of input q + 1 is requested
+                                  # behind block 7 of input q -- ONE exposed wait for the scalar cache per four inputs instead of four
+
+
 def gen(T, L, fused):
     nblk = T // NB
     s_per_buf = NB * L            # SGPRs of one tap buffer: NB taps of each of the L columns
@@ -52,13 +57,15 @@ def gen(T, L, fused):
 
     taps(0, 0)
     emit("s_waitcnt lgkmcnt(0)")
-    for b in range(nblk):
-        cur = b % 2
-        if b + 1 < nblk:
-            taps(1 - cur, b + 1)
+    total = NIN * nblk
+    for n in range(total):
+        q, b = divmod(n, nblk)
+        cur = n % 2
+        if n + 1 < total:
+            taps(1 - cur, (b + 1) % nblk)
         for j in range(NB):
             i = b * NB + j
-            x = f"%[w{i}]"
+            x = f"%[w{q + i}]"
             adds = []
             for p in range(L):
                 acc, tmp = acc_reg(L, p)
@@ -76,16 +83,19 @@ def gen(T, L, fused):
                     adds.append(f"v_pk_add_f32 {A}, {A}, {Tm}")
             for a in adds:
                 emit(a)
-        if b + 1 < nblk:
+        if b == nblk - 1:                                     # input q is complete: its L sums into the patch (32 bytes per input)
+            assert L == 4
+            emit(f"ds_write_b128 %[pa], v[{ACC0}:{ACC0 + 3}] offset:{32 * q}")
+            emit(f"ds_write_b128 %[pa], v[{ACC0 + 4}:{ACC0 + 7}] offset:{32 * q + 16}")
+            if q + 1 < NIN:
+                emit("s_nop 1")                               # (the next input's first products overwrite the registers the writes take their data from)
+        if n + 1 < total:
             emit("s_waitcnt lgkmcnt(0)")
-    assert L == 4
-    emit(f"ds_write_b128 %[pa], v[{ACC0}:{ACC0 + 3}]")
-    emit(f"ds_write_b128 %[pa], v[{ACC0 + 4}:{ACC0 + 7}] offset:16")
     body = "\n".join(f'        "{ln}\\n\\t"' for ln in lines)
     vclob = list(range(ACC0, ACC0 + 2 * L)) + ([] if fused else list(range(TMP0, TMP0 + 2 * L)))
     sclob = range(sbuf[0], 100)
     clob = ", ".join([f'"v{i}"' for i in vclob] + [f'"s{i}"' for i in sclob])
-    ins = ", ".join(f'[w{i}] "v"(w[{i}])' for i in range(T))
+    ins = ", ".join(f'[w{i}] "v"(w[{i}])' for i in range(T + NIN - 1))
     return (f"    if constexpr (T == {T} && L == {L} && FUSED == {'true' if fused else 'false'}) {{\n"
             f"        asm volatile(\n{body}\n"
             f"        :\n"
@@ -96,8 +106,8 @@ def gen(T, L, fused):
 
 def render():
     parts = ["// GENERATED by scripts/gen_interp_lane_asm.py -- do not edit; see that script for what the statements do and why they are assembly.\n"
-             "// Included inside interp_lane_quad<FUSED, T, L>(w, taps, patch) -- w[0 .. T-1]: the window, oldest sample first; patch: LDS byte address of\n"
-             "// this lane's L outputs (32 bytes).\n"]
+             "// Included inside interp_lane_quad<FUSED, T, L>(w, taps, patch) -- the outputs of FOUR consecutive inputs: w[0 .. T + 2]: the windows (input q:\n"
+             "// w[q .. q + T - 1], oldest sample first); patch: LDS byte address of this lane's 4 x L outputs (128 bytes).\n"]
     for (T, L) in SHAPES:
         for fused in (False, True):
             parts.append(gen(T, L, fused))

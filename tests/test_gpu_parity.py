@@ -1454,6 +1454,37 @@ def test_interp_lane_kernel_config3a_window_in_registers(pkg, O, torch_cuda, mon
         monkeypatch.delenv("MRHIP_INTERP_LANE")
 
 
+def test_phase_stationary_kernel_first_call_after_an_upload(pkg, O, torch_cuda, monkeypatch):
+    """poly_phase_stationary_kernel stages its tiles by LDS-DMA.  Rounds 3-5 let __syncthreads() stand for "this wave's DMA has landed"; it does
+    not (no vmcnt wait is part of a workgroup barrier, and the kernel's LDS reads are assembly the compiler's DMA bookkeeping cannot see): with
+    the signal JUST UPLOADED -- every line still to come from HBM -- a tile was read before its samples had arrived, and the first call after an
+    upload returned wrong outputs in later tiles (never the second call: the lines were in the cache by then).  Found by
+    tests/stress_random.py --seed 61 (4//33, 19 taps, 33 channels x 132 808 samples) in round 6; the wait is explicit now.  Every run below
+    uploads the signal afresh and calls the tuned kernel FIRST."""
+    torch = torch_cuda
+    rng = np.random.default_rng(1061)
+    for (L, M, taps, nch, n) in ((4, 33, 19, 33, 132_808), (4, 33, 19, 32, 265_616), (3, 40, 60, 33, 132_808)):
+        h = rng.standard_normal(taps).astype(np.float32)
+        x = (rng.random((nch, n), dtype=np.float32) - 0.5)
+        xt = torch.from_numpy(x).pin_memory()
+        for rep in range(4):
+            xd = xt.cuda()                                         # a fresh upload: nothing of it is in any cache
+            monkeypatch.delenv("MRHIP_FORCE_GENERIC", raising=False)
+            f = pkg.FIRFilter(h, Fraction(L, M))
+            y = f.filt(xd).cpu().numpy()
+            name = f.last_kernel_name()
+            f.close()
+            monkeypatch.setenv("MRHIP_FORCE_GENERIC", "1")
+            g = pkg.FIRFilter(h, Fraction(L, M))
+            yg = g.filt(xd).cpu().numpy()
+            g.close()
+            monkeypatch.delenv("MRHIP_FORCE_GENERIC")
+            assert name == "poly_phase_stationary_kernel", name
+            assert_bit_equal(y, yg, f"{L}//{M} {taps} taps {nch} ch x {n}, upload {rep}")
+        fo = O.FIRFilter(h, Fraction(L, M), tx=np.float32)
+        assert_bit_equal(y[nch - 1], fo.filt(x[nch - 1]), f"{L}//{M} vs oracle")
+
+
 def test_decim_lane_kernel_behind_its_switch(pkg, O, torch_cuda, monkeypatch):
     """decim_lane_kernel (kernels_decim_lane.hip: FIRDecimator 1//4 x 128 taps, ComplexF32, a lane per channel in TRANSPOSED form -- the 32
     outputs whose windows contain a sample are in flight in registers, every accumulator started from -0.0 or, where the reference's loop
