@@ -39,11 +39,12 @@ def tap_operand(first_sgpr, idx, fused):
     return pair, mod
 
 
-NIN = 4                           # inputs per statement: the tap blocks cycle (every input uses the same columns), so block 0 of input q + 1 is requested
-                                  # behind block 7 of input q -- ONE exposed wait for the scalar cache per four inputs instead of four
+NINS = (4,)                       # inputs per statement: the tap blocks cycle (every input uses the same columns), so block 0 of input q + 1 is requested
+                                  # behind block 7 of input q -- with four inputs ONE exposed wait for the scalar cache instead of four.  (Measured against one input per
+                                  # statement on config 3a, same box, alternating: 2.90-2.92 ms both -- the kernel runs at the power limit, not at its waits.)
 
 
-def gen(T, L, fused):
+def gen(T, L, fused, NIN):
     nblk = T // NB
     s_per_buf = NB * L            # SGPRs of one tap buffer: NB taps of each of the L columns
     sbuf = (100 - 2 * s_per_buf, 100 - s_per_buf)          # two buffers ending at s99
@@ -96,7 +97,7 @@ def gen(T, L, fused):
     sclob = range(sbuf[0], 100)
     clob = ", ".join([f'"v{i}"' for i in vclob] + [f'"s{i}"' for i in sclob])
     ins = ", ".join(f'[w{i}] "v"(w[{i}])' for i in range(T + NIN - 1))
-    return (f"    if constexpr (T == {T} && L == {L} && FUSED == {'true' if fused else 'false'}) {{\n"
+    return (f"    if constexpr (T == {T} && L == {L} && NIN == {NIN} && FUSED == {'true' if fused else 'false'}) {{\n"
             f"        asm volatile(\n{body}\n"
             f"        :\n"
             f'        : {ins}, [tp] "s"(taps), [pa] "v"(patch)\n'
@@ -106,11 +107,12 @@ def gen(T, L, fused):
 
 def render():
     parts = ["// GENERATED by scripts/gen_interp_lane_asm.py -- do not edit; see that script for what the statements do and why they are assembly.\n"
-             "// Included inside interp_lane_quad<FUSED, T, L>(w, taps, patch) -- the outputs of FOUR consecutive inputs: w[0 .. T + 2]: the windows (input q:\n"
-             "// w[q .. q + T - 1], oldest sample first); patch: LDS byte address of this lane's 4 x L outputs (128 bytes).\n"]
+             "// Included inside interp_lane_quad<FUSED, T, L, NIN>(w, taps, patch) -- the outputs of NIN consecutive inputs: w[0 .. T + NIN - 2]: the windows (input q:\n"
+             "// w[q .. q + T - 1], oldest sample first); patch: LDS byte address of this lane's NIN x L outputs (NIN x 32 bytes).\n"]
     for (T, L) in SHAPES:
-        for fused in (False, True):
-            parts.append(gen(T, L, fused))
+        for nin in NINS:
+            for fused in (False, True):
+                parts.append(gen(T, L, fused, nin))
     return "".join(parts)
 
 
