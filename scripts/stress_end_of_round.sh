@@ -9,6 +9,7 @@ run() { echo "== $*" >> "$OUT"; timeout -k 10 600 "$@" 2>&1 | grep -v "amdgpu.id
 run python tests/stress_random.py --cases 3000 --seed 61
 run python tests/stress_random.py --cases 2500 --seed 62
 run python scripts/stress_arb_lane.py 200 63
+run python scripts/stress_lane_kernels.py 240 7
 run python scripts/stress_schedule.py --cases 1500 --seed 1 --seconds 240
 run python scripts/stress_ring.py --cases 400 --seed 6 --seconds 150
 run python scripts/stress_blocks.py --cases 3000 --seed 6 --seconds 120
