@@ -156,11 +156,12 @@ __device__ __forceinline__ void decim_stretch(const PolyArgs &a, const DecimLane
 #pragma unroll
         for (int j = 0; j < 4; ++j) X[U + j] = unit_get(j);
     }
-    unsigned long long nx[8];                                   // the unit in flight
-    load_unit(u + 2, nx);
-    // The 32 outputs in flight.  At the top of the loop below slot k holds output g + k; inside an iteration of two groups the slots stay where
+    unsigned long long nxa[8], nxb[8];                          // TWO units in flight: a unit lasts two groups (~2 us of a wave's time at three
+    load_unit(u + 2, nxa);                                      // waves per SIMD), a trip to HBM under load is no shorter
+    load_unit(u + 3, nxb);
+    // The 32 outputs in flight.  At the top of the loop below slot k holds output g + k; inside an iteration of four groups the slots stay where
     // they are (the statement of the iteration's k-th group is handed the tap columns k places on: slot s then has age (s - k) mod 32, slot k
-    // completes and starts output g + k + 32 in place); after the second group the accumulators rotate by two registers (32 moves per 512
+    // completes and starts output g + k + 32 in place); after the fourth group the accumulators rotate by four registers (36 moves per 1 024
     // packed instructions).  No per-group choice of registers is left: a switch over the completing slot cost more than the arithmetic.
     const float neg0 = __uint_as_float(0x80000000u);
     auto fresh_for = [&](long long j) {                         // support.jl:46: an output whose window reaches into the history starts from +0
@@ -171,7 +172,7 @@ __device__ __forceinline__ void decim_stretch(const PolyArgs &a, const DecimLane
 #pragma unroll
     for (int s_ = 0; s_ < S; ++s_) acc[s_] = fresh_for(g_start + s_);
     const cfloat_t tab = (cfloat_t)(la.tab);
-    auto unit_shift = [&]() {                                   // the registers move on by one unit
+    auto unit_shift = [&](unsigned long long (&nx)[8]) {       // the registers move on by one unit: `nx` (the older unit in flight) goes in, and is requested anew
 #pragma unroll
         for (int i = 0; i < 4; ++i) X[i] = X[U + i];
 #pragma unroll
@@ -180,9 +181,9 @@ __device__ __forceinline__ void decim_stretch(const PolyArgs &a, const DecimLane
 #pragma unroll
         for (int i = 0; i < 4; ++i) X[U + i] = unit_get(i);
         ++u;
-        load_unit(u + 2, nx);
+        load_unit(u + 3, nx);
     };
-    // output g is complete.  g - j0 = 2 t - 33 + k (k: the group's place in the iteration): a line of 16 outputs is full only behind a k = 0 group
+    // output g is complete.  g - j0 = 4 t - 33 + k (k: the group's place in the iteration): a line of 16 outputs is full only behind a k = 0 group
     auto emit = [&](long long g, v2f_t done, bool may_flush) {
         if (g < j0 || g >= j1) return;                          // (uniform) warm-up, or the ragged end of the last stretch
         const int oi = static_cast<int>(g - j0);
@@ -194,31 +195,26 @@ __device__ __forceinline__ void decim_stretch(const PolyArgs &a, const DecimLane
     const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
 #endif
 #pragma clang loop unroll(disable)
-    for (long long g = g_start; g < j1; g += 2) {
-        {
-            const v2f_t x[M] = {X[O], X[O + 1], X[O + 2], X[O + 3]};
+    for (long long g = g_start; g < j1; g += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const v2f_t x[M] = {X[O + 4 * (k & 1)], X[O + 4 * (k & 1) + 1], X[O + 4 * (k & 1) + 2], X[O + 4 * (k & 1) + 3]};
 #ifdef MRHIP_DL_TRACE
             const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-            decim_lane_group<FUSED>(acc, x, tab + S);
+            decim_lane_group<FUSED>(acc, x, tab + (S - k));
 #ifdef MRHIP_DL_TRACE
-            p_stmt += 2 * (__builtin_amdgcn_s_memtime() - ts0);       // (the second statement of the iteration is taken to cost the same)
+            p_stmt += __builtin_amdgcn_s_memtime() - ts0;
 #endif
-            const v2f_t done = acc[0];
-            acc[0] = fresh_for(g + S);
-            emit(g, done, true);
+            const v2f_t done = acc[k];
+            acc[k] = fresh_for(g + k + S);
+            emit(g + k, done, k == 0);
+            if (k == 1) unit_shift(nxa);
+            if (k == 3) unit_shift(nxb);
         }
-        {
-            const v2f_t x[M] = {X[O + 4], X[O + 5], X[O + 6], X[O + 7]};
-            decim_lane_group<FUSED>(acc, x, tab + (S - 1));
-            const v2f_t done = acc[1];
-            acc[1] = fresh_for(g + 1 + S);
-            emit(g + 1, done, false);
-        }
-        unit_shift();
         {
             const v2f_t none[M] = {};
-            decim_lane_group<FUSED, true>(acc, none, tab);      // the accumulators move two registers down
+            decim_lane_group<FUSED, true>(acc, none, tab);      // the accumulators move four registers down
         }
     }
     if (kr & 15) flush(kr & ~15);
@@ -281,7 +277,8 @@ void decim_lane_table(const float *taps_oldest_first, float *tab)
         for (int k = 0; k < 2 * kDlSlots; ++k) tab[i * 2 * kDlSlots + k] = taps_oldest_first[kDlTaps - kDlM + i - kDlM * (k % kDlSlots)];
 }
 
-// NOT THE DEFAULT: measured on config 3b it is slower than fir_stream_kernel -- 1.07 against 0.87-0.90 ms on the same box (FUSED 0.87 / 0.68).
+// NOT THE DEFAULT: measured on config 3b it is slower than fir_stream_kernel -- 0.95-0.99 against 0.86 ms on the same box (FUSED 0.80 / 0.66; the
+// second form, with one unit in flight and a rotation every two groups: 1.07).
 // The statement itself runs as interp_lane_kernel's does, but a group is only four samples: per group the wave also retires an output, and
 // per two groups it moves the accumulators on (34 moves), takes a unit of samples through its LDS patch (two dependent LDS round trips) and
 // requests the next one -- in-kernel clocks (-DMRHIP_DL_TRACE): 28 % of a wave's time inside the statement; with 11 waves per CU (LDS) the

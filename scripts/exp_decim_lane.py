@@ -77,7 +77,7 @@ def timed():
     nch, n = 256, 1_000_000
     x = torch.view_as_complex(torch.rand((nch, n, 2), dtype=torch.float32, device="cuda"))
     L = "decim_lane_kernel"
-    for label, env in (("fir_stream_kernel", {"MRHIP_DECIM_LANE": "0"}), (L, {})) + tuple((L + f" stretch<={st}", {"MRHIP_DECIM_STRETCH": str(st)}) for st in (512, 256, 176, 112, 80, 64)) + (("fir_stream_kernel", {"MRHIP_DECIM_LANE": "0"}), (L, {})):
+    for label, env in (("fir_stream_kernel", {"MRHIP_DECIM_LANE": "0"}), (L, {"MRHIP_DECIM_LANE": "1"})) + tuple((L + f" stretch<={st}", {"MRHIP_DECIM_LANE": "1", "MRHIP_DECIM_STRETCH": str(st)}) for st in (512, 176, 112)) + (("fir_stream_kernel", {"MRHIP_DECIM_LANE": "0"}), (L, {"MRHIP_DECIM_LANE": "1"})):
         for numerics in (pkg.NUMERICS_STRICT, pkg.NUMERICS_FUSED):
             os.environ.update(env)
             f = pkg.FIRFilter(h, Fraction(1, 4), numerics=numerics).bind(np.complex64, nch)

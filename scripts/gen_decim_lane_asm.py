@@ -80,7 +80,7 @@ def gen(fused):
             f"    }}\n")
 
 
-ROT = 2                              # the kernel handles ROT groups per iteration with the slots in place, then moves every accumulator ROT registers down
+ROT = 4                              # the kernel handles ROT groups per iteration with the slots in place, then moves every accumulator ROT registers down
 
 
 def gen_rotate():
