@@ -8,6 +8,7 @@ cd "$R"
 run() { echo "== $*" >> "$OUT"; timeout -k 10 600 "$@" 2>&1 | grep -v "amdgpu.ids" | tail -2 >> "$OUT" || { echo "FAILED: $*" >> "$OUT"; tail -3 "$OUT"; exit 1; }; tail -1 "$OUT"; }
 run python tests/stress_random.py --cases 3000 --seed 61
 run python tests/stress_random.py --cases 2500 --seed 62
+run python tests/stress_random.py --cases 3000 --seed 91 --aligned      # (rows that are multiples of 16 bytes: every kernel's LDS-DMA path)
 run python scripts/stress_arb_lane.py 200 63
 run python scripts/stress_lane_kernels.py 240 7
 run python scripts/stress_schedule.py --cases 1500 --seed 1 --seconds 240

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--arb", type=float, default=None, help="fraction of FIRArbitrary / FIRFarrow cases (default 0.15)")
     ap.add_argument("--async-mix", type=float, default=0.0, help="fraction of the tuned filter's calls issued through filt_into_async "
                     "(planned on the device from the device-resident stream state; counts collected once per case)")
+    ap.add_argument("--aligned", action="store_true", help="sample counts (and with them the channel rows) are multiples of 16 bytes: every case takes "
+                    "the LDS-DMA paths of the kernels that have one (profiles/r06/experiments.md K)")
     ap.add_argument("--big", action="store_true", help="long launches: 32-96 channels x 0.5-4e6 samples, ratios the pair kernels take "
                     "(dynamic scheduling, two-stage tiles)")
     args = ap.parse_args()
@@ -52,6 +54,8 @@ def main():
         nch = int(rng.choice([1, 2, 3, 5, 8, 31, 32, 33, 64, 70]))
         n = int(rng.choice([1, 7, 300, 5_000, 40_000, 150_000]))
         n = max(1, int(n * (0.5 + rng.random())))
+        if args.aligned:
+            n = max(4, n // 4 * 4)
         if args.big:
             arbitrary = False
             th = np.float32
