@@ -163,7 +163,9 @@ def rows(which):
     R147 = 147 / 160
 
     def _c1():
-        run("C1 rational 147//160 f32 1ch x 1e6 (one call)", h147, Fraction(147, 160), 32, 1, 1_000_000, torch.float32, 7.675, 48 * R147)
+        # (200 passes: with the default 5 the row's wall time was the device synchronisation that ends the timed loop, ~60 us, shared by five calls --
+        #  24-25 us "per call"; a loop of reset() + filt!() runs at 13 us per call, filt!() alone at 9.5: scripts/attic/exp_c1_wall.py)
+        run("C1 rational 147//160 f32 1ch x 1e6 (one call)", h147, Fraction(147, 160), 32, 1, 1_000_000, torch.float32, 7.675, 48 * R147, reps=200)
     def _c2():
         run("C2 rational 147//160 f32 1ch x 1e8 in 1e6 chunks (resident signal: mrhip_filt_device_chunked)", h147, Fraction(147, 160), 32, 1, 100_000_000, torch.float32, 7.675, 48 * R147, reps=3, chunk=1_000_000)
     def _c2s():
